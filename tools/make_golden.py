@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REAL reference (imported from
+/root/reference, build container only) on the oracle's deterministic weights
+and inputs.  Re-run:  python tools/make_golden.py
+
+Each fixture stores the reference's outputs (embeddings, logits, loss), the
+gradient of every parameter reduced to (L2 norm, 16 strided samples), and for
+the small configs the full gradients.  torch / numpy versions are recorded.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import clip_oracle as O  # noqa: E402
+from oracle import ref_harness as R  # noqa: E402
+
+CASES = [
+    # name, config, batch, seq_len, weight seed, input seed, full grads?
+    ("tiny_b6_l24", "tiny", 6, 24, 1234, 3, True),
+    ("small_b5_l40", "small", 5, 40, 99, 7, False),
+    ("vitb16_bertbase_b4_l64", "vitb16_bertbase", 4, 64, 1234, 0, False),
+]
+
+
+def grad_digest(g: torch.Tensor):
+    flat = g.reshape(-1)
+    n = flat.numel()
+    idx = torch.linspace(0, n - 1, 16).long()
+    return float(flat.double().norm()), flat[idx].numpy().astype(np.float32), idx.numpy()
+
+
+def run_case(name, cfg_name, B, L, wseed, iseed, full):
+    torch.manual_seed(0)
+    cfg = O.CONFIGS[cfg_name]
+    sd = O.make_state_dict(cfg, wseed)
+    model = R.reference_chinese_clip(cfg, sd)
+    px, ids = O.make_inputs(cfg, B, L, iseed)
+    img, txt = model(px, ids)                                   # modeling_chineseclip.py:352-365
+    lpt = torch.matmul(txt, img.t()) * model.logit_scale.exp()  # appzoo/clip/model.py:148
+    ar = torch.arange(B)
+    loss = (torch.nn.functional.cross_entropy(lpt, ar)
+            + torch.nn.functional.cross_entropy(lpt.T, ar)) / 2.0   # model.py:154-160
+    loss.backward()
+    out = {
+        "meta": np.array([cfg_name, str(B), str(L), str(wseed), str(iseed),
+                          torch.__version__, np.__version__]),
+        "image_embeds": img.detach().numpy(), "text_embeds": txt.detach().numpy(),
+        "logits_per_text": lpt.detach().numpy(), "loss": np.float32(loss.item()),
+    }
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            out["nograd/" + n] = np.zeros(0, np.float32)
+            continue
+        norm, samp, idx = grad_digest(p.grad)
+        out["gnorm/" + n] = np.float64(norm)
+        out["gsamp/" + n] = samp
+        if full:
+            out["grad/" + n] = p.grad.numpy()
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "loss", loss.item(), "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    only = sys.argv[1:]
+    for case in CASES:
+        if only and case[0] not in only:
+            continue
+        run_case(*case)

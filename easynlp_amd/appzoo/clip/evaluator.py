@@ -1,0 +1,85 @@
+"""Recall@k evaluator -- mirror of ``easynlp.appzoo.clip.evaluator.CLIPEvaluator``
+(easynlp/appzoo/clip/evaluator.py:27-72; base easynlp/core/evaluator.py:19-34).
+
+Same contract: ``evaluate(model) -> [("mean_recall", float)]`` with text->image
+R@1/5/10 over the whole validation set.  The per-row Python loop with a full
+``torch.sort`` (evaluator.py:53-61) is replaced by one HIP call that builds the
+similarity matrix on the f32 MFMA GEMM and counts, per query, how many images
+score above the paired one (``ezclip_recall_ranks``): hit@k  <=>  rank < k.
+"""
+from __future__ import annotations
+
+import time
+
+import torch
+from torch.utils.data import DataLoader
+
+from ... import lib as L
+
+
+class Evaluator(object):
+    def __init__(self, valid_dataset, **kwargs):
+        eval_batch_size = kwargs.get("eval_batch_size", 32)
+        self.valid_loader = DataLoader(valid_dataset, batch_size=eval_batch_size, shuffle=False,
+                                       collate_fn=valid_dataset.batch_fn)
+        self.best_valid_score = float("-inf")
+
+    def evaluate(self, model):
+        raise NotImplementedError
+
+    @property
+    def eval_metrics(self):
+        raise NotImplementedError
+
+
+def recall_ranks(text_embeds: torch.Tensor, image_embeds: torch.Tensor) -> torch.Tensor:
+    """rank[i] = #{j : <t_i, v_j> > <t_i, v_i>} (+ ties with j < i) on the GPU."""
+    lib = L.load()
+    t = text_embeds.detach().float().contiguous()
+    v = image_embeds.detach().float().contiguous()
+    n, e = t.shape
+    rank = torch.empty(n, dtype=torch.int32, device=t.device)
+    scratch = torch.empty(n * n, dtype=torch.float32, device=t.device)
+    L.check(lib.ezclip_recall_ranks(L.ptr(t), L.ptr(v), n, e, L.ptr(rank), L.ptr(scratch), L.stream_ptr()),
+            "recall_ranks")
+    return rank
+
+
+def recall_at_k(text_embeds, image_embeds, ks=(1, 5, 10)):
+    rank = recall_ranks(text_embeds, image_embeds)
+    n = rank.numel()
+    stats = [int((rank < k).sum().item()) for k in ks]
+    rs = [s * 1.0 / n for s in stats]
+    return (sum(rs) / len(rs),) + tuple(rs), stats
+
+
+class CLIPEvaluator(Evaluator):
+
+    def __init__(self, valid_dataset, **kwargs):
+        super().__init__(valid_dataset, **kwargs)
+        self.metrics = ["accuracy", "f1"]
+        self.before = 0.0
+
+    def evaluate(self, model):
+        model.eval()
+        total_spent_time = 0.0
+        image_embeds_all, text_embeds_all = [], []
+        for _step, batch in enumerate(self.valid_loader):
+            infer_start_time = time.time()
+            with torch.no_grad():
+                outputs = model(batch, feat=True) if getattr(model, "_engine", None) is not None else model(batch)
+            total_spent_time += time.time() - infer_start_time
+            image_embeds_all.append(outputs["image_embeds"])
+            text_embeds_all.append(outputs["text_embeds"])
+        image_embeds_tensor = torch.cat(image_embeds_all, dim=0)
+        text_embeds_tensor = torch.cat(text_embeds_all, dim=0)
+        query_len = text_embeds_tensor.size()[0]
+        (mean_recall, r1, r5, r10), (r1_stat, r5_stat, r10_stat) = recall_at_k(text_embeds_tensor, image_embeds_tensor)
+        result = [item * 100 for item in (mean_recall, r1, r5, r10)]
+        print("r1_num:" + str(r1_stat), "r5_num:" + str(r5_stat), "r10_num:" + str(r10_stat),
+              "query_num:" + str(query_len))
+        print("r1(%):" + str(result[1]), "r5(%):" + str(result[2]), "r10(%):" + str(result[3]),
+              "mean_recall(%):" + str(result[0]))
+        print("Inference time = {:.2f}s, [{:.4f} ms / sample] ".format(total_spent_time,
+                                                                      total_spent_time * 1000 / query_len))
+        return [("mean_recall", mean_recall)]

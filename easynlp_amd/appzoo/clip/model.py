@@ -1,0 +1,501 @@
+"""MI355X-native drop-in for ``easynlp.appzoo.clip.model.CLIPApp``.
+
+Mirrors the reference application contract (easynlp/appzoo/clip/model.py:40-164,
+base class easynlp/appzoo/application.py:26-38):
+
+* ``CLIPApp(pretrained_model_name_or_path, user_defined_parameters=None)`` and
+  ``CLIPApp.from_pretrained(path, user_defined_parameters={})`` read
+  ``config.json`` (``model_type == "chinese_clip"``) + ``pytorch_model.bin``
+  (keys prefixed ``chinese_clip.``), model.py:52-72;
+* ``forward(inputs, feat=None)`` returns ``{'logits_per_text',
+  'logits_per_image', 'image_embeds', 'text_embeds'}`` (or only the embeds with
+  ``feat=True``), mutating ``inputs`` like the reference does (model.py:106-150);
+* ``compute_loss(forward_outputs, label_ids) -> {'loss': tensor}`` (model.py:154-164);
+* parameters are real ``nn.Parameter``s under the reference's names
+  (``chinese_clip.visual.*``, ``chinese_clip.bert.*``, ``chinese_clip.text_projection``,
+  ``chinese_clip.logit_scale``) so Trainer/AdamW/grad-clip/checkpoints work unchanged.
+
+Python/PyTorch here is orchestration only: device memory, streams, autograd
+plumbing, ``torch.distributed``.  Every FLOP of the dual-encoder, the similarity
+and the InfoNCE loss (forward and backward) runs in ``libezclip_hip.so``.
+There is no CPU fallback: without the HIP library / a GPU the model raises.
+"""
+from __future__ import annotations
+
+import json
+import os
+import warnings
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import lib as L
+from ..application import Application
+
+_CFG_FIELDS = ("embed_dim", "image_resolution", "vision_layers", "vision_width", "vision_patch_size",
+               "vocab_size", "text_hidden_size", "text_intermediate_size", "text_max_position_embeddings",
+               "text_num_attention_heads", "text_num_hidden_layers", "text_type_vocab_size")
+
+
+class Config_Wrapper:
+    """Same helper as the reference (model.py:32-38): Trainer calls
+    ``model.config.to_json_string()`` and reads ``model.config.__dict__``."""
+
+    def __init__(self, json_data):
+        self.json_data = json_data
+
+    def to_json_string(self):
+        return json.dumps(self.json_data, ensure_ascii=False)
+
+
+class _ParamTree(nn.Module):
+    """A bare module tree that only holds parameters under dotted reference names."""
+
+    def add(self, dotted: str, value: torch.Tensor, buffer: bool = False):
+        head, _, rest = dotted.partition(".")
+        if rest:
+            if head not in self._modules:
+                self.add_module(head, _ParamTree())
+            self._modules[head].add(rest, value, buffer)
+        elif buffer:
+            self.register_buffer(head, value, persistent=True)
+        else:
+            self.register_parameter(head, nn.Parameter(value))
+
+
+def _cfg_struct(cfg: dict, dtype_code: int) -> L.EzclipConfig:
+    if isinstance(cfg.get("vision_layers"), (list, tuple)):
+        raise L.EzclipError("ModifiedResNet vision towers are not on the HIP path (SURVEY.md 8f)")
+    c = L.EzclipConfig()
+    for f in _CFG_FIELDS:
+        setattr(c, f, int(cfg[f]))
+    c.compute_dtype = dtype_code
+    return c
+
+
+class HipClipEngine:
+    """Owns the C handle, the packed-weight shadow and the workspaces for one
+    module instance on one device."""
+
+    def __init__(self, cfg: dict, dtype_code: int):
+        self.lib = L.load()
+        self.cfg = cfg
+        self.dtype_code = dtype_code
+        self._cstruct = _cfg_struct(cfg, dtype_code)
+        h = L.C.c_void_p()
+        L.check(self.lib.ezclip_create(L.C.byref(self._cstruct), L.C.byref(h)), "ezclip_create")
+        self.handle = h
+        self.names: List[str] = []
+        self.shapes: Dict[str, tuple] = {}
+        name = L.C.c_char_p()
+        shape = (L.C.c_int64 * 8)()
+        ndim = L.C.c_int()
+        for i in range(self.lib.ezclip_num_params(h)):
+            L.check(self.lib.ezclip_param_info(h, i, L.C.byref(name), shape, L.C.byref(ndim)), "param_info")
+            n = name.value.decode()
+            self.names.append(n)
+            self.shapes[n] = tuple(int(shape[j]) for j in range(ndim.value))
+        self._shadow = None
+        self._shadow_backward = False
+        self._bind_sig = None
+        self._content_sig = None
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._grad_flat: Optional[torch.Tensor] = None
+        self.embed_dim = int(cfg["embed_dim"])
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ezclip_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # -- parameter binding ---------------------------------------------------------------
+    def sync_params(self, params: Dict[str, torch.Tensor], with_backward: bool,
+                    grads: Optional[Dict[str, torch.Tensor]] = None) -> None:
+        """(Re)bind device pointers when tensors moved, and refresh the packed
+        weights when the parameter *contents* changed (optimizer step /
+        load_state_dict bump ``_version``)."""
+        plist = [params[n] for n in self.names]
+        bind_sig = (tuple(p.data_ptr() for p in plist),
+                    None if grads is None else tuple(grads[n].data_ptr() for n in self.names))
+        dev = plist[0].device
+        rebound = False
+        if bind_sig != self._bind_sig:
+            for n, p in zip(self.names, plist):
+                if not p.is_cuda:
+                    raise L.EzclipError("parameter %s is on %s: move the model to a GPU (no CPU path)" % (n, p.device))
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise L.EzclipError("parameter %s must be contiguous float32" % n)
+                shp = (L.C.c_int64 * max(1, p.dim()))(*p.shape)
+                g = grads.get(n) if grads is not None else None
+                L.check(self.lib.ezclip_bind_param(self.handle, n.encode(), L.ptr(p), L.ptr(g), shp, p.dim()),
+                        "bind_param(%s)" % n)
+            rebound = self._bind_sig is None or bind_sig[0] != self._bind_sig[0]
+            self._bind_sig = bind_sig
+        grow = self._shadow is None or (with_backward and not self._shadow_backward) or self._shadow.device != dev
+        if grow:
+            wb = with_backward or self._shadow_backward
+            nbytes = self.lib.ezclip_shadow_bytes(self.handle, 1 if wb else 0)
+            self._shadow = L.alloc_bytes(nbytes, dev)
+            self._shadow_backward = wb
+            L.check(self.lib.ezclip_set_shadow(self.handle, L.ptr(self._shadow), self._shadow.numel(), 1 if wb else 0),
+                    "set_shadow")
+        content_sig = tuple(p._version for p in plist)
+        if grow or rebound or content_sig != self._content_sig:
+            L.check(self.lib.ezclip_refresh_weights(self.handle, L.stream_ptr()), "refresh_weights")
+            self._content_sig = content_sig
+
+    def workspace(self, kind: str, batch: int, seq_len: int, save: bool, device) -> torch.Tensor:
+        key = (kind, batch, seq_len, save, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            if kind == "image":
+                n = self.lib.ezclip_image_workspace_bytes(self.handle, batch, 1 if save else 0)
+            else:
+                n = self.lib.ezclip_text_workspace_bytes(self.handle, batch, seq_len, 1 if save else 0)
+            # keep at most one workspace per (kind, save): batch shape changes are rare
+            for k in [k for k in self._ws if k[0] == kind and k[3] == save]:
+                del self._ws[k]
+            ws = L.alloc_bytes(n, device)
+            self._ws[key] = ws
+        return ws
+
+    # -- forward -----------------------------------------------------------------------------
+    def encode_image(self, pixels: torch.Tensor, save: bool) -> (torch.Tensor, torch.Tensor):
+        pixels = pixels.contiguous()
+        if pixels.dtype != torch.float32:
+            pixels = pixels.float()
+        B = pixels.shape[0]
+        R = int(self.cfg["image_resolution"])
+        if tuple(pixels.shape[1:]) != (3, R, R):
+            raise L.EzclipError("pixel_values must be [B,3,%d,%d], got %s" % (R, R, tuple(pixels.shape)))
+        out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=pixels.device)
+        ws = self.workspace("image", B, 0, save, pixels.device)
+        L.check(self.lib.ezclip_encode_image(self.handle, L.ptr(pixels), B, L.ptr(out), L.ptr(ws), ws.numel(),
+                                             1 if save else 0, L.stream_ptr()), "encode_image")
+        return out, ws
+
+    def encode_text(self, ids: torch.Tensor, save: bool) -> (torch.Tensor, torch.Tensor):
+        ids = ids.contiguous()
+        if ids.dtype != torch.int64:
+            ids = ids.long()
+        B, S = ids.shape
+        out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=ids.device)
+        ws = self.workspace("text", B, S, save, ids.device)
+        L.check(self.lib.ezclip_encode_text(self.handle, L.ptr(ids), B, S, L.ptr(out), L.ptr(ws), ws.numel(),
+                                            1 if save else 0, L.stream_ptr()), "encode_text")
+        return out, ws
+
+    def backward_image(self, pixels, d_emb, ws):
+        L.check(self.lib.ezclip_backward_image(self.handle, L.ptr(pixels), pixels.shape[0], L.ptr(d_emb.contiguous()),
+                                               L.ptr(ws), ws.numel(), L.stream_ptr()), "backward_image")
+
+    def backward_text(self, ids, d_emb, ws):
+        L.check(self.lib.ezclip_backward_text(self.handle, L.ptr(ids), ids.shape[0], ids.shape[1],
+                                              L.ptr(d_emb.contiguous()), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                "backward_text")
+
+
+class _EncodeFn(torch.autograd.Function):
+    """(pixels, ids, *params) -> (image_embeds, text_embeds); backward runs the HIP
+    backward kernels into a zeroed flat gradient buffer and hands autograd views of it."""
+
+    @staticmethod
+    def forward(ctx, app, pixels, ids, *params):
+        eng = app._engine
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        named = dict(zip(eng.names, params))
+        eng.sync_params(named, with_backward=need_grad)
+        img = txt = None
+        ctx.ws_img = ctx.ws_txt = None
+        if pixels is not None:
+            pixels = pixels.contiguous().float()
+            img, ctx.ws_img = eng.encode_image(pixels, need_grad)
+        if ids is not None:
+            ids = ids.contiguous().long()
+            txt, ctx.ws_txt = eng.encode_text(ids, need_grad)
+        ctx.app, ctx.pixels, ctx.ids = app, pixels, ids
+        ctx.n_params = len(params)
+        ctx.has = (img is not None, txt is not None)
+        outs = tuple(o if o is not None else torch.zeros(0, device=params[0].device) for o in (img, txt))
+        if img is None:
+            ctx.mark_non_differentiable(outs[0])
+        if txt is None:
+            ctx.mark_non_differentiable(outs[1])
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_img, d_txt):
+        app = ctx.app
+        eng = app._engine
+        params = dict(zip(eng.names, [app._params[n] for n in eng.names]))
+        dev = next(iter(params.values())).device
+        total = sum(p.numel() + (-p.numel()) % 4 for p in params.values())
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        grads, off = {}, 0
+        for n, p in params.items():
+            grads[n] = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel() + (-p.numel()) % 4
+        eng.sync_params(params, with_backward=True, grads=grads)
+        if ctx.has[0]:
+            eng.backward_image(ctx.pixels, d_img, ctx.ws_img)
+        if ctx.has[1]:
+            eng.backward_text(ctx.ids, d_txt, ctx.ws_txt)
+        out = [grads[n] if params[n].requires_grad else None for n in eng.names]
+        return (None, None, None) + tuple(out)
+
+
+class _SimilarityFn(torch.autograd.Function):
+    """logits_per_text = T @ I^T * exp(logit_scale)  (model.py:148) on the f32 MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, txt, img, logit_scale):
+        txt, img = txt.contiguous(), img.contiguous()
+        out = L.similarity(txt, img, logit_scale)
+        ctx.save_for_backward(txt, img, logit_scale, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        txt, img, ls, out = ctx.saved_tensors
+        g = g.contiguous()
+        # dT = s * g @ I ; dI = s * g^T @ T ; d ls = sum(g * out)   (NT GEMMs on transposed copies)
+        d_txt = L.similarity(g, img.t().contiguous(), ls)
+        d_img = L.similarity(g.t().contiguous(), txt.t().contiguous(), ls)
+        d_ls = (g * out).sum().reshape(ls.shape)
+        return d_txt, d_img, d_ls
+
+
+class _InfoNCEFn(torch.autograd.Function):
+    """0.5 * (CE(S, arange) + CE(S^T, arange))  (model.py:154-160)."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        lib = L.load()
+        logits = logits.contiguous()
+        n = logits.shape[0]
+        if logits.dim() != 2 or logits.shape[1] != n:
+            raise L.EzclipError("compute_loss expects square logits_per_text")
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        scratch = torch.empty(4 * n, dtype=torch.float32, device=logits.device)
+        L.check(lib.ezclip_infonce_from_logits(L.ptr(logits), n, L.ptr(loss), L.ptr(scratch), L.stream_ptr()),
+                "infonce_from_logits")
+        ctx.save_for_backward(logits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        (logits,) = ctx.saved_tensors
+        n = logits.shape[0]
+        d = torch.empty_like(logits)
+        scratch = torch.empty(4 * n, dtype=torch.float32, device=logits.device)
+        g = g.contiguous().float()
+        L.check(lib.ezclip_infonce_from_logits_bwd(L.ptr(logits), n, L.ptr(g), L.ptr(d), L.ptr(scratch),
+                                                   L.stream_ptr()), "infonce_from_logits_bwd")
+        return d
+
+
+class CLIPApp(Application):
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, user_defined_parameters={}, **kwargs):
+        return cls(pretrained_model_name_or_path, user_defined_parameters)
+
+    def __init__(self, pretrained_model_name_or_path=None, user_defined_parameters=None, **kwargs):
+        super().__init__()
+        udp = user_defined_parameters or {}
+        if isinstance(udp, dict) and "app_parameters" in udp:
+            udp = dict(udp, **udp["app_parameters"])
+        self.compute_dtype = L.dtype_code(kwargs.get("compute_dtype", udp.get("clip_compute_dtype", "bf16")))
+        self._engine = None
+        self._params: Dict[str, nn.Parameter] = {}
+        if pretrained_model_name_or_path is None:
+            return
+        path = pretrained_model_name_or_path
+        with open(os.path.join(path, "config.json"), "r") as f:
+            self.raw_config = json.load(f)
+        if self.raw_config.get("model_type") != "chinese_clip":
+            raise L.EzclipError("the HIP path implements model_type == 'chinese_clip' (got %r); open_clip / "
+                                "huggingface_clip are listed as next in SURVEY.md 8f" % self.raw_config.get("model_type"))
+        self.model_type = "chinese_clip"
+        self.config = Config_Wrapper(self.raw_config)
+        for k in ("text_hidden_dropout_prob", "text_attention_probs_dropout_prob"):
+            if float(self.raw_config.get(k, 0.0)) != 0.0:
+                warnings.warn("%s=%s: dropout is not applied on the HIP path (treated as 0)" % (k, self.raw_config[k]))
+        self._build(self.raw_config)
+        ckpt = os.path.join(path, "pytorch_model.bin")
+        if os.path.exists(ckpt):
+            checkpoint = torch.load(ckpt, map_location="cpu")
+            state = {k.replace("chinese_clip.", ""): v for k, v in checkpoint.items()}   # model.py:69-70
+            self.chinese_clip.load_state_dict(state, strict=False)                          # model.py:72
+
+    # ------------------------------------------------------------------------------------
+    def _build(self, cfg: dict) -> None:
+        eng = HipClipEngine(cfg, self.compute_dtype)
+        tree = _ParamTree()
+        for n in eng.names:
+            shape = eng.shapes[n]
+            t = torch.zeros(shape, dtype=torch.float32)
+            if n == "logit_scale":
+                t.fill_(float(torch.log(torch.tensor(1.0 / 0.07))))       # modeling_chineseclip.py:316
+            tree.add(n, t)
+        # persistent buffer the reference BertEmbeddings carries in its state_dict (modeling_bert.py:88)
+        tree.add("bert.embeddings.position_ids",
+                 torch.arange(int(cfg["text_max_position_embeddings"])).expand((1, -1)).clone(), buffer=True)
+        self.chinese_clip = tree
+        self._engine = eng
+        named = dict(tree.named_parameters())
+        self._params = {n: named[n] for n in eng.names}
+
+    @classmethod
+    def from_config(cls, config: dict, seed: int = 0, device="cuda", compute_dtype="bf16"):
+        """Random-init model of a given architecture directly on the device (benchmarks,
+        smoke tests): reference-like init scales (VisualTransformer.__init__
+        modeling_chineseclip.py:226-234, BertPreTrainedModel._init_weights modeling_bert.py:624-638)."""
+        app = cls(None, compute_dtype=compute_dtype)
+        app.raw_config = dict(config)
+        app.model_type = "chinese_clip"
+        app.config = Config_Wrapper(app.raw_config)
+        app._build(app.raw_config)
+        app.to(device)
+        g = torch.Generator(device=device).manual_seed(seed)
+        W, H = int(config["vision_width"]), int(config["text_hidden_size"])
+        with torch.no_grad():
+            for n, p in app._params.items():
+                if n == "logit_scale":
+                    continue
+                if n.endswith("LayerNorm.weight") or (".ln_" in n and n.endswith(".weight")):
+                    p.fill_(1.0)
+                elif n.endswith(".bias") or n.endswith("in_proj_bias"):
+                    p.zero_()
+                else:
+                    if n in ("visual.class_embedding", "visual.positional_embedding", "visual.proj"):
+                        std = W ** -0.5
+                    elif n == "text_projection":
+                        std = H ** -0.5
+                    elif n == "visual.conv1.weight":
+                        std = (p.shape[1] * p.shape[2] * p.shape[3]) ** -0.5
+                    elif n.startswith("visual."):
+                        std = p.shape[-1] ** -0.5
+                    else:
+                        std = float(config.get("text_initializer_range", 0.02))
+                    p.copy_(torch.randn(p.shape, generator=g, device=device) * std)
+        return app
+
+    # ------------------------------------------------------------------------------------
+    def contrastive_step(self, pixel_values, input_ids, process_group=None, backward=False):
+        """Fast path without autograd bookkeeping: dual-encoder forward + InfoNCE
+        (+ full backward into ``.grad`` when ``backward=True``), one C call per stage.
+
+        With a ``process_group`` the contrastive batch is the *global* one
+        (SURVEY.md 8e): image/text embeddings are all-gathered over RCCL, each rank
+        evaluates its own rows of both directions (row-local LSE, no second
+        collective in the forward), and the embedding gradients are summed back
+        with a reduce-scatter.  Returns the (rank-local mean) loss tensor.
+        """
+        import torch.distributed as dist
+        eng = self._engine
+        lib = eng.lib
+        params = self._params
+        if backward:
+            grads = {}
+            for n, p in params.items():
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                grads[n] = p.grad
+            eng.sync_params(params, with_backward=True, grads=grads)
+        else:
+            eng.sync_params(params, with_backward=False)
+        pixel_values = pixel_values.contiguous()
+        input_ids = input_ids.contiguous()
+        img, ws_i = eng.encode_image(pixel_values, backward)
+        txt, ws_t = eng.encode_text(input_ids, backward)
+        n = img.shape[0]
+        e = img.shape[1]
+        world, rank = 1, 0
+        if process_group is not None or (dist.is_available() and dist.is_initialized() and process_group is not False):
+            pg = process_group if process_group not in (None, True) else None
+            world, rank = dist.get_world_size(pg), dist.get_rank(pg)
+        if world > 1:
+            both = torch.cat([img, txt], dim=1)                       # one collective for both towers
+            gathered = torch.empty((world * n, 2 * e), dtype=both.dtype, device=both.device)
+            dist.all_gather_into_tensor(gathered, both, group=pg)
+            img_all = gathered[:, :e].contiguous()
+            txt_all = gathered[:, e:].contiguous()
+        else:
+            img_all, txt_all = img, txt
+        N = world * n
+        key = ("nce", n, N, e)
+        ws = eng._ws.get(key)
+        if ws is None:
+            ws = L.alloc_bytes(lib.ezclip_infonce_workspace_bytes(n, N, e), img.device)
+            eng._ws[key] = ws
+        loss = torch.empty((), dtype=torch.float32, device=img.device)
+        if not backward:
+            L.check(lib.ezclip_infonce_fused(L.ptr(txt_all), L.ptr(img_all), n, N, rank * n, e,
+                                             L.ptr(self.logit_scale), 1.0, L.ptr(loss), None, None, None,
+                                             L.ptr(ws), ws.numel(), L.stream_ptr()), "infonce_fused")
+            return loss
+        d_txt = torch.empty((N, e), dtype=torch.float32, device=img.device)
+        d_img = torch.empty((N, e), dtype=torch.float32, device=img.device)
+        d_ls = torch.empty((), dtype=torch.float32, device=img.device)
+        L.check(lib.ezclip_infonce_fused(L.ptr(txt_all), L.ptr(img_all), n, N, rank * n, e, L.ptr(self.logit_scale),
+                                         1.0 / world, L.ptr(loss), L.ptr(d_txt), L.ptr(d_img), L.ptr(d_ls),
+                                         L.ptr(ws), ws.numel(), L.stream_ptr()), "infonce_fused")
+        if world > 1:
+            both = torch.cat([d_img, d_txt], dim=1)
+            mine = torch.empty((n, 2 * e), dtype=both.dtype, device=both.device)
+            dist.reduce_scatter_tensor(mine, both, op=dist.ReduceOp.SUM, group=pg)
+            d_img_l, d_txt_l = mine[:, :e].contiguous(), mine[:, e:].contiguous()
+        else:
+            d_img_l, d_txt_l = d_img, d_txt
+        self.logit_scale.grad.add_(d_ls)
+        eng.backward_image(pixel_values, d_img_l, ws_i)
+        eng.backward_text(input_ids, d_txt_l, ws_t)
+        return loss
+
+    @property
+    def logit_scale(self):
+        return self._params["logit_scale"]
+
+    def _plist(self):
+        return [self._params[n] for n in self._engine.names]
+
+    # ------------------------------------------------------------------------------------
+    def encode(self, pixel_values=None, input_ids=None):
+        img, txt = _EncodeFn.apply(self, pixel_values, input_ids, *self._plist())
+        return (img if pixel_values is not None else None), (txt if input_ids is not None else None)
+
+    def forward(self, inputs, feat=None):
+        _device = self._params["text_projection"].device
+        if "pixel_values" in inputs and inputs["pixel_values"] is not None:
+            inputs["pixel_values"] = inputs["pixel_values"].to(_device)
+        else:
+            inputs["pixel_values"] = None
+        if "input_ids" in inputs and inputs["input_ids"] is not None:
+            inputs["input_ids"] = inputs["input_ids"].to(_device)
+        else:
+            inputs["input_ids"] = None
+        assert inputs["pixel_values"] is not None or inputs["input_ids"] is not None, \
+            "text and image cannot both be None!"
+        image_embeds, text_embeds = self.encode(inputs["pixel_values"], inputs["input_ids"])
+        if feat is True:
+            return {"image_embeds": image_embeds, "text_embeds": text_embeds}
+        logits_per_text = _SimilarityFn.apply(text_embeds, image_embeds, self.logit_scale)
+        logits_per_image = logits_per_text.T
+        return {"logits_per_text": logits_per_text, "logits_per_image": logits_per_image,
+                "image_embeds": image_embeds, "text_embeds": text_embeds}
+
+    def contrastive_loss(self, logits: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError("use clip_loss: both directions are fused in one HIP call")
+
+    def clip_loss(self, similarity: torch.Tensor) -> torch.Tensor:
+        return _InfoNCEFn.apply(similarity)
+
+    def compute_loss(self, forward_outputs, label_ids, **kwargs):
+        loss = self.clip_loss(forward_outputs["logits_per_text"])
+        return {"loss": loss}

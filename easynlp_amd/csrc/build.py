@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Build libezclip_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python easynlp_amd/csrc/build.py [--force] [--debug-asm]
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["gemm.hip", "attention.hip", "rowops.hip", "loss.hip", "profile.hip", "model.hip", "capi.hip"]
+HEADERS = ["ezclip_common.h", "kernels.h", "model.h", "../../include/ezclip.h"]
+LIB = os.path.join(HERE, "libezclip_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(HERE, src)
+        o = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append((s, o))
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+
+    def compile_one(job):
+        s, o = job
+        cmd = [hipcc()] + FLAGS + ["-c", s, "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return s, r.returncode, r.stdout + r.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for s, rc, log in ex.map(compile_one, jobs):
+                if verbose and log.strip():
+                    print(log)
+                if rc != 0:
+                    raise RuntimeError("hipcc failed on %s\n%s" % (s, log))
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed\n" + r.stdout + r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

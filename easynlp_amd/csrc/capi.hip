@@ -1,0 +1,297 @@
+// extern "C" surface of libezclip_hip.so (declared in include/ezclip.h).
+#include <cstring>
+
+#include "model.h"
+
+using namespace ezclip;
+
+namespace {
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Arena {
+  char* base;
+  size_t off = 0;
+  explicit Arena(void* b) : base(reinterpret_cast<char*>(b)) {}
+  float* takef(size_t n) {
+    off = (off + 255) & ~size_t(255);
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += n * 4;
+    return p;
+  }
+};
+
+int sim_gemm(const float* a, int64_t lda, const float* b, int64_t ldb, int na, int nb, int k, const float* scale_log,
+             float* out, int64_t ldc, const float* residual, hipStream_t st) {
+  GemmArgs g;
+  g.A = a; g.lda = lda; g.B = b; g.ldb = ldb; g.C = out; g.ldc = ldc;
+  g.M = na; g.N = nb; g.K = k;
+  g.scale_log = scale_log;
+  g.R = residual; g.ldr = ldc;
+  return gemm_nt(g, EZCLIP_F32, st);
+}
+
+struct NceWS {
+  float *St, *Si, *dSt, *dSi, *lse_t, *lse_i, *rl_t, *rl_i, *IallT, *TallT, *dStT, *dSiT, *TlocT, *IlocT, *partial;
+  int Np, np;
+};
+size_t layout_nce(int n, int N, int e, void* base, NceWS* out) {
+  Arena a(base);
+  NceWS w;
+  w.Np = round_up(N, 32); w.np = round_up(n, 32);
+  w.St = a.takef((size_t)n * w.Np); w.Si = a.takef((size_t)n * w.Np);
+  w.dSt = a.takef((size_t)n * w.Np); w.dSi = a.takef((size_t)n * w.Np);
+  w.lse_t = a.takef(n); w.lse_i = a.takef(n); w.rl_t = a.takef(n); w.rl_i = a.takef(n);
+  w.IallT = a.takef((size_t)e * w.Np); w.TallT = a.takef((size_t)e * w.Np);
+  w.dStT = a.takef((size_t)N * w.np); w.dSiT = a.takef((size_t)N * w.np);
+  w.TlocT = a.takef((size_t)e * w.np); w.IlocT = a.takef((size_t)e * w.np);
+  w.partial = a.takef(256);
+  if (out) *out = w;
+  return a.off + 256;
+}
+
+}  // namespace
+
+#define API_TRY(expr)                \
+  do {                               \
+    int _rc = (expr);                \
+    if (_rc != EZ_OK) return _rc;    \
+  } while (0)
+
+extern "C" {
+
+const char* ezclip_last_error(void) { return ezclip::last_error(); }
+const char* ezclip_version(void) { return "ezclip-hip 0.1 (gfx950)"; }
+
+int ezclip_create(const ezclip_config* cfg, ezclip_handle* out) { return model_create(cfg, out); }
+
+void ezclip_destroy(ezclip_handle h) { delete h; }
+
+int ezclip_num_params(ezclip_handle h) { return h ? (int)h->params.size() : 0; }
+
+int ezclip_param_info(ezclip_handle h, int index, const char** name, int64_t* shape, int* ndim) {
+  EZ_REQUIRE(h && index >= 0 && index < (int)h->params.size(), "ezclip_param_info: bad index %d", index);
+  const auto& p = h->params[index];
+  if (name) *name = p.name.c_str();
+  if (ndim) *ndim = (int)p.shape.size();
+  if (shape) for (size_t i = 0; i < p.shape.size(); ++i) shape[i] = p.shape[i];
+  return EZ_OK;
+}
+
+int ezclip_bind_param(ezclip_handle h, const char* name, void* w, void* g, const int64_t* shape, int ndim) {
+  EZ_REQUIRE(h && name && w, "ezclip_bind_param: null argument");
+  auto it = h->index.find(name);
+  EZ_REQUIRE(it != h->index.end(), "ezclip_bind_param: unknown parameter '%s'", name);
+  auto& p = h->params[it->second];
+  EZ_REQUIRE(ndim == (int)p.shape.size(), "ezclip_bind_param: %s expects %d dims, got %d", name, (int)p.shape.size(), ndim);
+  for (int i = 0; i < ndim; ++i)
+    EZ_REQUIRE(shape[i] == p.shape[i], "ezclip_bind_param: %s dim %d is %lld, expected %lld", name, i,
+               (long long)shape[i], (long long)p.shape[i]);
+  EZ_REQUIRE(((uintptr_t)w % 16) == 0 && ((uintptr_t)g % 16) == 0, "ezclip_bind_param: %s must be 16-byte aligned", name);
+  if (p.w != reinterpret_cast<float*>(w)) h->weights_fresh = false;   // grad-only rebinding keeps the packs valid
+  p.w = reinterpret_cast<float*>(w);
+  p.g = reinterpret_cast<float*>(g);
+  return EZ_OK;
+}
+
+size_t ezclip_shadow_bytes(ezclip_handle h, int with_backward) {
+  return h ? model_shadow_layout(h, nullptr, with_backward != 0) : 0;
+}
+
+int ezclip_set_shadow(ezclip_handle h, void* buf, size_t bytes, int with_backward) {
+  EZ_REQUIRE(h && buf, "ezclip_set_shadow: null argument");
+  EZ_REQUIRE(((uintptr_t)buf % 256) == 0, "ezclip_set_shadow: buffer must be 256-byte aligned");
+  const size_t need = model_shadow_layout(h, nullptr, with_backward != 0);
+  EZ_REQUIRE(bytes >= need, "ezclip_set_shadow: buffer too small (%zu < %zu)", bytes, need);
+  model_shadow_layout(h, reinterpret_cast<char*>(buf), with_backward != 0);
+  h->shadow = buf; h->shadow_bytes = bytes; h->shadow_backward = with_backward != 0;
+  h->weights_fresh = false;
+  return EZ_OK;
+}
+
+int ezclip_refresh_weights(ezclip_handle h, void* stream) {
+  EZ_REQUIRE(h, "ezclip_refresh_weights: null handle");
+  return model_refresh_weights(h, S(stream));
+}
+
+size_t ezclip_image_workspace_bytes(ezclip_handle h, int batch, int save) {
+  return h ? image_workspace_bytes(h, batch, save != 0) : 0;
+}
+size_t ezclip_text_workspace_bytes(ezclip_handle h, int batch, int seq_len, int save) {
+  return h ? text_workspace_bytes(h, batch, seq_len, save != 0) : 0;
+}
+
+int ezclip_encode_image(ezclip_handle h, const float* pixels, int batch, float* out, void* ws, size_t ws_bytes, int save,
+                        void* stream) {
+  EZ_REQUIRE(h, "ezclip_encode_image: null handle");
+  return encode_image(h, pixels, batch, out, ws, ws_bytes, save != 0, S(stream));
+}
+
+int ezclip_encode_text(ezclip_handle h, const int64_t* ids, int batch, int seq_len, float* out, void* ws,
+                       size_t ws_bytes, int save, void* stream) {
+  EZ_REQUIRE(h, "ezclip_encode_text: null handle");
+  return encode_text(h, ids, batch, seq_len, out, ws, ws_bytes, save != 0, S(stream));
+}
+
+int ezclip_similarity(const float* a, const float* b, int na, int nb, int e, const float* logit_scale, float* out,
+                      void* stream) {
+  EZ_REQUIRE(a && b && out && na > 0 && nb > 0, "ezclip_similarity: null/empty argument");
+  return sim_gemm(a, e, b, e, na, nb, e, logit_scale, out, nb, nullptr, S(stream));
+}
+
+int ezclip_infonce_from_logits(const float* logits, int n, float* loss, float* scratch, void* stream) {
+  EZ_REQUIRE(logits && loss && scratch && n > 0, "ezclip_infonce_from_logits: null/empty argument");
+  hipStream_t st = S(stream);
+  float *lse_r = scratch, *rl = scratch + n, *lse_c = scratch + 2 * n, *cl = scratch + 3 * n;
+  API_TRY(ce_rows_fwd(logits, n, n, n, 0, lse_r, rl, st));
+  API_TRY(ce_cols_fwd(logits, n, n, lse_c, cl, st));
+  API_TRY(sum_scaled(rl, n, 0.5f / n, loss, 0, st));
+  API_TRY(sum_scaled(cl, n, 0.5f / n, loss, 1, st));
+  return EZ_OK;
+}
+
+int ezclip_infonce_from_logits_bwd(const float* logits, int n, const float* grad_out, float* dlogits, float* scratch,
+                                   void* stream) {
+  EZ_REQUIRE(logits && dlogits && scratch && n > 0, "ezclip_infonce_from_logits_bwd: null/empty argument");
+  hipStream_t st = S(stream);
+  float *lse_r = scratch, *rl = scratch + n, *lse_c = scratch + 2 * n, *cl = scratch + 3 * n;
+  API_TRY(ce_rows_fwd(logits, n, n, n, 0, lse_r, rl, st));
+  API_TRY(ce_cols_fwd(logits, n, n, lse_c, cl, st));
+  API_TRY(infonce_dlogits(logits, n, lse_r, lse_c, grad_out, 0.5f / n, dlogits, st));
+  return EZ_OK;
+}
+
+size_t ezclip_infonce_workspace_bytes(int n_local, int n_global, int e) {
+  return layout_nce(n_local, n_global, e, nullptr, nullptr);
+}
+
+int ezclip_infonce_fused(const float* T, const float* I, int n, int N, int off, int e, const float* ls,
+                         float grad_scale, float* loss, float* dT, float* dI, float* dls, void* wsp, size_t ws_bytes,
+                         void* stream) {
+  EZ_REQUIRE(T && I && loss && wsp, "ezclip_infonce_fused: null argument");
+  EZ_REQUIRE(n > 0 && N >= n && off >= 0 && off + n <= N, "ezclip_infonce_fused: bad shard n=%d N=%d offset=%d", n, N, off);
+  EZ_REQUIRE(e % 32 == 0, "ezclip_infonce_fused: embed dim %d must be a multiple of 32", e);
+  EZ_REQUIRE(((uintptr_t)wsp % 256) == 0, "ezclip_infonce_fused: workspace must be 256-byte aligned");
+  NceWS w;
+  const size_t need = layout_nce(n, N, e, wsp, &w);
+  EZ_REQUIRE(ws_bytes >= need, "ezclip_infonce_fused: workspace too small (%zu < %zu)", ws_bytes, need);
+  hipStream_t st = S(stream);
+  const float* Tl = T + (size_t)off * e;
+  const float* Il = I + (size_t)off * e;
+  // S_t = s * T_loc I_all^T ; S_i = s * I_loc T_all^T         (appzoo/clip/model.py:148, both directions)
+  API_TRY(sim_gemm(Tl, e, I, e, n, N, e, ls, w.St, w.Np, nullptr, st));
+  API_TRY(sim_gemm(Il, e, T, e, n, N, e, ls, w.Si, w.Np, nullptr, st));
+  API_TRY(ce_rows_fwd(w.St, w.Np, n, N, off, w.lse_t, w.rl_t, st));      // model.py:154-160
+  API_TRY(ce_rows_fwd(w.Si, w.Np, n, N, off, w.lse_i, w.rl_i, st));
+  API_TRY(sum_scaled(w.rl_t, n, 0.5f / n, loss, 0, st));
+  API_TRY(sum_scaled(w.rl_i, n, 0.5f / n, loss, 1, st));
+  if (dT == nullptr && dI == nullptr && dls == nullptr) return EZ_OK;
+  EZ_REQUIRE(dT && dI && dls, "ezclip_infonce_fused: d_text/d_image/d_logit_scale must be all set or all NULL");
+  const float c = grad_scale * 0.5f / n;
+  EZ_HIP(hipMemsetAsync(w.dSt, 0, (size_t)n * w.Np * 4, st));
+  EZ_HIP(hipMemsetAsync(w.dSi, 0, (size_t)n * w.Np * 4, st));
+  API_TRY(ce_rows_bwd(w.St, w.Np, n, N, off, w.lse_t, nullptr, c, w.dSt, w.Np, 0, st));
+  API_TRY(ce_rows_bwd(w.Si, w.Np, n, N, off, w.lse_i, nullptr, c, w.dSi, w.Np, 0, st));
+  // d logit_scale = sum dS .* S   (S = exp(ls) * X  =>  dS/dls = S)
+  API_TRY(dot_scaled(w.dSt, w.St, (int64_t)n * w.Np, 1.0f, w.partial, dls, 0, st));
+  API_TRY(dot_scaled(w.dSi, w.Si, (int64_t)n * w.Np, 1.0f, w.partial, dls, 1, st));
+  // operand transposes (f32, tiny)
+  API_TRY(transpose_cast(I, e, N, e, w.IallT, w.Np, EZCLIP_F32, st));
+  API_TRY(transpose_cast(T, e, N, e, w.TallT, w.Np, EZCLIP_F32, st));
+  API_TRY(transpose_cast(Tl, e, n, e, w.TlocT, w.np, EZCLIP_F32, st));
+  API_TRY(transpose_cast(Il, e, n, e, w.IlocT, w.np, EZCLIP_F32, st));
+  API_TRY(transpose_cast(w.dSt, w.Np, n, N, w.dStT, w.np, EZCLIP_F32, st));
+  API_TRY(transpose_cast(w.dSi, w.Np, n, N, w.dSiT, w.np, EZCLIP_F32, st));
+  EZ_HIP(hipMemsetAsync(dT, 0, (size_t)N * e * 4, st));
+  EZ_HIP(hipMemsetAsync(dI, 0, (size_t)N * e * 4, st));
+  // remote-column terms: dI_all = s * dS_t^T T_loc ; dT_all = s * dS_i^T I_loc
+  API_TRY(sim_gemm(w.dStT, w.np, w.TlocT, w.np, N, e, w.np, ls, dI, e, nullptr, st));
+  API_TRY(sim_gemm(w.dSiT, w.np, w.IlocT, w.np, N, e, w.np, ls, dT, e, nullptr, st));
+  // local-row terms (accumulated through the residual input): dT_loc += s * dS_t I_all ; dI_loc += s * dS_i T_all
+  float* dTl = dT + (size_t)off * e;
+  float* dIl = dI + (size_t)off * e;
+  API_TRY(sim_gemm(w.dSt, w.Np, w.IallT, w.Np, n, e, w.Np, ls, dTl, e, dTl, st));
+  API_TRY(sim_gemm(w.dSi, w.Np, w.TallT, w.Np, n, e, w.Np, ls, dIl, e, dIl, st));
+  return EZ_OK;
+}
+
+int ezclip_backward_image(ezclip_handle h, const float* pixels, int batch, const float* d_emb, void* ws, size_t ws_bytes,
+                          void* stream) {
+  EZ_REQUIRE(h, "ezclip_backward_image: null handle");
+  return backward_image(h, pixels, batch, d_emb, ws, ws_bytes, S(stream));
+}
+int ezclip_backward_text(ezclip_handle h, const int64_t* ids, int batch, int seq_len, const float* d_emb, void* ws,
+                         size_t ws_bytes, void* stream) {
+  EZ_REQUIRE(h, "ezclip_backward_text: null handle");
+  return backward_text(h, ids, batch, seq_len, d_emb, ws, ws_bytes, S(stream));
+}
+
+int ezclip_recall_ranks(const float* text, const float* image, int n, int e, int32_t* rank_out, float* scratch,
+                        void* stream) {
+  EZ_REQUIRE(text && image && rank_out && scratch && n > 0, "ezclip_recall_ranks: null/empty argument");
+  API_TRY(sim_gemm(text, e, image, e, n, n, e, nullptr, scratch, n, nullptr, S(stream)));   // evaluator.py:50
+  return recall_ranks(scratch, n, rank_out, S(stream));
+}
+
+int ezclip_profile_begin(void) { return profile_begin(); }
+int ezclip_profile_end(int kernel_class, double* ms, double* work, int* launches) {
+  return profile_end(kernel_class, ms, work, launches);
+}
+
+// ---- operator-level -------------------------------------------------------------------
+int ezclip_op_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, void* c, int64_t ldc, const float* bias,
+                      const void* residual, int64_t ldr, int m, int n, int k, int act, int dtype, int out_f32,
+                      void* stream) {
+  GemmArgs g;
+  g.A = a; g.lda = lda; g.B = b; g.ldb = ldb; g.C = c; g.ldc = ldc;
+  g.bias = bias; g.R = residual; g.ldr = ldr;
+  g.M = m; g.N = n; g.K = k; g.act = act; g.out_f32 = out_f32;
+  return gemm_nt(g, dtype, S(stream));
+}
+
+int ezclip_op_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc, int m, int n, int k,
+                      int accumulate, int dtype, void* stream) {
+  GemmTNArgs g;
+  g.A = a; g.lda = lda; g.B = b; g.ldb = ldb; g.C = c; g.ldc = ldc;
+  g.M = m; g.N = n; g.K = k; g.accumulate = accumulate;
+  return gemm_tn(g, dtype, S(stream));
+}
+
+int ezclip_op_layernorm(const void* x, int64_t xs, void* y, int64_t ys, const float* g, const float* b, float eps,
+                        int rows, int d, int dtype, float* mean, float* rstd, void* stream) {
+  return layernorm_fwd(x, xs, y, ys, g, b, eps, rows, d, dtype, mean, rstd, S(stream));
+}
+
+int ezclip_op_layernorm_bwd(const void* x, const void* dy, const float* g, const float* mean, const float* rstd, void* dx,
+                            float* dg, float* db, int rows, int d, int dtype, void* stream) {
+  return layernorm_bwd(x, d, dy, d, g, mean, rstd, dx, d, nullptr, 0, dg, db, rows, d, dtype, S(stream));
+}
+
+int ezclip_op_attention(const void* q, const void* k, const void* v, int64_t row_stride, void* ctx, int64_t ctx_stride,
+                        const float* key_bias, float* lse, int batch, int seq_len, int heads, int dtype, void* stream) {
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.row_stride = row_stride; a.ctx = ctx; a.ctx_stride = ctx_stride;
+  a.key_bias = key_bias; a.lse = lse; a.B = batch; a.L = seq_len; a.H = heads; a.scale = 0.125f;
+  return attention_fwd(a, dtype, S(stream));
+}
+
+int ezclip_op_attention_bwd(const void* q, const void* k, const void* v, int64_t row_stride, const void* ctx,
+                            const void* dctx, int64_t ctx_stride, const float* key_bias, const float* lse, void* dq,
+                            void* dk, void* dv, int batch, int seq_len, int heads, int dtype, void* stream) {
+  AttnBwdArgs b;
+  b.f.q = q; b.f.k = k; b.f.v = v; b.f.row_stride = row_stride; b.f.ctx = const_cast<void*>(ctx);
+  b.f.ctx_stride = ctx_stride; b.f.key_bias = key_bias; b.f.lse = const_cast<float*>(lse);
+  b.f.B = batch; b.f.L = seq_len; b.f.H = heads; b.f.scale = 0.125f;
+  b.dctx = dctx; b.dq = dq; b.dk = dk; b.dv = dv;
+  return attention_bwd(b, dtype, S(stream));
+}
+
+int ezclip_op_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, void* stream) {
+  return cast_from_f32(src, dst, n, dtype, S(stream));
+}
+int ezclip_op_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, void* stream) {
+  return cast_to_f32(src, dst, n, dtype, S(stream));
+}
+
+}  // extern "C"

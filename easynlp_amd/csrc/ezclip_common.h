@@ -1,0 +1,186 @@
+// Shared device/host helpers for the ezclip HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ezclip {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+enum Act { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2 };
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+
+// round-to-nearest-even, NaN-preserving
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kPerChunk = 4;  // elements per 16-byte chunk
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kPerChunk = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// load / store 4 consecutive elements (16-byte aligned for float, 8 for bf16)
+__device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void ld4(const bf16_t* p, float (&v)[4]) {
+  uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+
+// unpack a 16-byte chunk into floats (4 for f32, 8 for bf16)
+__device__ __forceinline__ void unpack_chunk(const uint4& c, float (&v)[4], float) {
+  v[0] = __uint_as_float(c.x); v[1] = __uint_as_float(c.y);
+  v[2] = __uint_as_float(c.z); v[3] = __uint_as_float(c.w);
+}
+__device__ __forceinline__ void unpack_chunk(const uint4& c, float (&v)[8], bf16_t) {
+  v[0] = __uint_as_float(c.x << 16); v[1] = __uint_as_float(c.x & 0xffff0000u);
+  v[2] = __uint_as_float(c.y << 16); v[3] = __uint_as_float(c.y & 0xffff0000u);
+  v[4] = __uint_as_float(c.z << 16); v[5] = __uint_as_float(c.z & 0xffff0000u);
+  v[6] = __uint_as_float(c.w << 16); v[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+
+// erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): used where the result is
+// rounded to bf16 anyway; the f32 path calls erff.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  float y = 1.061405429f;
+  y = fmaf(y, t, -1.453152027f);
+  y = fmaf(y, t, 1.421413741f);
+  y = fmaf(y, t, -0.284496736f);
+  y = fmaf(y, t, 0.254829592f);
+  y = 1.0f - y * t * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+
+// FAST = true for the bf16 pipeline (hardware exp, polynomial erf)
+template <bool FAST>
+__device__ __forceinline__ float act_apply(float x, int act) {
+  if (act == ACT_QUICKGELU) {
+    const float e = FAST ? __expf(-1.702f * x) : expf(-1.702f * x);
+    return x / (1.0f + e);
+  }
+  if (act == ACT_GELU_ERF) {
+    const float z = x * 0.70710678118654752440f;
+    return 0.5f * x * (1.0f + (FAST ? erf_fast(z) : erff(z)));
+  }
+  return x;
+}
+
+// d act(x) / dx
+template <bool FAST>
+__device__ __forceinline__ float act_grad(float x, int act) {
+  if (act == ACT_QUICKGELU) {
+    const float e = FAST ? __expf(-1.702f * x) : expf(-1.702f * x);
+    const float s = 1.0f / (1.0f + e);
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+  }
+  if (act == ACT_GELU_ERF) {
+    const float z = x * 0.70710678118654752440f;
+    const float cdf = 0.5f * (1.0f + (FAST ? erf_fast(z) : erff(z)));
+    const float pdf = 0.39894228040143267794f * (FAST ? __expf(-0.5f * x * x) : expf(-0.5f * x * x));
+    return cdf + x * pdf;
+  }
+  return 1.0f;
+}
+
+template <typename T> struct IsFast { static constexpr bool value = false; };
+template <> struct IsFast<bf16_t> { static constexpr bool value = true; };
+
+// One 32x32 accumulate step over one 16-byte K chunk per lane.
+//   A_hw lane (i = lane&31, g = lane>>5) supplies chunk a; B_hw lane (j = lane&31, g) supplies b.
+//   D[i][j] += sum over the chunk's K elements; D layout: col j = lane&31,
+//   row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// bf16: one v_mfma_f32_32x32x16_bf16 (K=16: 8 per half-wave).
+// f32 : four v_mfma_f32_32x32x2_f32 (K=2 each: element e of both half-waves).
+__device__ __forceinline__ void mma32(f32x16_t& acc, const uint4& a, const uint4& b, bf16_t) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16_t& acc, const uint4& a, const uint4& b, float) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware bijective remap of a 1-D block id: consecutive logical ids land on
+// the same XCD (block b is dispatched to XCD b % 8 -- a speed assumption only).
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+}  // namespace ezclip
+
+// ---- host side ------------------------------------------------------------
+#define EZ_OK 0
+#define EZ_ERR_INVALID 1
+#define EZ_ERR_HIP 2
+#define EZ_ERR_UNSUPPORTED 3
+#define EZ_ERR_STATE 4
+
+namespace ezclip {
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+}  // namespace ezclip
+
+#define EZ_HIP(expr)                                                   \
+  do {                                                                 \
+    int _rc = ::ezclip::check_hip((expr), #expr);                      \
+    if (_rc != EZ_OK) return _rc;                                      \
+  } while (0)
+
+#define EZ_LAUNCH_CHECK() EZ_HIP(hipGetLastError())
+
+#define EZ_REQUIRE(cond, ...)                                          \
+  do {                                                                 \
+    if (!(cond)) {                                                     \
+      ::ezclip::set_error(__VA_ARGS__);                                \
+      return EZ_ERR_INVALID;                                           \
+    }                                                                  \
+  } while (0)

@@ -1,0 +1,132 @@
+// Internal launcher declarations for the ezclip HIP kernels (not the C ABI;
+// see include/ezclip.h for that).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EZCLIP_F32 0
+#define EZCLIP_BF16 1
+
+namespace ezclip {
+
+inline int dtype_size(int dtype) { return dtype == EZCLIP_BF16 ? 2 : 4; }
+
+// ---- GEMM (gemm.hip) --------------------------------------------------------
+struct GemmArgs {
+  const void* A = nullptr; int64_t lda = 0;   // [M, K], dtype T
+  const void* B = nullptr; int64_t ldb = 0;   // [N, K], dtype T
+  void* C = nullptr; int64_t ldc = 0;         // [M, N], dtype T (or f32 if out_f32)
+  void* C2 = nullptr;                         // optional second output: value before act/residual (ldc)
+  const float* bias = nullptr;                // [N] f32
+  const void* R = nullptr; int64_t ldr = 0;   // optional residual [M, N], dtype T
+  const float* scale_log = nullptr;           // optional device scalar s: acc *= exp(s)
+  float alpha = 1.0f;                         // acc *= alpha
+  int M = 0, N = 0, K = 0;
+  int act = 0;                                // ezclip::Act
+  int out_f32 = 0;                            // bf16 inputs, f32 output
+  int vec_ok = 0;                             // (set by the launcher)
+};
+// C = act(alpha * exp(scale) * A.B^T + bias) + R
+int gemm_nt(GemmArgs p, int dtype, hipStream_t stream);
+
+// C[N,K] (+)= A[M,N]^T . B[M,K]   (weight gradients; contraction over rows)
+struct GemmTNArgs {
+  const void* A = nullptr; int64_t lda = 0;   // [M, N], dtype T
+  const void* B = nullptr; int64_t ldb = 0;   // [M, K], dtype T
+  float* C = nullptr; int64_t ldc = 0;        // [N, K] f32
+  int M = 0, N = 0, K = 0;
+  int accumulate = 0;                         // C += instead of C =
+};
+int gemm_tn(GemmTNArgs p, int dtype, hipStream_t stream);
+
+// ---- attention (attention.hip) ---------------------------------------------
+struct AttnArgs {
+  const void* q = nullptr;        // element (b, t, h, d) at q + ((b*L + t)*row_stride + h*64 + d)
+  const void* k = nullptr;
+  const void* v = nullptr;
+  int64_t row_stride = 0;         // in elements
+  void* ctx = nullptr;            // [B*L, ctx_stride] heads merged
+  int64_t ctx_stride = 0;
+  const float* key_bias = nullptr;  // optional [B*L] additive key bias (BERT: 0 / -10000)
+  float* lse = nullptr;           // optional [B, H, L] log-sum-exp of the scaled scores
+  int B = 0, L = 0, H = 0;
+  float scale = 0.125f;
+};
+int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream);
+
+struct AttnBwdArgs {
+  AttnArgs f;                     // forward tensors (q, k, v, key_bias, lse; ctx = forward output)
+  const void* dctx = nullptr;     // [B*L, ctx_stride]
+  void* dq = nullptr;             // same addressing as q/k/v (row_stride)
+  void* dk = nullptr;
+  void* dv = nullptr;
+};
+int attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream);
+
+// ---- row-wise / elementwise kernels (rowops.hip) ------------------------------
+// y = LN(x) * g + b over the last dim D; rows may be strided (x_stride/y_stride in elements).
+// Optional: mean/rstd [rows] for the backward pass.
+int layernorm_fwd(const void* x, int64_t x_stride, void* y, int64_t y_stride, const float* g,
+                  const float* b, float eps, int rows, int D, int dtype, float* mean, float* rstd,
+                  hipStream_t stream);
+// dx = LN backward; dg/db accumulate (+=) into f32 [D] via atomics.  If dres != nullptr the result is
+// dx = dres + LNbwd(dy) (residual branch merge).
+int layernorm_bwd(const void* x, int64_t x_stride, const void* dy, int64_t dy_stride, const float* g,
+                  const float* mean, const float* rstd, void* dx, int64_t dx_stride, const void* dres,
+                  int64_t dres_stride, float* dg, float* db, int rows, int D, int dtype, hipStream_t stream);
+
+int cast_from_f32(const float* src, void* dst, int64_t n, int dtype, hipStream_t stream);
+int cast_to_f32(const void* src, float* dst, int64_t n, int dtype, hipStream_t stream);
+// dst[c][r] = src[r][c]; src [R, C] f32 (row stride src_ld) -> dst [C, ld] T (ld >= R, pad zero-filled)
+int transpose_cast(const float* src, int64_t src_ld, int R, int C, void* dst, int64_t ld, int dtype, hipStream_t stream);
+// src [R, C] f32 -> dst [R, ld] T with zero padding of columns C..ld-1
+int pad_cast(const float* src, int R, int C, void* dst, int64_t ld, int dtype, hipStream_t stream);
+
+// pixels [B,3,R,R] f32 NCHW -> patches [B*G*G, Kpad] T, inner index (c, ky, kx); cols >= 3*P*P zero.
+int im2col_patches(const float* pixels, void* out, int B, int R, int P, int Kpad, int dtype, hipStream_t stream);
+// x0[b, 0] = cls + pos[0]; x0[b, 1+p] = patch[b*G2 + p] + pos[1+p]; y = LN(x0).  x0 optional (saved for bwd).
+int vit_assemble_ln(const void* patch, const float* cls, const float* pos, const float* g, const float* b,
+                    float eps, void* x0, void* y, float* mean, float* rstd, int B, int Lv, int W, int dtype,
+                    hipStream_t stream);
+// BERT embeddings (word + type[0] + pos[t]) -> LN; also key_bias[b*L+t] = ids==0 ? -10000 : 0.
+int bert_embed_ln(const int64_t* ids, const float* word, const float* pos, const float* type, const float* g,
+                  const float* b, float eps, void* x0, void* y, float* mean, float* rstd, float* key_bias,
+                  int B, int L, int Hd, int vocab, int dtype, hipStream_t stream);
+// out[b] = x[b] / ||x[b]||_2 (no eps: reference modeling_chineseclip.py:360,363); inv_norm optional.
+int l2_normalize_fwd(const float* x, float* out, float* inv_norm, int B, int E, hipStream_t stream);
+// dx = (dy - y * <dy, y>) * inv_norm
+int l2_normalize_bwd(const float* y, const float* dy, const float* inv_norm, float* dx, int B, int E,
+                     hipStream_t stream);
+
+// ---- InfoNCE (loss.hip) -----------------------------------------------------------
+// Row-wise cross entropy against the diagonal: for local row i (global column diag0 + i):
+//   lse[i] = logsumexp_j S[i][j];  row_loss[i] = lse[i] - S[i][diag0 + i]
+int ce_rows_fwd(const float* S, int64_t ld, int rows, int cols, int diag0, float* lse, float* row_loss,
+                hipStream_t stream);
+// dS[i][j] (+)= coef * (*coef_dev) * (exp(S[i][j] - lse[i]) - [j == diag0 + i])   (coef_dev optional)
+int ce_rows_bwd(const float* S, int64_t ld, int rows, int cols, int diag0, const float* lse, const float* coef_dev,
+                float coef, float* dS, int64_t ldd, int accumulate, hipStream_t stream);
+// out (+)= scale * sum(x), fixed summation order
+int sum_scaled(const float* x, int n, float scale, float* out, int accumulate, hipStream_t stream);
+// out (+)= scale * <a, b>; partial: scratch of >= 256 floats
+int dot_scaled(const float* a, const float* b, int64_t n, float scale, float* partial, float* out, int accumulate,
+               hipStream_t stream);
+
+int ce_cols_fwd(const float* S, int64_t ld, int n, float* lse, float* col_loss, hipStream_t stream);
+int infonce_dlogits(const float* S, int n, const float* lse_r, const float* lse_c, const float* g, float coef, float* dS,
+                    hipStream_t stream);
+int recall_ranks(const float* sim, int n, int32_t* rank, hipStream_t stream);
+const char* last_error();
+
+// ---- optional per-launch timing (profile.hip) --------------------------------------
+enum ProfClass { PROF_GEMM = 0, PROF_ATTN = 1, PROF_ROWOP = 2 };
+struct ProfScope {   // RAII: records HIP events around the launches issued in its lifetime
+  ProfScope(int cls, double work, hipStream_t stream);
+  ~ProfScope();
+  hipStream_t stream_;
+  int idx_;
+};
+int profile_begin();
+int profile_end(int cls, double* ms, double* work, int* launches);
+
+}  // namespace ezclip

@@ -1,0 +1,79 @@
+// Host-side model state for the ezclip library: parameter table (reference
+// names -> caller-owned device pointers), packed weight shadows, workspace
+// layouts, and the layer loops that enqueue the kernels.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ezclip.h"
+#include "ezclip_common.h"
+#include "kernels.h"
+
+struct ezclip_model {
+  ezclip_config cfg;
+  int dtype = 0;
+  // derived
+  int Lv = 0, G = 0, Kpatch = 0, Kpad = 0, vheads = 0, theads = 0;
+
+  struct Param {
+    std::string name;
+    std::vector<int64_t> shape;
+    int64_t numel = 0;
+    float* w = nullptr;   // caller-owned f32 master weight
+    float* g = nullptr;   // caller-owned f32 grad buffer (may be null)
+  };
+  std::vector<Param> params;
+  std::map<std::string, int> index;
+
+  // A GEMM weight [N, K] (nn.Linear layout) and its packed copies
+  struct Weight {
+    int p = -1;             // index into params (weight)
+    int N = 0, K = 0;
+    int ldk = 0;            // leading dim of the packed [N, ldk] copy (K padded to the tile multiple)
+    bool transposed_src = false;  // master stored [K, N] (visual.proj / text_projection)
+    void* s = nullptr;      // packed [N, ldk] in compute dtype (== master for plain f32)
+    void* st = nullptr;     // packed transposed [K(ld N), N] for input gradients (with_backward only)
+    int ldn = 0;            // leading dim of st ([K, ldn])
+  };
+  struct VitLayer {
+    Weight in_w, out_w, fc_w, proj_w;
+    int in_b, out_b, fc_b, proj_b, ln1_w, ln1_b, ln2_w, ln2_b;
+  };
+  struct BertLayer {
+    Weight q_w, k_w, v_w, o_w, i_w, d_w;
+    int q_b, k_b, v_b, o_b, i_b, d_b, ln1_w, ln1_b, ln2_w, ln2_b;
+  };
+  Weight conv_w, vproj_w, tproj_w;
+  int cls_p, pos_p, lnpre_w, lnpre_b, lnpost_w, lnpost_b;
+  int word_p, tpos_p, type_p, eln_w, eln_b, logit_scale_p;
+  std::vector<VitLayer> vit;
+  std::vector<BertLayer> bert;
+
+  void* shadow = nullptr;
+  size_t shadow_bytes = 0;
+  bool shadow_backward = false;
+  bool weights_fresh = false;
+
+  float* P(int i) const { return params[i].w; }
+  float* Gp(int i) const { return params[i].g; }
+};
+
+namespace ezclip {
+
+int model_create(const ezclip_config* cfg, ezclip_model** out);
+size_t model_shadow_layout(ezclip_model* m, char* base, bool with_backward);  // returns bytes; assigns when base != null
+int model_refresh_weights(ezclip_model* m, hipStream_t stream);
+
+size_t image_workspace_bytes(const ezclip_model* m, int B, bool save);
+size_t text_workspace_bytes(const ezclip_model* m, int B, int L, bool save);
+int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* ws, size_t ws_bytes, bool save,
+                 hipStream_t stream);
+int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, void* ws, size_t ws_bytes, bool save,
+                hipStream_t stream);
+int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_emb, void* ws, size_t ws_bytes,
+                   hipStream_t stream);
+int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float* d_emb, void* ws, size_t ws_bytes,
+                  hipStream_t stream);
+
+}  // namespace ezclip

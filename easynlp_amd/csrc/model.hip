@@ -1,0 +1,511 @@
+// Dual-encoder forward/backward orchestration (host code; enqueues HIP kernels).
+//
+// Reference call tree being replaced (all stock torch ops there):
+//   CLIPApp.forward            easynlp/appzoo/clip/model.py:106-150
+//   CHINESE_CLIP.forward       easynlp/modelzoo/models/clip/modeling_chineseclip.py:352-365
+//   VisualTransformer.forward  modeling_chineseclip.py:236-253
+//   ResidualAttentionBlock     modeling_chineseclip.py:184-205 (pre-LN, QuickGELU)
+//   BertModel.forward          easynlp/modelzoo/models/bert/modeling_bert.py:792-920
+//   BertLayer / BertSelfOutput / BertOutput   modeling_bert.py:257-268,320-346,363-429 (post-LN, erf-GELU)
+//
+// HBM layout: activations are [tokens, features] row-major in the compute dtype
+// (batch-first; the reference's seq-first permute for the ViT is immaterial,
+// attention is per sample).  With save_for_backward every layer keeps its own
+// set of buffers in the caller's workspace (no recompute; ~32 bytes/token/feature
+// per ViT layer in bf16 -- 60 GB at B=1024, far inside 288 GB of HBM3E).
+#include "model.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+
+namespace ezclip {
+
+// ------------------------------------------------------------------ errors --
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return EZ_OK;
+  set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+  return EZ_ERR_HIP;
+}
+
+// ------------------------------------------------------------------ arena ---
+namespace {
+
+struct Arena {
+  char* base;
+  size_t off = 0;
+  explicit Arena(void* b) : base(reinterpret_cast<char*>(b)) {}
+  void* take(size_t bytes) {
+    off = (off + 255) & ~size_t(255);
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+  float* takef(size_t n) { return reinterpret_cast<float*>(take(n * 4)); }
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+// ------------------------------------------------------------------ create --
+static int add_param(ezclip_model* m, const std::string& name, std::vector<int64_t> shape) {
+  ezclip_model::Param p;
+  p.name = name;
+  p.shape = shape;
+  p.numel = 1;
+  for (auto d : shape) p.numel *= d;
+  m->params.push_back(p);
+  m->index[name] = (int)m->params.size() - 1;
+  return (int)m->params.size() - 1;
+}
+
+static ezclip_model::Weight make_weight(ezclip_model* m, int p, int N, int K, bool transposed_src = false) {
+  ezclip_model::Weight w;
+  w.p = p; w.N = N; w.K = K; w.transposed_src = transposed_src;
+  const int kmult = 128 / dtype_size(m->dtype);
+  w.ldk = round_up(K, kmult);
+  w.ldn = N;
+  return w;
+}
+
+int model_create(const ezclip_config* c, ezclip_model** out) {
+  EZ_REQUIRE(c != nullptr && out != nullptr, "ezclip_create: null argument");
+  EZ_REQUIRE(c->compute_dtype == EZCLIP_F32 || c->compute_dtype == EZCLIP_BF16, "ezclip_create: bad compute_dtype %d", c->compute_dtype);
+  const int kmult = 128 / dtype_size(c->compute_dtype);
+  const int W = c->vision_width, H = c->text_hidden_size, F = c->text_intermediate_size, E = c->embed_dim;
+  EZ_REQUIRE(W > 0 && W % 64 == 0 && W <= 1024, "vision_width %d must be a multiple of 64 (head_dim 64) and <= 1024", W);
+  EZ_REQUIRE(c->text_num_attention_heads > 0 && H == 64 * c->text_num_attention_heads && H <= 1024,
+             "text_hidden_size %d must be 64 * heads (head_dim 64) and <= 1024", H);
+  EZ_REQUIRE(F % kmult == 0 && F % 4 == 0, "text_intermediate_size %d must be a multiple of %d", F, kmult);
+  EZ_REQUIRE(E % 32 == 0 && E <= 1024, "embed_dim %d must be a multiple of 32 and <= 1024", E);
+  EZ_REQUIRE(c->vision_patch_size > 0 && c->image_resolution >= c->vision_patch_size, "bad patch/resolution");
+  EZ_REQUIRE(c->vision_layers > 0 && c->text_num_hidden_layers > 0, "layer counts must be positive");
+  EZ_REQUIRE(c->vocab_size > 0 && c->text_max_position_embeddings > 0 && c->text_type_vocab_size > 0, "bad text table sizes");
+
+  ezclip_model* m = new ezclip_model();
+  m->cfg = *c;
+  m->dtype = c->compute_dtype;
+  m->G = c->image_resolution / c->vision_patch_size;
+  m->Lv = m->G * m->G + 1;
+  m->Kpatch = 3 * c->vision_patch_size * c->vision_patch_size;
+  m->Kpad = round_up(m->Kpatch, kmult);
+  m->vheads = W / 64;
+  m->theads = c->text_num_attention_heads;
+  const int P = c->vision_patch_size;
+
+  m->cls_p = add_param(m, "visual.class_embedding", {W});
+  m->pos_p = add_param(m, "visual.positional_embedding", {m->Lv, W});
+  int vproj = add_param(m, "visual.proj", {W, E});
+  int conv = add_param(m, "visual.conv1.weight", {W, 3, P, P});
+  m->lnpre_w = add_param(m, "visual.ln_pre.weight", {W});
+  m->lnpre_b = add_param(m, "visual.ln_pre.bias", {W});
+  m->conv_w = make_weight(m, conv, W, m->Kpatch);
+  m->vproj_w = make_weight(m, vproj, E, W, true);
+  for (int i = 0; i < c->vision_layers; ++i) {
+    const std::string p = "visual.transformer.resblocks." + std::to_string(i) + ".";
+    ezclip_model::VitLayer L;
+    L.in_w = make_weight(m, add_param(m, p + "attn.in_proj_weight", {3 * W, W}), 3 * W, W);
+    L.in_b = add_param(m, p + "attn.in_proj_bias", {3 * W});
+    L.out_w = make_weight(m, add_param(m, p + "attn.out_proj.weight", {W, W}), W, W);
+    L.out_b = add_param(m, p + "attn.out_proj.bias", {W});
+    L.ln1_w = add_param(m, p + "ln_1.weight", {W});
+    L.ln1_b = add_param(m, p + "ln_1.bias", {W});
+    L.fc_w = make_weight(m, add_param(m, p + "mlp.c_fc.weight", {4 * W, W}), 4 * W, W);
+    L.fc_b = add_param(m, p + "mlp.c_fc.bias", {4 * W});
+    L.proj_w = make_weight(m, add_param(m, p + "mlp.c_proj.weight", {W, 4 * W}), W, 4 * W);
+    L.proj_b = add_param(m, p + "mlp.c_proj.bias", {W});
+    L.ln2_w = add_param(m, p + "ln_2.weight", {W});
+    L.ln2_b = add_param(m, p + "ln_2.bias", {W});
+    m->vit.push_back(L);
+  }
+  m->lnpost_w = add_param(m, "visual.ln_post.weight", {W});
+  m->lnpost_b = add_param(m, "visual.ln_post.bias", {W});
+  m->word_p = add_param(m, "bert.embeddings.word_embeddings.weight", {c->vocab_size, H});
+  m->tpos_p = add_param(m, "bert.embeddings.position_embeddings.weight", {c->text_max_position_embeddings, H});
+  m->type_p = add_param(m, "bert.embeddings.token_type_embeddings.weight", {c->text_type_vocab_size, H});
+  m->eln_w = add_param(m, "bert.embeddings.LayerNorm.weight", {H});
+  m->eln_b = add_param(m, "bert.embeddings.LayerNorm.bias", {H});
+  for (int i = 0; i < c->text_num_hidden_layers; ++i) {
+    const std::string p = "bert.encoder.layer." + std::to_string(i) + ".";
+    ezclip_model::BertLayer L;
+    L.q_w = make_weight(m, add_param(m, p + "attention.self.query.weight", {H, H}), H, H);
+    L.q_b = add_param(m, p + "attention.self.query.bias", {H});
+    L.k_w = make_weight(m, add_param(m, p + "attention.self.key.weight", {H, H}), H, H);
+    L.k_b = add_param(m, p + "attention.self.key.bias", {H});
+    L.v_w = make_weight(m, add_param(m, p + "attention.self.value.weight", {H, H}), H, H);
+    L.v_b = add_param(m, p + "attention.self.value.bias", {H});
+    L.o_w = make_weight(m, add_param(m, p + "attention.output.dense.weight", {H, H}), H, H);
+    L.o_b = add_param(m, p + "attention.output.dense.bias", {H});
+    L.ln1_w = add_param(m, p + "attention.output.LayerNorm.weight", {H});
+    L.ln1_b = add_param(m, p + "attention.output.LayerNorm.bias", {H});
+    L.i_w = make_weight(m, add_param(m, p + "intermediate.dense.weight", {F, H}), F, H);
+    L.i_b = add_param(m, p + "intermediate.dense.bias", {F});
+    L.d_w = make_weight(m, add_param(m, p + "output.dense.weight", {H, F}), H, F);
+    L.d_b = add_param(m, p + "output.dense.bias", {H});
+    L.ln2_w = add_param(m, p + "output.LayerNorm.weight", {H});
+    L.ln2_b = add_param(m, p + "output.LayerNorm.bias", {H});
+    m->bert.push_back(L);
+  }
+  // computed by the reference but unused on this path (kept for the checkpoint contract)
+  add_param(m, "bert.pooler.dense.weight", {H, H});
+  add_param(m, "bert.pooler.dense.bias", {H});
+  m->tproj_w = make_weight(m, add_param(m, "text_projection", {H, E}), E, H, true);
+  m->logit_scale_p = add_param(m, "logit_scale", {});
+  *out = m;
+  return EZ_OK;
+}
+
+// -------------------------------------------------------- weight shadows ---
+static void for_each_weight(ezclip_model* m, const std::function<void(ezclip_model::Weight&)>& f) {
+  f(m->conv_w);
+  f(m->vproj_w);
+  f(m->tproj_w);
+  for (auto& L : m->vit) { f(L.in_w); f(L.out_w); f(L.fc_w); f(L.proj_w); }
+  for (auto& L : m->bert) { f(L.q_w); f(L.k_w); f(L.v_w); f(L.o_w); f(L.i_w); f(L.d_w); }
+}
+
+static bool needs_pack(const ezclip_model* m, const ezclip_model::Weight& w) {
+  return m->dtype != EZCLIP_F32 || w.ldk != w.K || w.transposed_src;
+}
+
+size_t model_shadow_layout(ezclip_model* m, char* base, bool with_backward) {
+  Arena a(base);
+  const size_t esz = dtype_size(m->dtype);
+  for_each_weight(m, [&](ezclip_model::Weight& w) {
+    void* s = needs_pack(m, w) ? a.take((size_t)w.N * w.ldk * esz) : nullptr;
+    void* st = nullptr;
+    // conv1 needs no input gradient (pixels are data)
+    if (with_backward && &w != &m->conv_w) st = a.take((size_t)w.K * w.ldn * esz);
+    if (base) { w.s = s; w.st = st; }
+  });
+  a.take(0);
+  return a.off + 256;
+}
+
+int model_refresh_weights(ezclip_model* m, hipStream_t stream) {
+  for (auto& p : m->params)
+    EZ_REQUIRE(p.w != nullptr || p.name.find("pooler") != std::string::npos, "parameter %s is not bound", p.name.c_str());
+  int rc = EZ_OK;
+  for_each_weight(m, [&](ezclip_model::Weight& w) {
+    if (rc != EZ_OK) return;
+    const float* src = m->P(w.p);
+    if (!needs_pack(m, w)) { w.s = const_cast<float*>(src); }
+    else {
+      if (w.s == nullptr) { set_error("weight shadow not set (call ezclip_set_shadow first)"); rc = EZ_ERR_STATE; return; }
+      // master [N, K] -> [N, ldk]   or master [K, N] -> [N, ldk]
+      rc = w.transposed_src ? transpose_cast(src, w.N, w.K, w.N, w.s, w.ldk, m->dtype, stream)
+                            : pad_cast(src, w.N, w.K, w.s, w.ldk, m->dtype, stream);
+      if (rc != EZ_OK) return;
+    }
+    if (w.st != nullptr) {
+      // [K, N] copy for dX = dY . W
+      rc = w.transposed_src ? pad_cast(src, w.K, w.N, w.st, w.ldn, m->dtype, stream)
+                            : transpose_cast(src, w.K, w.N, w.K, w.st, w.ldn, m->dtype, stream);
+    }
+  });
+  if (rc == EZ_OK) m->weights_fresh = true;
+  return rc;
+}
+
+// --------------------------------------------------------------- helpers ---
+static int linear(const ezclip_model* m, const void* A, int64_t lda, const ezclip_model::Weight& w, int bias_p,
+                  void* C, int64_t ldc, int M, int act, const void* R, int64_t ldr, void* C2, bool out_f32,
+                  hipStream_t stream) {
+  GemmArgs g;
+  g.A = A; g.lda = lda;
+  g.B = w.s; g.ldb = w.ldk;
+  g.C = C; g.ldc = ldc; g.C2 = C2;
+  g.bias = bias_p >= 0 ? m->P(bias_p) : nullptr;
+  g.R = R; g.ldr = ldr;
+  g.M = M; g.N = w.N; g.K = w.ldk;
+  g.act = act;
+  g.out_f32 = (out_f32 && m->dtype == EZCLIP_BF16) ? 1 : 0;
+  return gemm_nt(g, m->dtype, stream);
+}
+
+#define EZ_TRY(expr)                 \
+  do {                               \
+    int _rc = (expr);                \
+    if (_rc != EZ_OK) return _rc;    \
+  } while (0)
+
+// ------------------------------------------------------- image workspace ---
+namespace {
+
+struct VitBufs {
+  void *x_in, *ln1, *qkv, *ctx, *x_mid, *ln2, *u, *h, *x_out;
+  float *m1, *r1, *m2, *r2, *lse;
+};
+struct ImgWS {
+  void *patches, *pemb, *x0;
+  float *m0, *r0;
+  std::vector<VitBufs> layers;
+  void* cls_ln;
+  float *mpost, *rpost, *feat, *emb, *inv_norm;
+  // backward scratch
+  void *gx, *gx2, *gqkv, *gbig, *gtmp;
+  float *gfeat, *gcls;
+};
+
+size_t layout_image(const ezclip_model* m, int B, bool save, void* base, ImgWS* ws) {
+  Arena a(base);
+  const size_t esz = dtype_size(m->dtype);
+  const int W = m->cfg.vision_width, E = m->cfg.embed_dim;
+  const size_t Mp = (size_t)B * (m->Lv - 1), M = (size_t)B * m->Lv;
+  ImgWS w;
+  w.patches = a.take(Mp * m->Kpad * esz);
+  w.pemb = a.take(Mp * W * esz);
+  w.x0 = save ? a.take(M * W * esz) : nullptr;
+  w.m0 = save ? a.takef(M) : nullptr;
+  w.r0 = save ? a.takef(M) : nullptr;
+  const int nl = m->cfg.vision_layers;
+  w.layers.resize(nl);
+  if (!save) {
+    VitBufs b;
+    b.x_in = b.x_mid = b.x_out = a.take(M * W * esz);
+    b.ln1 = b.ln2 = a.take(M * W * esz);
+    b.qkv = a.take(M * 3 * W * esz);
+    b.ctx = a.take(M * W * esz);
+    b.u = nullptr;
+    b.h = a.take(M * 4 * W * esz);
+    b.m1 = b.r1 = b.m2 = b.r2 = b.lse = nullptr;
+    for (int i = 0; i < nl; ++i) w.layers[i] = b;
+  } else {
+    void* x = a.take(M * W * esz);
+    for (int i = 0; i < nl; ++i) {
+      VitBufs& b = w.layers[i];
+      b.x_in = x;
+      b.ln1 = a.take(M * W * esz);
+      b.qkv = a.take(M * 3 * W * esz);
+      b.ctx = a.take(M * W * esz);
+      b.x_mid = a.take(M * W * esz);
+      b.ln2 = a.take(M * W * esz);
+      b.u = a.take(M * 4 * W * esz);
+      b.h = a.take(M * 4 * W * esz);
+      b.x_out = a.take(M * W * esz);
+      b.m1 = a.takef(M); b.r1 = a.takef(M); b.m2 = a.takef(M); b.r2 = a.takef(M);
+      b.lse = a.takef((size_t)B * m->vheads * m->Lv);
+      x = b.x_out;
+    }
+  }
+  w.cls_ln = a.take((size_t)B * W * esz);
+  w.mpost = a.takef(B); w.rpost = a.takef(B);
+  w.feat = a.takef((size_t)B * E);
+  w.emb = a.takef((size_t)B * E);
+  w.inv_norm = a.takef(B);
+  if (save) {
+    w.gx = a.take(M * W * esz);
+    w.gx2 = a.take(M * W * esz);
+    w.gtmp = a.take(M * W * esz);
+    w.gqkv = a.take(M * 3 * W * esz);
+    w.gbig = a.take(M * 4 * W * esz);
+    w.gfeat = a.takef((size_t)B * E);
+    w.gcls = a.takef((size_t)B * W);
+  } else {
+    w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = nullptr; w.gfeat = w.gcls = nullptr;
+  }
+  if (ws) *ws = w;
+  return a.off + 256;
+}
+
+struct BertBufs {
+  void *x_in, *qkv, *ctx, *y, *a, *u, *hh, *z, *x_out;
+  float *m1, *r1, *m2, *r2, *lse;
+};
+struct TxtWS {
+  void* x0;
+  float *m0, *r0, *key_bias;
+  std::vector<BertBufs> layers;
+  float *feat, *emb, *inv_norm;
+  void *gx, *gx2, *gtmp, *gqkv, *gbig;
+  float *gfeat;
+};
+
+size_t layout_text(const ezclip_model* m, int B, int L, bool save, void* base, TxtWS* ws) {
+  Arena a(base);
+  const size_t esz = dtype_size(m->dtype);
+  const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, E = m->cfg.embed_dim;
+  const size_t M = (size_t)B * L;
+  TxtWS w;
+  w.x0 = save ? a.take(M * H * esz) : nullptr;
+  w.m0 = save ? a.takef(M) : nullptr;
+  w.r0 = save ? a.takef(M) : nullptr;
+  w.key_bias = a.takef(M);
+  const int nl = m->cfg.text_num_hidden_layers;
+  w.layers.resize(nl);
+  if (!save) {
+    BertBufs b;
+    b.x_in = b.x_out = a.take(M * H * esz);
+    b.qkv = a.take(M * 3 * H * esz);
+    b.ctx = a.take(M * H * esz);
+    b.y = b.a = a.take(M * H * esz);
+    b.u = nullptr;
+    b.hh = a.take(M * F * esz);
+    b.z = b.x_in;
+    b.m1 = b.r1 = b.m2 = b.r2 = b.lse = nullptr;
+    for (int i = 0; i < nl; ++i) w.layers[i] = b;
+  } else {
+    void* x = a.take(M * H * esz);
+    for (int i = 0; i < nl; ++i) {
+      BertBufs& b = w.layers[i];
+      b.x_in = x;
+      b.qkv = a.take(M * 3 * H * esz);
+      b.ctx = a.take(M * H * esz);
+      b.y = a.take(M * H * esz);
+      b.a = a.take(M * H * esz);
+      b.u = a.take(M * F * esz);
+      b.hh = a.take(M * F * esz);
+      b.z = a.take(M * H * esz);
+      b.x_out = a.take(M * H * esz);
+      b.m1 = a.takef(M); b.r1 = a.takef(M); b.m2 = a.takef(M); b.r2 = a.takef(M);
+      b.lse = a.takef((size_t)B * m->theads * L);
+      x = b.x_out;
+    }
+  }
+  w.feat = a.takef((size_t)B * E);
+  w.emb = a.takef((size_t)B * E);
+  w.inv_norm = a.takef(B);
+  if (save) {
+    w.gx = a.take(M * H * esz);
+    w.gx2 = a.take(M * H * esz);
+    w.gtmp = a.take(M * H * esz);
+    w.gqkv = a.take(M * 3 * H * esz);
+    w.gbig = a.take(M * F * esz);
+    w.gfeat = a.takef((size_t)B * E);
+  } else {
+    w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = nullptr; w.gfeat = nullptr;
+  }
+  if (ws) *ws = w;
+  return a.off + 256;
+}
+
+}  // namespace
+
+size_t image_workspace_bytes(const ezclip_model* m, int B, bool save) { return layout_image(m, B, save, nullptr, nullptr); }
+size_t text_workspace_bytes(const ezclip_model* m, int B, int L, bool save) { return layout_text(m, B, L, save, nullptr, nullptr); }
+
+// ------------------------------------------------------------ image fwd ----
+int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* wsp, size_t ws_bytes, bool save,
+                 hipStream_t stream) {
+  EZ_REQUIRE(B > 0 && pixels && out && wsp, "encode_image: null/empty argument");
+  EZ_REQUIRE(m->weights_fresh, "encode_image: call ezclip_refresh_weights after binding/updating parameters");
+  EZ_REQUIRE(((uintptr_t)wsp % 256) == 0, "encode_image: workspace must be 256-byte aligned");
+  ImgWS ws;
+  const size_t need = layout_image(m, B, save, wsp, &ws);
+  EZ_REQUIRE(ws_bytes >= need, "encode_image: workspace too small (%zu < %zu)", ws_bytes, need);
+  const int W = m->cfg.vision_width, E = m->cfg.embed_dim, Lv = m->Lv;
+  const int Mp = B * (Lv - 1), M = B * Lv;
+  const int dt = m->dtype;
+  const float eps = 1e-5f;  // nn.LayerNorm default (modeling_chineseclip.py:170)
+
+  // conv1 (stride == kernel, no bias) = im2col + GEMM              :237-239
+  EZ_TRY(im2col_patches(pixels, ws.patches, B, m->cfg.image_resolution, m->cfg.vision_patch_size, m->Kpad, dt, stream));
+  EZ_TRY(linear(m, ws.patches, m->Kpad, m->conv_w, -1, ws.pemb, W, Mp, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  // cls token, + positional embedding, ln_pre                       :240-242
+  EZ_TRY(vit_assemble_ln(ws.pemb, m->P(m->cls_p), m->P(m->pos_p), m->P(m->lnpre_w), m->P(m->lnpre_b), eps, ws.x0,
+                         ws.layers[0].x_in, ws.m0, ws.r0, B, Lv, W, dt, stream));
+  for (int i = 0; i < m->cfg.vision_layers; ++i) {
+    const auto& Lw = m->vit[i];
+    const VitBufs& b = ws.layers[i];
+    // x = x + attn(ln_1(x))                                          :203
+    EZ_TRY(layernorm_fwd(b.x_in, W, b.ln1, W, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, M, W, dt, b.m1, b.r1, stream));
+    EZ_TRY(linear(m, b.ln1, W, Lw.in_w, Lw.in_b, b.qkv, 3 * W, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+    AttnArgs at;
+    at.q = b.qkv;
+    at.k = (const char*)b.qkv + (size_t)W * dtype_size(dt);
+    at.v = (const char*)b.qkv + (size_t)2 * W * dtype_size(dt);
+    at.row_stride = 3 * W;
+    at.ctx = b.ctx; at.ctx_stride = W;
+    at.key_bias = nullptr; at.lse = b.lse;
+    at.B = B; at.L = Lv; at.H = m->vheads; at.scale = 0.125f;
+    EZ_TRY(attention_fwd(at, dt, stream));
+    EZ_TRY(linear(m, b.ctx, W, Lw.out_w, Lw.out_b, b.x_mid, W, M, ACT_NONE, b.x_in, W, nullptr, false, stream));
+    // x = x + c_proj(QuickGELU(c_fc(ln_2(x))))                      :204
+    EZ_TRY(layernorm_fwd(b.x_mid, W, b.ln2, W, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, M, W, dt, b.m2, b.r2, stream));
+    EZ_TRY(linear(m, b.ln2, W, Lw.fc_w, Lw.fc_b, b.h, 4 * W, M, ACT_QUICKGELU, nullptr, 0, b.u, false, stream));
+    EZ_TRY(linear(m, b.h, 4 * W, Lw.proj_w, Lw.proj_b, b.x_out, W, M, ACT_NONE, b.x_mid, W, nullptr, false, stream));
+  }
+  // ln_post(x[:, 0, :]) @ proj                                        :248-251
+  const void* xl = ws.layers[m->cfg.vision_layers - 1].x_out;
+  EZ_TRY(layernorm_fwd(xl, (int64_t)Lv * W, ws.cls_ln, W, m->P(m->lnpost_w), m->P(m->lnpost_b), eps, B, W, dt,
+                       ws.mpost, ws.rpost, stream));
+  EZ_TRY(linear(m, ws.cls_ln, W, m->vproj_w, -1, ws.feat, E, B, ACT_NONE, nullptr, 0, nullptr, true, stream));
+  // image_features / image_features.norm(dim=-1, keepdim=True)       :360
+  EZ_TRY(l2_normalize_fwd(ws.feat, ws.emb, ws.inv_norm, B, E, stream));
+  EZ_HIP(hipMemcpyAsync(out, ws.emb, (size_t)B * E * 4, hipMemcpyDeviceToDevice, stream));
+  return EZ_OK;
+}
+
+// ------------------------------------------------------------- text fwd ----
+int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, void* wsp, size_t ws_bytes, bool save,
+                hipStream_t stream) {
+  EZ_REQUIRE(B > 0 && L > 0 && ids && out && wsp, "encode_text: null/empty argument");
+  EZ_REQUIRE(L <= m->cfg.text_max_position_embeddings, "encode_text: seq_len %d > max_position_embeddings %d", L,
+             m->cfg.text_max_position_embeddings);
+  EZ_REQUIRE(m->weights_fresh, "encode_text: call ezclip_refresh_weights after binding/updating parameters");
+  EZ_REQUIRE(((uintptr_t)wsp % 256) == 0, "encode_text: workspace must be 256-byte aligned");
+  TxtWS ws;
+  const size_t need = layout_text(m, B, L, save, wsp, &ws);
+  EZ_REQUIRE(ws_bytes >= need, "encode_text: workspace too small (%zu < %zu)", ws_bytes, need);
+  const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, E = m->cfg.embed_dim;
+  const int M = B * L;
+  const int dt = m->dtype;
+  const size_t esz = dtype_size(dt);
+  const float eps = 1e-12f;  // layer_norm_eps (modeling_chineseclip.py:311)
+
+  // BertEmbeddings.forward                                   modeling_bert.py:95-129
+  EZ_TRY(bert_embed_ln(ids, m->P(m->word_p), m->P(m->tpos_p), m->P(m->type_p), m->P(m->eln_w), m->P(m->eln_b), eps,
+                       ws.x0, ws.layers[0].x_in, ws.m0, ws.r0, ws.key_bias, B, L, H, m->cfg.vocab_size, dt, stream));
+  for (int i = 0; i < m->cfg.text_num_hidden_layers; ++i) {
+    const auto& Lw = m->bert[i];
+    const BertBufs& b = ws.layers[i];
+    // BertSelfAttention: separate q/k/v Linear                        :172-200
+    char* qkv = (char*)b.qkv;
+    EZ_TRY(linear(m, b.x_in, H, Lw.q_w, Lw.q_b, qkv, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+    EZ_TRY(linear(m, b.x_in, H, Lw.k_w, Lw.k_b, qkv + H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+    EZ_TRY(linear(m, b.x_in, H, Lw.v_w, Lw.v_b, qkv + 2 * H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+    AttnArgs at;
+    at.q = qkv; at.k = qkv + H * esz; at.v = qkv + 2 * H * esz;
+    at.row_stride = 3 * H;
+    at.ctx = b.ctx; at.ctx_stride = H;
+    at.key_bias = ws.key_bias; at.lse = b.lse;
+    at.B = B; at.L = L; at.H = m->theads; at.scale = 0.125f;
+    EZ_TRY(attention_fwd(at, dt, stream));                          // :210-248
+    // BertSelfOutput: LN(dense(ctx) + x)                              :264-267
+    EZ_TRY(linear(m, b.ctx, H, Lw.o_w, Lw.o_b, b.y, H, M, ACT_NONE, b.x_in, H, nullptr, false, stream));
+    EZ_TRY(layernorm_fwd(b.y, H, b.a, H, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, M, H, dt, b.m1, b.r1, stream));
+    // BertIntermediate (erf GELU) + BertOutput                        :330-345
+    EZ_TRY(linear(m, b.a, H, Lw.i_w, Lw.i_b, b.hh, F, M, ACT_GELU_ERF, nullptr, 0, b.u, false, stream));
+    EZ_TRY(linear(m, b.hh, F, Lw.d_w, Lw.d_b, b.z, H, M, ACT_NONE, b.a, H, nullptr, false, stream));
+    EZ_TRY(layernorm_fwd(b.z, H, b.x_out, H, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, M, H, dt, b.m2, b.r2, stream));
+  }
+  // x[:, 0, :] @ text_projection  (pooler skipped: unused)    modeling_chineseclip.py:349-350
+  const void* xl = ws.layers[m->cfg.text_num_hidden_layers - 1].x_out;
+  EZ_TRY(linear(m, xl, (int64_t)L * H, m->tproj_w, -1, ws.feat, E, B, ACT_NONE, nullptr, 0, nullptr, true, stream));
+  EZ_TRY(l2_normalize_fwd(ws.feat, ws.emb, ws.inv_norm, B, E, stream));   // :363
+  EZ_HIP(hipMemcpyAsync(out, ws.emb, (size_t)B * E * 4, hipMemcpyDeviceToDevice, stream));
+  return EZ_OK;
+}
+
+int backward_image(ezclip_model*, const float*, int, const float*, void*, size_t, hipStream_t) {
+  set_error("ezclip_backward_image: not implemented yet");
+  return EZ_ERR_UNSUPPORTED;
+}
+int backward_text(ezclip_model*, const int64_t*, int, int, const float*, void*, size_t, hipStream_t) {
+  set_error("ezclip_backward_text: not implemented yet");
+  return EZ_ERR_UNSUPPORTED;
+}
+
+}  // namespace ezclip

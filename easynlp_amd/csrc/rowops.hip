@@ -1,0 +1,470 @@
+// HBM-bound row-wise kernels: LayerNorm (fwd/bwd), embedding assembly for both
+// towers, L2-normalise, dtype casts / weight re-packing, im2col for the
+// stride==kernel patch-embedding conv.  One wavefront (64 lanes) per row, rows
+// held in registers, wave-shuffle reductions, no LDS.
+#include "ezclip_common.h"
+#include "kernels.h"
+
+namespace ezclip {
+namespace {
+
+constexpr int kMaxChunks = 4;  // 4-element chunks per lane: D <= 1024
+constexpr int kRowsPerBlock = 4;
+
+// Load a row of D (multiple of 4) elements into registers: lane owns chunks lane, lane+64, ...
+template <typename T>
+__device__ __forceinline__ void load_row(const T* x, int D, int lane, float (&v)[kMaxChunks][4]) {
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int col = (lane + c * 64) * 4;
+    if (col < D) ld4(x + col, v[c]);
+    else { v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f; }
+  }
+}
+
+__device__ __forceinline__ void row_stats(const float (&v)[kMaxChunks][4], int D, int lane, float eps,
+                                          float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+  mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    if ((lane + c * 64) * 4 < D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[c][e] - mean; q += d * d; }
+    }
+  }
+  const float var = wave_sum(q) / (float)D;
+  rstd = rsqrtf(var + eps);
+  // one Newton step: rsqrtf is ~1 ulp-ish approximate on AMD; keeps f32 parity tight
+  rstd = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);
+}
+
+template <typename T>
+__device__ __forceinline__ void norm_store(const float (&v)[kMaxChunks][4], T* y, const float* g, const float* b,
+                                           int D, int lane, float mean, float rstd) {
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int col = (lane + c * 64) * 4;
+    if (col < D) {
+      const float4 gv = *reinterpret_cast<const float4*>(g + col);
+      const float4 bv = *reinterpret_cast<const float4*>(b + col);
+      float o[4];
+      o[0] = (v[c][0] - mean) * rstd * gv.x + bv.x;
+      o[1] = (v[c][1] - mean) * rstd * gv.y + bv.y;
+      o[2] = (v[c][2] - mean) * rstd * gv.z + bv.z;
+      o[3] = (v[c][3] - mean) * rstd * gv.w + bv.w;
+      st4(y + col, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, int64_t xs, T* y, int64_t ys, const float* g,
+                                                      const float* b, float eps, int rows, int D, float* mean_o,
+                                                      float* rstd_o) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[kMaxChunks][4];
+  load_row(x + (int64_t)row * xs, D, lane, v);
+  float mean, rstd;
+  row_stats(v, D, lane, eps, mean, rstd);
+  norm_store(v, y + (int64_t)row * ys, g, b, D, lane, mean, rstd);
+  if (mean_o != nullptr && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+
+// LayerNorm backward for one row per wave:
+//   xhat = (x - mean) * rstd;  gy = dy * g
+//   dx = rstd * (gy - mean(gy) - xhat * mean(gy * xhat))   [+ dres]
+//   dg += dy * xhat; db += dy   (block-level partial sums in registers -> atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* x, int64_t xs, const T* dy, int64_t dys, const float* g,
+                                                      const float* mean_i, const float* rstd_i, T* dx, int64_t dxs,
+                                                      const T* dres, int64_t drs, float* dg, float* db, int rows,
+                                                      int D, int rows_per_wave) {
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  float ag[kMaxChunks][4], ab[kMaxChunks][4];
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ag[c][e] = ab[c][e] = 0.f;
+  float gv[kMaxChunks][4];
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int col = (lane + c * 64) * 4;
+    if (col < D) ld4(g + col, gv[c]);
+    else gv[c][0] = gv[c][1] = gv[c][2] = gv[c][3] = 0.f;
+  }
+  const int r0 = gw * rows_per_wave;
+  for (int row = r0; row < r0 + rows_per_wave && row < rows; ++row) {
+    float xv[kMaxChunks][4], dv[kMaxChunks][4];
+    load_row(x + (int64_t)row * xs, D, lane, xv);
+    load_row(dy + (int64_t)row * dys, D, lane, dv);
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+      if ((lane + c * 64) * 4 < D) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xv[c][e] - mean) * rstd;
+          const float gy = dv[c][e] * gv[c][e];
+          s1 += gy; s2 += gy * xh;
+          ag[c][e] += dv[c][e] * xh; ab[c][e] += dv[c][e];
+          xv[c][e] = xh; dv[c][e] = gy;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+      const int col = (lane + c * 64) * 4;
+      if (col < D) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (dv[c][e] - s1 - xv[c][e] * s2);
+        if (dres != nullptr) {
+          float rr[4];
+          ld4(dres + (int64_t)row * drs + col, rr);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += rr[e];
+        }
+        st4(dx + (int64_t)row * dxs + col, o);
+      }
+    }
+  }
+  if (dg != nullptr) {
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+      const int col = (lane + c * 64) * 4;
+      if (col < D) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(dg + col + e, ag[c][e]);
+          atomicAdd(db + col + e, ab[c][e]);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* src, T* dst, int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[4];
+    ld4(src + i * 4, v);
+    st4(dst + i * 4, v);
+  }
+}
+template <typename T>
+__global__ void cast_from_f32_tail(const float* src, T* dst, int64_t start, int64_t n) {
+  const int64_t i = start + threadIdx.x;
+  if (i < n) Elem<T>::st(dst + i, src[i]);
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* src, float* dst, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = Elem<T>::ld(src + i);
+}
+
+// dst[c*ld + r] = src[r*C + c]; 32x32 tile through LDS (+1 pad)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, int64_t sld, int R, int C, T* dst, int64_t ld) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? src[(int64_t)r * sld + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < ld) Elem<T>::st(dst + (int64_t)c * ld + r, r < R ? tile[tx][i] : 0.f);
+  }
+}
+
+template <typename T>
+__global__ void pad_cast_kernel(const float* src, int R, int C, T* dst, int64_t ld) {
+  const int64_t total = (int64_t)R * ld;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld), c = (int)(i % ld);
+    Elem<T>::st(dst + i, c < C ? src[(int64_t)r * C + c] : 0.f);
+  }
+}
+
+// out[(b*G*G + gy*G + gx) * Kpad + c*P*P + ky*P + kx] = px[b][c][gy*P+ky][gx*P+kx]
+template <typename T>
+__global__ void im2col_kernel(const float* px, T* out, int B, int R, int P, int G, int Kpad) {
+  const int K = 3 * P * P;
+  const int kq = Kpad / 4;
+  const int64_t total = (int64_t)B * G * G * kq;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t rowi = i / kq;
+    const int k0 = (int)(i % kq) * 4;
+    const int b = (int)(rowi / (G * G));
+    const int p = (int)(rowi % (G * G));
+    const int gy = p / G, gx = p % G;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + e;
+      if (k < K) {
+        const int c = k / (P * P), rem = k % (P * P);
+        const int ky = rem / P, kx = rem % P;
+        v[e] = px[(((int64_t)b * 3 + c) * R + gy * P + ky) * R + gx * P + kx];
+      } else v[e] = 0.f;
+    }
+    st4(out + rowi * Kpad + k0, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const T* patch, const float* cls, const float* pos,
+                                                               const float* g, const float* b, float eps, T* x0, T* y,
+                                                               float* mean_o, float* rstd_o, int B, int Lv, int W) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * Lv) return;
+  const int bi = (int)(row / Lv), t = (int)(row % Lv);
+  float v[kMaxChunks][4];
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int col = (lane + c * 64) * 4;
+    if (col < W) {
+      float pv[4], sv[4];
+      ld4(pos + (int64_t)t * W + col, pv);
+      if (t == 0) ld4(cls + col, sv);
+      else ld4(patch + ((int64_t)bi * (Lv - 1) + (t - 1)) * W + col, sv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[c][e] = sv[e] + pv[e];
+      if (x0 != nullptr) st4(x0 + row * W + col, v[c]);
+    } else { v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f; }
+  }
+  float mean, rstd;
+  row_stats(v, W, lane, eps, mean, rstd);
+  norm_store(v, y + row * W, g, b, W, lane, mean, rstd);
+  if (mean_o != nullptr && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int64_t* ids, const float* word, const float* pos,
+                                                             const float* type, const float* g, const float* b,
+                                                             float eps, T* x0, T* y, float* mean_o, float* rstd_o,
+                                                             float* key_bias, int B, int L, int Hd, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * L) return;
+  const int t = (int)(row % L);
+  int64_t id = ids[row];
+  if (lane == 0) key_bias[row] = (id == 0) ? -10000.0f : 0.0f;
+  if (id < 0) id = 0;
+  if (id >= vocab) id = vocab - 1;
+  float v[kMaxChunks][4];
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int col = (lane + c * 64) * 4;
+    if (col < Hd) {
+      float wv[4], pv[4], tv[4];
+      ld4(word + id * Hd + col, wv);
+      ld4(type + col, tv);
+      ld4(pos + (int64_t)t * Hd + col, pv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[c][e] = (wv[e] + tv[e]) + pv[e];
+      if (x0 != nullptr) st4(x0 + row * Hd + col, v[c]);
+    } else { v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f; }
+  }
+  float mean, rstd;
+  row_stats(v, Hd, lane, eps, mean, rstd);
+  norm_store(v, y + row * Hd, g, b, Hd, lane, mean, rstd);
+  if (mean_o != nullptr && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* x, float* out, float* inv_o, int B, int E) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float v[kMaxChunks][4];
+  load_row(x + (int64_t)row * E, E, lane, v);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += v[c][e] * v[c][e];
+  s = wave_sum(s);
+  const float inv = 1.0f / sqrtf(s);
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int col = (lane + c * 64) * 4;
+    if (col < E) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = v[c][e] * inv;
+      st4(out + (int64_t)row * E + col, o);
+    }
+  }
+  if (inv_o != nullptr && lane == 0) inv_o[row] = inv;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* y, const float* dy, const float* inv_i,
+                                                          float* dx, int B, int E) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float yv[kMaxChunks][4], dv[kMaxChunks][4];
+  load_row(y + (int64_t)row * E, E, lane, yv);
+  load_row(dy + (int64_t)row * E, E, lane, dv);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += yv[c][e] * dv[c][e];
+  s = wave_sum(s);
+  const float inv = inv_i[row];
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int col = (lane + c * 64) * 4;
+    if (col < E) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (dv[c][e] - yv[c][e] * s) * inv;
+      st4(dx + (int64_t)row * E + col, o);
+    }
+  }
+}
+
+inline int grid_for(int64_t work, int block) {
+  int64_t g = (work + block - 1) / block;
+  const int64_t cap = 256 * 8;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+#define EZ_DISPATCH_T(dtype, ...)                                  \
+  do {                                                             \
+    if ((dtype) == EZCLIP_F32) { using T = float; __VA_ARGS__; }   \
+    else if ((dtype) == EZCLIP_BF16) { using T = bf16_t; __VA_ARGS__; } \
+    else { set_error("bad dtype %d", (int)(dtype)); return EZ_ERR_INVALID; } \
+  } while (0)
+
+int layernorm_fwd(const void* x, int64_t xs, void* y, int64_t ys, const float* g, const float* b, float eps,
+                  int rows, int D, int dtype, float* mean, float* rstd, hipStream_t stream) {
+  EZ_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * kMaxChunks, "layernorm_fwd: D=%d must be a multiple of 4 and <= 1024", D);
+  EZ_REQUIRE(xs % 4 == 0 && ys % 4 == 0, "layernorm_fwd: row strides must be multiples of 4 elements");
+  const int blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+  ProfScope ps(PROF_ROWOP, 2.0 * rows * (double)D * dtype_size(dtype), stream);   // bytes: read + write
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)x, xs,
+                                          (T*)y, ys, g, b, eps, rows, D, mean, rstd));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int layernorm_bwd(const void* x, int64_t xs, const void* dy, int64_t dys, const float* g, const float* mean,
+                  const float* rstd, void* dx, int64_t dxs, const void* dres, int64_t drs, float* dg, float* db,
+                  int rows, int D, int dtype, hipStream_t stream) {
+  EZ_REQUIRE(rows > 0 && D % 4 == 0 && D <= 256 * kMaxChunks, "layernorm_bwd: D=%d unsupported", D);
+  // ~2048 waves total; each wave owns a contiguous run of rows and flushes dg/db once
+  int rows_per_wave = (rows + 2047) / 2048;
+  if (rows_per_wave < 1) rows_per_wave = 1;
+  const int waves = (rows + rows_per_wave - 1) / rows_per_wave;
+  const int blocks = (waves + 3) / 4;
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)x, xs,
+                                          (const T*)dy, dys, g, mean, rstd, (T*)dx, dxs, (const T*)dres, drs, dg, db,
+                                          rows, D, rows_per_wave));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int cast_from_f32(const float* src, void* dst, int64_t n, int dtype, hipStream_t stream) {
+  if (n <= 0) return EZ_OK;
+  const int64_t n4 = n / 4;
+  EZ_DISPATCH_T(dtype, {
+    if (n4 > 0) hipLaunchKernelGGL((cast_from_f32_kernel<T>), dim3(grid_for(n4, 256)), dim3(256), 0, stream, src, (T*)dst, n4);
+    if (n4 * 4 < n) hipLaunchKernelGGL((cast_from_f32_tail<T>), dim3(1), dim3(64), 0, stream, src, (T*)dst, n4 * 4, n);
+  });
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int cast_to_f32(const void* src, float* dst, int64_t n, int dtype, hipStream_t stream) {
+  if (n <= 0) return EZ_OK;
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((cast_to_f32_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, stream,
+                                          (const T*)src, dst, n));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int transpose_cast(const float* src, int64_t src_ld, int R, int C, void* dst, int64_t ld, int dtype, hipStream_t stream) {
+  EZ_REQUIRE(R > 0 && C > 0 && ld >= R && src_ld >= C, "transpose_cast: bad shape");
+  dim3 grid((C + 31) / 32, (int)((ld + 31) / 32));
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((transpose_cast_kernel<T>), grid, dim3(256), 0, stream, src, src_ld, R, C, (T*)dst, ld));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int pad_cast(const float* src, int R, int C, void* dst, int64_t ld, int dtype, hipStream_t stream) {
+  EZ_REQUIRE(R > 0 && C > 0 && ld >= C, "pad_cast: bad shape");
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((pad_cast_kernel<T>), dim3(grid_for((int64_t)R * ld, 256)), dim3(256), 0,
+                                          stream, src, R, C, (T*)dst, ld));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int im2col_patches(const float* pixels, void* out, int B, int R, int P, int Kpad, int dtype, hipStream_t stream) {
+  const int G = R / P;
+  EZ_REQUIRE(B > 0 && G > 0 && Kpad % 4 == 0 && Kpad >= 3 * P * P, "im2col: bad shape");
+  const int64_t work = (int64_t)B * G * G * (Kpad / 4);
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_kernel<T>), dim3(grid_for(work, 256)), dim3(256), 0, stream, pixels,
+                                          (T*)out, B, R, P, G, Kpad));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int vit_assemble_ln(const void* patch, const float* cls, const float* pos, const float* g, const float* b, float eps,
+                    void* x0, void* y, float* mean, float* rstd, int B, int Lv, int W, int dtype,
+                    hipStream_t stream) {
+  EZ_REQUIRE(W % 4 == 0 && W <= 256 * kMaxChunks, "vit_assemble_ln: width %d unsupported", W);
+  const int64_t rows = (int64_t)B * Lv;
+  const int blocks = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((vit_assemble_ln_kernel<T>), dim3(blocks), dim3(256), 0, stream,
+                                          (const T*)patch, cls, pos, g, b, eps, (T*)x0, (T*)y, mean, rstd, B, Lv, W));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int bert_embed_ln(const int64_t* ids, const float* word, const float* pos, const float* type, const float* g,
+                  const float* b, float eps, void* x0, void* y, float* mean, float* rstd, float* key_bias, int B,
+                  int L, int Hd, int vocab, int dtype, hipStream_t stream) {
+  EZ_REQUIRE(Hd % 4 == 0 && Hd <= 256 * kMaxChunks, "bert_embed_ln: hidden %d unsupported", Hd);
+  const int64_t rows = (int64_t)B * L;
+  const int blocks = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((bert_embed_ln_kernel<T>), dim3(blocks), dim3(256), 0, stream, ids, word, pos,
+                                          type, g, b, eps, (T*)x0, (T*)y, mean, rstd, key_bias, B, L, Hd, vocab));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int l2_normalize_fwd(const float* x, float* out, float* inv_norm, int B, int E, hipStream_t stream) {
+  EZ_REQUIRE(E % 4 == 0 && E <= 256 * kMaxChunks, "l2_normalize: E=%d unsupported", E);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((B + kRowsPerBlock - 1) / kRowsPerBlock), dim3(256), 0, stream, x, out,
+                     inv_norm, B, E);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int l2_normalize_bwd(const float* y, const float* dy, const float* inv_norm, float* dx, int B, int E,
+                     hipStream_t stream) {
+  EZ_REQUIRE(E % 4 == 0 && E <= 256 * kMaxChunks, "l2_normalize: E=%d unsupported", E);
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((B + kRowsPerBlock - 1) / kRowsPerBlock), dim3(256), 0, stream, y, dy,
+                     inv_norm, dx, B, E);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+}  // namespace ezclip

@@ -1,0 +1,188 @@
+"""ctypes binding of libezclip_hip.so (the C ABI in include/ezclip.h).
+
+PyTorch is used for device memory and streams only: every call here passes raw
+``tensor.data_ptr()`` device pointers and the current HIP stream handle.
+There is NO CPU fallback: if the shared library is missing or a tensor is not
+on a GPU, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libezclip_hip.so")
+
+DTYPE_F32 = 0
+DTYPE_BF16 = 1
+ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
+
+
+class EzclipError(RuntimeError):
+    pass
+
+
+class EzclipConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "embed_dim", "image_resolution", "vision_layers", "vision_width", "vision_patch_size",
+        "vocab_size", "text_hidden_size", "text_intermediate_size", "text_max_position_embeddings",
+        "text_num_attention_heads", "text_num_hidden_layers", "text_type_vocab_size", "compute_dtype")]
+
+
+_vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes): every symbol include/ezclip.h declares
+SIGNATURES = {
+    "ezclip_last_error": (C.c_char_p, []),
+    "ezclip_version": (C.c_char_p, []),
+    "ezclip_create": (_i, [C.POINTER(EzclipConfig), C.POINTER(_vp)]),
+    "ezclip_destroy": (None, [_vp]),
+    "ezclip_num_params": (_i, [_vp]),
+    "ezclip_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i)]),
+    "ezclip_bind_param": (_i, [_vp, C.c_char_p, _vp, _vp, C.POINTER(_i64), _i]),
+    "ezclip_shadow_bytes": (_sz, [_vp, _i]),
+    "ezclip_set_shadow": (_i, [_vp, _vp, _sz, _i]),
+    "ezclip_refresh_weights": (_i, [_vp, _vp]),
+    "ezclip_image_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "ezclip_text_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "ezclip_encode_image": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _i, _vp]),
+    "ezclip_encode_text": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _i, _vp]),
+    "ezclip_similarity": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ezclip_infonce_from_logits": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "ezclip_infonce_from_logits_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "ezclip_infonce_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ezclip_infonce_fused": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ezclip_backward_image": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "ezclip_backward_text": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "ezclip_recall_ranks": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "ezclip_profile_begin": (_i, []),
+    "ezclip_profile_end": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
+    "ezclip_op_gemm_nt": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
+    "ezclip_op_gemm_tn": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+    "ezclip_op_layernorm": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
+    "ezclip_op_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ezclip_op_attention": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ezclip_op_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ezclip_op_cast_from_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "ezclip_op_cast_to_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EzclipError(
+            "libezclip_hip.so not found at %s -- build it with `python easynlp_amd/csrc/build.py` "
+            "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().ezclip_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise EzclipError("%s failed (rc=%d): %s" % (what or "ezclip call", rc, last_error()))
+
+
+def stream_ptr() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous GPU tensor (None passes NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise EzclipError("ezclip needs GPU tensors (got device %s); there is no CPU path" % t.device)
+    if not t.is_contiguous():
+        raise EzclipError("ezclip needs contiguous tensors")
+    return int(t.data_ptr())
+
+
+def torch_dtype(dtype: int) -> torch.dtype:
+    return torch.bfloat16 if dtype == DTYPE_BF16 else torch.float32
+
+
+def dtype_code(name) -> int:
+    if name in (DTYPE_F32, DTYPE_BF16):
+        return int(name)
+    s = str(name).lower().replace("torch.", "")
+    if s in ("bf16", "bfloat16"):
+        return DTYPE_BF16
+    if s in ("fp32", "f32", "float32", "float"):
+        return DTYPE_F32
+    raise EzclipError("unknown compute dtype %r (use 'bf16' or 'fp32')" % (name,))
+
+
+def alloc_bytes(nbytes: int, device) -> torch.Tensor:
+    """256-byte aligned scratch owned by the torch caching allocator."""
+    t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+    off = (-t.data_ptr()) % 256
+    return t[off:off + int(nbytes)]
+
+
+# ---------------------------------------------------------------- op wrappers (tests, microbench)
+
+def op_gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, residual=None, act=ACT_NONE, out_f32=False,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = act(A @ B^T + bias) + residual with A [M,K], B [N,K] (row stride = K)."""
+    lib = load()
+    dt = DTYPE_BF16 if a.dtype == torch.bfloat16 else DTYPE_F32
+    M, K = a.shape
+    N = b.shape[0]
+    odt = torch.float32 if (out_f32 or dt == DTYPE_F32) else torch.bfloat16
+    c = out if out is not None else torch.empty((M, N), dtype=odt, device=a.device)
+    check(lib.ezclip_op_gemm_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(c), c.stride(0), ptr(bias),
+                                ptr(residual), residual.stride(0) if residual is not None else 0, M, N, K, act, dt,
+                                1 if (out_f32 and dt == DTYPE_BF16) else 0, stream_ptr()), "op_gemm_nt")
+    return c
+
+
+def op_layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float, want_stats=False):
+    lib = load()
+    dt = DTYPE_BF16 if x.dtype == torch.bfloat16 else DTYPE_F32
+    rows, d = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    check(lib.ezclip_op_layernorm(ptr(x), x.stride(0), ptr(y), y.stride(0), ptr(g), ptr(b), eps, rows, d, dt,
+                                  ptr(mean), ptr(rstd), stream_ptr()), "op_layernorm")
+    return (y, mean, rstd) if want_stats else y
+
+
+def op_attention(qkv: torch.Tensor, batch: int, seq_len: int, heads: int, key_bias=None, want_lse=False):
+    """qkv: [batch*seq_len, 3*heads*64] packed (q | k | v); returns ctx [batch*seq_len, heads*64]."""
+    lib = load()
+    dt = DTYPE_BF16 if qkv.dtype == torch.bfloat16 else DTYPE_F32
+    D = heads * 64
+    esz = qkv.element_size()
+    ctx = torch.empty((batch * seq_len, D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((batch, heads, seq_len), dtype=torch.float32, device=qkv.device) if want_lse else None
+    base = ptr(qkv)
+    check(lib.ezclip_op_attention(base, base + D * esz, base + 2 * D * esz, 3 * D, ptr(ctx), D, ptr(key_bias),
+                                  ptr(lse), batch, seq_len, heads, dt, stream_ptr()), "op_attention")
+    return (ctx, lse) if want_lse else ctx
+
+
+def similarity(a: torch.Tensor, b: torch.Tensor, logit_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = load()
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    check(lib.ezclip_similarity(ptr(a), ptr(b), a.shape[0], b.shape[0], a.shape[1], ptr(logit_scale), ptr(out),
+                                stream_ptr()), "similarity")
+    return out

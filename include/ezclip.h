@@ -1,0 +1,187 @@
+/* ezclip -- MI355X (gfx950) native CLIP text-image retrieval hot path.
+ *
+ * C ABI of libezclip_hip.so.  Plain pointers and sizes only; every pointer
+ * named `*_dev` / documented as "device" is a HIP device pointer owned by the
+ * caller (e.g. a PyTorch-ROCm tensor's data_ptr()).  `stream` is a hipStream_t
+ * passed as void* (torch.cuda.current_stream().cuda_stream); every call only
+ * enqueues work on that stream -- no hidden synchronisation.
+ *
+ * What each entry point replaces in alibaba/EasyNLP (paths relative to the
+ * reference checkout).  The reference has no native code on this path: each
+ * symbol below stands in for a composition of stock torch ops.
+ *
+ *   ezclip_encode_image   CHINESE_CLIP.encode_image + L2 normalise
+ *                         easynlp/modelzoo/models/clip/modeling_chineseclip.py:343-344,358-360
+ *                         (VisualTransformer.forward :236-253, ResidualAttentionBlock :184-205)
+ *   ezclip_encode_text    CHINESE_CLIP.encode_text + L2 normalise
+ *                         modeling_chineseclip.py:346-350,361-363
+ *                         (BertModel.forward easynlp/modelzoo/models/bert/modeling_bert.py:792-920)
+ *   ezclip_similarity     logits_per_text = T @ I^T * exp(logit_scale)
+ *                         easynlp/appzoo/clip/model.py:148
+ *   ezclip_infonce_*      CLIPApp.compute_loss / clip_loss / contrastive_loss
+ *                         easynlp/appzoo/clip/model.py:154-164
+ *   ezclip_backward_*     autograd backward of the above (easynlp/core/trainer.py:658-661)
+ *   ezclip_recall_ranks   CLIPEvaluator.evaluate's sort loop
+ *                         easynlp/appzoo/clip/evaluator.py:50-61
+ *   ezclip_bind_param     names/shapes of CHINESE_CLIP.state_dict()
+ *                         (checkpoint contract, easynlp/appzoo/clip/model.py:63-72)
+ *
+ * Error handling: every function returns 0 on success, non-zero otherwise;
+ * ezclip_last_error() returns a thread-local message.  Nothing throws across
+ * the ABI.  A handle is not thread-safe; use one handle per (device, stream).
+ */
+#ifndef EZCLIP_H_
+#define EZCLIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EZCLIP_OK 0
+#define EZCLIP_ERR_INVALID 1
+#define EZCLIP_ERR_HIP 2
+#define EZCLIP_ERR_UNSUPPORTED 3
+#define EZCLIP_ERR_STATE 4
+
+#define EZCLIP_DTYPE_F32 0
+#define EZCLIP_DTYPE_BF16 1
+
+#define EZCLIP_ACT_NONE 0
+#define EZCLIP_ACT_QUICKGELU 1
+#define EZCLIP_ACT_GELU_ERF 2
+
+/* CHINESE_CLIP constructor kwargs (modeling_chineseclip.py:256-276) + compute dtype. */
+typedef struct ezclip_config {
+  int32_t embed_dim;
+  int32_t image_resolution;
+  int32_t vision_layers;
+  int32_t vision_width;
+  int32_t vision_patch_size;
+  int32_t vocab_size;
+  int32_t text_hidden_size;
+  int32_t text_intermediate_size;
+  int32_t text_max_position_embeddings;
+  int32_t text_num_attention_heads;
+  int32_t text_num_hidden_layers;
+  int32_t text_type_vocab_size;
+  int32_t compute_dtype; /* EZCLIP_DTYPE_* : dtype of activations / GEMM operands; accumulation is f32 */
+} ezclip_config;
+
+typedef struct ezclip_model* ezclip_handle;
+
+const char* ezclip_last_error(void);
+const char* ezclip_version(void);
+
+/* ---- model lifetime / parameters ------------------------------------------ */
+int ezclip_create(const ezclip_config* cfg, ezclip_handle* out);
+void ezclip_destroy(ezclip_handle h);
+/* Number of parameters the model expects and the i-th reference name (state_dict key without
+ * the "chinese_clip." prefix); shape is written to shape[0..*ndim). */
+int ezclip_num_params(ezclip_handle h);
+int ezclip_param_info(ezclip_handle h, int index, const char** name, int64_t* shape, int* ndim);
+/* Bind a float32 device tensor (and optionally its float32 gradient buffer) to a reference
+ * parameter name.  The library reads weights through these pointers; it never owns them. */
+int ezclip_bind_param(ezclip_handle h, const char* name, void* weight_dev, void* grad_dev,
+                      const int64_t* shape, int ndim);
+/* Packed weight copies (bf16 casts, transposes for the projections / input gradients).  The
+ * caller allocates `ezclip_shadow_bytes` bytes of device memory, hands it over once, and calls
+ * ezclip_refresh_weights after every update of the bound parameters (optimizer step, load). */
+size_t ezclip_shadow_bytes(ezclip_handle h, int with_backward);
+int ezclip_set_shadow(ezclip_handle h, void* shadow_dev, size_t bytes, int with_backward);
+int ezclip_refresh_weights(ezclip_handle h, void* stream);
+
+/* ---- forward ------------------------------------------------------------------ */
+/* Workspace (activations; with save_for_backward != 0 also everything backward needs). */
+size_t ezclip_image_workspace_bytes(ezclip_handle h, int batch, int save_for_backward);
+size_t ezclip_text_workspace_bytes(ezclip_handle h, int batch, int seq_len, int save_for_backward);
+/* pixels: device float32 [batch, 3, R, R] (NCHW, as CLIPDataset.batch_fn produces);
+ * out_embeds: device float32 [batch, embed_dim], L2-normalised. */
+int ezclip_encode_image(ezclip_handle h, const float* pixels_dev, int batch, float* out_embeds_dev,
+                        void* workspace_dev, size_t workspace_bytes, int save_for_backward, void* stream);
+/* input_ids: device int64 [batch, seq_len]; attention mask = ids != 0 (modeling_chineseclip.py:347). */
+int ezclip_encode_text(ezclip_handle h, const int64_t* input_ids_dev, int batch, int seq_len,
+                       float* out_embeds_dev, void* workspace_dev, size_t workspace_bytes,
+                       int save_for_backward, void* stream);
+/* out[i][j] = exp(*logit_scale) * <a[i], b[j]>;  a [na, e], b [nb, e], out [na, nb] float32.
+ * logit_scale_dev may be NULL (scale 1: CLIPEvaluator's `agreement`). */
+int ezclip_similarity(const float* a_dev, const float* b_dev, int na, int nb, int e,
+                      const float* logit_scale_dev, float* out_dev, void* stream);
+
+/* ---- InfoNCE ------------------------------------------------------------------- */
+/* Loss of the reference's compute_loss on a materialised logits_per_text [n, n]:
+ *   0.5 * (CE(S, arange) + CE(S^T, arange)).  scratch: >= 4*n floats.  */
+int ezclip_infonce_from_logits(const float* logits_dev, int n, float* loss_dev, float* scratch_dev,
+                               void* stream);
+/* d loss / d logits for the above, scaled by *grad_out_dev (scalar, device). */
+int ezclip_infonce_from_logits_bwd(const float* logits_dev, int n, const float* grad_out_dev,
+                                   float* dlogits_dev, float* scratch_dev, void* stream);
+/* Fused contrastive step on embeddings (local or all-gathered global batch):
+ *   text_all/image_all: float32 [n_global, e] (rows rank_offset..rank_offset+n_local are this rank's)
+ *   loss = 0.5 * (mean_i CE(s * T_loc I_all^T)_i + mean_i CE(s * I_loc T_all^T)_i),  s = exp(*logit_scale)
+ *   outputs (any may be NULL to skip the backward part):
+ *     d_text_all / d_image_all  float32 [n_global, e] : gradient contributions of THIS rank's loss
+ *        w.r.t. every row (sum over ranks = reduce-scatter / all-reduce by the caller)
+ *     d_logit_scale float32 scalar (overwritten)
+ *   grad_scale multiplies every gradient (1/world_size for DDP-style averaging).
+ *   workspace: ezclip_infonce_workspace_bytes(n_local, n_global, e). */
+size_t ezclip_infonce_workspace_bytes(int n_local, int n_global, int e);
+int ezclip_infonce_fused(const float* text_all_dev, const float* image_all_dev, int n_local, int n_global,
+                         int rank_offset, int e, const float* logit_scale_dev, float grad_scale,
+                         float* loss_dev, float* d_text_all_dev, float* d_image_all_dev,
+                         float* d_logit_scale_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---- backward ------------------------------------------------------------------- */
+/* Gradients are ACCUMULATED (+=) into the grad buffers bound with ezclip_bind_param (float32),
+ * like autograd does; parameters bound without a grad buffer are skipped.
+ * workspace must be the one the matching forward (save_for_backward=1) filled. */
+int ezclip_backward_image(ezclip_handle h, const float* pixels_dev, int batch, const float* d_embeds_dev,
+                          void* workspace_dev, size_t workspace_bytes, void* stream);
+int ezclip_backward_text(ezclip_handle h, const int64_t* input_ids_dev, int batch, int seq_len,
+                         const float* d_embeds_dev, void* workspace_dev, size_t workspace_bytes,
+                         void* stream);
+
+/* ---- retrieval metric -------------------------------------------------------------- */
+/* rank_out[i] = number of images j with sim(text i, image j) > sim(text i, image i)
+ * (+ ties with j < i, matching a stable descending sort); text/image: float32 [n, e]. */
+int ezclip_recall_ranks(const float* text_dev, const float* image_dev, int n, int e, int32_t* rank_out_dev,
+                        float* scratch_dev /* n*n floats */, void* stream);
+
+/* ---- measurement hooks ---------------------------------------------------------------- */
+/* Between begin and end every launch of the hot kernels is bracketed by HIP events on its
+ * own stream.  kernel_class: 0 = MFMA GEMM (work = algorithmic FLOPs), 1 = fused attention
+ * (FLOPs), 2 = LayerNorm (bytes).  ezclip_profile_end synchronises on the recorded events. */
+#define EZCLIP_PROF_GEMM 0
+#define EZCLIP_PROF_ATTN 1
+#define EZCLIP_PROF_ROWOP 2
+int ezclip_profile_begin(void);
+int ezclip_profile_end(int kernel_class, double* total_ms, double* total_work, int* launches);
+
+/* ---- operator-level entry points (unit parity tests, micro-benchmarks) ------------- */
+int ezclip_op_gemm_nt(const void* a_dev, int64_t lda, const void* b_dev, int64_t ldb, void* c_dev, int64_t ldc,
+                      const float* bias_dev, const void* residual_dev, int64_t ldr, int m, int n, int k,
+                      int act, int dtype, int out_f32, void* stream);
+int ezclip_op_gemm_tn(const void* a_dev, int64_t lda, const void* b_dev, int64_t ldb, float* c_dev, int64_t ldc,
+                      int m, int n, int k, int accumulate, int dtype, void* stream);
+int ezclip_op_layernorm(const void* x_dev, int64_t x_stride, void* y_dev, int64_t y_stride, const float* g_dev,
+                        const float* b_dev, float eps, int rows, int d, int dtype, float* mean_dev, float* rstd_dev,
+                        void* stream);
+int ezclip_op_layernorm_bwd(const void* x_dev, const void* dy_dev, const float* g_dev, const float* mean_dev,
+                            const float* rstd_dev, void* dx_dev, float* dg_dev, float* db_dev, int rows, int d,
+                            int dtype, void* stream);
+int ezclip_op_attention(const void* q_dev, const void* k_dev, const void* v_dev, int64_t row_stride, void* ctx_dev,
+                        int64_t ctx_stride, const float* key_bias_dev, float* lse_dev, int batch, int seq_len,
+                        int heads, int dtype, void* stream);
+int ezclip_op_attention_bwd(const void* q_dev, const void* k_dev, const void* v_dev, int64_t row_stride,
+                            const void* ctx_dev, const void* dctx_dev, int64_t ctx_stride, const float* key_bias_dev,
+                            const float* lse_dev, void* dq_dev, void* dk_dev, void* dv_dev, int batch, int seq_len,
+                            int heads, int dtype, void* stream);
+int ezclip_op_cast_from_f32(const float* src_dev, void* dst_dev, int64_t n, int dtype, void* stream);
+int ezclip_op_cast_to_f32(const void* src_dev, float* dst_dev, int64_t n, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EZCLIP_H_ */

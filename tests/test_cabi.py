@@ -1,0 +1,115 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol include/ezclip.h declares, the parameter table equals the
+reference's state_dict contract, and the host logic fails loudly (no compute
+calls here -- there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from easynlp_amd import lib as L
+from oracle import clip_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "ezclip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ezclip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), "include/ezclip.h declares %s but the .so does not export it" % s
+    # and the Python binding knows a signature for each of them
+    assert set(syms) == set(L.SIGNATURES), set(syms) ^ set(L.SIGNATURES)
+    assert b"gfx950" in lib.ezclip_version()
+
+
+def make_handle(cfg_name, dtype):
+    from easynlp_amd.appzoo.clip.model import _cfg_struct
+    lib = L.load()
+    cs = _cfg_struct(O.CONFIGS[cfg_name], dtype)
+    h = C.c_void_p()
+    rc = lib.ezclip_create(C.byref(cs), C.byref(h))
+    return lib, h, rc
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny", "small", "vitb16_bertbase", "vitl14_robertabase"])
+@pytest.mark.parametrize("dtype", [L.DTYPE_F32, L.DTYPE_BF16])
+def test_param_table_matches_reference_state_dict(cfg_name, dtype):
+    lib, h, rc = make_handle(cfg_name, dtype)
+    assert rc == 0, L.last_error()
+    shapes = O.param_shapes(O.CONFIGS[cfg_name])
+    n = lib.ezclip_num_params(h)
+    name, shape, ndim = C.c_char_p(), (C.c_int64 * 8)(), C.c_int()
+    got = {}
+    for i in range(n):
+        assert lib.ezclip_param_info(h, i, C.byref(name), shape, C.byref(ndim)) == 0
+        got[name.value.decode()] = tuple(shape[j] for j in range(ndim.value))
+    assert got == shapes
+    # workspace sizes are monotone in batch and larger with save_for_backward
+    a = lib.ezclip_image_workspace_bytes(h, 2, 0)
+    b = lib.ezclip_image_workspace_bytes(h, 4, 0)
+    c = lib.ezclip_image_workspace_bytes(h, 4, 1)
+    assert 0 < a < b < c
+    t0 = lib.ezclip_text_workspace_bytes(h, 4, 16, 0)
+    t1 = lib.ezclip_text_workspace_bytes(h, 4, 32, 0)
+    t2 = lib.ezclip_text_workspace_bytes(h, 4, 32, 1)
+    assert 0 < t0 < t1 < t2
+    assert lib.ezclip_shadow_bytes(h, 1) > lib.ezclip_shadow_bytes(h, 0) > 0
+    lib.ezclip_destroy(h)
+
+
+def test_bad_config_and_bad_calls_fail_loudly():
+    from easynlp_amd.appzoo.clip.model import _cfg_struct
+    lib = L.load()
+    bad = dict(O.CONFIGS["tiny"], vision_width=100)
+    h = C.c_void_p()
+    cs = _cfg_struct(bad, L.DTYPE_BF16)
+    assert lib.ezclip_create(C.byref(cs), C.byref(h)) != 0
+    assert "vision_width" in L.last_error()
+    lib, h, rc = make_handle("tiny", L.DTYPE_F32)
+    assert rc == 0
+    shp = (C.c_int64 * 1)(7)
+    assert lib.ezclip_bind_param(h, b"no.such.param", 16, None, shp, 1) != 0
+    assert "unknown parameter" in L.last_error()
+    assert lib.ezclip_bind_param(h, b"visual.class_embedding", 16, None, shp, 1) != 0   # wrong shape
+    # forward before binding parameters must refuse, not crash
+    assert lib.ezclip_encode_image(h, 256, 1, 256, 256, 1 << 30, 0, None) != 0
+    assert "refresh_weights" in L.last_error()
+    lib.ezclip_destroy(h)
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "easynlp_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt, fn
+
+
+def test_no_cpu_fallback_in_host_module(tmp_path):
+    """The app refuses CPU tensors instead of silently computing elsewhere."""
+    import torch
+    from easynlp_amd.appzoo.clip import CLIPApp
+    from oracle import ref_harness as R
+    cfg = O.CONFIGS["tiny"]
+    R.write_checkpoint_dir(str(tmp_path), cfg, O.make_state_dict(cfg, 3))
+    app = CLIPApp(str(tmp_path))
+    # reference checkpoint contract: same keys as the reference state_dict (+ chinese_clip. prefix)
+    keys = set(app.state_dict().keys())
+    want = {"chinese_clip." + k for k in O.param_shapes(cfg)} | {"chinese_clip.bert.embeddings.position_ids"}
+    assert keys == want
+    sd = O.make_state_dict(cfg, 3)
+    for k, v in sd.items():
+        assert torch.equal(app.state_dict()["chinese_clip." + k], v), k
+    px, ids = O.make_inputs(cfg, 2, 8, 0)
+    with pytest.raises(L.EzclipError):
+        app({"pixel_values": px, "input_ids": ids})

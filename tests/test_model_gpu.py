@@ -1,0 +1,146 @@
+"""Model-level parity (GPU): the HIP dual encoder behind the CLIPApp API against
+(a) the committed golden fixtures produced by the real reference and (b) the
+CPU oracle run on the same seeded inputs.
+
+Tolerances: f32 path -- embeddings max-abs <= 1e-5 (unit vectors),
+logits <= 2e-4 * scale, loss <= 1e-5 rel; bf16 path -- embedding max-abs <= 1e-2
+/ cosine >= 0.9995, logits <= 0.15, loss <= 5e-3 abs.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from easynlp_amd import lib as L
+from easynlp_amd.appzoo.clip import CLIPApp, CLIPEvaluator, CLIPPredictor
+from oracle import clip_oracle as O
+from oracle import ref_harness as R
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_gold(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg_name, B, Lq, wseed, iseed = [str(x) for x in z["meta"][:5]]
+    return z, O.CONFIGS[cfg_name], int(B), int(Lq), int(wseed), int(iseed)
+
+
+def make_app(tmp_path, cfg, seed, dtype):
+    sd = O.make_state_dict(cfg, seed)
+    R.write_checkpoint_dir(str(tmp_path), cfg, sd)
+    app = CLIPApp(str(tmp_path), user_defined_parameters={"clip_compute_dtype": dtype}).cuda()
+    return app, sd
+
+
+@pytest.mark.parametrize("name", ["tiny_b6_l24", "small_b5_l40", "vitb16_bertbase_b4_l64"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_forward_matches_reference_golden(tmp_path, name, dtype):
+    z, cfg, B, Lq, wseed, iseed = load_gold(name)
+    app, _ = make_app(tmp_path, cfg, wseed, dtype)
+    app.eval()
+    px, ids = O.make_inputs(cfg, B, Lq, iseed)
+    with torch.no_grad():
+        out = app({"pixel_values": px, "input_ids": ids})
+        loss = app.compute_loss(out, [])["loss"]
+    assert set(out) == {"logits_per_text", "logits_per_image", "image_embeds", "text_embeds"}
+    img, txt = out["image_embeds"].cpu(), out["text_embeds"].cpu()
+    gi, gt = torch.from_numpy(z["image_embeds"]), torch.from_numpy(z["text_embeds"])
+    lpt = out["logits_per_text"].cpu()
+    assert torch.equal(out["logits_per_image"].cpu(), lpt.t())
+    scale = float(np.exp(O.make_state_dict(cfg, wseed)["logit_scale"]))
+    if dtype == "fp32":
+        assert float((img - gi).abs().max()) < 1e-5
+        assert float((txt - gt).abs().max()) < 1e-5
+        assert float((lpt - torch.from_numpy(z["logits_per_text"])).abs().max()) < 2e-4 * scale / 14.3 * 2
+        assert abs(loss.item() - float(z["loss"])) < 1e-5 * max(1.0, abs(float(z["loss"])))
+    else:
+        assert float((img - gi).abs().max()) < 1e-2
+        assert float((txt - gt).abs().max()) < 1e-2
+        assert float(torch.nn.functional.cosine_similarity(img, gi).min()) > 0.9995
+        assert float(torch.nn.functional.cosine_similarity(txt, gt).min()) > 0.9995
+        assert float((lpt - torch.from_numpy(z["logits_per_text"])).abs().max()) < 0.15
+        assert abs(loss.item() - float(z["loss"])) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_ragged_batches_and_single_modality(tmp_path, dtype):
+    cfg = O.CONFIGS["small"]
+    app, sd = make_app(tmp_path, cfg, 5, dtype)
+    app.eval()
+    tol = 2e-5 if dtype == "fp32" else 1e-2
+    for B, Lq in [(1, 1), (3, 7), (7, 33), (2, 128)]:
+        px, ids = O.make_inputs(cfg, B, Lq, B + Lq)
+        with torch.no_grad():
+            ref = O.clip_forward(sd, cfg, px, ids)
+            oi = app({"pixel_values": px}, feat=True)
+            ot = app({"input_ids": ids}, feat=True)
+        assert oi["text_embeds"] is None and ot["image_embeds"] is None
+        assert float((oi["image_embeds"].cpu() - ref["image_embeds"]).abs().max()) < tol
+        assert float((ot["text_embeds"].cpu() - ref["text_embeds"]).abs().max()) < tol
+
+
+def test_all_padding_rows_and_pad_id_inside_sequence(tmp_path):
+    """mask = ids != 0 (modeling_chineseclip.py:347): zeros inside a sentence are masked keys too,
+    and a fully padded row (all keys at -10000) must still give the reference's finite output."""
+    cfg = O.CONFIGS["tiny"]
+    app, sd = make_app(tmp_path, cfg, 9, "fp32")
+    app.eval()
+    _, ids = O.make_inputs(cfg, 4, 16, 2)
+    ids[1, 3] = 0
+    ids[1, 7] = 0
+    ids[2, :] = 0
+    with torch.no_grad():
+        ref = O.encode_text(sd, cfg, ids)
+        got = app({"input_ids": ids}, feat=True)["text_embeds"].cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) < 2e-5
+
+
+class _DS(torch.utils.data.Dataset):
+    def __init__(self, px, ids):
+        self.px, self.ids = px, ids
+
+    def __len__(self):
+        return self.px.shape[0]
+
+    def __getitem__(self, i):
+        return {"pixel_values": self.px[i:i + 1], "text": {"input_ids": self.ids[i:i + 1]}}
+
+    @staticmethod
+    def batch_fn(features):   # shape of CLIPDataset.batch_fn (appzoo/clip/data.py:275-295)
+        return {"pixel_values": torch.cat([f["pixel_values"] for f in features]),
+                "input_ids": torch.cat([f["text"]["input_ids"] for f in features]), "label_ids": []}
+
+
+def test_evaluator_and_predictor_contract(tmp_path):
+    cfg = O.CONFIGS["tiny"]
+    app, sd = make_app(tmp_path, cfg, 21, "fp32")
+    px, ids = O.make_inputs(cfg, 24, 12, 4)
+    ev = CLIPEvaluator(_DS(px, ids), eval_batch_size=7)
+    res = ev.evaluate(app)
+    assert res[0][0] == "mean_recall"
+    with torch.no_grad():
+        ref = O.clip_forward(sd, cfg, px, ids)
+    want = O.recall_at_k(ref["text_embeds"], ref["image_embeds"])
+    assert abs(res[0][1] - want[0]) <= 1e-3
+    pred = CLIPPredictor(str(tmp_path), CLIPApp, user_defined_parameters={"clip_compute_dtype": "fp32"})
+    rows = pred.run([{"input_ids": ids[i:i + 1]} for i in range(3)])
+    assert len(rows) == 3 and set(rows[0]) == {"text_feat"}
+    vals = np.array([float(x) for x in rows[0]["text_feat"].split("\t")])
+    assert np.abs(vals - ref["text_embeds"][0].numpy()).max() < 2e-5
+    rows = pred.run([{"pixel_values": px[i:i + 1]} for i in range(2)])
+    assert set(rows[0]) == {"image_feat"}
+
+
+def test_weights_refresh_after_inplace_update(tmp_path):
+    cfg = O.CONFIGS["tiny"]
+    app, sd = make_app(tmp_path, cfg, 2, "bf16")
+    app.eval()
+    px, ids = O.make_inputs(cfg, 3, 8, 1)
+    with torch.no_grad():
+        a = app({"pixel_values": px, "input_ids": ids}, feat=True)["image_embeds"].clone()
+        app.chinese_clip.visual.proj.mul_(-1.0)    # optimizer-style in-place update
+        b = app({"pixel_values": px, "input_ids": ids}, feat=True)["image_embeds"]
+    assert float((a + b).abs().max()) < 1e-6

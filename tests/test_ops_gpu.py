@@ -1,0 +1,224 @@
+"""Operator-level parity (GPU): each HIP kernel, called through the C ABI,
+against the CPU oracle's formula on the same seeded inputs.
+
+Tolerances: the f32 path uses exact-f32 MFMA (an fmaf chain), so it differs
+from the CPU only by summation order: |err| <= ~1e-5 * scale.  The bf16 path
+rounds operands/outputs to bf16 (8 bits of mantissa): rel 2^-8 per rounding.
+"""
+import math
+
+import pytest
+import torch
+
+from easynlp_amd import lib as L
+from oracle import clip_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def max_err(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+
+GEMM_SHAPES = [
+    (128, 128, 64), (256, 384, 128), (197, 768, 768), (1, 512, 768), (130, 136, 256),
+    (394, 2304, 768), (64, 100, 64), (6, 6, 64), (257, 68, 192), (1000, 3072, 768), (520, 768, 3072),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gemm_nt_plain(M, N, K, dtype):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    if dtype == "bf16":
+        a, b = a.bfloat16(), b.bfloat16()
+    ref = a.double() @ b.double().t()
+    c = L.op_gemm_nt(a.to(DEV), b.to(DEV))
+    torch.cuda.synchronize()
+    tol = 2e-6 if dtype == "f32" else 4e-3   # bf16: output rounding 2^-9 relative
+    assert rel_err(c.float(), ref) < tol
+    scale = math.sqrt(K)
+    assert max_err(c.float(), ref) < (2e-5 if dtype == "f32" else 0.02) * scale
+
+
+@pytest.mark.parametrize("act", [L.ACT_NONE, L.ACT_QUICKGELU, L.ACT_GELU_ERF])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(197, 768, 256), (70, 132, 64), (33, 7, 64)])
+def test_gemm_nt_epilogues(M, N, K, dtype, act):
+    g = torch.Generator().manual_seed(act + M)
+    a = torch.randn(M, K, generator=g) * 0.5
+    b = torch.randn(N, K, generator=g) * 0.2
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    if dtype == "bf16":
+        a, b, res = a.bfloat16(), b.bfloat16(), res.bfloat16()
+    z = a.double() @ b.double().t() + bias.double()
+    if act == L.ACT_QUICKGELU:
+        z = O.quick_gelu(z)
+    elif act == L.ACT_GELU_ERF:
+        z = O.gelu_erf(z)
+    ref = z + res.double()
+    c = L.op_gemm_nt(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=res.to(DEV), act=act)
+    torch.cuda.synchronize()
+    assert max_err(c.float(), ref) < (3e-5 if dtype == "f32" else 0.06)
+    # bf16 inputs, f32 output (projection / logits path)
+    if dtype == "bf16":
+        c32 = L.op_gemm_nt(a.to(DEV), b.to(DEV), bias=bias.to(DEV), act=act, out_f32=True)
+        assert c32.dtype == torch.float32
+        assert max_err(c32, z) < 2e-3
+
+
+def test_gemm_nt_strided_rows_and_inplace_residual():
+    # A rows strided (CLS rows of [B, L, D]), residual aliasing the output (x += ...)
+    g = torch.Generator().manual_seed(5)
+    B_, Lq, D = 9, 5, 128
+    x = torch.randn(B_, Lq, D, generator=g).to(DEV)
+    w = torch.randn(64, D, generator=g).to(DEV)
+    a = x[:, 0, :]
+    assert a.stride(0) == Lq * D
+    lib = L.load()
+    c = torch.empty(B_, 64, device=DEV)
+    L.check(lib.ezclip_op_gemm_nt(a.data_ptr(), a.stride(0), w.data_ptr(), D, c.data_ptr(), 64, None, None, 0,
+                                  B_, 64, D, 0, L.DTYPE_F32, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert max_err(c, a.cpu().double() @ w.cpu().double().t()) < 1e-4
+    y = torch.randn(200, 128, generator=g).to(DEV)
+    a2 = torch.randn(200, 64, generator=g).to(DEV)
+    w2 = torch.randn(128, 64, generator=g).to(DEV)
+    ref = y.cpu().double() + a2.cpu().double() @ w2.cpu().double().t()
+    L.op_gemm_nt(a2, w2, residual=y, out=y)
+    torch.cuda.synchronize()
+    assert max_err(y, ref) < 1e-4
+
+
+@pytest.mark.parametrize("rows,D", [(5, 128), (197, 768), (64, 1024), (33, 192)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("eps", [1e-5, 1e-12])
+def test_layernorm(rows, D, dtype, eps):
+    g = torch.Generator().manual_seed(rows + D)
+    x = torch.randn(rows, D, generator=g) * 2 + 0.3
+    w = 1 + 0.1 * torch.randn(D, generator=g)
+    b = 0.1 * torch.randn(D, generator=g)
+    if dtype == "bf16":
+        x = x.bfloat16()
+    ref = O.layer_norm(x.double(), w.double(), b.double(), eps)
+    y, mean, rstd = L.op_layernorm(x.to(DEV), w.to(DEV), b.to(DEV), eps, want_stats=True)
+    torch.cuda.synchronize()
+    assert max_err(y.float(), ref) < (5e-6 if dtype == "f32" else 0.03)
+    assert max_err(mean, x.double().mean(-1)) < 1e-5
+    var = x.double().var(-1, unbiased=False)
+    assert rel_err(rstd, torch.rsqrt(var + eps)) < 1e-5
+
+
+def ref_attention(qkv, B_, Lq, H, key_bias=None):
+    D = H * 64
+    q, k, v = qkv.double().split(D, dim=-1)
+    q = q.reshape(B_, Lq, H, 64).transpose(1, 2)
+    k = k.reshape(B_, Lq, H, 64).transpose(1, 2)
+    v = v.reshape(B_, Lq, H, 64).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if key_bias is not None:
+        s = s + key_bias.double().reshape(B_, 1, 1, Lq)
+    p = torch.softmax(s, -1)
+    ctx = (p @ v).transpose(1, 2).reshape(B_ * Lq, D)
+    return ctx, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B_,Lq,H", [(2, 197, 12), (3, 64, 2), (2, 26, 3), (1, 1, 2), (2, 33, 2), (1, 257, 4), (2, 288, 1)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention(B_, Lq, H, dtype, masked):
+    g = torch.Generator().manual_seed(B_ * 1000 + Lq + H)
+    qkv = torch.randn(B_ * Lq, 3 * H * 64, generator=g) * 1.5
+    kb = None
+    if masked:
+        lens = torch.randint(1, Lq + 1, (B_,), generator=g)
+        lens[0] = Lq
+        kb = torch.zeros(B_, Lq)
+        for i in range(B_):
+            kb[i, lens[i]:] = -10000.0
+        kb = kb.reshape(-1)
+    if dtype == "bf16":
+        qkv = qkv.bfloat16()
+    ref, ref_lse = ref_attention(qkv, B_, Lq, H, kb)
+    ctx, lse = L.op_attention(qkv.to(DEV), B_, Lq, H, key_bias=None if kb is None else kb.to(DEV), want_lse=True)
+    torch.cuda.synchronize()
+    assert max_err(ctx.float(), ref) < (2e-5 if dtype == "f32" else 0.03)
+    assert max_err(lse, ref_lse) < (1e-4 if dtype == "f32" else 0.05)
+
+
+def test_attention_bf16_long_sequence_512():
+    B_, Lq, H = 1, 512, 2
+    g = torch.Generator().manual_seed(11)
+    qkv = (torch.randn(B_ * Lq, 3 * H * 64, generator=g)).bfloat16()
+    ref, _ = ref_attention(qkv, B_, Lq, H)
+    ctx = L.op_attention(qkv.to(DEV), B_, Lq, H)
+    torch.cuda.synchronize()
+    assert max_err(ctx.float(), ref) < 0.03
+
+
+@pytest.mark.parametrize("n,e", [(6, 64), (8, 512), (100, 128), (256, 512), (1000, 512)])
+def test_similarity_and_infonce(n, e):
+    lib = L.load()
+    g = torch.Generator().manual_seed(n)
+    t = torch.nn.functional.normalize(torch.randn(n, e, generator=g), dim=-1)
+    i = torch.nn.functional.normalize(t + 0.8 * torch.randn(n, e, generator=g), dim=-1)
+    ls = torch.tensor(math.log(1 / 0.07))
+    S = L.similarity(t.to(DEV), i.to(DEV), ls.to(DEV))
+    ref = (t.double() @ i.double().t()) * ls.double().exp()
+    assert max_err(S, ref) < 2e-4
+    loss = torch.empty((), device=DEV)
+    scratch = torch.empty(4 * n, device=DEV)
+    L.check(lib.ezclip_infonce_from_logits(S.data_ptr(), n, loss.data_ptr(), scratch.data_ptr(), L.stream_ptr()))
+    ref_loss = O.clip_loss(ref)
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
+    # d loss / d logits
+    Sr = ref.clone().requires_grad_(True)
+    O.clip_loss(Sr).backward()
+    d = torch.empty_like(S)
+    gout = torch.tensor(1.0, device=DEV)
+    L.check(lib.ezclip_infonce_from_logits_bwd(S.data_ptr(), n, gout.data_ptr(), d.data_ptr(), scratch.data_ptr(),
+                                               L.stream_ptr()))
+    assert max_err(d, Sr.grad) < 1e-5
+    # recall ranks == the reference evaluator's sort loop
+    from easynlp_amd.appzoo.clip.evaluator import recall_at_k
+    (mean, r1, r5, r10), _ = recall_at_k(t.to(DEV), i.to(DEV))
+    want = O.recall_at_k(t, i)
+    assert abs(r1 - want[1]) < 1e-12 and abs(r5 - want[2]) < 1e-12 and abs(r10 - want[3]) < 1e-12
+
+
+@pytest.mark.parametrize("n,N,off,e", [(4, 12, 4, 64), (8, 8, 0, 128), (32, 128, 64, 512), (100, 300, 200, 64)])
+def test_infonce_fused_shard(n, N, off, e):
+    """Fused loss + gradients of one rank's shard == autograd of the oracle's global loss share."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(N + off)
+    t = torch.nn.functional.normalize(torch.randn(N, e, generator=g), dim=-1)
+    i = torch.nn.functional.normalize(t + torch.randn(N, e, generator=g), dim=-1)
+    ls = torch.tensor(2.0)
+    td, idd, lsd = (x.double().clone().requires_grad_(True) for x in (t, i, ls))
+    ref = O.global_clip_loss_rank(td, idd, lsd, off // n, n) if off % n == 0 else None
+    if ref is None:
+        pytest.skip("offset must be a multiple of n in this test")
+    ref.backward()
+    wsb = lib.ezclip_infonce_workspace_bytes(n, N, e)
+    ws = L.alloc_bytes(wsb, DEV)
+    loss = torch.empty((), device=DEV)
+    dT = torch.empty(N, e, device=DEV)
+    dI = torch.empty(N, e, device=DEV)
+    dls = torch.empty((), device=DEV)
+    L.check(lib.ezclip_infonce_fused(t.to(DEV).data_ptr(), i.to(DEV).data_ptr(), n, N, off, e, ls.to(DEV).data_ptr(),
+                                     1.0, loss.data_ptr(), dT.data_ptr(), dI.data_ptr(), dls.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) < 1e-4 * max(1, abs(ref.item()))
+    assert max_err(dT, td.grad) < 1e-5
+    assert max_err(dI, idd.grad) < 1e-5
+    assert abs(dls.item() - lsd.grad.item()) < 1e-4 * max(1, abs(lsd.grad.item()))

@@ -65,7 +65,9 @@ def cpu_baseline(seconds_target=12.0):
     """The CPU oracle (torch-CPU restatement of the reference path, oracle/clip_oracle.py)
     on the host cores: fp32 forward + similarity + InfoNCE on 8-pair batches."""
     from oracle import clip_oracle as O
-    cores = os.cpu_count() or 1
+    # a small-batch CPU forward stops scaling (and collapses from oversubscription) beyond a few
+    # dozen threads: use at most 32 and report the number actually used
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     cfg = O.CONFIGS["vitb16_bertbase"]
     sd = O.make_state_dict(cfg, 1234)

@@ -416,9 +416,9 @@ class CLIPApp(Application):
         txt, ws_t = eng.encode_text(input_ids, backward)
         n = img.shape[0]
         e = img.shape[1]
-        world, rank = 1, 0
-        if process_group is not None or (dist.is_available() and dist.is_initialized() and process_group is not False):
-            pg = process_group if process_group not in (None, True) else None
+        world, rank, pg = 1, 0, None
+        if process_group is not False and dist.is_available() and dist.is_initialized():
+            pg = None if process_group in (None, True) else process_group
             world, rank = dist.get_world_size(pg), dist.get_rank(pg)
         if world > 1:
             both = torch.cat([img, txt], dim=1)                       # one collective for both towers

@@ -271,9 +271,380 @@ int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream) {
   return EZ_ERR_INVALID;
 }
 
-int attention_bwd(const AttnBwdArgs&, int, hipStream_t) {
-  set_error("attention_bwd: not implemented yet");
-  return EZ_ERR_UNSUPPORTED;
+// ---------------------------------------------------------------------------------
+// Backward (flash-style recompute from the saved log-sum-exp; nothing of size L x L is
+// ever stored).  With S = scale*Q K^T + bias, P = exp(S - lse), D_q = <dO_q, O_q>:
+//   dV = P^T dO      dP = dO V^T      dS = P o (dP - D)      dQ = scale dS K      dK = scale dS^T Q
+// Two kernels, both built on the forward's "the lane already holds its own fragment" trick:
+//   dQ  kernel: waves own 32-query blocks, sweep over key tiles; S^T and dP^T tiles leave the
+//               MFMA with one query per lane, so dS^T feeds mfma(K^T frag, dS) directly.
+//   dKV kernel: waves own 32-key blocks, sweep over query tiles; S and dP tiles leave the MFMA
+//               with one key per lane, so P / dS feed mfma(dO^T frag, P) and mfma(Q^T frag, dS).
+// The swept operand lives in LDS (row-major swizzled image by LDS-DMA + a transposed image),
+// in chunks of up to CH tiles when L is long.
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void stage_rows_dma(char* dst, const char* gbase, int64_t rs, int row0, int nrows, int L,
+                                               int wave, int nwaves, int lane) {
+  using G = Geo<T>;
+  const int ninst = nrows * G::RB / 1024;
+  for (int inst = wave; inst < ninst; inst += nwaves) {
+    const int r = inst * G::RPI + lane / G::CPR;
+    const int c = (lane % G::CPR) ^ G::swz(r);
+    int gr = row0 + r;
+    gr = gr < L ? gr : L - 1;   // clamp: finite values, always multiplied by an exact zero downstream
+    __builtin_amdgcn_global_load_lds((glb_void*)(gbase + gr * rs + c * 16), (lds_void*)(dst + inst * 1024), 16, 0, 0);
+  }
+}
+
+// dst[d][LP] (row-contiguous) <- rows row0 .. row0+nrows of a [*, 64] matrix; rows >= L are zero
+template <typename T>
+__device__ __forceinline__ void stage_rows_T(char* dst, const char* gbase, int64_t rs, int row0, int nrows, int L,
+                                             int LP, int tid, int nthreads) {
+  using G = Geo<T>;
+  const int nkq = nrows / 4;
+  for (int idx = tid; idx < nkq * G::CPR; idx += nthreads) {
+    const int dc = idx / nkq, kq = idx % nkq;
+    uint4 w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * kq + r;
+      if (row < L) w[r] = *reinterpret_cast<const uint4*>(gbase + row * rs + dc * 16);
+      else w[r] = make_uint4(0, 0, 0, 0);
+    }
+    const uint32_t w0[4] = {w[0].x, w[0].y, w[0].z, w[0].w};
+    const uint32_t w1[4] = {w[1].x, w[1].y, w[1].z, w[1].w};
+    const uint32_t w2[4] = {w[2].x, w[2].y, w[2].z, w[2].w};
+    const uint32_t w3[4] = {w[3].x, w[3].y, w[3].z, w[3].w};
+    if constexpr (G::SZ == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int sh = (e & 1) * 16;
+        const uint32_t v0 = (w0[e >> 1] >> sh) & 0xffffu, v1 = (w1[e >> 1] >> sh) & 0xffffu;
+        const uint32_t v2 = (w2[e >> 1] >> sh) & 0xffffu, v3 = (w3[e >> 1] >> sh) & 0xffffu;
+        *reinterpret_cast<uint2*>(dst + ((8 * dc + e) * LP + 4 * kq) * 2) = make_uint2(v0 | (v1 << 16), v2 | (v3 << 16));
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<uint4*>(dst + ((4 * dc + e) * LP + 4 * kq) * 4) = make_uint4(w0[e], w1[e], w2[e], w3[e]);
+    }
+  }
+}
+
+// acc[2] (D[d][lane column]) += Xt-fragment . regs, where `v[16]` are this lane's 16 values of tile t
+// (element r <-> inner index 32t + (r&3) + 8(r>>2) + 4h) and Xt is a [64][LP] transposed image.
+template <typename T>
+__device__ __forceinline__ void mma_T(f32x16_t (&acc)[2], const char* xt, int LP, int t, int l31, int h, const float (&v)[16]) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      uint4 pc;
+      pc.x = pack_bf16x2(v[8 * u + 0], v[8 * u + 1]);
+      pc.y = pack_bf16x2(v[8 * u + 2], v[8 * u + 3]);
+      pc.z = pack_bf16x2(v[8 * u + 4], v[8 * u + 5]);
+      pc.w = pack_bf16x2(v[8 * u + 6], v[8 * u + 7]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const char* vp = xt + ((dt * 32 + l31) * LP + 32 * t + 16 * u + 4 * h) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
+        mma32(acc[dt], make_uint4(lo.x, lo.y, hi.x, hi.y), pc, T());
+      }
+    }
+  } else {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const uint4 pc = make_uint4(__float_as_uint(v[4 * qd + 0]), __float_as_uint(v[4 * qd + 1]),
+                                  __float_as_uint(v[4 * qd + 2]), __float_as_uint(v[4 * qd + 3]));
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const uint4 vf = *reinterpret_cast<const uint4*>(xt + ((dt * 32 + l31) * LP + 32 * t + 8 * qd + 4 * h) * 4);
+        mma32(acc[dt], vf, pc, T());
+      }
+    }
+  }
+}
+
+// one 32x32 tile: D[image row][lane's fragment]  (image rows 32t.., lane fragment `f`)
+template <typename T>
+__device__ __forceinline__ void tile_rows_x_frag(const char* img, const uint4 (&f)[Geo<T>::NS], int t, int l31, int h,
+                                                 f32x16_t& acc) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < Geo<T>::NS; ++s) mma32(acc, read_k<T>(img, 32 * t + l31, 2 * s + h), f[s], T());
+}
+
+template <typename T>
+__device__ __forceinline__ void load_frag_row(const void* base, int64_t row_elems_off, int h, uint4 (&f)[Geo<T>::NS]) {
+  const char* p = reinterpret_cast<const char*>(base) + row_elems_off * Geo<T>::SZ;
+#pragma unroll
+  for (int s = 0; s < Geo<T>::NS; ++s) f[s] = *reinterpret_cast<const uint4*>(p + (2 * s + h) * 16);
+}
+
+template <typename T>
+__device__ __forceinline__ float frag_dot(const uint4 (&a)[Geo<T>::NS], const uint4 (&b)[Geo<T>::NS]) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < Geo<T>::NS; ++i) {
+    float x[Elem<T>::kPerChunk], y[Elem<T>::kPerChunk];
+    unpack_chunk(a[i], x, T());
+    unpack_chunk(b[i], y, T());
+#pragma unroll
+    for (int e = 0; e < Elem<T>::kPerChunk; ++e) s += x[e] * y[e];
+  }
+  return s;
+}
+
+template <typename T> struct BwdSmemA {   // dQ kernel: K rm | V rm | K^T | key bias
+  int rows, LP, vOff, ktOff, kbOff, bytes;
+  __host__ __device__ explicit BwdSmemA(int ch) {
+    rows = 32 * ch; LP = rows + 4;
+    vOff = rows * Geo<T>::RB; ktOff = 2 * vOff; kbOff = ktOff + 64 * LP * Geo<T>::SZ; bytes = kbOff + rows * 4;
+  }
+};
+template <typename T> struct BwdSmemB {   // dKV kernel: Q rm | dO rm | Q^T | dO^T | lse | delta
+  int rows, LP, doOff, qtOff, dotOff, lseOff, dlOff, bytes;
+  __host__ __device__ explicit BwdSmemB(int ch) {
+    rows = 32 * ch; LP = rows + 4;
+    doOff = rows * Geo<T>::RB; qtOff = 2 * doOff; dotOff = qtOff + 64 * LP * Geo<T>::SZ;
+    lseOff = dotOff + 64 * LP * Geo<T>::SZ; dlOff = lseOff + rows * 4; bytes = dlOff + rows * 4;
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnBwdArgs a, int nt, int ch) {
+  using G = Geo<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const BwdSmemA<T> S(ch);
+  const AttnArgs& f = a.f;
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthreads >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int L = f.L;
+  constexpr bool kFast = IsFast<T>::value;
+  const int64_t rs = f.row_stride * G::SZ;
+  const int64_t hoff = ((int64_t)b * L * f.row_stride + head * 64) * G::SZ;
+  const char* kbase = reinterpret_cast<const char*>(f.k) + hoff;
+  const char* vbase = reinterpret_cast<const char*>(f.v) + hoff;
+
+  const int qb = blockIdx.z * nwaves + wave;          // this wave's query block
+  const int q = qb * 32 + l31;
+  const bool active = qb * 32 < L;
+  const int qc = q < L ? q : L - 1;
+  uint4 qf[G::NS], dof[G::NS];
+  float lse_q = 0.f, dq_delta = 0.f;
+  if (active) {
+    uint4 of[G::NS];
+    load_frag_row<T>(f.q, ((int64_t)b * L + qc) * f.row_stride + head * 64, h, qf);
+    load_frag_row<T>(a.dctx, ((int64_t)b * L + qc) * f.ctx_stride + head * 64, h, dof);
+    load_frag_row<T>(f.ctx, ((int64_t)b * L + qc) * f.ctx_stride + head * 64, h, of);
+    dq_delta = frag_dot<T>(dof, of);
+    dq_delta += __shfl_xor(dq_delta, 32, 64);
+    lse_q = f.lse[((int64_t)b * f.H + head) * L + qc];
+  }
+  f32x16_t acc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+
+  float* kb = reinterpret_cast<float*>(smem + S.kbOff);
+  for (int c0 = 0; c0 < nt; c0 += ch) {
+    const int cht = min(ch, nt - c0);
+    const int row0 = 32 * c0;
+    __syncthreads();   // previous chunk fully consumed
+    stage_rows_dma<T>(smem, kbase, rs, row0, 32 * cht, L, wave, nwaves, lane);
+    stage_rows_dma<T>(smem + S.vOff, vbase, rs, row0, 32 * cht, L, wave, nwaves, lane);
+    stage_rows_T<T>(smem + S.ktOff, kbase, rs, row0, 32 * cht, L, S.LP, tid, nthreads);
+    for (int key = tid; key < 32 * cht; key += nthreads) {
+      const int gk = row0 + key;
+      kb[key] = gk < L ? (f.key_bias ? f.key_bias[(int64_t)b * L + gk] : 0.f) : -INFINITY;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (active) {
+#pragma unroll 1
+      for (int t = 0; t < cht; ++t) {
+        float x[16];
+        score_tile<T>(smem, kb, qf, t, l31, h, f.scale, x);                 // S^T[key][q]
+        f32x16_t dp;
+        tile_rows_x_frag<T>(smem + S.vOff, dof, t, l31, h, dp);              // dP^T[key][q] = V . dO^T
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = kFast ? __expf(x[r] - lse_q) : expf(x[r] - lse_q);
+          x[r] = p * (dp[r] - dq_delta);                                      // dS^T
+        }
+        mma_T<T>(acc, smem + S.ktOff, S.LP, t, l31, h, x);                    // dQ^T[d][q] += K^T . dS
+      }
+    }
+  }
+  if (active && q < L) {
+    T* dqp = reinterpret_cast<T*>(a.dq) + ((int64_t)b * L + q) * f.row_stride + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[dt][4 * qd + e] * f.scale;
+        st4(dqp + dt * 32 + 8 * qd + 4 * h, v);
+      }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnBwdArgs a, int nt, int ch) {
+  using G = Geo<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const BwdSmemB<T> S(ch);
+  const AttnArgs& f = a.f;
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthreads >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int L = f.L;
+  constexpr bool kFast = IsFast<T>::value;
+  const int64_t rs = f.row_stride * G::SZ;
+  const int64_t cs = f.ctx_stride * G::SZ;
+  const int64_t hoff = ((int64_t)b * L * f.row_stride + head * 64) * G::SZ;
+  const int64_t coff = ((int64_t)b * L * f.ctx_stride + head * 64) * G::SZ;
+  const char* qbase = reinterpret_cast<const char*>(f.q) + hoff;
+  const char* dobase = reinterpret_cast<const char*>(a.dctx) + coff;
+  const char* obase = reinterpret_cast<const char*>(f.ctx) + coff;
+
+  const int kblk = blockIdx.z * nwaves + wave;        // this wave's key block
+  const int key = kblk * 32 + l31;
+  const bool active = kblk * 32 < L;
+  const int kc = key < L ? key : L - 1;
+  uint4 kf[G::NS], vf[G::NS];
+  float kbias = -INFINITY;
+  if (active) {
+    load_frag_row<T>(f.k, ((int64_t)b * L + kc) * f.row_stride + head * 64, h, kf);
+    load_frag_row<T>(f.v, ((int64_t)b * L + kc) * f.row_stride + head * 64, h, vf);
+    if (key < L) kbias = f.key_bias ? f.key_bias[(int64_t)b * L + key] : 0.f;
+  }
+  f32x16_t accv[2], acck[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accv[dt][r] = 0.f; acck[dt][r] = 0.f; }
+
+  float* lse_s = reinterpret_cast<float*>(smem + S.lseOff);
+  float* dl_s = reinterpret_cast<float*>(smem + S.dlOff);
+  for (int c0 = 0; c0 < nt; c0 += ch) {
+    const int cht = min(ch, nt - c0);
+    const int row0 = 32 * c0;
+    __syncthreads();
+    stage_rows_dma<T>(smem, qbase, rs, row0, 32 * cht, L, wave, nwaves, lane);
+    stage_rows_dma<T>(smem + S.doOff, dobase, cs, row0, 32 * cht, L, wave, nwaves, lane);
+    stage_rows_T<T>(smem + S.qtOff, qbase, rs, row0, 32 * cht, L, S.LP, tid, nthreads);
+    stage_rows_T<T>(smem + S.dotOff, dobase, cs, row0, 32 * cht, L, S.LP, tid, nthreads);
+    for (int r = tid; r < 32 * cht; r += nthreads) {
+      const int gq = row0 + r;
+      float l = INFINITY, d = 0.f;
+      if (gq < L) {
+        l = f.lse[((int64_t)b * f.H + head) * L + gq];
+        const char* po = obase + gq * cs;
+        const char* pd = dobase + gq * cs;
+#pragma unroll
+        for (int c = 0; c < G::CPR; ++c) {
+          float x[Elem<T>::kPerChunk], y[Elem<T>::kPerChunk];
+          unpack_chunk(*reinterpret_cast<const uint4*>(po + c * 16), x, T());
+          unpack_chunk(*reinterpret_cast<const uint4*>(pd + c * 16), y, T());
+#pragma unroll
+          for (int e = 0; e < Elem<T>::kPerChunk; ++e) d += x[e] * y[e];
+        }
+      }
+      lse_s[r] = l;
+      dl_s[r] = d;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (active) {
+#pragma unroll 1
+      for (int t = 0; t < cht; ++t) {
+        f32x16_t sacc, dp;
+        tile_rows_x_frag<T>(smem, kf, t, l31, h, sacc);                      // S[q][key]   = Q . K^T
+        tile_rows_x_frag<T>(smem + S.doOff, vf, t, l31, h, dp);              // dP[q][key]  = dO . V^T
+        float p[16], ds[16];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 32 * t + 8 * qd + 4 * h);
+          const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 32 * t + 8 * qd + 4 * h);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+          const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * qd + e;
+            const float x = fmaf(sacc[r], f.scale, kbias) - lv[e];
+            p[r] = kFast ? __expf(x) : expf(x);
+            ds[r] = p[r] * (dp[r] - dv[e]);
+          }
+        }
+        mma_T<T>(accv, smem + S.dotOff, S.LP, t, l31, h, p);                  // dV^T[d][key] += dO^T . P
+        mma_T<T>(acck, smem + S.qtOff, S.LP, t, l31, h, ds);                  // dK^T[d][key] += Q^T . dS
+      }
+    }
+  }
+  if (active && key < L) {
+    T* dkp = reinterpret_cast<T*>(a.dk) + ((int64_t)b * L + key) * f.row_stride + head * 64;
+    T* dvp = reinterpret_cast<T*>(a.dv) + ((int64_t)b * L + key) * f.row_stride + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float v[4], k[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = accv[dt][4 * qd + e]; k[e] = acck[dt][4 * qd + e] * f.scale; }
+        st4(dvp + dt * 32 + 8 * qd + 4 * h, v);
+        st4(dkp + dt * 32 + 8 * qd + 4 * h, k);
+      }
+  }
+}
+
+template <typename T>
+int launch_bwd(const AttnBwdArgs& a, hipStream_t stream) {
+  const int nt = (a.f.L + 31) / 32;
+  const int budget = 150 * 1024;
+  int chA = nt, chB = nt;
+  while (chA > 1 && BwdSmemA<T>(chA).bytes > budget) --chA;
+  while (chB > 1 && BwdSmemB<T>(chB).bytes > budget) --chB;
+  const int ldsA = BwdSmemA<T>(chA).bytes, ldsB = BwdSmemB<T>(chB).bytes;
+  static int maxA = 0, maxB = 0;
+  if (ldsA > maxA) {
+    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsA));
+    maxA = ldsA;
+  }
+  if (ldsB > maxB) {
+    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsB));
+    maxB = ldsB;
+  }
+  const int nw = nt < 8 ? nt : 8;
+  const int gz = (nt + nw - 1) / nw;
+  ProfScope ps(PROF_ATTN, 10.0 * a.f.B * a.f.H * (double)a.f.L * a.f.L * 64, stream);   // 5 L x L x 64 products
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(a.f.H, a.f.B, gz), dim3(nw * 64), ldsA, stream, a, nt, chA);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(a.f.H, a.f.B, gz), dim3(nw * 64), ldsB, stream, a, nt, chB);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+}  // namespace
+
+int attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream) {
+  const AttnArgs& f = a.f;
+  EZ_REQUIRE(f.B > 0 && f.L > 0 && f.H > 0, "attention_bwd: empty problem");
+  EZ_REQUIRE(f.q && f.k && f.v && f.ctx && f.lse && a.dctx && a.dq && a.dk && a.dv, "attention_bwd: null tensor");
+  const int esz = dtype_size(dtype);
+  EZ_REQUIRE((f.row_stride * esz) % 16 == 0 && (f.ctx_stride * esz) % 16 == 0, "attention_bwd: strides must be 16-byte multiples");
+  EZ_REQUIRE(f.B <= 65535, "attention_bwd: batch %d > 65535", f.B);
+  if (dtype == EZCLIP_F32) return launch_bwd<float>(a, stream);
+  if (dtype == EZCLIP_BF16) return launch_bwd<bf16_t>(a, stream);
+  set_error("attention_bwd: bad dtype %d", dtype);
+  return EZ_ERR_INVALID;
 }
 
 }  // namespace ezclip

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(GemmArgs p) {
   TO* C = reinterpret_cast<TO*>(p.C);
   TO* C2 = reinterpret_cast<TO*>(p.C2);
   const T* R = reinterpret_cast<const T*>(p.R);
+  const T* U = reinterpret_cast<const T*>(p.U);
   constexpr bool kFast = IsFast<TO>::value;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -138,7 +139,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(GemmArgs p) {
             v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
           }
           if (C2) st4(C2 + (int64_t)m * p.ldc + n, v);
-          if (p.act != ACT_NONE) {
+          if (U) {   // dX = (dY . W) * act'(u)
+            float uv[4];
+            ld4(U + (int64_t)m * p.ldu + n, uv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad<kFast>(uv[e], p.act);
+          } else if (p.act != ACT_NONE) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_apply<kFast>(v[e], p.act);
           }
@@ -156,7 +162,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(GemmArgs p) {
             float x = v[e];
             if (p.bias) x += p.bias[n + e];
             if (C2) Elem<TO>::st(C2 + (int64_t)m * p.ldc + n + e, x);
-            x = act_apply<kFast>(x, p.act);
+            if (U) x *= act_grad<kFast>(Elem<T>::ld(U + (int64_t)m * p.ldu + n + e), p.act);
+            else x = act_apply<kFast>(x, p.act);
             if (R) x += Elem<T>::ld(R + (int64_t)m * p.ldr + n + e);
             Elem<TO>::st(C + (int64_t)m * p.ldc + n + e, x);
           }
@@ -196,7 +203,8 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
   bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && ((uintptr_t)p.C % 16 == 0) &&
              (p.C2 == nullptr || (uintptr_t)p.C2 % 16 == 0) &&
              (p.bias == nullptr || (uintptr_t)p.bias % 16 == 0) &&
-             (p.R == nullptr || (p.ldr % 4 == 0 && (uintptr_t)p.R % 16 == 0));
+             (p.R == nullptr || (p.ldr % 4 == 0 && (uintptr_t)p.R % 16 == 0)) &&
+             (p.U == nullptr || (p.ldu % 4 == 0 && (uintptr_t)p.U % 16 == 0));
   (void)osz;
   p.vec_ok = vec ? 1 : 0;
   if (dtype == EZCLIP_F32) return launch_nt<float, float>(p, stream);
@@ -208,9 +216,222 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
   return EZ_ERR_INVALID;
 }
 
-int gemm_tn(GemmTNArgs, int, hipStream_t) {
-  set_error("gemm_tn: not implemented yet");
-  return EZ_ERR_UNSUPPORTED;
+// ---------------------------------------------------------------------------------
+// Weight-gradient GEMM:  C[N,K] (+)= A[M,N]^T . B[M,K]   (contraction over the rows)
+//
+// dW = dY^T X for every nn.Linear of the path (autograd of easynlp/core/trainer.py:658-661).
+// Both operands are row-major with the contraction index m as the *slow* dimension,
+// but the bf16 MFMA wants 8 consecutive contraction elements per lane.  bf16: each
+// thread pulls an 8(m) x 8(n) block with eight coalesced 16-byte loads, transposes it
+// in registers (32 byte-permutes) and writes eight 16-byte chunks into the same
+// swizzled [row][m] LDS image the NT kernel uses -- the inner loop is then identical.
+// f32: the 32x32x2 MFMA takes one element per lane, so the row-major tile is used as is.
+// The huge M is split across workgroups (f32 atomics into C: gradients accumulate anyway).
+namespace {
+
+constexpr int TN_BM_BF16 = 64;   // contraction rows per LDS tile (128 B of bf16 per image row)
+constexpr int TN_BM_F32 = 32;
+
+__device__ __forceinline__ void transpose8x8_bf16(const uint4 (&r)[8], uint4 (&o)[8]) {
+  const uint32_t* w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = reinterpret_cast<const uint32_t*>(&r[i]);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    uint32_t d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t lo = w[2 * j][c >> 1], hi = w[2 * j + 1][c >> 1];
+      d[j] = (c & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+    }
+    o[c] = make_uint4(d[0], d[1], d[2], d[3]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(GemmTNArgs p, int tiles_k, int ntiles, int rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A image 16K + B image 16K)
+  constexpr bool kBf16 = sizeof(T) == 2;
+  constexpr int BMc = kBf16 ? TN_BM_BF16 : TN_BM_F32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+  const int n0 = (tile / tiles_k) * BM;     // C rows  (columns of A)
+  const int k0 = (tile % tiles_k) * BN;     // C cols  (columns of B)
+  const int m_begin = split * rows_per_split;
+  const int m_end = min(p.M, m_begin + rows_per_split);
+  const int nsteps = (m_end - m_begin + BMc - 1) / BMc;
+
+  // staging role: threads 0..127 -> A, 128..255 -> B
+  const bool isB = tid >= 128;
+  const int st = tid & 127;
+  const T* g = reinterpret_cast<const T*>(isB ? p.B : p.A);
+  const int64_t ld = isB ? p.ldb : p.lda;
+  const int c0 = isB ? k0 : n0;
+  const int cmax = isB ? p.K : p.N;
+  uint4 regs[8];
+
+  auto load_tile = [&](int step) {
+    const int mt = m_begin + step * BMc;
+    if constexpr (kBf16) {
+      const int mb = st & 7, nb = st >> 3;           // 8 x 16 blocks of 8(m) x 8(cols)
+      const int col = c0 + nb * 8;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int m = mt + mb * 8 + r;
+        regs[r] = (m < m_end && col < cmax) ? *reinterpret_cast<const uint4*>(g + (int64_t)m * ld + col)
+                                            : make_uint4(0, 0, 0, 0);
+      }
+    } else {
+      // [32 m][128 cols] f32: 1024 float4 chunks, 8 per staging thread; chunk = r*128 + st
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int ch = r * 128 + st;
+        const int m = mt + (ch >> 5), col = c0 + (ch & 31) * 4;
+        regs[r] = (m < m_end && col < cmax) ? *reinterpret_cast<const uint4*>(g + (int64_t)m * ld + col)
+                                            : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_tile = [&](char* buf) {
+    char* img = buf + (isB ? kTileBytes : 0);
+    if constexpr (kBf16) {
+      const int mb = st & 7, nb = st >> 3;
+      uint4 o[8];
+      transpose8x8_bf16(regs, o);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int row = nb * 8 + c;
+        *reinterpret_cast<uint4*>(img + row * 128 + ((mb ^ ((row >> 1) & 7)) << 4)) = o[c];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(img + (r * 128 + st) * 16) = regs[r];
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nsteps > 0) {
+    load_tile(0);
+    store_tile(smem);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    char* cur = smem + (s & 1) * 2 * kTileBytes;
+    char* nxt = smem + ((s + 1) & 1) * 2 * kTileBytes;
+    if (s + 1 < nsteps) load_tile(s + 1);          // global loads fly during the MFMAs
+    const char* tA = cur;
+    const char* tB = cur + kTileBytes;
+    if constexpr (kBf16) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = 2 * ks + h;
+        uint4 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = read_frag(tA, wm * 64 + i * 32 + l31, c);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = read_frag(tB, wn * 64 + j * 32 + l31, c);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma32(acc[i][j], b[j], a[i], T());
+      }
+    } else {
+      const float* fA = reinterpret_cast<const float*>(tA);
+      const float* fB = reinterpret_cast<const float*>(tB);
+#pragma unroll 4
+      for (int kk = 0; kk < 16; ++kk) {
+        const int m = 2 * kk + h;
+        float a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = fA[m * 128 + wm * 64 + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = fB[m * 128 + wn * 64 + j * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nsteps) store_tile(nxt);
+    __syncthreads();
+  }
+
+  // lane owns C row n, 4 consecutive k per (j, q)
+  const bool atomic = gridDim.x > (unsigned)ntiles;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = n0 + wm * 64 + i * 32 + l31;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + wn * 64 + j * 32 + q * 8 + h * 4;
+        float* c = p.C + (int64_t)n * p.ldc + k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (k + e >= p.K) break;
+          const float v = acc[i][j][q * 4 + e];
+          if (atomic) atomicAdd(c + e, v);
+          else c[e] = (p.accumulate ? c[e] : 0.f) + v;
+        }
+      }
+  }
+}
+
+template <typename T>
+int launch_tn(const GemmTNArgs& p, hipStream_t stream) {
+  const int tiles_n = (p.N + BM - 1) / BM, tiles_k = (p.K + BN - 1) / BN;
+  const int ntiles = tiles_n * tiles_k;
+  constexpr int BMc = sizeof(T) == 2 ? TN_BM_BF16 : TN_BM_F32;
+  // enough workgroups to fill 256 CUs x 2, but at least 8 contraction tiles each
+  int splits = (1024 + ntiles - 1) / ntiles;
+  const int max_splits = (p.M + 8 * BMc - 1) / (8 * BMc);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rows = (p.M + splits - 1) / splits;
+  rows = (rows + BMc - 1) / BMc * BMc;
+  splits = (p.M + rows - 1) / rows;
+  const size_t lds = 4 * kTileBytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  if (splits > 1 && !p.accumulate) EZ_HIP(hipMemset2DAsync(p.C, p.ldc * 4, 0, (size_t)p.K * 4, p.N, stream));
+  {
+    ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);
+    hipLaunchKernelGGL((gemm_tn_kernel<T>), dim3(ntiles * splits), dim3(kThreads), lds, stream, p, tiles_k, ntiles, rows);
+  }
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+}  // namespace
+
+int gemm_tn(GemmTNArgs p, int dtype, hipStream_t stream) {
+  EZ_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm_tn: empty problem");
+  const int esz = dtype_size(dtype);
+  const int g = 16 / esz;
+  EZ_REQUIRE(p.N % g == 0 && p.K % g == 0 && p.lda % g == 0 && p.ldb % g == 0, "gemm_tn: N, K, lda, ldb must be multiples of %d", g);
+  EZ_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0, "gemm_tn: A/B must be 16-byte aligned");
+  if (dtype == EZCLIP_F32) return launch_tn<float>(p, stream);
+  if (dtype == EZCLIP_BF16) return launch_tn<bf16_t>(p, stream);
+  set_error("gemm_tn: bad dtype %d", dtype);
+  return EZ_ERR_INVALID;
 }
 
 }  // namespace ezclip

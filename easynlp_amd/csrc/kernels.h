@@ -19,6 +19,7 @@ struct GemmArgs {
   void* C2 = nullptr;                         // optional second output: value before act/residual (ldc)
   const float* bias = nullptr;                // [N] f32
   const void* R = nullptr; int64_t ldr = 0;   // optional residual [M, N], dtype T
+  const void* U = nullptr; int64_t ldu = 0;   // optional pre-activation [M, N] (T): result *= act'(U) (backward)
   const float* scale_log = nullptr;           // optional device scalar s: acc *= exp(s)
   float alpha = 1.0f;                         // acc *= alpha
   int M = 0, N = 0, K = 0;
@@ -97,6 +98,15 @@ int l2_normalize_fwd(const float* x, float* out, float* inv_norm, int B, int E, 
 // dx = (dy - y * <dy, y>) * inv_norm
 int l2_normalize_bwd(const float* y, const float* dy, const float* inv_norm, float* dx, int B, int E,
                      hipStream_t stream);
+
+// backward helpers
+int colsum_add(const void* x, int64_t ld, int rows, int cols, float* out, int dtype, hipStream_t stream);      // out[c] += sum_r x[r][c]
+// out[t][c] += sum_b x[b][t][c] for t < t_count (x is [B, Tn, W])
+int batch_sum_add(const void* x, int B, int Tn, int t_count, int W, float* out, int dtype, hipStream_t stream);
+int vit_gather_patch_rows(const void* dx0, void* dpemb, int B, int Lv, int W, int dtype, hipStream_t stream);
+int bert_word_grad(const int64_t* ids, const void* dx0, float* dword, int64_t rows, int Hd, int vocab, int dtype,
+                   hipStream_t stream);
+int add_inplace_f32(float* dst, const float* src, int64_t n, hipStream_t stream);
 
 // ---- InfoNCE (loss.hip) -----------------------------------------------------------
 // Row-wise cross entropy against the diagonal: for local row i (global column diag0 + i):

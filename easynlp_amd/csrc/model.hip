@@ -255,8 +255,8 @@ struct ImgWS {
   void* cls_ln;
   float *mpost, *rpost, *feat, *emb, *inv_norm;
   // backward scratch
-  void *gx, *gx2, *gqkv, *gbig, *gtmp;
-  float *gfeat, *gcls;
+  void *gx, *gx2, *gqkv, *gbig, *gtmp, *gfeatT, *gcls;
+  float *gfeat;
 };
 
 size_t layout_image(const ezclip_model* m, int B, bool save, void* base, ImgWS* ws) {
@@ -312,9 +312,10 @@ size_t layout_image(const ezclip_model* m, int B, bool save, void* base, ImgWS* 
     w.gqkv = a.take(M * 3 * W * esz);
     w.gbig = a.take(M * 4 * W * esz);
     w.gfeat = a.takef((size_t)B * E);
-    w.gcls = a.takef((size_t)B * W);
+    w.gfeatT = a.take((size_t)B * E * esz);
+    w.gcls = a.take((size_t)B * W * esz);
   } else {
-    w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = nullptr; w.gfeat = w.gcls = nullptr;
+    w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = w.gfeatT = w.gcls = nullptr; w.gfeat = nullptr;
   }
   if (ws) *ws = w;
   return a.off + 256;
@@ -329,7 +330,7 @@ struct TxtWS {
   float *m0, *r0, *key_bias;
   std::vector<BertBufs> layers;
   float *feat, *emb, *inv_norm;
-  void *gx, *gx2, *gtmp, *gqkv, *gbig;
+  void *gx, *gx2, *gtmp, *gqkv, *gbig, *gfeatT;
   float *gfeat;
 };
 
@@ -384,8 +385,9 @@ size_t layout_text(const ezclip_model* m, int B, int L, bool save, void* base, T
     w.gqkv = a.take(M * 3 * H * esz);
     w.gbig = a.take(M * F * esz);
     w.gfeat = a.takef((size_t)B * E);
+    w.gfeatT = a.take((size_t)B * E * esz);
   } else {
-    w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = nullptr; w.gfeat = nullptr;
+    w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = w.gfeatT = nullptr; w.gfeat = nullptr;
   }
   if (ws) *ws = w;
   return a.off + 256;
@@ -499,13 +501,182 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
   return EZ_OK;
 }
 
-int backward_image(ezclip_model*, const float*, int, const float*, void*, size_t, hipStream_t) {
-  set_error("ezclip_backward_image: not implemented yet");
-  return EZ_ERR_UNSUPPORTED;
+// ------------------------------------------------------------- backward ----
+// dX[M, w.K] = (dY[M, w.N] . W) [* act'(U)] [+ R]      (NT GEMM against the packed W^T copy)
+static int dgrad(const ezclip_model* m, const void* dY, int64_t ldy, const ezclip_model::Weight& w, void* dX,
+                 int64_t ldx, int M, const void* U, int64_t ldu, int act, const void* R, int64_t ldr,
+                 hipStream_t stream) {
+  EZ_REQUIRE(w.st != nullptr, "backward needs ezclip_set_shadow(..., with_backward=1)");
+  GemmArgs g;
+  g.A = dY; g.lda = ldy;
+  g.B = w.st; g.ldb = w.ldn;
+  g.C = dX; g.ldc = ldx;
+  g.M = M; g.N = w.K; g.K = w.N;
+  g.U = U; g.ldu = ldu; g.act = act;
+  g.R = R; g.ldr = ldr;
+  return gemm_nt(g, m->dtype, stream);
 }
-int backward_text(ezclip_model*, const int64_t*, int, int, const float*, void*, size_t, hipStream_t) {
-  set_error("ezclip_backward_text: not implemented yet");
-  return EZ_ERR_UNSUPPORTED;
+
+// grad(W) += dY^T . X  (W is [N, K]);  for [K, N]-stored projections: grad += X^T . dY
+static int wgrad(const ezclip_model* m, const void* dY, int64_t ldy, const void* X, int64_t ldx,
+                 const ezclip_model::Weight& w, int M, hipStream_t stream) {
+  float* G = m->Gp(w.p);
+  if (G == nullptr) return EZ_OK;
+  GemmTNArgs g;
+  g.M = M; g.accumulate = 1; g.C = G;
+  if (!w.transposed_src) { g.A = dY; g.lda = ldy; g.B = X; g.ldb = ldx; g.N = w.N; g.K = w.K; g.ldc = w.K; }
+  else { g.A = X; g.lda = ldx; g.B = dY; g.ldb = ldy; g.N = w.K; g.K = w.N; g.ldc = w.N; }
+  return gemm_tn(g, m->dtype, stream);
+}
+
+static int bgrad(const ezclip_model* m, const void* dY, int64_t ldy, int M, int N, int bias_p, hipStream_t stream) {
+  float* G = m->Gp(bias_p);
+  if (G == nullptr) return EZ_OK;
+  return colsum_add(dY, ldy, M, N, G, m->dtype, stream);
+}
+
+static int ln_bwd(const ezclip_model* m, const void* x, int64_t xs, const void* dy, int64_t dys, int gamma_p, int beta_p,
+                  const float* mean, const float* rstd, void* dx, int64_t dxs, const void* dres, int64_t drs, int rows,
+                  int D, hipStream_t stream) {
+  return layernorm_bwd(x, xs, dy, dys, m->P(gamma_p), mean, rstd, dx, dxs, dres, drs, m->Gp(gamma_p), m->Gp(beta_p), rows,
+                       D, m->dtype, stream);
+}
+
+int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_emb, void* wsp, size_t ws_bytes,
+                   hipStream_t stream) {
+  EZ_REQUIRE(B > 0 && d_emb && wsp, "backward_image: null/empty argument");
+  EZ_REQUIRE(m->weights_fresh && m->shadow_backward, "backward_image: weights not packed for backward");
+  EZ_REQUIRE(m->Kpad == m->Kpatch, "backward_image: patch size %d (K=%d not a tile multiple) not supported in backward yet",
+             m->cfg.vision_patch_size, m->Kpatch);
+  ImgWS ws;
+  const size_t need = layout_image(m, B, true, wsp, &ws);
+  EZ_REQUIRE(ws_bytes >= need, "backward_image: workspace too small (%zu < %zu): was the forward run with save_for_backward?", ws_bytes, need);
+  const int W = m->cfg.vision_width, E = m->cfg.embed_dim, Lv = m->Lv;
+  const int Mp = B * (Lv - 1), M = B * Lv;
+  const int dt = m->dtype;
+  const size_t esz = dtype_size(dt);
+  (void)pixels;
+
+  // emb = feat / ||feat||  ->  d feat                                   modeling_chineseclip.py:360
+  EZ_TRY(l2_normalize_bwd(ws.emb, d_emb, ws.inv_norm, ws.gfeat, B, E, stream));
+  const void* gfeatT = ws.gfeat;
+  if (dt != EZCLIP_F32) { EZ_TRY(cast_from_f32(ws.gfeat, ws.gfeatT, (int64_t)B * E, dt, stream)); gfeatT = ws.gfeatT; }
+  // feat = ln_post(x[:,0]) @ proj                                         :248-251
+  EZ_TRY(dgrad(m, gfeatT, E, m->vproj_w, ws.gcls, W, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
+  EZ_TRY(wgrad(m, gfeatT, E, ws.cls_ln, W, m->vproj_w, B, stream));
+  EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * W * esz, stream));
+  const void* xl = ws.layers[m->cfg.vision_layers - 1].x_out;
+  EZ_TRY(ln_bwd(m, xl, (int64_t)Lv * W, ws.gcls, W, m->lnpost_w, m->lnpost_b, ws.mpost, ws.rpost, ws.gx, (int64_t)Lv * W,
+                nullptr, 0, B, W, stream));
+  for (int i = m->cfg.vision_layers - 1; i >= 0; --i) {
+    const auto& Lw = m->vit[i];
+    const VitBufs& b = ws.layers[i];
+    // x_out = x_mid + c_proj(h);  h = QuickGELU(u);  u = c_fc(ln_2(x_mid))        :204
+    EZ_TRY(dgrad(m, ws.gx, W, Lw.proj_w, ws.gbig, 4 * W, M, b.u, 4 * W, ACT_QUICKGELU, nullptr, 0, stream));   // d u
+    EZ_TRY(wgrad(m, ws.gx, W, b.h, 4 * W, Lw.proj_w, M, stream));
+    EZ_TRY(bgrad(m, ws.gx, W, M, W, Lw.proj_b, stream));
+    EZ_TRY(dgrad(m, ws.gbig, 4 * W, Lw.fc_w, ws.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));      // d ln_2
+    EZ_TRY(wgrad(m, ws.gbig, 4 * W, b.ln2, W, Lw.fc_w, M, stream));
+    EZ_TRY(bgrad(m, ws.gbig, 4 * W, M, 4 * W, Lw.fc_b, stream));
+    EZ_TRY(ln_bwd(m, b.x_mid, W, ws.gtmp, W, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, W, ws.gx, W, M, W, stream));   // d x_mid
+    // x_mid = x_in + out_proj(attn(in_proj(ln_1(x_in))))                           :203
+    EZ_TRY(dgrad(m, ws.gx2, W, Lw.out_w, ws.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));          // d ctx
+    EZ_TRY(wgrad(m, ws.gx2, W, b.ctx, W, Lw.out_w, M, stream));
+    EZ_TRY(bgrad(m, ws.gx2, W, M, W, Lw.out_b, stream));
+    AttnBwdArgs ab;
+    ab.f.q = b.qkv;
+    ab.f.k = (const char*)b.qkv + (size_t)W * esz;
+    ab.f.v = (const char*)b.qkv + (size_t)2 * W * esz;
+    ab.f.row_stride = 3 * W;
+    ab.f.ctx = b.ctx; ab.f.ctx_stride = W; ab.f.key_bias = nullptr; ab.f.lse = b.lse;
+    ab.f.B = B; ab.f.L = Lv; ab.f.H = m->vheads; ab.f.scale = 0.125f;
+    ab.dctx = ws.gtmp;
+    ab.dq = ws.gqkv;
+    ab.dk = (char*)ws.gqkv + (size_t)W * esz;
+    ab.dv = (char*)ws.gqkv + (size_t)2 * W * esz;
+    EZ_TRY(attention_bwd(ab, dt, stream));
+    EZ_TRY(dgrad(m, ws.gqkv, 3 * W, Lw.in_w, ws.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));      // d ln_1
+    EZ_TRY(wgrad(m, ws.gqkv, 3 * W, b.ln1, W, Lw.in_w, M, stream));
+    EZ_TRY(bgrad(m, ws.gqkv, 3 * W, M, 3 * W, Lw.in_b, stream));
+    EZ_TRY(ln_bwd(m, b.x_in, W, ws.gtmp, W, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx, W, ws.gx2, W, M, W, stream));    // d x_in
+  }
+  // x = ln_pre(cat(cls, conv(patches)) + pos)                                          :237-242
+  EZ_TRY(ln_bwd(m, ws.x0, W, ws.gx, W, m->lnpre_w, m->lnpre_b, ws.m0, ws.r0, ws.gx2, W, nullptr, 0, M, W, stream));
+  if (m->Gp(m->pos_p)) EZ_TRY(batch_sum_add(ws.gx2, B, Lv, Lv, W, m->Gp(m->pos_p), dt, stream));
+  if (m->Gp(m->cls_p)) EZ_TRY(batch_sum_add(ws.gx2, B, Lv, 1, W, m->Gp(m->cls_p), dt, stream));
+  if (m->Gp(m->conv_w.p)) {
+    EZ_TRY(vit_gather_patch_rows(ws.gx2, ws.gtmp, B, Lv, W, dt, stream));
+    GemmTNArgs g;
+    g.A = ws.gtmp; g.lda = W; g.B = ws.patches; g.ldb = m->Kpad; g.C = m->Gp(m->conv_w.p); g.ldc = m->Kpatch;
+    g.M = Mp; g.N = W; g.K = m->Kpatch; g.accumulate = 1;
+    EZ_TRY(gemm_tn(g, dt, stream));
+  }
+  return EZ_OK;
+}
+
+int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float* d_emb, void* wsp, size_t ws_bytes,
+                  hipStream_t stream) {
+  EZ_REQUIRE(B > 0 && L > 0 && ids && d_emb && wsp, "backward_text: null/empty argument");
+  EZ_REQUIRE(m->weights_fresh && m->shadow_backward, "backward_text: weights not packed for backward");
+  TxtWS ws;
+  const size_t need = layout_text(m, B, L, true, wsp, &ws);
+  EZ_REQUIRE(ws_bytes >= need, "backward_text: workspace too small (%zu < %zu): was the forward run with save_for_backward?", ws_bytes, need);
+  const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, E = m->cfg.embed_dim;
+  const int M = B * L;
+  const int dt = m->dtype;
+  const size_t esz = dtype_size(dt);
+
+  EZ_TRY(l2_normalize_bwd(ws.emb, d_emb, ws.inv_norm, ws.gfeat, B, E, stream));                     // chineseclip:363
+  const void* gfeatT = ws.gfeat;
+  if (dt != EZCLIP_F32) { EZ_TRY(cast_from_f32(ws.gfeat, ws.gfeatT, (int64_t)B * E, dt, stream)); gfeatT = ws.gfeatT; }
+  // feat = x[:, 0, :] @ text_projection                                                               :349-350
+  const void* xl = ws.layers[m->cfg.text_num_hidden_layers - 1].x_out;
+  EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * H * esz, stream));
+  EZ_TRY(dgrad(m, gfeatT, E, m->tproj_w, ws.gx, (int64_t)L * H, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
+  EZ_TRY(wgrad(m, gfeatT, E, xl, (int64_t)L * H, m->tproj_w, B, stream));
+  for (int i = m->cfg.text_num_hidden_layers - 1; i >= 0; --i) {
+    const auto& Lw = m->bert[i];
+    const BertBufs& b = ws.layers[i];
+    // x_out = LN(z);  z = dense(hh) + a;  hh = gelu(u);  u = dense(a)        modeling_bert.py:330-345
+    EZ_TRY(ln_bwd(m, b.z, H, ws.gx, H, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, H, nullptr, 0, M, H, stream));       // d z
+    EZ_TRY(dgrad(m, ws.gx2, H, Lw.d_w, ws.gbig, F, M, b.u, F, ACT_GELU_ERF, nullptr, 0, stream));                     // d u
+    EZ_TRY(wgrad(m, ws.gx2, H, b.hh, F, Lw.d_w, M, stream));
+    EZ_TRY(bgrad(m, ws.gx2, H, M, H, Lw.d_b, stream));
+    EZ_TRY(dgrad(m, ws.gbig, F, Lw.i_w, ws.gtmp, H, M, nullptr, 0, ACT_NONE, ws.gx2, H, stream));                     // d a = d z + d u W_i
+    EZ_TRY(wgrad(m, ws.gbig, F, b.a, H, Lw.i_w, M, stream));
+    EZ_TRY(bgrad(m, ws.gbig, F, M, F, Lw.i_b, stream));
+    // a = LN(y);  y = dense(ctx) + x_in                                           :264-267
+    EZ_TRY(ln_bwd(m, b.y, H, ws.gtmp, H, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx2, H, nullptr, 0, M, H, stream));      // d y
+    EZ_TRY(dgrad(m, ws.gx2, H, Lw.o_w, ws.gtmp, H, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));                     // d ctx
+    EZ_TRY(wgrad(m, ws.gx2, H, b.ctx, H, Lw.o_w, M, stream));
+    EZ_TRY(bgrad(m, ws.gx2, H, M, H, Lw.o_b, stream));
+    char* qkv = (char*)b.qkv;
+    char* gq = (char*)ws.gqkv;
+    AttnBwdArgs ab;
+    ab.f.q = qkv; ab.f.k = qkv + H * esz; ab.f.v = qkv + 2 * H * esz;
+    ab.f.row_stride = 3 * H;
+    ab.f.ctx = b.ctx; ab.f.ctx_stride = H; ab.f.key_bias = ws.key_bias; ab.f.lse = b.lse;
+    ab.f.B = B; ab.f.L = L; ab.f.H = m->theads; ab.f.scale = 0.125f;
+    ab.dctx = ws.gtmp;
+    ab.dq = gq; ab.dk = gq + H * esz; ab.dv = gq + 2 * H * esz;
+    EZ_TRY(attention_bwd(ab, dt, stream));                                                                           // :210-248
+    // d x_in = d y + d q W_q + d k W_k + d v W_v                                  :172-200
+    EZ_TRY(dgrad(m, gq, 3 * H, Lw.q_w, ws.gx, H, M, nullptr, 0, ACT_NONE, ws.gx2, H, stream));
+    EZ_TRY(dgrad(m, gq + H * esz, 3 * H, Lw.k_w, ws.gx, H, M, nullptr, 0, ACT_NONE, ws.gx, H, stream));
+    EZ_TRY(dgrad(m, gq + 2 * H * esz, 3 * H, Lw.v_w, ws.gx, H, M, nullptr, 0, ACT_NONE, ws.gx, H, stream));
+    EZ_TRY(wgrad(m, gq, 3 * H, b.x_in, H, Lw.q_w, M, stream));
+    EZ_TRY(wgrad(m, gq + H * esz, 3 * H, b.x_in, H, Lw.k_w, M, stream));
+    EZ_TRY(wgrad(m, gq + 2 * H * esz, 3 * H, b.x_in, H, Lw.v_w, M, stream));
+    EZ_TRY(bgrad(m, gq, 3 * H, M, H, Lw.q_b, stream));
+    EZ_TRY(bgrad(m, gq + H * esz, 3 * H, M, H, Lw.k_b, stream));
+    EZ_TRY(bgrad(m, gq + 2 * H * esz, 3 * H, M, H, Lw.v_b, stream));
+  }
+  // embeddings: LN(word[ids] + type[0] + pos[t])                                modeling_bert.py:117-127
+  EZ_TRY(ln_bwd(m, ws.x0, H, ws.gx, H, m->eln_w, m->eln_b, ws.m0, ws.r0, ws.gx2, H, nullptr, 0, M, H, stream));
+  if (m->Gp(m->word_p)) EZ_TRY(bert_word_grad(ids, ws.gx2, m->Gp(m->word_p), M, H, m->cfg.vocab_size, dt, stream));
+  if (m->Gp(m->tpos_p)) EZ_TRY(batch_sum_add(ws.gx2, B, L, L, H, m->Gp(m->tpos_p), dt, stream));
+  if (m->Gp(m->type_p)) EZ_TRY(colsum_add(ws.gx2, H, M, H, m->Gp(m->type_p), dt, stream));
+  return EZ_OK;
 }
 
 }  // namespace ezclip

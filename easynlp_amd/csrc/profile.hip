@@ -32,12 +32,12 @@ ProfScope::ProfScope(int cls, double work, hipStream_t stream) : stream_(stream)
   Rec r;
   r.a = g.next(); r.b = g.next(); r.cls = cls; r.work = work;
   if (!r.a || !r.b) return;
-  hipEventRecord(r.a, stream);
+  (void)hipEventRecord(r.a, stream);
   g.recs.push_back(r);
   idx_ = (int)g.recs.size() - 1;
 }
 ProfScope::~ProfScope() {
-  if (idx_ >= 0) hipEventRecord(g.recs[idx_].b, stream_);
+  if (idx_ >= 0) (void)hipEventRecord(g.recs[idx_].b, stream_);
 }
 
 int profile_begin() {

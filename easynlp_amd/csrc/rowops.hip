@@ -338,6 +338,88 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* y, const f
   }
 }
 
+
+// out[c] += sum_r x[r][c]  (bias gradients).  Block = 4 waves x 256 columns (4 per lane); each wave strides
+// the block's row range, LDS-combined, one atomic per column per block.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t ld, int rows, int cols, int rows_per_block,
+                                                      float* out) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < cols) {
+    for (int r = r0 + w; r < r1; r += 4) {
+      float v[4];
+      ld4(x + (int64_t)r * ld + c, v);
+      a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[w][lane * 4 + e] = a[e];
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < cols) atomicAdd(out + cc, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+// out[t][c] += sum_b x[(b*T + t)*W + c]   (positional-embedding gradients; fixed order over b)
+template <typename T>
+__global__ __launch_bounds__(256) void batch_sum_kernel(const T* x, int B, int Tn, int W, float* out) {
+  const int t = blockIdx.x;
+  const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (c >= W) return;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; ++b) {
+    float v[4];
+    ld4(x + ((int64_t)b * Tn + t) * W + c, v);
+    a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+  }
+  float* o = out + (int64_t)t * W + c;
+  o[0] += a[0]; o[1] += a[1]; o[2] += a[2]; o[3] += a[3];
+}
+
+// compact the patch rows of d_x0 [B, Lv, W] into d_pemb [B*(Lv-1), W]
+template <typename T>
+__global__ void vit_gather_patch_rows_kernel(const T* dx0, T* dpemb, int B, int Lv, int W) {
+  const int64_t n4 = (int64_t)B * (Lv - 1) * (W / 4);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / (W / 4);
+    const int c = (int)(i % (W / 4)) * 4;
+    const int64_t b = row / (Lv - 1), p = row % (Lv - 1);
+    float v[4];
+    ld4(dx0 + ((b * Lv) + 1 + p) * W + c, v);
+    st4(dpemb + row * W + c, v);
+  }
+}
+
+// word-embedding gradient: dword[ids[r]] += dx0[r]; rows with id == padding_idx (0) get no gradient
+// (nn.Embedding(padding_idx=0), bert/modeling_bert.py:77)
+template <typename T>
+__global__ __launch_bounds__(256) void bert_word_grad_kernel(const int64_t* ids, const T* dx0, float* dword, int64_t rows,
+                                                              int Hd, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t id = ids[row];
+  if (id <= 0 || id >= vocab) return;
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int col = (lane + c * 64) * 4;
+    if (col < Hd) {
+      float v[4];
+      ld4(dx0 + row * Hd + col, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(dword + id * Hd + col + e, v[e]);
+    }
+  }
+}
+
+__global__ void add_inplace_kernel(float* dst, const float* src, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
 inline int grid_for(int64_t work, int block) {
   int64_t g = (work + block - 1) / block;
   const int64_t cap = 256 * 8;
@@ -463,6 +545,51 @@ int l2_normalize_bwd(const float* y, const float* dy, const float* inv_norm, flo
   EZ_REQUIRE(E % 4 == 0 && E <= 256 * kMaxChunks, "l2_normalize: E=%d unsupported", E);
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((B + kRowsPerBlock - 1) / kRowsPerBlock), dim3(256), 0, stream, y, dy,
                      inv_norm, dx, B, E);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int colsum_add(const void* x, int64_t ld, int rows, int cols, float* out, int dtype, hipStream_t stream) {
+  EZ_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0, "colsum_add: cols/ld must be multiples of 4");
+  const int bx = (cols + 255) / 256;
+  int by = (1024 + bx - 1) / bx;
+  if (by > (rows + 63) / 64) by = (rows + 63) / 64;
+  if (by < 1) by = 1;
+  const int rpb = (rows + by - 1) / by;
+  by = (rows + rpb - 1) / rpb;
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(bx, by), dim3(256), 0, stream, (const T*)x, ld, rows,
+                                          cols, rpb, out));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int batch_sum_add(const void* x, int B, int Tn, int t_count, int W, float* out, int dtype, hipStream_t stream) {
+  EZ_REQUIRE(B > 0 && Tn > 0 && t_count > 0 && t_count <= Tn && W % 4 == 0, "batch_sum_add: bad shape");
+  dim3 grid(t_count, (W / 4 + 255) / 256);
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((batch_sum_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, B, Tn, W, out));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int vit_gather_patch_rows(const void* dx0, void* dpemb, int B, int Lv, int W, int dtype, hipStream_t stream) {
+  const int64_t n4 = (int64_t)B * (Lv - 1) * (W / 4);
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((vit_gather_patch_rows_kernel<T>), dim3(grid_for(n4, 256)), dim3(256), 0, stream,
+                                          (const T*)dx0, (T*)dpemb, B, Lv, W));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int bert_word_grad(const int64_t* ids, const void* dx0, float* dword, int64_t rows, int Hd, int vocab, int dtype,
+                   hipStream_t stream) {
+  const int blocks = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((bert_word_grad_kernel<T>), dim3(blocks), dim3(256), 0, stream, ids,
+                                          (const T*)dx0, dword, rows, Hd, vocab));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int add_inplace_f32(float* dst, const float* src, int64_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, dst, src, n);
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

@@ -214,7 +214,8 @@ def test_infonce_fused_shard(n, N, off, e):
     dT = torch.empty(N, e, device=DEV)
     dI = torch.empty(N, e, device=DEV)
     dls = torch.empty((), device=DEV)
-    L.check(lib.ezclip_infonce_fused(t.to(DEV).data_ptr(), i.to(DEV).data_ptr(), n, N, off, e, ls.to(DEV).data_ptr(),
+    tg, ig, lsg = t.to(DEV), i.to(DEV), ls.to(DEV)   # keep the device copies alive across the call
+    L.check(lib.ezclip_infonce_fused(tg.data_ptr(), ig.data_ptr(), n, N, off, e, lsg.data_ptr(),
                                      1.0, loss.data_ptr(), dT.data_ptr(), dI.data_ptr(), dls.data_ptr(),
                                      ws.data_ptr(), ws.numel(), L.stream_ptr()))
     torch.cuda.synchronize()
@@ -222,3 +223,97 @@ def test_infonce_fused_shard(n, N, off, e):
     assert max_err(dT, td.grad) < 1e-5
     assert max_err(dI, idd.grad) < 1e-5
     assert abs(dls.item() - lsd.grad.item()) < 1e-4 * max(1, abs(lsd.grad.item()))
+
+
+# ----------------------------------------------------------------------------- backward ops
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 768, 768), (197 * 3, 2304, 768), (130, 136, 264), (8, 64, 512),
+                                   (5000, 128, 512)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gemm_tn(M, N, K, dtype):
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, N, generator=g)
+    b = torch.randn(M, K, generator=g)
+    if dtype == "bf16":
+        a, b = a.bfloat16(), b.bfloat16()
+    c0 = torch.randn(N, K, generator=g)
+    ref = c0.double() + a.double().t() @ b.double()
+    ad, bd, cd = a.to(DEV), b.to(DEV), c0.to(DEV)
+    dt = L.DTYPE_BF16 if dtype == "bf16" else L.DTYPE_F32
+    L.check(lib.ezclip_op_gemm_tn(ad.data_ptr(), N, bd.data_ptr(), K, cd.data_ptr(), K, M, N, K, 1, dt, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert max_err(cd, ref) < (3e-5 if dtype == "f32" else 2e-3) * math.sqrt(M) * 3
+    assert rel_err(cd, ref) < (2e-6 if dtype == "f32" else 1e-3)
+    # overwrite mode
+    c1 = torch.full((N, K), 7.0, device=DEV)
+    L.check(lib.ezclip_op_gemm_tn(ad.data_ptr(), N, bd.data_ptr(), K, c1.data_ptr(), K, M, N, K, 0, dt, L.stream_ptr()))
+    assert rel_err(c1, a.double().t() @ b.double()) < (2e-6 if dtype == "f32" else 1e-3)
+
+
+@pytest.mark.parametrize("rows,D", [(7, 128), (394, 768), (4096, 768)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_layernorm_bwd(rows, D, dtype):
+    lib = L.load()
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, D, generator=g) * 1.7 + 0.2
+    dy = torch.randn(rows, D, generator=g)
+    w = 1 + 0.1 * torch.randn(D, generator=g)
+    b = 0.1 * torch.randn(D, generator=g)
+    if dtype == "bf16":
+        x, dy = x.bfloat16(), dy.bfloat16()
+    xd = x.double().requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    O.layer_norm(xd, wd, bd, 1e-5).backward(dy.double())
+    xg, dyg = x.to(DEV), dy.to(DEV)
+    y, mean, rstd = L.op_layernorm(xg, w.to(DEV), b.to(DEV), 1e-5, want_stats=True)
+    dx = torch.empty_like(xg)
+    dg = torch.zeros(D, device=DEV)
+    db = torch.zeros(D, device=DEV)
+    dt = L.DTYPE_BF16 if dtype == "bf16" else L.DTYPE_F32
+    wg = w.to(DEV)
+    L.check(lib.ezclip_op_layernorm_bwd(xg.data_ptr(), dyg.data_ptr(), wg.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                        dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, D, dt, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert max_err(dx.float(), xd.grad) < (2e-5 if dtype == "f32" else 0.03)
+    assert rel_err(dg, wd.grad) < (1e-5 if dtype == "f32" else 1e-3)
+    assert rel_err(db, bd.grad) < (1e-5 if dtype == "f32" else 1e-3)
+
+
+@pytest.mark.parametrize("B_,Lq,H", [(2, 197, 3), (3, 64, 2), (2, 26, 1), (1, 1, 1), (1, 257, 2), (1, 400, 1)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention_bwd(B_, Lq, H, dtype, masked):
+    if dtype == "f32" and Lq > 288:
+        pytest.skip("f32 forward keeps the whole K/V^T of a head in LDS: L <= 288")
+    lib = L.load()
+    g = torch.Generator().manual_seed(B_ * 100 + Lq + H)
+    D = H * 64
+    qkv = torch.randn(B_ * Lq, 3 * D, generator=g)
+    dctx = torch.randn(B_ * Lq, D, generator=g)
+    kb = None
+    if masked:
+        lens = torch.randint(1, Lq + 1, (B_,), generator=g)
+        lens[0] = Lq
+        kb = torch.zeros(B_, Lq)
+        for i in range(B_):
+            kb[i, lens[i]:] = -10000.0
+        kb = kb.reshape(-1)
+    if dtype == "bf16":
+        qkv, dctx = qkv.bfloat16(), dctx.bfloat16()
+    qd = qkv.double().requires_grad_(True)
+    ref, _ = ref_attention(qd, B_, Lq, H, kb)
+    ref.backward(dctx.double())
+    qg, dg_, kbg = qkv.to(DEV), dctx.to(DEV), (None if kb is None else kb.to(DEV))
+    ctx, lse = L.op_attention(qg, B_, Lq, H, key_bias=kbg, want_lse=True)
+    dqkv = torch.zeros_like(qg)
+    esz = qg.element_size()
+    dt = L.DTYPE_BF16 if dtype == "bf16" else L.DTYPE_F32
+    base, dbase = qg.data_ptr(), dqkv.data_ptr()
+    L.check(lib.ezclip_op_attention_bwd(base, base + D * esz, base + 2 * D * esz, 3 * D, ctx.data_ptr(), dg_.data_ptr(), D,
+                                        L.ptr(kbg), lse.data_ptr(), dbase, dbase + D * esz, dbase + 2 * D * esz,
+                                        B_, Lq, H, dt, L.stream_ptr()))
+    torch.cuda.synchronize()
+    scale = float(qd.grad.abs().max())
+    assert max_err(dqkv.float(), qd.grad) < (3e-5 if dtype == "f32" else 0.04) * max(1.0, scale)
+    assert rel_err(dqkv.float(), qd.grad) < (1e-5 if dtype == "f32" else 0.02)

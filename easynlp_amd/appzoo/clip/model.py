@@ -31,6 +31,7 @@ import torch
 import torch.nn as nn
 
 from ... import lib as L
+from ... import parallel as P
 from ..application import Application
 
 _CFG_FIELDS = ("embed_dim", "image_resolution", "vision_layers", "vision_width", "vision_patch_size",
@@ -262,9 +263,14 @@ class _SimilarityFn(torch.autograd.Function):
     def backward(ctx, g):
         txt, img, ls, out = ctx.saved_tensors
         g = g.contiguous()
-        # dT = s * g @ I ; dI = s * g^T @ T ; d ls = sum(g * out)   (NT GEMMs on transposed copies)
-        d_txt = L.similarity(g, img.t().contiguous(), ls)
-        d_img = L.similarity(g.t().contiguous(), txt.t().contiguous(), ls)
+        # dT = s * g @ I ; dI = s * g^T @ T ; d ls = sum(g * out)   (NT GEMMs on transposed copies;
+        # the contraction dim -- the batch -- is zero-padded to the f32 tile multiple of 32)
+        pad = (-g.shape[1]) % 32
+        padk = (lambda t: torch.nn.functional.pad(t, (0, pad)).contiguous()) if pad else (lambda t: t.contiguous())
+        d_txt = L.similarity(padk(g), padk(img.t()), ls)
+        pad = (-g.shape[0]) % 32
+        padk = (lambda t: torch.nn.functional.pad(t, (0, pad)).contiguous()) if pad else (lambda t: t.contiguous())
+        d_img = L.similarity(padk(g.t()), padk(txt.t()), ls)
         d_ls = (g * out).sum().reshape(ls.shape)
         return d_txt, d_img, d_ls
 
@@ -421,11 +427,7 @@ class CLIPApp(Application):
             pg = None if process_group in (None, True) else process_group
             world, rank = dist.get_world_size(pg), dist.get_rank(pg)
         if world > 1:
-            both = torch.cat([img, txt], dim=1)                       # one collective for both towers
-            gathered = torch.empty((world * n, 2 * e), dtype=both.dtype, device=both.device)
-            dist.all_gather_into_tensor(gathered, both, group=pg)
-            img_all = gathered[:, :e].contiguous()
-            txt_all = gathered[:, e:].contiguous()
+            img_all, txt_all, _ = P.gather_embeddings(img, txt, pg)     # one RCCL all-gather for both towers
         else:
             img_all, txt_all = img, txt
         N = world * n
@@ -447,10 +449,7 @@ class CLIPApp(Application):
                                          1.0 / world, L.ptr(loss), L.ptr(d_txt), L.ptr(d_img), L.ptr(d_ls),
                                          L.ptr(ws), ws.numel(), L.stream_ptr()), "infonce_fused")
         if world > 1:
-            both = torch.cat([d_img, d_txt], dim=1)
-            mine = torch.empty((n, 2 * e), dtype=both.dtype, device=both.device)
-            dist.reduce_scatter_tensor(mine, both, op=dist.ReduceOp.SUM, group=pg)
-            d_img_l, d_txt_l = mine[:, :e].contiguous(), mine[:, e:].contiguous()
+            d_img_l, d_txt_l = P.scatter_embedding_grads(d_img, d_txt, n, pg)   # one RCCL reduce-scatter
         else:
             d_img_l, d_txt_l = d_img, d_txt
         self.logit_scale.grad.add_(d_ls)

@@ -234,6 +234,11 @@ int ezclip_recall_ranks(const float* text, const float* image, int n, int e, int
   return recall_ranks(scratch, n, rank_out, S(stream));
 }
 
+int ezclip_debug_set(int key, int value) {
+  if (key == 0) { set_gemm_variant(value); return EZ_OK; }
+  set_error("ezclip_debug_set: unknown key %d", key);
+  return EZ_ERR_INVALID;
+}
 int ezclip_profile_begin(void) { return profile_begin(); }
 int ezclip_profile_end(int kernel_class, double* ms, double* work, int* launches) {
   return profile_end(kernel_class, ms, work, launches);

@@ -21,6 +21,8 @@
 //   bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate.
 //   f32 : v_mfma_f32_32x32x2_f32 (exact f32 fmaf chain).
 //   1-D grid with an XCD-aware remap: consecutive tiles (same A panel) share an L2.
+#include <type_traits>
+
 #include "ezclip_common.h"
 #include "kernels.h"
 
@@ -35,13 +37,41 @@ constexpr int kThreads = 256;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-// Stage a (<=128)-row x 128-byte tile into LDS with LDS-DMA.  16 wave-instructions
-// of 1 KiB (8 rows); wave w issues instructions 4w..4w+3.
-__device__ __forceinline__ void stage_tile(const char* __restrict__ g, int64_t ld_bytes, int row0,
-                                           int row_max, int64_t kbyte, char* lds_tile, int wave, int lane) {
+__device__ __forceinline__ uint4 read_frag(const char* lds_tile, int row, int chunk) {
+  return *reinterpret_cast<const uint4*>(lds_tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+
+// Tile-shape template: WM x WN waves, each owning TI x TJ MFMA 32x32 accumulators.
+//   <2,2,2,2>: 128x128 tile, 4 waves, 64 KB LDS, 2 workgroups / CU   (small / ragged problems)
+//   <2,4,4,2>: 256x256 tile, 8 waves of 128x64, 128 KB LDS, 1 workgroup / CU: 0.75 ds_read_b128 per
+//              MFMA instead of 1.0 and half the LDS-DMA bytes per MFMA -- the 128x128 shape is LDS-bound
+//              at ~50% MFMA utilisation (4 LDS cycles per read, 8 CU cycles per MFMA).
+// Fragments are double-buffered in registers across the four 16-byte K chunks of a tile so the LDS
+// latency of chunk s+1 hides under the MFMAs of chunk s.
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int WM, int WN, int TI, int TJ>
+struct Shape {
+  static constexpr int kBM = WM * TI * 32, kBN = WN * TJ * 32, kWaves = WM * WN, kThreadsS = kWaves * 64;
+  static constexpr int kABytes = kBM * 128, kBBytes = kBN * 128, kStage = kABytes + kBBytes;
+  static constexpr int kLds = 2 * kStage;
+};
+
+template <int ROWS, int NWAVES>
+__device__ __forceinline__ void stage_rows(const char* __restrict__ g, int64_t ld_bytes, int row0, int row_max,
+                                           int64_t kbyte, char* lds_tile, int wave, int lane) {
+  constexpr int kInst = ROWS / 8;            // 1 KiB wave-instructions
+  constexpr int kPer = kInst / NWAVES;
+  static_assert(kInst % NWAVES == 0, "tile rows must split evenly over the waves");
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int inst = wave * 4 + i;
+  for (int i = 0; i < kPer; ++i) {
+    const int inst = wave * kPer + i;
     const int r = inst * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     int gr = row0 + r;
@@ -51,64 +81,68 @@ __device__ __forceinline__ void stage_tile(const char* __restrict__ g, int64_t l
   }
 }
 
-__device__ __forceinline__ uint4 read_frag(const char* lds_tile, int row, int chunk) {
-  return *reinterpret_cast<const uint4*>(lds_tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-}
-
-template <typename T, typename TO>
-__global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A 16K + B 16K)
+template <typename T, typename TO, int WM, int WN, int TI, int TJ>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void gemm_nt_kernel(GemmArgs p) {
+  using SH = Shape<WM, WN, TI, TJ>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BK = 128 / (int)sizeof(T);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_n = (p.N + SH::kBN - 1) / SH::kBN;
   const int nwg = gridDim.x;
   const int t = xcd_remap(blockIdx.x, nwg);
-  const int m0 = (t / tiles_n) * BM;
-  const int n0 = (t % tiles_n) * BN;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = (t / tiles_n) * SH::kBM;
+  const int n0 = (t % tiles_n) * SH::kBN;
+  const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, l31 = lane & 31;
 
   const char* gA = reinterpret_cast<const char*>(p.A);
   const char* gB = reinterpret_cast<const char*>(p.B);
   const int64_t lda_b = p.lda * (int64_t)sizeof(T), ldb_b = p.ldb * (int64_t)sizeof(T);
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / BK;
-  stage_tile(gA, lda_b, m0, p.M, 0, smem, wave, lane);
-  stage_tile(gB, ldb_b, n0, p.N, 0, smem + kTileBytes, wave, lane);
+  stage_rows<SH::kBM, SH::kWaves>(gA, lda_b, m0, p.M, 0, smem, wave, lane);
+  stage_rows<SH::kBN, SH::kWaves>(gB, ldb_b, n0, p.N, 0, smem + SH::kABytes, wave, lane);
 
+  const int arow = wm * TI * 32 + l31, brow = wn * TJ * 32 + l31;
   for (int kt = 0; kt < nk; ++kt) {
-    char* cur = smem + (kt & 1) * 2 * kTileBytes;
-    char* nxt = smem + ((kt + 1) & 1) * 2 * kTileBytes;
+    char* cur = smem + (kt & 1) * SH::kStage;
+    char* nxt = smem + ((kt + 1) & 1) * SH::kStage;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt landed everywhere; everyone is done reading `nxt`
     if (kt + 1 < nk) {
       const int64_t kb = (int64_t)(kt + 1) * 128;
-      stage_tile(gA, lda_b, m0, p.M, kb, nxt, wave, lane);
-      stage_tile(gB, ldb_b, n0, p.N, kb, nxt + kTileBytes, wave, lane);
+      stage_rows<SH::kBM, SH::kWaves>(gA, lda_b, m0, p.M, kb, nxt, wave, lane);
+      stage_rows<SH::kBN, SH::kWaves>(gB, ldb_b, n0, p.N, kb, nxt + SH::kABytes, wave, lane);
     }
     const char* tA = cur;
-    const char* tB = cur + kTileBytes;
+    const char* tB = cur + SH::kABytes;
+    uint4 a[2][TI], b[2][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) a[0][i] = read_frag(tA, arow + i * 32, h);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) b[0][j] = read_frag(tB, brow + j * 32, h);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int c = 2 * s + h;
-      uint4 a[2], b[2];
+      if (s < 3) {
+        const int c = 2 * (s + 1) + h;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = read_frag(tA, wm * 64 + i * 32 + l31, c);
+        for (int i = 0; i < TI; ++i) a[(s + 1) & 1][i] = read_frag(tA, arow + i * 32, c);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = read_frag(tB, wn * 64 + j * 32 + l31, c);
+        for (int j = 0; j < TJ; ++j) b[(s + 1) & 1][j] = read_frag(tB, brow + j * 32, c);
+      }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma32(acc[i][j], b[j], a[i], T());
+        for (int j = 0; j < TJ; ++j) mma32(acc[i][j], b[s & 1][j], a[s & 1][i], T());
     }
   }
 
@@ -120,15 +154,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(GemmArgs p) {
   const T* R = reinterpret_cast<const T*>(p.R);
   const T* U = reinterpret_cast<const T*>(p.U);
   constexpr bool kFast = IsFast<TO>::value;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + l31;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
+  // (static_for: compile-time i/j keep the accumulators in registers whatever the unroller decides)
+  static_for<TI>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const int m = m0 + wm * TI * 32 + i * 32 + l31;
+    if (m >= p.M) return;
+    static_for<TJ>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + j * 32 + q * 8 + h * 4;
+        const int n = n0 + wn * TJ * 32 + j * 32 + q * 8 + h * 4;
         if (n >= p.N) continue;
         float v[4];
 #pragma unroll
@@ -169,29 +204,41 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(GemmArgs p) {
           }
         }
       }
-    }
-  }
+    });
+  });
 }
 
-template <typename T, typename TO>
-int launch_nt(const GemmArgs& p, hipStream_t stream) {
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  const size_t lds = 4 * kTileBytes;
+template <typename T, typename TO, int WM, int WN, int TI, int TJ>
+int launch_nt_shape(const GemmArgs& p, hipStream_t stream) {
+  using SH = Shape<WM, WN, TI, TJ>;
+  const int tiles = ((p.M + SH::kBM - 1) / SH::kBM) * ((p.N + SH::kBN - 1) / SH::kBN);
   static bool attr_set = false;
   if (!attr_set) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, TI, TJ>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SH::kLds));
     attr_set = true;
   }
   {
     ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), dim3(tiles), dim3(kThreads), lds, stream, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, TI, TJ>), dim3(tiles), dim3(SH::kThreadsS), SH::kLds, stream, p);
   }
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }
 
+int g_gemm_variant = -1;   // -1: heuristic; 0: 128x128; 1: 256x256  (ezclip_debug_set(0, v))
+
+template <typename T, typename TO>
+int launch_nt(const GemmArgs& p, hipStream_t stream) {
+  int v = g_gemm_variant;
+  if (v < 0) v = (p.M >= 1024 && p.N >= 256 && p.N % 256 == 0) ? 1 : 0;
+  if (v == 1) return launch_nt_shape<T, TO, 2, 4, 4, 2>(p, stream);
+  return launch_nt_shape<T, TO, 2, 2, 2, 2>(p, stream);
+}
+
 }  // namespace
+
+void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
   EZ_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
@@ -199,13 +246,11 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
   EZ_REQUIRE((p.K * esz) % 128 == 0, "gemm_nt: K=%d must be a multiple of %d", p.K, 128 / esz);
   EZ_REQUIRE((p.lda * esz) % 16 == 0 && (p.ldb * esz) % 16 == 0, "gemm_nt: lda/ldb must be 16-byte multiples");
   EZ_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0, "gemm_nt: A/B must be 16-byte aligned");
-  const int osz = (dtype == EZCLIP_BF16 && !p.out_f32) ? 2 : 4;
   bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && ((uintptr_t)p.C % 16 == 0) &&
              (p.C2 == nullptr || (uintptr_t)p.C2 % 16 == 0) &&
              (p.bias == nullptr || (uintptr_t)p.bias % 16 == 0) &&
              (p.R == nullptr || (p.ldr % 4 == 0 && (uintptr_t)p.R % 16 == 0)) &&
              (p.U == nullptr || (p.ldu % 4 == 0 && (uintptr_t)p.U % 16 == 0));
-  (void)osz;
   p.vec_ok = vec ? 1 : 0;
   if (dtype == EZCLIP_F32) return launch_nt<float, float>(p, stream);
   if (dtype == EZCLIP_BF16) {

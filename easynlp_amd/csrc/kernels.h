@@ -29,6 +29,7 @@ struct GemmArgs {
 };
 // C = act(alpha * exp(scale) * A.B^T + bias) + R
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream);
+void set_gemm_variant(int v);   // debugging / sweeps: -1 heuristic, 0 = 128x128 tile, 1 = 256x256 tile
 
 // C[N,K] (+)= A[M,N]^T . B[M,K]   (weight gradients; contraction over rows)
 struct GemmTNArgs {

@@ -156,6 +156,8 @@ int ezclip_recall_ranks(const float* text_dev, const float* image_dev, int n, in
 #define EZCLIP_PROF_GEMM 0
 #define EZCLIP_PROF_ATTN 1
 #define EZCLIP_PROF_ROWOP 2
+/* Tuning switches for sweeps (key 0: GEMM tile variant, -1 = heuristic, 0 = 128x128, 1 = 256x256). */
+int ezclip_debug_set(int key, int value);
 int ezclip_profile_begin(void);
 int ezclip_profile_end(int kernel_class, double* total_ms, double* total_work, int* launches);
 

@@ -149,7 +149,16 @@ def test_weights_refresh_after_inplace_update(tmp_path):
 
 # ----------------------------------------------------------------------------- backward
 
-def _grad_check(app, z, tol_rel, tol_norm, skip_tiny=1e-7):
+def _grad_check(app, z, tol_rel, tol_norm, skip_tiny=1e-7, abs_tol=None):
+    """abs_tol: per-parameter absolute floors.  Two gradients are differences of nearly cancelling
+    terms and carry no relative information in bf16: attention key biases (mathematically 0: softmax
+    is shift invariant) and logit_scale on random-init weights (all embeddings nearly collinear)."""
+    abs_tol = abs_tol or {}
+    def floor(n):
+        for k, v in abs_tol.items():
+            if k in n:
+                return v
+        return skip_tiny
     bad = []
     for key in z.files:
         if key.startswith("nograd/"):
@@ -160,14 +169,14 @@ def _grad_check(app, z, tol_rel, tol_norm, skip_tiny=1e-7):
             n = key[len("gnorm/"):]
             ref = float(z[key])
             got = float(app._params[n].grad.double().norm())
-            if abs(got - ref) > tol_norm * ref + skip_tiny:
+            if abs(got - ref) > tol_norm * ref + floor(n):
                 bad.append((n, "norm", got, ref))
         elif key.startswith("grad/"):
             n = key[len("grad/"):]
             ref = torch.from_numpy(z[key]).double()
             got = app._params[n].grad.detach().cpu().double()
             err = float((got - ref).norm())
-            if err > tol_rel * float(ref.norm()) + skip_tiny:
+            if err > tol_rel * float(ref.norm()) + floor(n):
                 bad.append((n, "rel", err / (float(ref.norm()) + 1e-30), float(ref.norm())))
     assert not bad, bad[:12]
 
@@ -194,7 +203,8 @@ def test_backward_matches_reference_golden(tmp_path, name, dtype, path):
     if dtype == "fp32":
         _grad_check(app, z, tol_rel=1e-4, tol_norm=1e-4)
     else:
-        _grad_check(app, z, tol_rel=6e-2, tol_norm=6e-2, skip_tiny=1e-5)
+        _grad_check(app, z, tol_rel=6e-2, tol_norm=6e-2, skip_tiny=1e-5,
+                    abs_tol={"attention.self.key.bias": 2e-4, "logit_scale": 3e-3})
 
 
 def test_gradient_accumulation_and_optimizer_step(tmp_path):

@@ -317,3 +317,26 @@ def test_attention_bwd(B_, Lq, H, dtype, masked):
     scale = float(qd.grad.abs().max())
     assert max_err(dqkv.float(), qd.grad) < (3e-5 if dtype == "f32" else 0.04) * max(1.0, scale)
     assert rel_err(dqkv.float(), qd.grad) < (1e-5 if dtype == "f32" else 0.02)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1000, 768, 768), (513, 512, 128), (2049, 256, 3072), (300, 100, 64)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gemm_nt_tile_variants(M, N, K, dtype, variant):
+    """Both tile shapes (128x128 / 256x256) on ragged M/N, with the full epilogue."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N + K + variant)
+    a = torch.randn(M, K, generator=g) * 0.5
+    b = torch.randn(N, K, generator=g) * 0.2
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    if dtype == "bf16":
+        a, b, res = a.bfloat16(), b.bfloat16(), res.bfloat16()
+    ref = O.quick_gelu(a.double() @ b.double().t() + bias.double()) + res.double()
+    L.check(lib.ezclip_debug_set(0, variant))
+    try:
+        c = L.op_gemm_nt(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=res.to(DEV), act=L.ACT_QUICKGELU)
+        torch.cuda.synchronize()
+    finally:
+        L.check(lib.ezclip_debug_set(0, -1))
+    assert max_err(c.float(), ref) < (5e-5 if dtype == "f32" else 0.06) * max(1.0, math.sqrt(K) / 8)

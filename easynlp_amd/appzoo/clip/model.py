@@ -205,9 +205,8 @@ class _EncodeFn(torch.autograd.Function):
     backward kernels into a zeroed flat gradient buffer and hands autograd views of it."""
 
     @staticmethod
-    def forward(ctx, app, pixels, ids, *params):
-        eng = app._engine
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    def forward(ctx, app, need_grad, pixels, ids, *params):
+        eng = app._engine   # (grad mode is always off inside Function.forward: the caller decides need_grad)
         named = dict(zip(eng.names, params))
         eng.sync_params(named, with_backward=need_grad)
         img = txt = None
@@ -246,7 +245,7 @@ class _EncodeFn(torch.autograd.Function):
         if ctx.has[1]:
             eng.backward_text(ctx.ids, d_txt, ctx.ws_txt)
         out = [grads[n] if params[n].requires_grad else None for n in eng.names]
-        return (None, None, None) + tuple(out)
+        return (None, None, None, None) + tuple(out)
 
 
 class _SimilarityFn(torch.autograd.Function):
@@ -466,7 +465,9 @@ class CLIPApp(Application):
 
     # ------------------------------------------------------------------------------------
     def encode(self, pixel_values=None, input_ids=None):
-        img, txt = _EncodeFn.apply(self, pixel_values, input_ids, *self._plist())
+        plist = self._plist()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
+        img, txt = _EncodeFn.apply(self, need_grad, pixel_values, input_ids, *plist)
         return (img if pixel_values is not None else None), (txt if input_ids is not None else None)
 
     def forward(self, inputs, feat=None):

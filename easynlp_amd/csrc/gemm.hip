@@ -226,12 +226,12 @@ int launch_nt_shape(const GemmArgs& p, hipStream_t stream) {
   return EZ_OK;
 }
 
-int g_gemm_variant = -1;   // -1: heuristic; 0: 128x128; 1: 256x256  (ezclip_debug_set(0, v))
+int g_gemm_variant = -1;   // -1: heuristic; 0: 128x128; 1: 256x256 (2-phase); 2: 256x256 8-phase (gemm8p.hip)
 
 template <typename T, typename TO>
 int launch_nt(const GemmArgs& p, hipStream_t stream) {
   int v = g_gemm_variant;
-  if (v < 0) v = (p.M >= 1024 && p.N >= 256 && p.N % 256 == 0) ? 1 : 0;
+  if (v < 0 || v > 1) v = (p.M >= 1024 && p.N >= 256 && p.N % 256 == 0) ? 1 : 0;
   if (v == 1) return launch_nt_shape<T, TO, 2, 4, 4, 2>(p, stream);
   return launch_nt_shape<T, TO, 2, 2, 2, 2>(p, stream);
 }
@@ -252,6 +252,7 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
              (p.R == nullptr || (p.ldr % 4 == 0 && (uintptr_t)p.R % 16 == 0)) &&
              (p.U == nullptr || (p.ldu % 4 == 0 && (uintptr_t)p.U % 16 == 0));
   p.vec_ok = vec ? 1 : 0;
+  if ((g_gemm_variant < 0 || g_gemm_variant == 2) && gemm_nt_8p_eligible(p, dtype)) return gemm_nt_8p(p, stream);
   if (dtype == EZCLIP_F32) return launch_nt<float, float>(p, stream);
   if (dtype == EZCLIP_BF16) {
     if (p.out_f32) return launch_nt<bf16_t, float>(p, stream);

@@ -1,0 +1,150 @@
+// Stand-alone GEMM check + timing on the path's real shapes (no torch: starts in ~1 s on the GPU box).
+//   build:  python tools/build_tools.py        (links against easynlp_amd/csrc/libezclip_hip.so)
+//   run:    tools/bin/gemm_bench [batch=1024] [iters=20] [variants=0,2]
+// For every shape it runs the reference variant 0 (128x128 kernel, verified against the oracle by the
+// pytest suite) and the listed variants on the same uniform[-1,1) operands, reports TFLOP/s and the max
+// absolute difference of the bf16 outputs (expected 0: same accumulation order, same epilogue math).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../easynlp_amd/csrc/kernels.h"
+
+#define CK(x)                                                                     \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(2);                                                                    \
+    }                                                                             \
+  } while (0)
+
+namespace {
+
+__global__ void fill_bf16(uint16_t* p, size_t n, uint32_t seed, float scale) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint32_t x = (uint32_t)i * 2654435761u + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    const float f = ((x >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;   // uniform [-scale, scale)
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    p[i] = (uint16_t)(u >> 16);
+  }
+}
+__global__ void fill_f32(float* p, size_t n, uint32_t seed) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) {
+    uint32_t x = (uint32_t)i * 2654435761u + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+    p[i] = (x >> 8) * (1.0f / 8388608.0f) - 1.0f;
+  }
+}
+__global__ void maxdiff_bf16(const uint16_t* a, const uint16_t* b, size_t n, float* out, unsigned long long* nbad) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  float m = 0.f;
+  unsigned long long bad = 0;
+  for (; i < n; i += stride) {
+    const float x = __uint_as_float((uint32_t)a[i] << 16), y = __uint_as_float((uint32_t)b[i] << 16);
+    const float d = fabsf(x - y);
+    if (!(d <= m)) m = d;   // NaN propagates
+    if (a[i] != b[i]) ++bad;
+  }
+  atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));   // non-negative floats order as ints
+  if (bad) atomicAdd(nbad, bad);
+}
+
+struct Shape { const char* name; int M, N, K, act; bool res, c2; };
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  const int batch = argc > 1 ? atoi(argv[1]) : 1024;
+  const int iters = argc > 2 ? atoi(argv[2]) : 20;
+  std::vector<int> variants;
+  {
+    std::string v = argc > 3 ? argv[3] : "0,2";
+    size_t pos = 0;
+    while (pos < v.size()) {
+      variants.push_back(atoi(v.c_str() + pos));
+      pos = v.find(',', pos);
+      if (pos == std::string::npos) break;
+      ++pos;
+    }
+  }
+  const int Mv = batch * 197, Mt = batch * 64;
+  const Shape shapes[] = {
+      {"vit.qkv", Mv, 2304, 768, 0, false, false},     {"vit.out+res", Mv, 768, 768, 0, true, false},
+      {"vit.fc+qgelu", Mv, 3072, 768, 1, false, false}, {"vit.proj+res", Mv, 768, 3072, 0, true, false},
+      {"bert.qkvo+res", Mt, 768, 768, 0, true, false},  {"bert.ffn1+gelu", Mt, 3072, 768, 2, false, false},
+      {"bert.ffn2+res", Mt, 768, 3072, 0, true, false}, {"patch", batch * 196, 768, 768, 0, false, false},
+      {"train.fc+c2", Mv, 3072, 768, 1, false, true},   {"ragged.M", Mv - 100, 768, 768, 0, true, false},
+  };
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  float* d_md;
+  unsigned long long* d_bad;
+  CK(hipMalloc(&d_md, 4));
+  CK(hipMalloc(&d_bad, 8));
+  printf("batch %d iters %d\n", batch, iters);
+  for (const Shape& s : shapes) {
+    const size_t nA = (size_t)s.M * s.K, nB = (size_t)s.N * s.K, nC = (size_t)s.M * s.N;
+    uint16_t *A, *B, *R = nullptr, *C0, *C1, *P0 = nullptr, *P1 = nullptr;
+    float* bias;
+    CK(hipMalloc(&A, nA * 2)); CK(hipMalloc(&B, nB * 2)); CK(hipMalloc(&C0, nC * 2)); CK(hipMalloc(&C1, nC * 2));
+    CK(hipMalloc(&bias, s.N * 4));
+    if (s.res) CK(hipMalloc(&R, nC * 2));
+    if (s.c2) { CK(hipMalloc(&P0, nC * 2)); CK(hipMalloc(&P1, nC * 2)); }
+    fill_bf16<<<2048, 256, 0, st>>>(A, nA, 1u, 1.0f);
+    fill_bf16<<<2048, 256, 0, st>>>(B, nB, 2u, 0.05f);
+    fill_f32<<<(s.N + 255) / 256, 256, 0, st>>>(bias, s.N, 3u);
+    if (R) fill_bf16<<<2048, 256, 0, st>>>(R, nC, 4u, 1.0f);
+    CK(hipMemsetAsync(C0, 0xff, nC * 2, st));
+    CK(hipMemsetAsync(C1, 0xff, nC * 2, st));
+    printf("%-15s M=%7d N=%5d K=%5d :", s.name, s.M, s.N, s.K);
+    for (size_t vi = 0; vi < variants.size(); ++vi) {
+      const int v = variants[vi];
+      ezclip::set_gemm_variant(v);
+      ezclip::GemmArgs g;
+      g.A = A; g.lda = s.K; g.B = B; g.ldb = s.K;
+      g.C = vi == 0 ? C0 : C1; g.ldc = s.N;
+      g.C2 = s.c2 ? (vi == 0 ? P0 : P1) : nullptr;
+      g.bias = bias; g.R = R; g.ldr = s.N; g.M = s.M; g.N = s.N; g.K = s.K; g.act = s.act;
+      if (ezclip::gemm_nt(g, EZCLIP_BF16, st) != 0) { printf(" v%d ERROR %s", v, ezclip::last_error()); continue; }
+      CK(hipStreamSynchronize(st));
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      CK(hipEventRecord(e0, st));
+      for (int it = 0; it < iters; ++it) ezclip::gemm_nt(g, EZCLIP_BF16, st);
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= iters;
+      printf("  v%d %7.1f TF (%.3f ms)", v, 2.0 * s.M * s.N * s.K / ms / 1e9, ms);
+      if (vi > 0) {
+        CK(hipMemsetAsync(d_md, 0, 4, st)); CK(hipMemsetAsync(d_bad, 0, 8, st));
+        maxdiff_bf16<<<1024, 256, 0, st>>>(C0, C1, nC, d_md, d_bad);
+        if (s.c2) maxdiff_bf16<<<1024, 256, 0, st>>>(P0, P1, nC, d_md, d_bad);
+        float md; unsigned long long bad;
+        CK(hipMemcpyAsync(&md, d_md, 4, hipMemcpyDeviceToHost, st));
+        CK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        printf(" [maxdiff %.3g, %llu differ]", md, bad);
+      }
+    }
+    printf("\n");
+    fflush(stdout);
+    hipFree(A); hipFree(B); hipFree(C0); hipFree(C1); hipFree(bias);
+    if (R) hipFree(R);
+    if (P0) { hipFree(P0); hipFree(P1); }
+  }
+  ezclip::set_gemm_variant(-1);
+  return 0;
+}

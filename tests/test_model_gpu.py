@@ -149,35 +149,37 @@ def test_weights_refresh_after_inplace_update(tmp_path):
 
 # ----------------------------------------------------------------------------- backward
 
-def _grad_check(app, z, tol_rel, tol_norm, skip_tiny=1e-7, abs_tol=None):
-    """abs_tol: per-parameter absolute floors.  Two gradients are differences of nearly cancelling
-    terms and carry no relative information in bf16: attention key biases (mathematically 0: softmax
-    is shift invariant) and logit_scale on random-init weights (all embeddings nearly collinear)."""
-    abs_tol = abs_tol or {}
-    def floor(n):
-        for k, v in abs_tol.items():
-            if k in n:
-                return v
-        return skip_tiny
+def _grad_check(app, z, tol_rel, tol_norm, skip_tiny=1e-7, noise_factor=0.0):
+    """Every parameter gradient against the reference's (tools/make_golden.py).
+    noise_factor > 0 (bf16 pipeline): the per-parameter tolerance is max(tol, noise_factor * bf16dev[p]) where
+    bf16dev is the deviation, stored in the fixture, of a plain torch-CPU bfloat16 evaluation of the same
+    algorithm from the fp32 reference.  On random-init weights the towers rank-collapse and a few gradients
+    (BERT query/key weights ~1e-3 of their layer's gradient scale, attention key biases that are
+    mathematically 0, logit_scale, the last layer's biases) are differences of nearly equal terms: no bf16
+    implementation reproduces them to a fixed relative tolerance, and the fp32 pipeline checks the very
+    same tensors at 1e-4."""
     bad = []
     for key in z.files:
         if key.startswith("nograd/"):
             n = key[len("nograd/"):]
             p = app._params[n]
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
-        elif key.startswith("gnorm/"):
-            n = key[len("gnorm/"):]
+            continue
+        if not (key.startswith("gnorm/") or key.startswith("grad/")):
+            continue
+        n = key.split("/", 1)[1]
+        noise = noise_factor * float(z["bf16dev/" + n]) if noise_factor > 0 else 0.0
+        if key.startswith("gnorm/"):
             ref = float(z[key])
             got = float(app._params[n].grad.double().norm())
-            if abs(got - ref) > tol_norm * ref + floor(n):
-                bad.append((n, "norm", got, ref))
-        elif key.startswith("grad/"):
-            n = key[len("grad/"):]
+            if abs(got - ref) > max(tol_norm, noise) * ref + skip_tiny:
+                bad.append((n, "norm", got, ref, noise))
+        else:
             ref = torch.from_numpy(z[key]).double()
             got = app._params[n].grad.detach().cpu().double()
             err = float((got - ref).norm())
-            if err > tol_rel * float(ref.norm()) + floor(n):
-                bad.append((n, "rel", err / (float(ref.norm()) + 1e-30), float(ref.norm())))
+            if err > max(tol_rel, noise) * float(ref.norm()) + skip_tiny:
+                bad.append((n, "rel", err / (float(ref.norm()) + 1e-30), float(ref.norm()), noise))
     assert not bad, bad[:12]
 
 
@@ -186,7 +188,8 @@ def _grad_check(app, z, tol_rel, tol_norm, skip_tiny=1e-7, abs_tol=None):
 @pytest.mark.parametrize("path", ["autograd", "fused"])
 def test_backward_matches_reference_golden(tmp_path, name, dtype, path):
     """Gradients of every parameter vs the real reference's autograd (tools/make_golden.py).
-    f32: rel-L2 <= 1e-4; bf16: rel-L2 <= 3e-2 on the small models (2e-2 full size)."""
+    f32: rel-L2 <= 1e-4; bf16: max(6e-2, 1.5 x the measured deviation of a torch-CPU bf16 evaluation
+    of the same algorithm) per parameter -- see _grad_check."""
     z, cfg, B, Lq, wseed, iseed = load_gold(name)
     app, _ = make_app(tmp_path, cfg, wseed, dtype)
     app.train()
@@ -203,14 +206,7 @@ def test_backward_matches_reference_golden(tmp_path, name, dtype, path):
     if dtype == "fp32":
         _grad_check(app, z, tol_rel=1e-4, tol_norm=1e-4)
     else:
-        # BERT query/key weights at random init: the towers rank-collapse (all tokens of a sentence
-        # nearly equal by layer ~6), so the reference gradient norm is ~4e-4 against ~0.45 for the value /
-        # dense weights of the same layer -- three orders below the layer's gradient scale and below the
-        # bf16 rounding noise of dS (2^-9 relative, times the common K component).  Absolute floor 3e-3
-        # (< 1 % of the layer's gradient scale); the f32 pipeline checks the same tensors at 1e-4 relative.
-        _grad_check(app, z, tol_rel=6e-2, tol_norm=6e-2, skip_tiny=1e-5,
-                    abs_tol={"attention.self.key.bias": 2e-4, "logit_scale": 3e-3,
-                             "attention.self.query": 3e-3, "attention.self.key.weight": 3e-3})
+        _grad_check(app, z, tol_rel=6e-2, tol_norm=6e-2, skip_tiny=1e-5, noise_factor=1.5)
 
 
 def test_gradient_accumulation_and_optimizer_step(tmp_path):

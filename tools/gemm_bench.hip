@@ -60,7 +60,7 @@ __global__ void maxdiff_bf16(const uint16_t* a, const uint16_t* b, size_t n, flo
   if (bad) atomicAdd(nbad, bad);
 }
 
-struct Shape { const char* name; int M, N, K, act; bool res, c2; };
+struct Shape { const char* name; int M, N, K, act; bool res, c2; bool u = false; };
 
 }  // namespace
 
@@ -85,6 +85,8 @@ int main(int argc, char** argv) {
       {"bert.qkvo+res", Mt, 768, 768, 0, true, false},  {"bert.ffn1+gelu", Mt, 3072, 768, 2, false, false},
       {"bert.ffn2+res", Mt, 768, 3072, 0, true, false}, {"patch", batch * 196, 768, 768, 0, false, false},
       {"train.fc+c2", Mv, 3072, 768, 1, false, true},   {"ragged.M", Mv - 100, 768, 768, 0, true, false},
+      {"bwd.dgrad*act'", Mv, 3072, 768, 1, false, false, true}, {"bwd.gelu' ragged", 788, 3072, 768, 2, false, false, true},
+      {"small.M=788", 788, 768, 3072, 0, true, false},
   };
   hipStream_t st;
   CK(hipStreamCreate(&st));
@@ -95,7 +97,7 @@ int main(int argc, char** argv) {
   printf("batch %d iters %d\n", batch, iters);
   for (const Shape& s : shapes) {
     const size_t nA = (size_t)s.M * s.K, nB = (size_t)s.N * s.K, nC = (size_t)s.M * s.N;
-    uint16_t *A, *B, *R = nullptr, *C0, *C1, *P0 = nullptr, *P1 = nullptr;
+    uint16_t *A, *B, *R = nullptr, *C0, *C1, *P0 = nullptr, *P1 = nullptr, *Uu = nullptr;
     float* bias;
     CK(hipMalloc(&A, nA * 2)); CK(hipMalloc(&B, nB * 2)); CK(hipMalloc(&C0, nC * 2)); CK(hipMalloc(&C1, nC * 2));
     CK(hipMalloc(&bias, s.N * 4));
@@ -105,6 +107,7 @@ int main(int argc, char** argv) {
     fill_bf16<<<2048, 256, 0, st>>>(B, nB, 2u, 0.05f);
     fill_f32<<<(s.N + 255) / 256, 256, 0, st>>>(bias, s.N, 3u);
     if (R) fill_bf16<<<2048, 256, 0, st>>>(R, nC, 4u, 1.0f);
+    if (s.u) { CK(hipMalloc(&Uu, nC * 2)); fill_bf16<<<2048, 256, 0, st>>>(Uu, nC, 5u, 3.0f); }
     CK(hipMemsetAsync(C0, 0xff, nC * 2, st));
     CK(hipMemsetAsync(C1, 0xff, nC * 2, st));
     printf("%-15s M=%7d N=%5d K=%5d :", s.name, s.M, s.N, s.K);
@@ -116,6 +119,7 @@ int main(int argc, char** argv) {
       g.C = vi == 0 ? C0 : C1; g.ldc = s.N;
       g.C2 = s.c2 ? (vi == 0 ? P0 : P1) : nullptr;
       g.bias = bias; g.R = R; g.ldr = s.N; g.M = s.M; g.N = s.N; g.K = s.K; g.act = s.act;
+      g.U = Uu; g.ldu = s.N;
       if (ezclip::gemm_nt(g, EZCLIP_BF16, st) != 0) { printf(" v%d ERROR %s", v, ezclip::last_error()); continue; }
       CK(hipStreamSynchronize(st));
       hipEvent_t e0, e1;
@@ -143,6 +147,7 @@ int main(int argc, char** argv) {
     fflush(stdout);
     hipFree(A); hipFree(B); hipFree(C0); hipFree(C1); hipFree(bias);
     if (R) hipFree(R);
+    if (Uu) hipFree(Uu);
     if (P0) { hipFree(P0); hipFree(P1); }
   }
   ezclip::set_gemm_variant(-1);

@@ -19,17 +19,16 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
 
-// round-to-nearest-even, NaN-preserving
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even, NaN-preserving: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_hw_t;
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const f32x2_hw_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_t));
 }
+
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -76,7 +75,7 @@ __device__ __forceinline__ void unpack_chunk(const uint4& c, float (&v)[8], bf16
 // rounded to bf16 anyway; the f32 path calls erff.
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);   // v_rcp_f32 (1 ulp)
   float y = 1.061405429f;
   y = fmaf(y, t, -1.453152027f);
   y = fmaf(y, t, 1.421413741f);
@@ -90,8 +89,8 @@ __device__ __forceinline__ float erf_fast(float x) {
 template <bool FAST>
 __device__ __forceinline__ float act_apply(float x, int act) {
   if (act == ACT_QUICKGELU) {
-    const float e = FAST ? __expf(-1.702f * x) : expf(-1.702f * x);
-    return x / (1.0f + e);
+    if (FAST) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    return x / (1.0f + expf(-1.702f * x));
   }
   if (act == ACT_GELU_ERF) {
     const float z = x * 0.70710678118654752440f;
@@ -105,7 +104,7 @@ template <bool FAST>
 __device__ __forceinline__ float act_grad(float x, int act) {
   if (act == ACT_QUICKGELU) {
     const float e = FAST ? __expf(-1.702f * x) : expf(-1.702f * x);
-    const float s = 1.0f / (1.0f + e);
+    const float s = FAST ? __builtin_amdgcn_rcpf(1.0f + e) : 1.0f / (1.0f + e);
     return s * (1.0f + 1.702f * x * (1.0f - s));
   }
   if (act == ACT_GELU_ERF) {

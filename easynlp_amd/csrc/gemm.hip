@@ -238,7 +238,11 @@ int launch_nt(const GemmArgs& p, hipStream_t stream) {
 
 }  // namespace
 
-void set_gemm_variant(int v) { g_gemm_variant = v; }
+void set_gemm8p_ablate(int v);
+void set_gemm_variant(int v) {   // 2x = 8-phase kernel with ablation code x (timing experiments)
+  if (v >= 20 && v < 30) { set_gemm8p_ablate(v - 20); v = 2; } else set_gemm8p_ablate(0);
+  g_gemm_variant = v;
+}
 
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
   EZ_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);

@@ -32,9 +32,14 @@
 //   * The two wave rows run one barrier apart (wave row 1 executes one extra s_barrier up front, wave
 //     row 0 one at the end): while one wave of a SIMD is in its MFMA segment the other is in its
 //     read/DMA segment, so the matrix pipe always has a feeder.
-//   * Epilogue: the accumulators go through a wave-private 16 KiB LDS region (the ring is dead by then)
-//     so that every global access of C / residual / pre-activation is a 16-byte-per-lane access covering
-//     8 full 128-byte rows per wave instruction.
+//   * Epilogue: the fp32 accumulators go through a wave-private 8 KiB LDS image (outside ring slots 0..5),
+//     one 32-row block at a time, so that the epilogue math runs on row-coalesced registers and every global
+//     access of C / residual / pre-activation is 16 B per lane = 8 full 128-byte rows per wave instruction.
+//   * The kernel is PERSISTENT (one workgroup per CU walks its tiles): the first six half-tiles of the next
+//     tile are DMA'd while the current epilogue runs, bias / residual loads are issued one block ahead, and
+//     there is no workgroup launch, kernarg load or cold pipeline between tiles.
+#include <type_traits>
+
 #include "ezclip_common.h"
 #include "kernels.h"
 
@@ -181,20 +186,51 @@ __device__ __forceinline__ void ktile(const Ctx& c, Frags& f, f32x16_t (&acc)[4]
   }
 }
 
-// wave-private epilogue staging image: [128 rows][128 B], 16-byte chunk index XORed with row & 7
-__device__ __forceinline__ uint32_t stage_off(int row, int c16) { return row * 128 + ((c16 ^ (row & 7)) << 4); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
 
-template <bool FAST>
-__global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p) {
+// ---- epilogue helpers ---------------------------------------------------------------------------
+// Every global LOAD of the epilogue is hand-issued too (buffer_load in inline asm, bounds-checked): with
+// LDS-DMA of the NEXT tile in flight, a compiler-counted vmcnt would drain the DMA queue at every use.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+__device__ __forceinline__ void ldg16(u32x4_t& dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+// counted wait that also pins the destinations: nothing may read them above this statement
+template <int N>
+__device__ __forceinline__ void wait_vm4(u32x4_t& a, u32x4_t& b, u32x4_t& c, u32x4_t& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm2(u32x4_t& a, u32x4_t& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
+__device__ __forceinline__ void unpack8(const u32x4_t& c, float (&v)[8]) {
+  v[0] = __uint_as_float(c.x << 16); v[1] = __uint_as_float(c.x & 0xffff0000u);
+  v[2] = __uint_as_float(c.y << 16); v[3] = __uint_as_float(c.y & 0xffff0000u);
+  v[4] = __uint_as_float(c.z << 16); v[5] = __uint_as_float(c.z & 0xffff0000u);
+  v[6] = __uint_as_float(c.w << 16); v[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+
+constexpr int kStage = 6 * kSlot;      // epilogue staging lives in [96 KiB, 160 KiB): ring slots 6, 7 + 32 KiB
+constexpr int kLds = 160 * 1024;
+
+// Persistent kernel: workgroup b walks tiles b, b + grid, b + 2*grid, ... (XCD-aware order).
+template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2>
+__global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int h = lane >> 5, l31 = lane & 31;
   const int tiles_n = p.N >> 8;
-  const int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (t / tiles_n) << 8;
-  const int n0 = (t % tiles_n) << 8;
 
   Ctx c;
   c.smem = smem;
@@ -205,14 +241,14 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p) {
   c.hiA = 64u * lda_b;
   c.hiB = 32u * ldb_b;
   c.dma_dst = wave * 2048;
+  // tile-independent part of the per-lane DMA source offsets
+  uint32_t rowA[2], rowB[2], chk[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int lr = (wave * 2 + i) * 8 + (lane >> 3);             // row of the half-tile image
-    const uint32_t ch = (uint32_t)((lane & 7) ^ ((lr >> 1) & 7)) << 4;
-    const uint32_t ra = (uint32_t)(m0 + (lr >> 6) * 128 + (lr & 63));
-    const uint32_t rb = (uint32_t)(n0 + (lr >> 5) * 64 + (lr & 31));
-    c.voffA[i] = ra * lda_b + ch;
-    c.voffB[i] = rb * ldb_b + ch;
+    chk[i] = (uint32_t)((lane & 7) ^ ((lr >> 1) & 7)) << 4;
+    rowA[i] = (uint32_t)((lr >> 6) * 128 + (lr & 63));
+    rowB[i] = (uint32_t)((lr >> 5) * 64 + (lr & 31));
   }
   {
     const int sw = (l31 >> 1) & 7;
@@ -223,17 +259,20 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p) {
       c.rdB[s] = (uint32_t)(wn * 32 + l31) * 128 + ch;
     }
   }
-
-  f32x16_t acc[4][2];
+  auto tile_origin = [&](int v, int& m0, int& n0) {
+    const int t = xcd_remap(v, ntiles);
+    const int tm = t / tiles_n;
+    m0 = tm << 8;
+    n0 = (t - tm * tiles_n) << 8;
+  };
+  auto set_tile = [&](int m0, int n0) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- prologue: half-tiles 0..5 (tile 0 complete, A-lo / B-lo of tile 1) ---------------------
-  {
+    for (int i = 0; i < 2; ++i) {
+      c.voffA[i] = ((uint32_t)m0 + rowA[i]) * lda_b + chk[i];
+      c.voffB[i] = ((uint32_t)n0 + rowB[i]) * ldb_b + chk[i];
+    }
+  };
+  auto issue_prologue = [&]() {      // half-tiles 0..5 of the tile described by c.voff*
     const uint32_t d = c.lds_base + c.dma_dst;
     dma16(d + 0 * kSlot, c.voffA[0], c.srdA, 0);
     dma16(d + 0 * kSlot + 1024, c.voffA[1], c.srdA, 0);
@@ -247,149 +286,181 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p) {
     dma16(d + 4 * kSlot + 1024, c.voffA[1], c.srdA, 128);
     dma16(d + 5 * kSlot, c.voffB[0], c.srdB, 128);
     dma16(d + 5 * kSlot + 1024, c.voffB[1], c.srdB, 128);
-    wait_vm<8>();                       // half-tiles 0 and 1 (this wave's pieces)
+  };
+
+  // epilogue constants
+  const int crow = lane >> 3, g = lane & 7;
+  const uint32_t ldc_b = (uint32_t)p.ldc * 2u, ldr_b = (uint32_t)p.ldr * 2u, ldu_b = (uint32_t)p.ldu * 2u;
+  const i32x4_t srdR = make_srd(p.R, HAS_R ? (uint32_t)p.M * ldr_b : 0u);
+  const i32x4_t srdU = make_srd(p.U, HAS_U ? (uint32_t)p.M * ldu_b : 0u);
+  const i32x4_t srdBias = make_srd(p.bias, p.bias ? (uint32_t)p.N * 4u : 0u);   // no bias: reads return 0
+  const __amdgpu_buffer_rsrc_t rsC =
+      __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((uint32_t)p.M * ldc_b), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC2 =
+      __builtin_amdgcn_make_buffer_rsrc(HAS_C2 ? p.C2 : p.C, 0, (int)((uint32_t)p.M * ldc_b), 0x00020000);
+  const uint32_t lane_c = (uint32_t)crow * ldc_b + (uint32_t)g * 16u;
+  const uint32_t lane_r = (uint32_t)crow * ldr_b + (uint32_t)g * 16u;
+  const uint32_t lane_u = (uint32_t)crow * ldu_b + (uint32_t)g * 16u;
+  char* W = smem + kStage + wave * 8192;
+  const uint32_t wr_row = (uint32_t)l31 * 256u, wr_sw = (uint32_t)(l31 & 7);
+  const float scale = p.alpha;
+  constexpr int NL = 4 * ((HAS_R ? 1 : 0) + (HAS_U ? 1 : 0));   // loads per 32-row block
+  constexpr int NS = 4 * (HAS_C2 ? 2 : 1);                       // stores per 32-row block
+
+  int v = blockIdx.x, m0, n0;
+  tile_origin(v, m0, n0);
+  set_tile(m0, n0);
+  issue_prologue();
+  wait_vm<8>();                         // half-tiles 0 and 1 (this wave's pieces)
+
+  for (;;) {
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();       // ... and everyone else's
+    __builtin_amdgcn_s_barrier();       // ... and everyone else's; every wave is out of the previous epilogue
     if (wm == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
-  }
 
-  Frags f;
-  const int nk = p.K >> 6;              // even, >= 4 (checked by the launcher)
-  uint32_t kb = 0;                      // byte offset of the current tile's k range
-  for (int kt = 0; kt < nk - 2; kt += 2) {
-    ktile<0, 0>(c, f, acc, kb + 128, kb + 256);
-    ktile<1, 0>(c, f, acc, kb + 256, kb + 384);
-    kb += 256;
-  }
-  ktile<0, 1>(c, f, acc, kb + 128, kb + 256);
-  ktile<1, 2>(c, f, acc, 0, 0);
-  if (wm == 0) __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  // every wave is past its last LDS read and no DMA is in flight: the ring is free
-
-  // ---- epilogue -----------------------------------------------------------------------------
-  char* W = smem + wave * kSlot;                       // wave-private [128][128 B]
-  const int mw = m0 + wm * 128, nw = n0 + wn * 64;     // wave tile origin
-  const float scale = p.alpha;
-  bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
-  bf16_t* C2 = reinterpret_cast<bf16_t*>(p.C2);
-  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.R);
-  const bf16_t* U = reinterpret_cast<const bf16_t*>(p.U);
-  const int crow = lane >> 3, cc = lane & 7;           // coalesced view: 8 rows x 8 chunks per instruction
-
-  // global [128 x 64] bf16 block (row stride ld) -> staging image
-  auto stage_in = [&](const bf16_t* src, int64_t ld) {
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      uint4 v[8];
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = (g * 8 + it) * 8 + crow;
-        v[it] = (mw + row < p.M) ? *reinterpret_cast<const uint4*>(src + (int64_t)(mw + row) * ld + nw + cc * 8)
-                                 : make_uint4(0, 0, 0, 0);
-      }
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = (g * 8 + it) * 8 + crow;
-        *reinterpret_cast<uint4*>(W + stage_off(row, cc)) = v[it];
-      }
-    }
-  };
-  // staging image -> global
-  auto stage_out = [&](bf16_t* dst, int64_t ld) {
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      uint4 v[8];
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = (g * 8 + it) * 8 + crow;
-        v[it] = *reinterpret_cast<const uint4*>(W + stage_off(row, cc));
-      }
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = (g * 8 + it) * 8 + crow;
-        if (mw + row < p.M) *reinterpret_cast<uint4*>(dst + (int64_t)(mw + row) * ld + nw + cc * 8) = v[it];
-      }
-    }
-  };
-  // MFMA-layout view of the image: lane (row l31 of block i) holds n = j*32 + q*8 + h*4 + e
-  auto frag_ptr = [&](int i, int j, int q) -> char* {
-    const int row = i * 32 + l31;
-    return W + stage_off(row, j * 4 + q) + h * 8;
-  };
-
-  // 1. acc = alpha * acc + bias
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + nw + j * 32 + q * 8 + h * 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acc[i][j][q * 4 + 0] = acc[i][j][q * 4 + 0] * scale + bv.x;
-        acc[i][j][q * 4 + 1] = acc[i][j][q * 4 + 1] * scale + bv.y;
-        acc[i][j][q * 4 + 2] = acc[i][j][q * 4 + 2] * scale + bv.z;
-        acc[i][j][q * 4 + 3] = acc[i][j][q * 4 + 3] * scale + bv.w;
-      }
-    }
-  // 2. optional second output: the pre-activation value
-  if (C2) {
+    f32x16_t acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<uint2*>(frag_ptr(i, j, q)) =
-              make_uint2(pack_bf16x2(acc[i][j][q * 4], acc[i][j][q * 4 + 1]),
-                         pack_bf16x2(acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]));
-    stage_out(C2, p.ldc);
-  }
-  // 3. activation, or (backward) multiply by act'(U)
-  if (U) {
-    stage_in(U, p.ldu);
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Frags f;
+    const int nk = p.K >> 6;              // even, >= 4 (checked by the launcher)
+    uint32_t kb = 0;                      // byte offset of the current tile's k range
+    for (int kt = 0; kt < nk - 2; kt += 2) {
+      ktile<0, 0>(c, f, acc, kb + 128, kb + 256);
+      ktile<1, 0>(c, f, acc, kb + 256, kb + 384);
+      kb += 256;
+    }
+    ktile<0, 1>(c, f, acc, kb + 128, kb + 256);
+    ktile<1, 2>(c, f, acc, 0, 0);
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // every wave is past its last LDS read and no DMA is in flight: the ring is free
+
+    // ---- epilogue --------------------------------------------------------------------------------
+    // One 32-row block of the wave tile at a time: its 32 x 64 fp32 accumulators go through a wave-private
+    // 8 KiB LDS image (16-byte chunk index XORed with row & 7: conflict-free both ways) and come back
+    // row-coalesced: lane (crow = lane >> 3, g = lane & 7) holds 8 consecutive columns of row it*8 + crow.
+    // All epilogue math (alpha, bias, activation or act'(U), residual) runs in that layout in fp32 with
+    // one rounding; every global access is 16 B per lane = 8 full 128-byte rows per wave instruction.
+    // VMEM stream of one epilogue (all counts static):
+    //   bias(2) L0 L1 [D = 12 DMA of the next tile] | S0 L2 | S1 L3 | S2 | S3      (Lb: NL loads, Sb: NS stores)
+    const int mw = m0 + wm * 128, nw = n0 + wn * 64;     // wave tile origin
+    u32x4_t bq[2];
+    u32x4_t ld_r[2][4], ld_u[2][4];
+    ldg16(bq[0], (uint32_t)g * 32u, srdBias, (uint32_t)nw * 4u);
+    ldg16(bq[1], (uint32_t)g * 32u + 16u, srdBias, (uint32_t)nw * 4u);
+    auto issue_loads = [&](auto bc, auto ic) {
+      constexpr int b = decltype(bc)::value, i = decltype(ic)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int it = 0; it < 4; ++it) {
+        const uint32_t row = (uint32_t)(mw + i * 32 + it * 8);
+        if constexpr (HAS_R) ldg16(ld_r[b][it], lane_r, srdR, row * ldr_b + (uint32_t)nw * 2u);
+        if constexpr (HAS_U) ldg16(ld_u[b][it], lane_u, srdU, row * ldu_b + (uint32_t)nw * 2u);
+      }
+    };
+    if constexpr (NL > 0) {
+      issue_loads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      issue_loads(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    }
+    const int vn = v + (int)gridDim.x;
+    const bool has_next = vn < ntiles;
+    int m0n = 0, n0n = 0;
+    if (has_next) {
+      tile_origin(vn, m0n, n0n);
+      set_tile(m0n, n0n);
+    }
+    // Lands in ring slots 0..5 while this epilogue runs.  After the last tile the same twelve DMAs are issued
+    // anyway (re-reading this tile's first half-tiles into the dead ring): every counted wait below is then
+    // a single unconditional statement -- a branch around two asm waits made hipcc copy load destinations
+    // before the wait that guards them.
+    issue_prologue();
+    float bv[8];
+
+    static_for<4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int b = i & 1;
+      // accumulators -> LDS (MFMA layout: row l31, columns j*32 + q*8 + h*4 .. +3)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const uint2 u = *reinterpret_cast<const uint2*>(frag_ptr(i, j, q));
-          acc[i][j][q * 4 + 0] *= act_grad<FAST>(__uint_as_float(u.x << 16), p.act);
-          acc[i][j][q * 4 + 1] *= act_grad<FAST>(__uint_as_float(u.x & 0xffff0000u), p.act);
-          acc[i][j][q * 4 + 2] *= act_grad<FAST>(__uint_as_float(u.y << 16), p.act);
-          acc[i][j][q * 4 + 3] *= act_grad<FAST>(__uint_as_float(u.y & 0xffff0000u), p.act);
+          const uint32_t ch = (uint32_t)(j * 8 + q * 2 + h) ^ wr_sw;
+          *reinterpret_cast<float4*>(W + wr_row + (ch << 4)) =
+              make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
         }
-  } else if (p.act != ACT_NONE) {
+      float x[4][8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = act_apply<FAST>(acc[i][j][r], p.act);
-  }
-  // 4. residual, round once, store
-  if (R) stage_in(R, p.ldr);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        char* ptr = frag_ptr(i, j, q);
-        float v0 = acc[i][j][q * 4], v1 = acc[i][j][q * 4 + 1], v2 = acc[i][j][q * 4 + 2], v3 = acc[i][j][q * 4 + 3];
-        if (R) {
-          const uint2 r = *reinterpret_cast<const uint2*>(ptr);
-          v0 += __uint_as_float(r.x << 16);
-          v1 += __uint_as_float(r.x & 0xffff0000u);
-          v2 += __uint_as_float(r.y << 16);
-          v3 += __uint_as_float(r.y & 0xffff0000u);
-        }
-        *reinterpret_cast<uint2*>(ptr) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      for (int it = 0; it < 4; ++it) {
+        const int rr = it * 8 + crow;
+        const uint32_t sw = (uint32_t)(rr & 7);
+        const float4 x0 = *reinterpret_cast<const float4*>(W + rr * 256 + (((uint32_t)(2 * g) ^ sw) << 4));
+        const float4 x1 = *reinterpret_cast<const float4*>(W + rr * 256 + (((uint32_t)(2 * g + 1) ^ sw) << 4));
+        x[it][0] = x0.x; x[it][1] = x0.y; x[it][2] = x0.z; x[it][3] = x0.w;
+        x[it][4] = x1.x; x[it][5] = x1.y; x[it][6] = x1.z; x[it][7] = x1.w;
       }
-  stage_out(C, p.ldc);
+      // wait for this block's loads (block 0: also the bias)
+      if constexpr (i == 0) {
+        wait_vm2<NL + 12>(bq[0], bq[1]);
+        bv[0] = __uint_as_float(bq[0].x); bv[1] = __uint_as_float(bq[0].y);
+        bv[2] = __uint_as_float(bq[0].z); bv[3] = __uint_as_float(bq[0].w);
+        bv[4] = __uint_as_float(bq[1].x); bv[5] = __uint_as_float(bq[1].y);
+        bv[6] = __uint_as_float(bq[1].z); bv[7] = __uint_as_float(bq[1].w);
+      }
+      if constexpr (NL > 0) {
+        // newer than block i's loads:  i=0: L1 (+D)   i=1: D, S0, L2   i=2: S1, L3   i=3: S2
+        constexpr int cnt = (i == 0) ? NL + 12 : (i == 1) ? NS + NL + 12 : (i == 2) ? NS + NL : NS;
+        if constexpr (HAS_R) wait_vm4<cnt>(ld_r[b][0], ld_r[b][1], ld_r[b][2], ld_r[b][3]);
+        if constexpr (HAS_U) wait_vm4<cnt>(ld_u[b][0], ld_u[b][1], ld_u[b][2], ld_u[b][3]);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float (&y)[8] = x[it];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = y[e] * scale + bv[e];
+        const uint32_t soff = (uint32_t)(mw + i * 32 + it * 8) * ldc_b + (uint32_t)nw * 2u;
+        if constexpr (HAS_C2) {
+          const u32x4_t o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
+                             pack_bf16x2(y[6], y[7])};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rsC2, lane_c, soff, 0);
+        }
+        if constexpr (HAS_U) {
+          float uf[8];
+          unpack8(ld_u[b][it], uf);
+          if (p.act == ACT_QUICKGELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] *= act_grad<FAST>(uf[e], ACT_QUICKGELU);
+          } else if (p.act == ACT_GELU_ERF) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] *= act_grad<FAST>(uf[e], ACT_GELU_ERF);
+          }
+        } else if (p.act == ACT_QUICKGELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = act_apply<FAST>(y[e], ACT_QUICKGELU);
+        } else if (p.act == ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = act_apply<FAST>(y[e], ACT_GELU_ERF);
+        }
+        if constexpr (HAS_R) {
+          float rf[8];
+          unpack8(ld_r[b][it], rf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] += rf[e];
+        }
+        const u32x4_t o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
+                           pack_bf16x2(y[6], y[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsC, lane_c, soff, 0);
+      }
+      if constexpr (NL > 0 && i < 2) issue_loads(std::integral_constant<int, b>{}, std::integral_constant<int, i + 2>{});
+    });
+    if (!has_next) break;
+    wait_vm<0>();       // store acks (+ the next tile's first half-tiles, landed long ago)
+    v = vn; m0 = m0n; n0 = n0n;
+  }
 }
 
 }  // namespace
@@ -404,24 +475,61 @@ bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype) {
   if (p.R && ((p.ldr & 7) || ((uintptr_t)p.R & 15))) return false;
   if (p.U && ((p.ldu & 7) || ((uintptr_t)p.U & 15))) return false;
   if (p.bias && ((uintptr_t)p.bias & 15)) return false;
+  // instantiated epilogue combinations: plain, +R, +C2, +U
+  const int combo = (p.R ? 1 : 0) + (p.U ? 2 : 0) + (p.C2 ? 4 : 0);
+  if (!(combo == 0 || combo == 1 || combo == 2 || combo == 4)) return false;
   // 32-bit buffer offsets
-  if ((uint64_t)p.M * (uint64_t)p.lda * 2u >= 0xffff0000ull || (uint64_t)p.N * (uint64_t)p.ldb * 2u >= 0xffff0000ull)
+  const uint64_t lim = 0xffff0000ull;
+  if ((uint64_t)p.M * (uint64_t)p.lda * 2u >= lim || (uint64_t)p.N * (uint64_t)p.ldb * 2u >= lim ||
+      (uint64_t)p.M * (uint64_t)p.ldc * 2u >= lim)
     return false;
+  if (p.R && (uint64_t)p.M * (uint64_t)p.ldr * 2u >= lim) return false;
+  if (p.U && (uint64_t)p.M * (uint64_t)p.ldu * 2u >= lim) return false;
   return true;
 }
 
-int gemm_nt_8p(const GemmArgs& p, hipStream_t stream) {
-  const int tiles = ((p.M + 255) >> 8) * (p.N >> 8);
+int g_gemm8p_ablate = 0;
+void set_gemm8p_ablate(int v) { g_gemm8p_ablate = v; }
+
+namespace {
+int g_num_cus = 0;
+
+template <bool R, bool U, bool C2>
+int launch_8p(const GemmArgs& p, int tiles, int grid, hipStream_t stream) {
   static bool attr_set = false;
+  auto* kern = &gemm_nt_8p_kernel<true, R, U, C2>;
   if (!attr_set) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_8p_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kRing));
+    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     attr_set = true;
   }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads8), kLds, stream, p, tiles);
+  return EZ_OK;
+}
+}  // namespace
+
+int gemm_nt_8p(const GemmArgs& p_in, hipStream_t stream) {
+  GemmArgs p = p_in;
+  p.vec_ok = g_gemm8p_ablate;
+  if (g_num_cus == 0) {
+    int dev = 0;
+    EZ_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    EZ_HIP(hipGetDeviceProperties(&prop, dev));
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int tiles = ((p.M + 255) >> 8) * (p.N >> 8);
+  int grid = tiles;                                         // one workgroup per CU (160 KiB LDS each)
+  if (tiles > g_num_cus) grid = g_num_cus >= 8 ? (g_num_cus & ~7) : g_num_cus;   // multiple of 8: tile -> XCD affinity across rounds
+  if (g_gemm8p_ablate == 4) grid = tiles;                   // debugging: one tile per workgroup
+  int rc;
   {
     ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);
-    hipLaunchKernelGGL((gemm_nt_8p_kernel<true>), dim3(tiles), dim3(kThreads8), kRing, stream, p);
+    if (p.U) rc = launch_8p<false, true, false>(p, tiles, grid, stream);
+    else if (p.C2) rc = launch_8p<false, false, true>(p, tiles, grid, stream);
+    else if (p.R) rc = launch_8p<true, false, false>(p, tiles, grid, stream);
+    else rc = launch_8p<false, false, false>(p, tiles, grid, stream);
   }
+  if (rc != EZ_OK) return rc;
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

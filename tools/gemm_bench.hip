@@ -60,6 +60,25 @@ __global__ void maxdiff_bf16(const uint16_t* a, const uint16_t* b, size_t n, flo
   if (bad) atomicAdd(nbad, bad);
 }
 
+// where do the outputs differ?  bins: [0..15] (row%128)/8, [16..23] (col%64)/8, [24..31] wave = ((row%256)/128)*4 + (col%256)/64,
+// [32] tiles with a difference (approx: counts elements at tile origin rows), [33..40] row%8
+__global__ void diffmap(const uint16_t* a, const uint16_t* b, int M, int N, unsigned long long* bins) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t n = (size_t)M * N, stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    if (a[i] == b[i]) continue;
+    const int r = (int)(i / N), c = (int)(i % N);
+    atomicAdd(&bins[(r % 128) / 8], 1ull);
+    atomicAdd(&bins[16 + (c % 64) / 8], 1ull);
+    atomicAdd(&bins[24 + ((r % 256) / 128) * 4 + (c % 256) / 64], 1ull);
+    atomicAdd(&bins[33 + r % 8], 1ull);
+    atomicAdd(&bins[41 + (c % 8)], 1ull);
+    if (b[i] == 0xffff) atomicAdd(&bins[32], 1ull);
+  }
+}
+
+constexpr size_t kGuard = 256 * 3072;   // elements after the last row of C
+
 struct Shape { const char* name; int M, N, K, act; bool res, c2; bool u = false; };
 
 }  // namespace
@@ -99,7 +118,7 @@ int main(int argc, char** argv) {
     const size_t nA = (size_t)s.M * s.K, nB = (size_t)s.N * s.K, nC = (size_t)s.M * s.N;
     uint16_t *A, *B, *R = nullptr, *C0, *C1, *P0 = nullptr, *P1 = nullptr, *Uu = nullptr;
     float* bias;
-    CK(hipMalloc(&A, nA * 2)); CK(hipMalloc(&B, nB * 2)); CK(hipMalloc(&C0, nC * 2)); CK(hipMalloc(&C1, nC * 2));
+    CK(hipMalloc(&A, nA * 2)); CK(hipMalloc(&B, nB * 2)); CK(hipMalloc(&C0, nC * 2)); CK(hipMalloc(&C1, (nC + kGuard) * 2));
     CK(hipMalloc(&bias, s.N * 4));
     if (s.res) CK(hipMalloc(&R, nC * 2));
     if (s.c2) { CK(hipMalloc(&P0, nC * 2)); CK(hipMalloc(&P1, nC * 2)); }
@@ -110,6 +129,7 @@ int main(int argc, char** argv) {
     if (s.u) { CK(hipMalloc(&Uu, nC * 2)); fill_bf16<<<2048, 256, 0, st>>>(Uu, nC, 5u, 3.0f); }
     CK(hipMemsetAsync(C0, 0xff, nC * 2, st));
     CK(hipMemsetAsync(C1, 0xff, nC * 2, st));
+    CK(hipMemsetAsync(C1 + nC, 0x5a, kGuard * 2, st));   // guard: rows >= M must never be written
     printf("%-15s M=%7d N=%5d K=%5d :", s.name, s.M, s.N, s.K);
     for (size_t vi = 0; vi < variants.size(); ++vi) {
       const int v = variants[vi];
@@ -141,6 +161,27 @@ int main(int argc, char** argv) {
         CK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, st));
         CK(hipStreamSynchronize(st));
         printf(" [maxdiff %.3g, %llu differ]", md, bad);
+        {
+          std::vector<uint16_t> hg(kGuard);
+          CK(hipMemcpyAsync(hg.data(), C1 + nC, kGuard * 2, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+          size_t gb = 0;
+          for (uint16_t x : hg) gb += (x != 0x5a5a);
+          if (gb) printf(" [GUARD VIOLATED: %zu elements past M rows written]", gb);
+        }
+        if (bad && getenv("DIFFMAP")) {
+          unsigned long long* dbins; unsigned long long hb[49];
+          CK(hipMalloc(&dbins, sizeof(hb))); CK(hipMemsetAsync(dbins, 0, sizeof(hb), st));
+          diffmap<<<1024, 256, 0, st>>>(C0, C1, s.M, s.N, dbins);
+          CK(hipMemcpyAsync(hb, dbins, sizeof(hb), hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+          printf("\n   by (row%%128)/8:"); for (int q = 0; q < 16; ++q) printf(" %llu", hb[q]);
+          printf("\n   by (col%%64)/8:"); for (int q = 16; q < 24; ++q) printf(" %llu", hb[q]);
+          printf("\n   by wave:"); for (int q = 24; q < 32; ++q) printf(" %llu", hb[q]);
+          printf("\n   unwritten(0xffff): %llu", hb[32]);
+          printf("\n   by row%%8:"); for (int q = 33; q < 41; ++q) printf(" %llu", hb[q]);
+          printf("\n   by col%%8:"); for (int q = 41; q < 49; ++q) printf(" %llu", hb[q]);
+          printf("\n");
+          hipFree(dbins);
+        }
       }
     }
     printf("\n");

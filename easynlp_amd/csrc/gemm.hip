@@ -478,6 +478,7 @@ int gemm_tn(GemmTNArgs p, int dtype, hipStream_t stream) {
   const int g = 16 / esz;
   EZ_REQUIRE(p.N % g == 0 && p.K % g == 0 && p.lda % g == 0 && p.ldb % g == 0, "gemm_tn: N, K, lda, ldb must be multiples of %d", g);
   EZ_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0, "gemm_tn: A/B must be 16-byte aligned");
+  if ((g_gemm_variant < 0 || g_gemm_variant == 2) && gemm_tn_8p_eligible(p, dtype)) return gemm_tn_8p(p, stream);
   if (dtype == EZCLIP_F32) return launch_tn<float>(p, stream);
   if (dtype == EZCLIP_BF16) return launch_tn<bf16_t>(p, stream);
   set_error("gemm_tn: bad dtype %d", dtype);

@@ -463,6 +463,264 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
   }
 }
 
+
+// =====================================================================================================
+// Weight-gradient GEMM on the same pipeline:  C[P, Q] (+)= A[M, P]^T . B[M, Q]   (contraction over the ROWS)
+//
+// dW = dY^T X for every nn.Linear of the path (autograd of easynlp/core/trainer.py:658-661).  Both operands are
+// row-major with the contraction index m as the slow dimension, so a K-tile is 64 consecutive rows and its
+// half-tiles are [64 m][128 columns] images (256 B per image row, full 128-byte lines from HBM): A-lo / A-hi =
+// columns p0 + 0..127 / 128..255, B-lo / B-hi likewise.  The MFMA wants 8 consecutive m per lane for one
+// column: ds_read_b64_tr_b16 (the CDNA4 LDS transpose read) delivers exactly that from the row-major image --
+// 16 lanes read a 4(m) x 16(col) block, lane c receives column c -- two reads per operand fragment.  The
+// 64-byte granule index of an image row is XORed with m & 3 (on the DMA source address and on the read), which
+// puts the four rows of a transpose block on four different bank quarters: conflict-free.
+// The wave tile is 4 x 2 MFMA blocks as in the NT kernel, but the blocks sit at columns
+//   p: wm*64 + i*32 (i = 0,1), 128 + wm*64 + (i-2)*32 (i = 2,3);   q: wn*32 (j = 0), 128 + wn*32 (j = 1)
+// so that "lo" and "hi" are contiguous 128-column halves.  Phases, ring, counted waits and the barrier stagger
+// are those of the NT kernel.
+// The contraction (M ~ 2e5) is split over workgroups: split s of tile t writes its 256 x 256 fp32 partial to
+// scratch[s][P][Q] (row-coalesced through LDS), and tn_reduce_kernel adds the partials in a fixed order:
+// gradients are bit-reproducible (no atomics).
+
+struct CtxTN {
+  const char* smem;
+  uint32_t lds_base;
+  i32x4_t srdA, srdB;
+  uint32_t voffA[2], voffB[2];
+  uint32_t dma_dst;
+  uint32_t rdA[2], rdB;        // per-lane LDS byte offsets of the transpose reads (A: i' = 0, 1)
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+
+// one operand fragment (8 consecutive m for column l31): two transpose reads
+__device__ __forceinline__ uint4 read_tr(const char* base) {
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 1024));
+  const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+  return make_uint4(a.x, a.y, b.x, b.y);
+}
+
+template <int P, int PAR, bool ISSUE, int VM>
+__device__ __forceinline__ void phase_tn(const CtxTN& c, Frags& f, f32x16_t (&acc)[4][2], uint32_t soff1,
+                                         uint32_t soff2) {
+  constexpr int k8 = 4 * PAR + P;
+  if constexpr (P == 0) {
+    constexpr int sB = ((k8 + 1) & 7) * kSlot, sA = (k8 & 7) * kSlot;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f.bl[s] = read_tr(c.smem + sB + c.rdB + s * 4096);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f.a[0][s] = read_tr(c.smem + sA + c.rdA[0] + s * 4096);
+      f.a[1][s] = read_tr(c.smem + sA + c.rdA[1] + s * 4096);
+    }
+  } else if constexpr (P == 1) {
+    constexpr int sB = ((k8 + 1) & 7) * kSlot;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f.bh[s] = read_tr(c.smem + sB + c.rdB + s * 4096);
+  } else if constexpr (P == 2) {
+    constexpr int sA = ((k8 + 1) & 7) * kSlot;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f.a[0][s] = read_tr(c.smem + sA + c.rdA[0] + s * 4096);
+      f.a[1][s] = read_tr(c.smem + sA + c.rdA[1] + s * 4096);
+    }
+  }
+  // soff1 / soff2: byte offset of the first row of K-tile t+1 / t+2 (per operand: A uses .x, B .y -- see caller)
+  if constexpr (ISSUE) {
+    constexpr int slot = ((k8 + 6) & 7) * kSlot;
+    const uint32_t dst = c.lds_base + slot + c.dma_dst;
+    if constexpr (P == 0) {          // B-hi(t+1)
+      dma16(dst, c.voffB[0], c.srdB, soff1 + 256);
+      dma16(dst + 1024, c.voffB[1], c.srdB, soff1 + 256);
+    } else if constexpr (P == 1) {   // A-hi(t+1)
+      dma16(dst, c.voffA[0], c.srdA, soff1 + 256);
+      dma16(dst + 1024, c.voffA[1], c.srdA, soff1 + 256);
+    } else if constexpr (P == 2) {   // A-lo(t+2)
+      dma16(dst, c.voffA[0], c.srdA, soff2);
+      dma16(dst + 1024, c.voffA[1], c.srdA, soff2);
+    } else {                         // B-lo(t+2)
+      dma16(dst, c.voffB[0], c.srdB, soff2);
+      dma16(dst + 1024, c.voffB[1], c.srdB, soff2);
+    }
+  }
+  wait_vm<VM>();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
+  constexpr int i0 = (P >= 2) ? 2 : 0;
+  constexpr int j = (P == 1 || P == 2) ? 1 : 0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4& b = (j == 0) ? f.bl[s] : f.bh[s];
+    mma32(acc[i0][j], b, f.a[0][s], bf16_t());
+    mma32(acc[i0 + 1][j], b, f.a[1][s], bf16_t());
+  }
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// The A and B operands have different row strides, so the K-tile byte offsets differ: the caller passes the
+// A offsets and the phases derive B's from the ratio-free pair below.
+struct KOff { uint32_t a1, a2, b1, b2; };
+
+template <int PAR, int TAIL>
+__device__ __forceinline__ void ktile_tn(const CtxTN& c, Frags& f, f32x16_t (&acc)[4][2], const KOff& k) {
+  // P0 issues B (t+1), P1 issues A (t+1), P2 issues A (t+2), P3 issues B (t+2)
+  if constexpr (TAIL == 0) {
+    phase_tn<0, PAR, true, 8>(c, f, acc, k.b1, 0);
+    phase_tn<1, PAR, true, 8>(c, f, acc, k.a1, 0);
+    phase_tn<2, PAR, true, 8>(c, f, acc, 0, k.a2);
+    phase_tn<3, PAR, true, 8>(c, f, acc, 0, k.b2);
+  } else if constexpr (TAIL == 1) {
+    phase_tn<0, PAR, true, 8>(c, f, acc, k.b1, 0);
+    phase_tn<1, PAR, true, 8>(c, f, acc, k.a1, 0);
+    phase_tn<2, PAR, false, 6>(c, f, acc, 0, 0);
+    phase_tn<3, PAR, false, 4>(c, f, acc, 0, 0);
+  } else {
+    phase_tn<0, PAR, false, 2>(c, f, acc, 0, 0);
+    phase_tn<1, PAR, false, 0>(c, f, acc, 0, 0);
+    phase_tn<2, PAR, false, -1>(c, f, acc, 0, 0);
+    phase_tn<3, PAR, false, -1>(c, f, acc, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(kThreads8, 2) void gemm_tn_8p_kernel(GemmTNArgs p, float* part, int ntiles, int tiles_q,
+                                                                  int kt_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = id / ntiles, tile = id - split * ntiles;
+  const int tp = tile / tiles_q, tq = tile - tp * tiles_q;
+  const int p0 = tp << 8, q0 = tq << 8;          // output tile origin: rows = columns of A, cols = columns of B
+  const uint32_t m_begin = (uint32_t)split * (uint32_t)kt_per_split * 64u;
+
+  CtxTN c;
+  c.smem = smem;
+  c.lds_base = (uint32_t)(size_t)smem;
+  const uint32_t lda_b = (uint32_t)p.lda * 2u, ldb_b = (uint32_t)p.ldb * 2u;
+  c.srdA = make_srd(p.A, (uint32_t)(p.M - 1) * lda_b + (uint32_t)p.N * 2u);    // rows >= M read as zeros
+  c.srdB = make_srd(p.B, (uint32_t)(p.M - 1) * ldb_b + (uint32_t)p.K * 2u);
+  c.dma_dst = wave * 2048;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 4 + (lane >> 4);                 // image row (m within the K-tile)
+    const uint32_t ch = (uint32_t)((lane & 15) ^ ((r & 3) << 2)) << 4;   // logical 16-byte chunk of the 256-byte row
+    c.voffA[i] = (m_begin + (uint32_t)r) * lda_b + (uint32_t)p0 * 2u + ch;
+    c.voffB[i] = (m_begin + (uint32_t)r) * ldb_b + (uint32_t)q0 * 2u + ch;
+  }
+  {
+    const int t = lane & 15, sub = (lane >> 4) & 1, g = h;
+    const int row = 8 * g + (t >> 2);                                // + 16*s + 4*kk via immediates
+    const uint32_t swz = (uint32_t)(t >> 2) << 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t colb = (uint32_t)(wm * 64 + i * 32 + sub * 16 + (t & 3) * 4) * 2u;
+      c.rdA[i] = (uint32_t)row * 256u + (colb ^ swz);
+    }
+    const uint32_t colb = (uint32_t)(wn * 32 + sub * 16 + (t & 3) * 4) * 2u;
+    c.rdB = (uint32_t)row * 256u + (colb ^ swz);
+  }
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const uint32_t stepA = 64u * lda_b, stepB = 64u * ldb_b;           // one K-tile further down
+  {
+    const uint32_t d = c.lds_base + c.dma_dst;
+    dma16(d + 0 * kSlot, c.voffA[0], c.srdA, 0);
+    dma16(d + 0 * kSlot + 1024, c.voffA[1], c.srdA, 0);
+    dma16(d + 1 * kSlot, c.voffB[0], c.srdB, 0);
+    dma16(d + 1 * kSlot + 1024, c.voffB[1], c.srdB, 0);
+    dma16(d + 2 * kSlot, c.voffB[0], c.srdB, 256);
+    dma16(d + 2 * kSlot + 1024, c.voffB[1], c.srdB, 256);
+    dma16(d + 3 * kSlot, c.voffA[0], c.srdA, 256);
+    dma16(d + 3 * kSlot + 1024, c.voffA[1], c.srdA, 256);
+    dma16(d + 4 * kSlot, c.voffA[0], c.srdA, stepA);
+    dma16(d + 4 * kSlot + 1024, c.voffA[1], c.srdA, stepA);
+    dma16(d + 5 * kSlot, c.voffB[0], c.srdB, stepB);
+    dma16(d + 5 * kSlot + 1024, c.voffB[1], c.srdB, stepB);
+    wait_vm<8>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  Frags f;
+  const int nk = kt_per_split;          // even, >= 4
+  KOff k;
+  k.a1 = stepA; k.a2 = 2 * stepA; k.b1 = stepB; k.b2 = 2 * stepB;
+  for (int kt = 0; kt < nk - 2; kt += 2) {
+    ktile_tn<0, 0>(c, f, acc, k);
+    k.a1 += stepA; k.a2 += stepA; k.b1 += stepB; k.b2 += stepB;
+    ktile_tn<1, 0>(c, f, acc, k);
+    k.a1 += stepA; k.a2 += stepA; k.b1 += stepB; k.b2 += stepB;
+  }
+  ktile_tn<0, 1>(c, f, acc, k);
+  ktile_tn<1, 2>(c, f, acc, k);
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue: fp32 partial tile, row-coalesced through LDS (16 lanes x 16 B = one 256-byte row segment) ----
+  char* W = smem + wave * 8192;
+  const uint32_t wr_row = (uint32_t)l31 * 256u, wr_sw = (uint32_t)(l31 & 7);
+  float* out = part + (size_t)split * (size_t)p.N * (size_t)p.K;
+  const int r4 = lane >> 4, c16 = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t ch = (uint32_t)(j * 8 + q * 2 + h) ^ wr_sw;
+        *reinterpret_cast<float4*>(W + wr_row + (ch << 4)) =
+            make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+      }
+    const int prow0 = p0 + ((i >> 1) << 7) + wm * 64 + (i & 1) * 32;     // first output row of this block
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rr = it * 4 + r4;
+      const float4 v = *reinterpret_cast<const float4*>(W + rr * 256 + (((uint32_t)c16 ^ (uint32_t)(rr & 7)) << 4));
+      // image columns 0..31 are the j = 0 block (q0 + wn*32 ..), 32..63 the j = 1 block (q0 + 128 + wn*32 ..)
+      const int col = q0 + ((c16 >> 3) << 7) + wn * 32 + (c16 & 7) * 4;
+      *reinterpret_cast<float4*>(out + (size_t)(prow0 + rr) * (size_t)p.K + col) = v;
+    }
+  }
+}
+
+// C = (accumulate ? C : 0) + sum_s part[s]   (fixed order)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* part, int splits, int P, int Q, float* C, int64_t ldc,
+                                                        int accumulate) {
+  const size_t n4 = (size_t)P * Q / 4;
+  const size_t stride = (size_t)P * Q;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 4;
+    const int r = (int)(e / Q), cidx = (int)(e - (size_t)r * Q);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < splits; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * stride + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* dst = C + (size_t)r * ldc + cidx;
+    if (accumulate) { s.x += dst[0]; s.y += dst[1]; s.z += dst[2]; s.w += dst[3]; }
+    dst[0] = s.x; dst[1] = s.y; dst[2] = s.z; dst[3] = s.w;
+  }
+}
+
 }  // namespace
 
 bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype) {
@@ -530,6 +788,64 @@ int gemm_nt_8p(const GemmArgs& p_in, hipStream_t stream) {
     else rc = launch_8p<false, false, false>(p, tiles, grid, stream);
   }
   if (rc != EZ_OK) return rc;
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+// ---- weight-gradient launcher ---------------------------------------------------------------------------
+namespace {
+float* g_tn_scratch = nullptr;
+size_t g_tn_scratch_bytes = 0;
+}  // namespace
+
+bool gemm_tn_8p_eligible(const GemmTNArgs& p, int dtype) {
+  if (dtype != EZCLIP_BF16) return false;
+  if ((p.N & 255) || (p.K & 255) || p.M < 2048) return false;
+  if ((p.lda & 7) || (p.ldb & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15) || ((uintptr_t)p.C & 15) || (p.ldc & 3))
+    return false;
+  const uint64_t lim = 0xffff0000ull;
+  if (((uint64_t)p.M + 65536) * (uint64_t)p.lda * 2u >= lim || ((uint64_t)p.M + 65536) * (uint64_t)p.ldb * 2u >= lim) return false;
+  return true;
+}
+
+int gemm_tn_8p(const GemmTNArgs& p, hipStream_t stream) {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    EZ_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    EZ_HIP(hipGetDeviceProperties(&prop, dev));
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int tiles_p = p.N >> 8, tiles_q = p.K >> 8, ntiles = tiles_p * tiles_q;
+  const int kt_total = (p.M + 63) / 64;
+  int splits = g_num_cus / ntiles;
+  if (splits < 1) splits = 1;
+  int kt = (kt_total + splits - 1) / splits;
+  if (kt < 4) kt = 4;
+  kt = (kt + 1) & ~1;                                  // even, >= 4
+  splits = (kt_total + kt - 1) / kt;                   // drop splits that would start past M
+  const size_t need = (size_t)splits * (size_t)p.N * (size_t)p.K * sizeof(float);
+  if (need > g_tn_scratch_bytes) {
+    // library-owned scratch for the split partials (grown on first use; one stream at a time per handle)
+    if (g_tn_scratch) { EZ_HIP(hipStreamSynchronize(stream)); EZ_HIP(hipFree(g_tn_scratch)); g_tn_scratch = nullptr; }
+    EZ_HIP(hipMalloc(reinterpret_cast<void**>(&g_tn_scratch), need));
+    g_tn_scratch_bytes = need;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_8p_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kRing));
+    attr_set = true;
+  }
+  {
+    ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);
+    hipLaunchKernelGGL(gemm_tn_8p_kernel, dim3(ntiles * splits), dim3(kThreads8), kRing, stream, p, g_tn_scratch, ntiles,
+                       tiles_q, kt);
+    const size_t n4 = (size_t)p.N * p.K / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g_tn_scratch, splits, p.N, p.K, p.C, p.ldc,
+                       p.accumulate);
+  }
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

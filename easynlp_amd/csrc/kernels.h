@@ -43,6 +43,10 @@ struct GemmTNArgs {
   int accumulate = 0;                         // C += instead of C =
 };
 int gemm_tn(GemmTNArgs p, int dtype, hipStream_t stream);
+// 256x256 8-phase bf16 weight-gradient kernel (gemm8p.hip): N % 256 == 0, K % 256 == 0, large M; split partials +
+// fixed-order reduction (bit-reproducible)
+bool gemm_tn_8p_eligible(const GemmTNArgs& p, int dtype);
+int gemm_tn_8p(const GemmTNArgs& p, hipStream_t stream);
 
 // ---- attention (attention.hip) ---------------------------------------------
 struct AttnArgs {

@@ -340,3 +340,83 @@ def test_gemm_nt_tile_variants(M, N, K, dtype, variant):
     finally:
         L.check(lib.ezclip_debug_set(0, -1))
     assert max_err(c.float(), ref) < (5e-5 if dtype == "f32" else 0.06) * max(1.0, math.sqrt(K) / 8)
+
+
+# ----------------------------------------------------------------------------- 256x256 8-phase kernels (gemm8p.hip)
+
+@pytest.mark.parametrize("M,N,K", [(2049, 256, 3072), (1000, 768, 768), (512, 512, 256), (300, 256, 512), (4096, 1024, 384)])
+@pytest.mark.parametrize("epi", ["plain", "bias", "bias_res_gelu", "res_qgelu_strided"])
+def test_gemm_nt_8phase(M, N, K, epi):
+    """The persistent 8-phase bf16 kernel (forced with variant 2) against the fp64 product and, bit for bit,
+    against the 128x128 kernel (same accumulation order, same epilogue math): ragged M (bounds-checked DMA and
+    stores), the minimum K (4 K-tiles), more tiles than CUs is covered by the model tests / gemm_bench."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    wide = torch.randn(M, 2 * K, generator=g) * 0.5
+    a = (wide[:, K:] if epi.endswith("strided") else wide[:, :K].contiguous()).bfloat16()
+    b = (torch.randn(N, K, generator=g) * 0.2).bfloat16()
+    bias = torch.randn(N, generator=g) if epi != "plain" else None
+    res = torch.randn(M, N, generator=g).bfloat16() if "res" in epi else None
+    act = L.ACT_GELU_ERF if "gelu" in epi and "qgelu" not in epi else (L.ACT_QUICKGELU if "qgelu" in epi else L.ACT_NONE)
+    ref = a.double() @ b.double().t()
+    if bias is not None:
+        ref = ref + bias.double()
+    if act == L.ACT_GELU_ERF:
+        ref = O.gelu_erf(ref)
+    elif act == L.ACT_QUICKGELU:
+        ref = O.quick_gelu(ref)
+    if res is not None:
+        ref = ref + res.double()
+    ad = a.to(DEV)
+    if epi.endswith("strided"):
+        ad = wide.bfloat16().to(DEV)[:, K:]
+        assert ad.stride(0) == 2 * K
+    outs = {}
+    for variant in (0, 2):
+        L.check(lib.ezclip_debug_set(0, variant))
+        try:
+            bd_ = b.to(DEV)
+            biasd = None if bias is None else bias.to(DEV)
+            resd = None if res is None else res.to(DEV)
+            c = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+            L.check(lib.ezclip_op_gemm_nt(ad.data_ptr(), ad.stride(0), bd_.data_ptr(), K, c.data_ptr(), N,
+                                          None if biasd is None else biasd.data_ptr(),
+                                          None if resd is None else resd.data_ptr(), N if resd is not None else 0,
+                                          M, N, K, act, L.DTYPE_BF16, 0, L.stream_ptr()))
+            torch.cuda.synchronize()
+            outs[variant] = c
+        finally:
+            L.check(lib.ezclip_debug_set(0, -1))
+    assert max_err(outs[2].float(), ref) < 0.06 * max(1.0, math.sqrt(K) / 8)
+    assert torch.equal(outs[0], outs[2]), "8-phase kernel differs from the 128x128 kernel"
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 768, 768), (2100, 256, 512), (9000, 512, 256)])
+@pytest.mark.parametrize("strided", [False, True])
+def test_gemm_tn_8phase(M, N, K, strided):
+    """Weight-gradient kernel with LDS transpose reads + split partials: fp64 reference, strided dY (a column
+    slice of a packed qkv gradient), ragged M (rows past M read as zeros), accumulate / overwrite, and
+    bit-reproducibility (fixed-order reduction instead of atomics)."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    wide = torch.randn(M, 3 * N, generator=g).bfloat16()
+    a = wide[:, N:2 * N] if strided else wide[:, :N].contiguous()
+    b = torch.randn(M, K, generator=g).bfloat16()
+    c0 = torch.randn(N, K, generator=g)
+    prod = a.double().t() @ b.double()
+    ad = wide.to(DEV)[:, N:2 * N] if strided else a.to(DEV)
+    bd = b.to(DEV)
+    outs = []
+    for rep in range(2):
+        cd = c0.to(DEV)
+        L.check(lib.ezclip_op_gemm_tn(ad.data_ptr(), ad.stride(0), bd.data_ptr(), K, cd.data_ptr(), K, M, N, K, 1,
+                                      L.DTYPE_BF16, L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(cd)
+    assert rel_err(outs[0], c0.double() + prod) < 1e-5
+    assert torch.equal(outs[0], outs[1]), "weight gradient is not bit-reproducible"
+    c1 = torch.full((N, K), 7.0, device=DEV)
+    L.check(lib.ezclip_op_gemm_tn(ad.data_ptr(), ad.stride(0), bd.data_ptr(), K, c1.data_ptr(), K, M, N, K, 0,
+                                  L.DTYPE_BF16, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(c1, prod) < 1e-5

@@ -8,7 +8,9 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -190,6 +192,54 @@ int main(int argc, char** argv) {
     if (R) hipFree(R);
     if (Uu) hipFree(Uu);
     if (P0) { hipFree(P0); hipFree(P1); }
+  }
+  // ---- weight-gradient (TN) shapes: C[N,K] += A[M,N]^T . B[M,K], fp32 output --------------------------------
+  {
+    struct TN { const char* name; int M, N, K; };
+    const TN tns[] = {{"wgrad.out", Mv, 768, 768},   {"wgrad.qkv", Mv, 2304, 768}, {"wgrad.fc", Mv, 3072, 768},
+                      {"wgrad.proj", Mv, 768, 3072}, {"wgrad.bert.ffn1", Mt, 3072, 768}, {"wgrad.ragged", Mv - 77, 768, 768}};
+    for (const TN& t : tns) {
+      const size_t nA = (size_t)t.M * t.N, nB = (size_t)t.M * t.K, nC = (size_t)t.N * t.K;
+      uint16_t *A, *B; float *C0, *C1;
+      std::vector<float> h0;
+      CK(hipMalloc(&A, nA * 2)); CK(hipMalloc(&B, nB * 2)); CK(hipMalloc(&C0, nC * 4)); CK(hipMalloc(&C1, nC * 4));
+      fill_bf16<<<2048, 256, 0, st>>>(A, nA, 11u, 1.0f);
+      fill_bf16<<<2048, 256, 0, st>>>(B, nB, 12u, 1.0f);
+      printf("%-15s M=%7d N=%5d K=%5d :", t.name, t.M, t.N, t.K);
+      for (size_t vi = 0; vi < variants.size(); ++vi) {
+        const int v = variants[vi];
+        float* C = vi == 0 ? C0 : C1;
+        ezclip::set_gemm_variant(v);
+        ezclip::GemmTNArgs g;
+        g.A = A; g.lda = t.N; g.B = B; g.ldb = t.K; g.C = C; g.ldc = t.K; g.M = t.M; g.N = t.N; g.K = t.K; g.accumulate = 1;
+        fill_f32<<<(unsigned)((nC + 255) / 256), 256, 0, st>>>(C, nC, 13u);       // accumulate onto a known pattern
+        if (ezclip::gemm_tn(g, EZCLIP_BF16, st) != 0) { printf(" v%d ERROR %s", v, ezclip::last_error()); continue; }
+        CK(hipStreamSynchronize(st));
+        if (vi == 0) { h0.resize(nC); CK(hipMemcpy(h0.data(), C0, nC * 4, hipMemcpyDeviceToHost)); }
+        if (vi > 0) {
+          std::vector<float> b(nC);
+          const std::vector<float>& a = h0;
+          CK(hipMemcpy(b.data(), C1, nC * 4, hipMemcpyDeviceToHost));
+          double md = 0, mx = 0;
+          for (size_t i = 0; i < nC; ++i) { md = std::max(md, (double)fabsf(a[i] - b[i])); mx = std::max(mx, (double)fabsf(a[i])); }
+          printf(" [maxdiff %.3g of max %.3g]", md, mx);
+        }
+        ezclip::GemmTNArgs g2 = g; g2.accumulate = 0;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, st));
+        for (int it = 0; it < iters; ++it) ezclip::gemm_tn(g2, EZCLIP_BF16, st);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= iters;
+        printf("  v%d %7.1f TF (%.3f ms)", v, 2.0 * t.M * t.N * t.K / ms / 1e9, ms);
+      }
+      printf("\n");
+      fflush(stdout);
+      hipFree(A); hipFree(B); hipFree(C0); hipFree(C1);
+    }
   }
   ezclip::set_gemm_variant(-1);
   return 0;

@@ -79,10 +79,12 @@ int layernorm_fwd(const void* x, int64_t x_stride, void* y, int64_t y_stride, co
                   const float* b, float eps, int rows, int D, int dtype, float* mean, float* rstd,
                   hipStream_t stream);
 // dx = LN backward; dg/db accumulate (+=) into f32 [D] via atomics.  If dres != nullptr the result is
-// dx = dres + LNbwd(dy) (residual branch merge).
+// dx = dres + LNbwd(dy) (residual branch merge).  dsum (optional, [D] f32) += column sums of the dx written
+// (= the bias gradient of the Linear whose output gradient dx is).
 int layernorm_bwd(const void* x, int64_t x_stride, const void* dy, int64_t dy_stride, const float* g,
                   const float* mean, const float* rstd, void* dx, int64_t dx_stride, const void* dres,
-                  int64_t dres_stride, float* dg, float* db, int rows, int D, int dtype, hipStream_t stream);
+                  int64_t dres_stride, float* dg, float* db, int rows, int D, int dtype, hipStream_t stream,
+                  float* dsum = nullptr);
 
 int cast_from_f32(const float* src, void* dst, int64_t n, int dtype, hipStream_t stream);
 int cast_to_f32(const void* src, float* dst, int64_t n, int dtype, hipStream_t stream);

@@ -535,11 +535,13 @@ static int bgrad(const ezclip_model* m, const void* dY, int64_t ldy, int M, int 
   return colsum_add(dY, ldy, M, N, G, m->dtype, stream);
 }
 
+// bias_p >= 0: the dx written is the output gradient of a Linear with that bias; its column sums (= the bias
+// gradient) are accumulated by the same kernel instead of a separate pass over dx.
 static int ln_bwd(const ezclip_model* m, const void* x, int64_t xs, const void* dy, int64_t dys, int gamma_p, int beta_p,
                   const float* mean, const float* rstd, void* dx, int64_t dxs, const void* dres, int64_t drs, int rows,
-                  int D, hipStream_t stream) {
+                  int D, hipStream_t stream, int bias_p = -1) {
   return layernorm_bwd(x, xs, dy, dys, m->P(gamma_p), mean, rstd, dx, dxs, dres, drs, m->Gp(gamma_p), m->Gp(beta_p), rows,
-                       D, m->dtype, stream);
+                       D, m->dtype, stream, bias_p >= 0 ? m->Gp(bias_p) : nullptr);
 }
 
 int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_emb, void* wsp, size_t ws_bytes,
@@ -566,23 +568,24 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
   EZ_TRY(wgrad(m, gfeatT, E, ws.cls_ln, W, m->vproj_w, B, stream));
   EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * W * esz, stream));
   const void* xl = ws.layers[m->cfg.vision_layers - 1].x_out;
+  // (gx is zero outside the CLS rows: its column sums are the last block's c_proj bias gradient)
   EZ_TRY(ln_bwd(m, xl, (int64_t)Lv * W, ws.gcls, W, m->lnpost_w, m->lnpost_b, ws.mpost, ws.rpost, ws.gx, (int64_t)Lv * W,
-                nullptr, 0, B, W, stream));
+                nullptr, 0, B, W, stream, m->vit[m->cfg.vision_layers - 1].proj_b));
   for (int i = m->cfg.vision_layers - 1; i >= 0; --i) {
     const auto& Lw = m->vit[i];
     const VitBufs& b = ws.layers[i];
     // x_out = x_mid + c_proj(h);  h = QuickGELU(u);  u = c_fc(ln_2(x_mid))        :204
     EZ_TRY(dgrad(m, ws.gx, W, Lw.proj_w, ws.gbig, 4 * W, M, b.u, 4 * W, ACT_QUICKGELU, nullptr, 0, stream));   // d u
     EZ_TRY(wgrad(m, ws.gx, W, b.h, 4 * W, Lw.proj_w, M, stream));
-    EZ_TRY(bgrad(m, ws.gx, W, M, W, Lw.proj_b, stream));
+    // (c_proj bias gradient: accumulated by the ln_bwd that produced gx)
     EZ_TRY(dgrad(m, ws.gbig, 4 * W, Lw.fc_w, ws.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));      // d ln_2
     EZ_TRY(wgrad(m, ws.gbig, 4 * W, b.ln2, W, Lw.fc_w, M, stream));
     EZ_TRY(bgrad(m, ws.gbig, 4 * W, M, 4 * W, Lw.fc_b, stream));
-    EZ_TRY(ln_bwd(m, b.x_mid, W, ws.gtmp, W, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, W, ws.gx, W, M, W, stream));   // d x_mid
+    EZ_TRY(ln_bwd(m, b.x_mid, W, ws.gtmp, W, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, W, ws.gx, W, M, W, stream,
+                  Lw.out_b));   // d x_mid (+ out_proj bias gradient)
     // x_mid = x_in + out_proj(attn(in_proj(ln_1(x_in))))                           :203
     EZ_TRY(dgrad(m, ws.gx2, W, Lw.out_w, ws.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));          // d ctx
     EZ_TRY(wgrad(m, ws.gx2, W, b.ctx, W, Lw.out_w, M, stream));
-    EZ_TRY(bgrad(m, ws.gx2, W, M, W, Lw.out_b, stream));
     AttnBwdArgs ab;
     ab.f.q = b.qkv;
     ab.f.k = (const char*)b.qkv + (size_t)W * esz;
@@ -598,7 +601,8 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
     EZ_TRY(dgrad(m, ws.gqkv, 3 * W, Lw.in_w, ws.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));      // d ln_1
     EZ_TRY(wgrad(m, ws.gqkv, 3 * W, b.ln1, W, Lw.in_w, M, stream));
     EZ_TRY(bgrad(m, ws.gqkv, 3 * W, M, 3 * W, Lw.in_b, stream));
-    EZ_TRY(ln_bwd(m, b.x_in, W, ws.gtmp, W, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx, W, ws.gx2, W, M, W, stream));    // d x_in
+    EZ_TRY(ln_bwd(m, b.x_in, W, ws.gtmp, W, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx, W, ws.gx2, W, M, W, stream,
+                  i > 0 ? m->vit[i - 1].proj_b : -1));    // d x_in (+ the previous block's c_proj bias gradient)
   }
   // x = ln_pre(cat(cls, conv(patches)) + pos)                                          :237-242
   EZ_TRY(ln_bwd(m, ws.x0, W, ws.gx, W, m->lnpre_w, m->lnpre_b, ws.m0, ws.r0, ws.gx2, W, nullptr, 0, M, W, stream));
@@ -638,18 +642,16 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     const auto& Lw = m->bert[i];
     const BertBufs& b = ws.layers[i];
     // x_out = LN(z);  z = dense(hh) + a;  hh = gelu(u);  u = dense(a)        modeling_bert.py:330-345
-    EZ_TRY(ln_bwd(m, b.z, H, ws.gx, H, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, H, nullptr, 0, M, H, stream));       // d z
+    EZ_TRY(ln_bwd(m, b.z, H, ws.gx, H, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, H, nullptr, 0, M, H, stream, Lw.d_b));  // d z
     EZ_TRY(dgrad(m, ws.gx2, H, Lw.d_w, ws.gbig, F, M, b.u, F, ACT_GELU_ERF, nullptr, 0, stream));                     // d u
     EZ_TRY(wgrad(m, ws.gx2, H, b.hh, F, Lw.d_w, M, stream));
-    EZ_TRY(bgrad(m, ws.gx2, H, M, H, Lw.d_b, stream));
     EZ_TRY(dgrad(m, ws.gbig, F, Lw.i_w, ws.gtmp, H, M, nullptr, 0, ACT_NONE, ws.gx2, H, stream));                     // d a = d z + d u W_i
     EZ_TRY(wgrad(m, ws.gbig, F, b.a, H, Lw.i_w, M, stream));
     EZ_TRY(bgrad(m, ws.gbig, F, M, F, Lw.i_b, stream));
     // a = LN(y);  y = dense(ctx) + x_in                                           :264-267
-    EZ_TRY(ln_bwd(m, b.y, H, ws.gtmp, H, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx2, H, nullptr, 0, M, H, stream));      // d y
+    EZ_TRY(ln_bwd(m, b.y, H, ws.gtmp, H, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx2, H, nullptr, 0, M, H, stream, Lw.o_b)); // d y
     EZ_TRY(dgrad(m, ws.gx2, H, Lw.o_w, ws.gtmp, H, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));                     // d ctx
     EZ_TRY(wgrad(m, ws.gx2, H, b.ctx, H, Lw.o_w, M, stream));
-    EZ_TRY(bgrad(m, ws.gx2, H, M, H, Lw.o_b, stream));
     char* qkv = (char*)b.qkv;
     char* gq = (char*)ws.gqkv;
     AttnBwdArgs ab;
@@ -672,10 +674,10 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     EZ_TRY(bgrad(m, gq + 2 * H * esz, 3 * H, M, H, Lw.v_b, stream));
   }
   // embeddings: LN(word[ids] + type[0] + pos[t])                                modeling_bert.py:117-127
-  EZ_TRY(ln_bwd(m, ws.x0, H, ws.gx, H, m->eln_w, m->eln_b, ws.m0, ws.r0, ws.gx2, H, nullptr, 0, M, H, stream));
+  EZ_TRY(ln_bwd(m, ws.x0, H, ws.gx, H, m->eln_w, m->eln_b, ws.m0, ws.r0, ws.gx2, H, nullptr, 0, M, H, stream, m->type_p));
   if (m->Gp(m->word_p)) EZ_TRY(bert_word_grad(ids, ws.gx2, m->Gp(m->word_p), M, H, m->cfg.vocab_size, dt, stream));
   if (m->Gp(m->tpos_p)) EZ_TRY(batch_sum_add(ws.gx2, B, L, L, H, m->Gp(m->tpos_p), dt, stream));
-  if (m->Gp(m->type_p)) EZ_TRY(colsum_add(ws.gx2, H, M, H, m->Gp(m->type_p), dt, stream));
+  // (token-type embedding gradient = column sums of gx2: accumulated by the ln_bwd above; only type 0 is used)
   return EZ_OK;
 }
 

@@ -76,80 +76,103 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, int64_t xs, T* 
   if (mean_o != nullptr && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
 
-// LayerNorm backward for one row per wave:
+// LayerNorm backward, one row per wave at a time, two rows in flight per wave (loads of the second row are issued
+// before the first is reduced), rows interleaved across ~16 waves per CU:
 //   xhat = (x - mean) * rstd;  gy = dy * g
 //   dx = rstd * (gy - mean(gy) - xhat * mean(gy * xhat))   [+ dres]
-//   dg += dy * xhat; db += dy   (block-level partial sums in registers -> atomics)
-template <typename T>
+//   dg += dy * xhat; db += dy; optional dsum += dx_out (the bias gradient of the Linear that produced x's branch)
+// Column sums live in registers, are combined across the block's four waves in LDS and leave as one hardware
+// fp32 atomic per column per block.
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* x, int64_t xs, const T* dy, int64_t dys, const float* g,
                                                       const float* mean_i, const float* rstd_i, T* dx, int64_t dxs,
-                                                      const T* dres, int64_t drs, float* dg, float* db, int rows,
-                                                      int D, int rows_per_wave) {
-  const int lane = threadIdx.x & 63;
-  const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  float ag[kMaxChunks][4], ab[kMaxChunks][4];
+                                                      const T* dres, int64_t drs, float* dg, float* db, float* dsum,
+                                                      int rows, int D) {
+  __shared__ float red[3][4][NC * 256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nwaves = gridDim.x * 4;
+  const int gw = blockIdx.x * 4 + w;
+  float ag[NC][4], ab[NC][4], ac[NC][4], gv[NC][4];
 #pragma unroll
-  for (int c = 0; c < kMaxChunks; ++c)
+  for (int c = 0; c < NC; ++c) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ag[c][e] = ab[c][e] = 0.f;
-  float gv[kMaxChunks][4];
-#pragma unroll
-  for (int c = 0; c < kMaxChunks; ++c) {
+    for (int e = 0; e < 4; ++e) ag[c][e] = ab[c][e] = ac[c][e] = 0.f;
     const int col = (lane + c * 64) * 4;
     if (col < D) ld4(g + col, gv[c]);
     else gv[c][0] = gv[c][1] = gv[c][2] = gv[c][3] = 0.f;
   }
-  const int r0 = gw * rows_per_wave;
-  for (int row = r0; row < r0 + rows_per_wave && row < rows; ++row) {
-    float xv[kMaxChunks][4], dv[kMaxChunks][4];
-    load_row(x + (int64_t)row * xs, D, lane, xv);
-    load_row(dy + (int64_t)row * dys, D, lane, dv);
-    const float mean = mean_i[row], rstd = rstd_i[row];
+  auto load = [&](int row, float (&xv)[NC][4], float (&dv)[NC][4], float (&rv)[NC][4], float& mean, float& rstd) {
+    const bool ok = row < rows;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = (lane + c * 64) * 4;
+      if (ok && col < D) {
+        ld4(x + (int64_t)row * xs + col, xv[c]);
+        ld4(dy + (int64_t)row * dys + col, dv[c]);
+        if (dres != nullptr) ld4(dres + (int64_t)row * drs + col, rv[c]);
+        else rv[c][0] = rv[c][1] = rv[c][2] = rv[c][3] = 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[c][e] = dv[c][e] = rv[c][e] = 0.f;
+      }
+    }
+    mean = ok ? mean_i[row] : 0.f;
+    rstd = ok ? rstd_i[row] : 0.f;
+  };
+  auto process = [&](int row, float (&xv)[NC][4], float (&dv)[NC][4], float (&rv)[NC][4], float mean, float rstd) {
+    if (row >= rows) return;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
-      if ((lane + c * 64) * 4 < D) {
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xh = (xv[c][e] - mean) * rstd;
-          const float gy = dv[c][e] * gv[c][e];
-          s1 += gy; s2 += gy * xh;
-          ag[c][e] += dv[c][e] * xh; ab[c][e] += dv[c][e];
-          xv[c][e] = xh; dv[c][e] = gy;
-        }
+      for (int e = 0; e < 4; ++e) {       // columns >= D hold zeros: they add nothing
+        const float xh = (xv[c][e] - mean) * rstd;
+        const float gy = dv[c][e] * gv[c][e];
+        s1 += gy; s2 += gy * xh;
+        ag[c][e] += dv[c][e] * xh; ab[c][e] += dv[c][e];
+        xv[c][e] = xh; dv[c][e] = gy;
       }
     }
     s1 = wave_sum(s1) / (float)D;
     s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int col = (lane + c * 64) * 4;
       if (col < D) {
         float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rstd * (dv[c][e] - s1 - xv[c][e] * s2);
-        if (dres != nullptr) {
-          float rr[4];
-          ld4(dres + (int64_t)row * drs + col, rr);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] += rr[e];
+        for (int e = 0; e < 4; ++e) {
+          o[e] = rstd * (dv[c][e] - s1 - xv[c][e] * s2) + rv[c][e];
+          ac[c][e] += o[e];
         }
         st4(dx + (int64_t)row * dxs + col, o);
       }
     }
+  };
+  for (int row = gw; row < rows; row += 2 * nwaves) {
+    float xa[NC][4], da[NC][4], ra[NC][4], xb[NC][4], dbb[NC][4], rb[NC][4];
+    float ma, sa, mb, sb;
+    load(row, xa, da, ra, ma, sa);
+    load(row + nwaves, xb, dbb, rb, mb, sb);
+    process(row, xa, da, ra, ma, sa);
+    process(row + nwaves, xb, dbb, rb, mb, sb);
   }
-  if (dg != nullptr) {
+  if (dg == nullptr && dsum == nullptr) return;
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
-      const int col = (lane + c * 64) * 4;
-      if (col < D) {
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          atomicAdd(dg + col + e, ag[c][e]);
-          atomicAdd(db + col + e, ab[c][e]);
-        }
-      }
+    for (int e = 0; e < 4; ++e) {
+      const int idx = c * 256 + lane * 4 + e;
+      red[0][w][idx] = ag[c][e]; red[1][w][idx] = ab[c][e]; red[2][w][idx] = ac[c][e];
     }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < NC * 256; idx += 256) {
+    if (idx >= D) break;
+    if (dg != nullptr) {
+      unsafeAtomicAdd(dg + idx, (red[0][0][idx] + red[0][1][idx]) + (red[0][2][idx] + red[0][3][idx]));
+      unsafeAtomicAdd(db + idx, (red[1][0][idx] + red[1][1][idx]) + (red[1][2][idx] + red[1][3][idx]));
+    }
+    if (dsum != nullptr) unsafeAtomicAdd(dsum + idx, (red[2][0][idx] + red[2][1][idx]) + (red[2][2][idx] + red[2][3][idx]));
   }
 }
 
@@ -449,16 +472,19 @@ int layernorm_fwd(const void* x, int64_t xs, void* y, int64_t ys, const float* g
 
 int layernorm_bwd(const void* x, int64_t xs, const void* dy, int64_t dys, const float* g, const float* mean,
                   const float* rstd, void* dx, int64_t dxs, const void* dres, int64_t drs, float* dg, float* db,
-                  int rows, int D, int dtype, hipStream_t stream) {
+                  int rows, int D, int dtype, hipStream_t stream, float* dsum) {
   EZ_REQUIRE(rows > 0 && D % 4 == 0 && D <= 256 * kMaxChunks, "layernorm_bwd: D=%d unsupported", D);
-  // ~2048 waves total; each wave owns a contiguous run of rows and flushes dg/db once
-  int rows_per_wave = (rows + 2047) / 2048;
-  if (rows_per_wave < 1) rows_per_wave = 1;
-  const int waves = (rows + rows_per_wave - 1) / rows_per_wave;
-  const int blocks = (waves + 3) / 4;
-  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)x, xs,
-                                          (const T*)dy, dys, g, mean, rstd, (T*)dx, dxs, (const T*)dres, drs, dg, db,
-                                          rows, D, rows_per_wave));
+  EZ_REQUIRE(xs % 4 == 0 && dys % 4 == 0 && dxs % 4 == 0 && drs % 4 == 0, "layernorm_bwd: row strides must be multiples of 4");
+  // ~16 waves per CU, rows interleaved across them
+  int blocks = (rows + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  const int nc = (D + 255) / 256;
+#define EZ_LNB(NC)                                                                                                  \
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NC>), dim3(blocks), dim3(256), 0, stream, (const T*)x, xs, \
+                                          (const T*)dy, dys, g, mean, rstd, (T*)dx, dxs, (const T*)dres, drs, dg, db, \
+                                          dsum, rows, D))
+  if (nc == 1) EZ_LNB(1); else if (nc == 2) EZ_LNB(2); else if (nc == 3) EZ_LNB(3); else EZ_LNB(4);
+#undef EZ_LNB
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

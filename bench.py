@@ -51,6 +51,33 @@ GFLOP_FWD_PER_PAIR = 46.152
 GFLOP_TRAIN_PER_PAIR = 138.46
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 
+# launches of the dominant kernel in one forward step at 1024 pairs (shape names of tools/gemm_bench):
+FWD_GEMM_MIX = {"vit.qkv": 12, "vit.out+res": 12, "vit.fc+qgelu": 12, "vit.proj+res": 12, "bert.qkvo+res": 48,
+                "bert.ffn1+gelu": 12, "bert.ffn2+res": 12, "patch": 1}
+
+
+def pmc_traffic(workload):
+    """Average HBM-side bytes per launch of the dominant kernel (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc passes of
+    tools/pmc_gemm.sh summarised by tools/pmc_summary.py into profiles/*_gemm_traffic.json; MALL hits are counted as
+    fetches on gfx950).  Measured offline with the same kernels, shapes and batch: bench.py cannot run a profiler
+    around itself.  None when no summary is committed or the workload is not the 1024-pair forward."""
+    if workload != "bf16_b1024_fwd_loss":
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gemm_traffic.json")))
+    if not files:
+        return None
+    t = json.load(open(files[-1]))
+    tot, n = 0.0, 0
+    for name, cnt in FWD_GEMM_MIX.items():
+        if name not in t:
+            return None
+        tot += cnt * (t[name]["fetch_bytes"] + t[name]["write_bytes"])
+        n += cnt
+    return {"bytes_per_launch": round(tot / n), "algorithmic_bytes_per_launch":
+            round(sum(c * t[k]["algorithmic_bytes"] for k, c in FWD_GEMM_MIX.items()) / n),
+            "source": os.path.basename(files[-1])}
+
 
 def synth_batch(batch, seq, vocab, device, seed):
     g = torch.Generator(device=device).manual_seed(seed)
@@ -181,8 +208,10 @@ def main():
         peak = PEAK_TFLOPS[wl["dtype"]]
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None,
-                "kernel": "ezclip::gemm_nt_kernel<%s>" % wl["dtype"],
+                "frac": round(ach / peak, 4), "traffic": (pmc_traffic(args.workload) or {}).get("bytes_per_launch"),
+                "traffic_detail": pmc_traffic(args.workload),
+                "kernel": ("ezclip::gemm_nt_8p_kernel / gemm_tn_8p_kernel (bf16, 256x256x64 8-phase)"
+                           if wl["dtype"] == "bf16" else "ezclip::gemm_nt_kernel<fp32> (128x128, exact-f32 MFMA)"),
                 "launches_per_step": n // nprof, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
                 "algorithmic_gflop_per_launch": round(flops / max(n, 1) / 1e9, 3)}
         step_ms = elapsed / args.steps * 1e3

@@ -42,51 +42,11 @@
 
 #include "ezclip_common.h"
 #include "kernels.h"
+#include "gemm_pipe.h"
 
 namespace ezclip {
 
 namespace {
-
-typedef __attribute__((ext_vector_type(4))) int i32x4_t;
-
-constexpr int kSlot = 16384;           // one half-tile: 128 rows x 128 B
-constexpr int kRing = 8 * kSlot;       // 128 KiB
-constexpr int kThreads8 = 512;
-
-// LDS-DMA: 64 lanes x 16 B land at lds_dst + lane*16 (wave-uniform destination).
-__device__ __forceinline__ void dma16(uint32_t lds_dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %1\n\t"
-      "s_nop 0\n\t"
-      "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff)
-      : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  if constexpr (N >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ __forceinline__ i32x4_t make_srd(const void* base, uint32_t bytes) {
-  const uint64_t a = (uint64_t)base;
-  i32x4_t r;
-  r.x = (int)(uint32_t)a;
-  r.y = (int)(uint32_t)((a >> 32) & 0xffffu);
-  r.z = (int)bytes;
-  r.w = 0x00020000;
-  return r;
-}
-
-struct Frags {
-  uint4 a[2][4];   // current A half: [i'][k-step]
-  uint4 bl[4];     // B-lo, kept from P0 to P3
-  uint4 bh[4];     // B-hi, kept from P1 to P2
-};
 
 struct Ctx {
   const char* smem;
@@ -100,9 +60,9 @@ struct Ctx {
 
 // One phase.  P: quadrant; PAR: tile parity (static slot bases); ISSUE: issue half-tile k+6;
 // VM: vmcnt to wait for afterwards (-1: none).
-template <int P, int PAR, bool ISSUE, int VM>
+template <int P, int PAR, bool ISSUE, int VM, int VMR = VM>
 __device__ __forceinline__ void phase(const Ctx& c, Frags& f, f32x16_t (&acc)[4][2], uint32_t kbyte_next1,
-                                      uint32_t kbyte_next2) {
+                                      uint32_t kbyte_next2, bool relaxed = false) {
   constexpr int k8 = 4 * PAR + P;                 // phase number mod 8
   // ---- read segment -----------------------------------------------------------------------
   if constexpr (P == 0) {
@@ -144,7 +104,11 @@ __device__ __forceinline__ void phase(const Ctx& c, Frags& f, f32x16_t (&acc)[4]
       dma16(dst + 1024, c.voffB[1], c.srdB, kbyte_next2);
     }
   }
-  wait_vm<VM>();
+  if constexpr (VMR != VM) {   // first K-tile of a tile: the previous tile's stores may still be queued (see ktile)
+    if (relaxed) wait_vm<VMR>(); else wait_vm<VM>();
+  } else {
+    wait_vm<VM>();
+  }
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -166,13 +130,16 @@ __device__ __forceinline__ void phase(const Ctx& c, Frags& f, f32x16_t (&acc)[4]
 
 // One K-tile = 4 phases.  TAIL: 0 = steady state (all issue, vmcnt 8);
 // 1 = second-to-last tile (P0,P1 issue; then 6, 4); 2 = last tile (2, 0, -, -).
-template <int PAR, int TAIL>
-__device__ __forceinline__ void ktile(const Ctx& c, Frags& f, f32x16_t (&acc)[4][2], uint32_t kb1, uint32_t kb2) {
+// VMR (with relaxed = true): the count for the first K-tile of a tile whose predecessor's stores are still in the
+// queue (they sit between this tile's half-tiles 0..5 and 6.. in issue order).
+template <int PAR, int TAIL, int VMR = 8>
+__device__ __forceinline__ void ktile(const Ctx& c, Frags& f, f32x16_t (&acc)[4][2], uint32_t kb1, uint32_t kb2,
+                                      bool relaxed = false) {
   if constexpr (TAIL == 0) {
-    phase<0, PAR, true, 8>(c, f, acc, kb1, kb2);
-    phase<1, PAR, true, 8>(c, f, acc, kb1, kb2);
-    phase<2, PAR, true, 8>(c, f, acc, kb1, kb2);
-    phase<3, PAR, true, 8>(c, f, acc, kb1, kb2);
+    phase<0, PAR, true, 8, VMR>(c, f, acc, kb1, kb2, relaxed);
+    phase<1, PAR, true, 8, VMR>(c, f, acc, kb1, kb2, relaxed);
+    phase<2, PAR, true, 8, VMR>(c, f, acc, kb1, kb2, relaxed);
+    phase<3, PAR, true, 8, VMR>(c, f, acc, kb1, kb2, relaxed);
   } else if constexpr (TAIL == 1) {
     phase<0, PAR, true, 8>(c, f, acc, kb1, kb2);
     phase<1, PAR, true, 8>(c, f, acc, kb1, kb2);
@@ -184,39 +151,6 @@ __device__ __forceinline__ void ktile(const Ctx& c, Frags& f, f32x16_t (&acc)[4]
     phase<2, PAR, false, -1>(c, f, acc, kb1, kb2);
     phase<3, PAR, false, -1>(c, f, acc, kb1, kb2);
   }
-}
-
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-
-// ---- epilogue helpers ---------------------------------------------------------------------------
-// Every global LOAD of the epilogue is hand-issued too (buffer_load in inline asm, bounds-checked): with
-// LDS-DMA of the NEXT tile in flight, a compiler-counted vmcnt would drain the DMA queue at every use.
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-
-__device__ __forceinline__ void ldg16(u32x4_t& dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory");
-}
-// counted wait that also pins the destinations: nothing may read them above this statement
-template <int N>
-__device__ __forceinline__ void wait_vm4(u32x4_t& a, u32x4_t& b, u32x4_t& c, u32x4_t& d) {
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vm2(u32x4_t& a, u32x4_t& b) {
-  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
-}
-
-__device__ __forceinline__ void unpack8(const u32x4_t& c, float (&v)[8]) {
-  v[0] = __uint_as_float(c.x << 16); v[1] = __uint_as_float(c.x & 0xffff0000u);
-  v[2] = __uint_as_float(c.y << 16); v[3] = __uint_as_float(c.y & 0xffff0000u);
-  v[4] = __uint_as_float(c.z << 16); v[5] = __uint_as_float(c.z & 0xffff0000u);
-  v[6] = __uint_as_float(c.w << 16); v[7] = __uint_as_float(c.w & 0xffff0000u);
 }
 
 constexpr int kStage = 6 * kSlot;      // epilogue staging lives in [96 KiB, 160 KiB): ring slots 6, 7 + 32 KiB
@@ -241,15 +175,6 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
   c.hiA = 64u * lda_b;
   c.hiB = 32u * ldb_b;
   c.dma_dst = wave * 2048;
-  // tile-independent part of the per-lane DMA source offsets
-  uint32_t rowA[2], rowB[2], chk[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int lr = (wave * 2 + i) * 8 + (lane >> 3);             // row of the half-tile image
-    chk[i] = (uint32_t)((lane & 7) ^ ((lr >> 1) & 7)) << 4;
-    rowA[i] = (uint32_t)((lr >> 6) * 128 + (lr & 63));
-    rowB[i] = (uint32_t)((lr >> 5) * 64 + (lr & 31));
-  }
   {
     const int sw = (l31 >> 1) & 7;
 #pragma unroll
@@ -265,11 +190,16 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
     m0 = tm << 8;
     n0 = (t - tm * tiles_n) << 8;
   };
+  // per-lane DMA source offsets of a tile; recomputed from the lane id every time (a handful of integer ops):
+  // kept live across the main loop they get spilled, and the reload's compiler-counted vmcnt drains the queue
   auto set_tile = [&](int m0, int n0) {
+    const int ln = lane_id_now();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      c.voffA[i] = ((uint32_t)m0 + rowA[i]) * lda_b + chk[i];
-      c.voffB[i] = ((uint32_t)n0 + rowB[i]) * ldb_b + chk[i];
+      const int lr = (wave * 2 + i) * 8 + (ln >> 3);             // row of the half-tile image
+      const uint32_t chk = (uint32_t)((ln & 7) ^ ((lr >> 1) & 7)) << 4;
+      c.voffA[i] = (uint32_t)(m0 + (lr >> 6) * 128 + (lr & 63)) * lda_b + chk;
+      c.voffB[i] = (uint32_t)(n0 + (lr >> 5) * 64 + (lr & 31)) * ldb_b + chk;
     }
   };
   auto issue_prologue = [&]() {      // half-tiles 0..5 of the tile described by c.voff*
@@ -288,30 +218,22 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
     dma16(d + 5 * kSlot + 1024, c.voffB[1], c.srdB, 128);
   };
 
-  // epilogue constants
-  const int crow = lane >> 3, g = lane & 7;
-  const uint32_t ldc_b = (uint32_t)p.ldc * 2u, ldr_b = (uint32_t)p.ldr * 2u, ldu_b = (uint32_t)p.ldu * 2u;
-  const i32x4_t srdR = make_srd(p.R, HAS_R ? (uint32_t)p.M * ldr_b : 0u);
-  const i32x4_t srdU = make_srd(p.U, HAS_U ? (uint32_t)p.M * ldu_b : 0u);
-  const i32x4_t srdBias = make_srd(p.bias, p.bias ? (uint32_t)p.N * 4u : 0u);   // no bias: reads return 0
-  const __amdgpu_buffer_rsrc_t rsC =
-      __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((uint32_t)p.M * ldc_b), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsC2 =
-      __builtin_amdgcn_make_buffer_rsrc(HAS_C2 ? p.C2 : p.C, 0, (int)((uint32_t)p.M * ldc_b), 0x00020000);
-  const uint32_t lane_c = (uint32_t)crow * ldc_b + (uint32_t)g * 16u;
-  const uint32_t lane_r = (uint32_t)crow * ldr_b + (uint32_t)g * 16u;
-  const uint32_t lane_u = (uint32_t)crow * ldu_b + (uint32_t)g * 16u;
-  char* W = smem + kStage + wave * 8192;
-  const uint32_t wr_row = (uint32_t)l31 * 256u, wr_sw = (uint32_t)(l31 & 7);
-  const float scale = p.alpha;
-  constexpr int NL = 4 * ((HAS_R ? 1 : 0) + (HAS_U ? 1 : 0));   // loads per 32-row block
+  const EpiCtx ep = make_epi_ctx<HAS_R, HAS_U, HAS_C2>(p);
   constexpr int NS = 4 * (HAS_C2 ? 2 : 1);                       // stores per 32-row block
-
   int v = blockIdx.x, m0, n0;
   tile_origin(v, m0, n0);
   set_tile(m0, n0);
   issue_prologue();
   wait_vm<8>();                         // half-tiles 0 and 1 (this wave's pieces)
+  bool first = true;
+
+  f32x16_t acc[4][2];                   // (re-zeroed block by block in the epilogue)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   for (;;) {
     __builtin_amdgcn_sched_barrier(0);
@@ -319,18 +241,14 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
     if (wm == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
 
-    f32x16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     Frags f;
     const int nk = p.K >> 6;              // even, >= 4 (checked by the launcher)
     uint32_t kb = 0;                      // byte offset of the current tile's k range
-    for (int kt = 0; kt < nk - 2; kt += 2) {
+    // first K-tile: the previous tile's 4*NS stores may still be in flight between half-tiles 0..5 and 6..
+    ktile<0, 0, 8 + 4 * NS>(c, f, acc, kb + 128, kb + 256, !first);
+    ktile<1, 0>(c, f, acc, kb + 256, kb + 384);
+    kb += 256;
+    for (int kt = 2; kt < nk - 2; kt += 2) {
       ktile<0, 0>(c, f, acc, kb + 128, kb + 256);
       ktile<1, 0>(c, f, acc, kb + 256, kb + 384);
       kb += 256;
@@ -348,117 +266,25 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
     // All epilogue math (alpha, bias, activation or act'(U), residual) runs in that layout in fp32 with
     // one rounding; every global access is 16 B per lane = 8 full 128-byte rows per wave instruction.
     // VMEM stream of one epilogue (all counts static):
-    //   bias(2) L0 L1 [D = 12 DMA of the next tile] | S0 L2 | S1 L3 | S2 | S3      (Lb: NL loads, Sb: NS stores)
-    const int mw = m0 + wm * 128, nw = n0 + wn * 64;     // wave tile origin
-    u32x4_t bq[2];
-    u32x4_t ld_r[2][4], ld_u[2][4];
-    ldg16(bq[0], (uint32_t)g * 32u, srdBias, (uint32_t)nw * 4u);
-    ldg16(bq[1], (uint32_t)g * 32u + 16u, srdBias, (uint32_t)nw * 4u);
-    auto issue_loads = [&](auto bc, auto ic) {
-      constexpr int b = decltype(bc)::value, i = decltype(ic)::value;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const uint32_t row = (uint32_t)(mw + i * 32 + it * 8);
-        if constexpr (HAS_R) ldg16(ld_r[b][it], lane_r, srdR, row * ldr_b + (uint32_t)nw * 2u);
-        if constexpr (HAS_U) ldg16(ld_u[b][it], lane_u, srdU, row * ldu_b + (uint32_t)nw * 2u);
-      }
-    };
-    if constexpr (NL > 0) {
-      issue_loads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-      issue_loads(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-    }
+    //   bias(2) L0 L1 L2 [D = 12 DMA of the next tile] | S0 L3 | S1 | S2 | S3       (Lb: NL loads, Sb: NS stores)
+    // (three of the four residual / u blocks are requested up front -- the fragment registers are dead by now --
+    // and the fourth as soon as block 0's accumulators are gone, so that only block 0 can see HBM latency)
     const int vn = v + (int)gridDim.x;
     const bool has_next = vn < ntiles;
     int m0n = 0, n0n = 0;
-    if (has_next) {
-      tile_origin(vn, m0n, n0n);
-      set_tile(m0n, n0n);
-    }
-    // Lands in ring slots 0..5 while this epilogue runs.  After the last tile the same twelve DMAs are issued
-    // anyway (re-reading this tile's first half-tiles into the dead ring): every counted wait below is then
-    // a single unconditional statement -- a branch around two asm waits made hipcc copy load destinations
-    // before the wait that guards them.
-    issue_prologue();
-    float bv[8];
-
-    static_for<4>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      constexpr int b = i & 1;
-      // accumulators -> LDS (MFMA layout: row l31, columns j*32 + q*8 + h*4 .. +3)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint32_t ch = (uint32_t)(j * 8 + q * 2 + h) ^ wr_sw;
-          *reinterpret_cast<float4*>(W + wr_row + (ch << 4)) =
-              make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
-        }
-      float x[4][8];
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int rr = it * 8 + crow;
-        const uint32_t sw = (uint32_t)(rr & 7);
-        const float4 x0 = *reinterpret_cast<const float4*>(W + rr * 256 + (((uint32_t)(2 * g) ^ sw) << 4));
-        const float4 x1 = *reinterpret_cast<const float4*>(W + rr * 256 + (((uint32_t)(2 * g + 1) ^ sw) << 4));
-        x[it][0] = x0.x; x[it][1] = x0.y; x[it][2] = x0.z; x[it][3] = x0.w;
-        x[it][4] = x1.x; x[it][5] = x1.y; x[it][6] = x1.z; x[it][7] = x1.w;
-      }
-      // wait for this block's loads (block 0: also the bias)
-      if constexpr (i == 0) {
-        wait_vm2<NL + 12>(bq[0], bq[1]);
-        bv[0] = __uint_as_float(bq[0].x); bv[1] = __uint_as_float(bq[0].y);
-        bv[2] = __uint_as_float(bq[0].z); bv[3] = __uint_as_float(bq[0].w);
-        bv[4] = __uint_as_float(bq[1].x); bv[5] = __uint_as_float(bq[1].y);
-        bv[6] = __uint_as_float(bq[1].z); bv[7] = __uint_as_float(bq[1].w);
-      }
-      if constexpr (NL > 0) {
-        // newer than block i's loads:  i=0: L1 (+D)   i=1: D, S0, L2   i=2: S1, L3   i=3: S2
-        constexpr int cnt = (i == 0) ? NL + 12 : (i == 1) ? NS + NL + 12 : (i == 2) ? NS + NL : NS;
-        if constexpr (HAS_R) wait_vm4<cnt>(ld_r[b][0], ld_r[b][1], ld_r[b][2], ld_r[b][3]);
-        if constexpr (HAS_U) wait_vm4<cnt>(ld_u[b][0], ld_u[b][1], ld_u[b][2], ld_u[b][3]);
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        float (&y)[8] = x[it];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = y[e] * scale + bv[e];
-        const uint32_t soff = (uint32_t)(mw + i * 32 + it * 8) * ldc_b + (uint32_t)nw * 2u;
-        if constexpr (HAS_C2) {
-          const u32x4_t o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
-                             pack_bf16x2(y[6], y[7])};
-          __builtin_amdgcn_raw_buffer_store_b128(o, rsC2, lane_c, soff, 0);
-        }
-        if constexpr (HAS_U) {
-          float uf[8];
-          unpack8(ld_u[b][it], uf);
-          if (p.act == ACT_QUICKGELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] *= act_grad<FAST>(uf[e], ACT_QUICKGELU);
-          } else if (p.act == ACT_GELU_ERF) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] *= act_grad<FAST>(uf[e], ACT_GELU_ERF);
-          }
-        } else if (p.act == ACT_QUICKGELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) y[e] = act_apply<FAST>(y[e], ACT_QUICKGELU);
-        } else if (p.act == ACT_GELU_ERF) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) y[e] = act_apply<FAST>(y[e], ACT_GELU_ERF);
-        }
-        if constexpr (HAS_R) {
-          float rf[8];
-          unpack8(ld_r[b][it], rf);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) y[e] += rf[e];
-        }
-        const u32x4_t o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
-                           pack_bf16x2(y[6], y[7])};
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsC, lane_c, soff, 0);
-      }
-      if constexpr (NL > 0 && i < 2) issue_loads(std::integral_constant<int, b>{}, std::integral_constant<int, i + 2>{});
-    });
+    if (has_next) tile_origin(vn, m0n, n0n);
+    // The next tile's first six half-tiles land in ring slots 0..5 while this epilogue runs.  After the last tile the
+    // same twelve DMAs are issued anyway (re-reading this tile's first half-tiles into the dead ring): every counted
+    // wait of the epilogue is then a single unconditional statement -- a branch around two asm waits made hipcc copy
+    // load destinations before the wait that guards them.
+    epilogue_rows<FAST, HAS_R, HAS_U, HAS_C2, 12>(ep, acc, m0 + wm * 128, n0 + wn * 64, smem + kStage + wave * 8192, p.act,
+                                                  [&]() {
+                                                    if (has_next) set_tile(m0n, n0n);
+                                                    issue_prologue();
+                                                  });
     if (!has_next) break;
-    wait_vm<0>();       // store acks (+ the next tile's first half-tiles, landed long ago)
+    wait_vm<6 + 4 * NS>();   // half-tiles 0..2 of the next tile have landed; 3..5 and this tile's stores may still fly
+    first = false;
     v = vn; m0 = m0n; n0 = n0n;
   }
 }

@@ -1,0 +1,244 @@
+// Shared pieces of the 8-phase GEMM pipelines (gemm8p.hip, gemm4w.hip): hand-issued LDS-DMA and counted waits,
+// buffer descriptors, the row-coalesced fp32 epilogue.  gfx950 only.
+#pragma once
+#include <type_traits>
+
+#include "ezclip_common.h"
+#include "kernels.h"
+
+namespace ezclip {
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+constexpr int kSlot = 16384;           // one half-tile: 128 rows x 128 B
+constexpr int kRing = 8 * kSlot;       // 128 KiB
+constexpr int kThreads8 = 512;
+
+// LDS-DMA: 64 lanes x 16 B land at lds_dst + lane*16 (wave-uniform destination).
+__device__ __forceinline__ void dma16(uint32_t lds_dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff)
+      : "memory");
+}
+
+// Lane id recomputed on the spot (v_mbcnt): an asm volatile cannot be hoisted out of the tile loop, so values
+// derived from it are not kept live (and spilled) across the main loop.
+__device__ __forceinline__ int lane_id_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  if constexpr (N >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ i32x4_t make_srd(const void* base, uint32_t bytes) {
+  const uint64_t a = (uint64_t)base;
+  i32x4_t r;
+  r.x = (int)(uint32_t)a;
+  r.y = (int)(uint32_t)((a >> 32) & 0xffffu);
+  r.z = (int)bytes;
+  r.w = 0x00020000;
+  return r;
+}
+
+struct Frags {
+  uint4 a[2][4];   // current A half: [i'][k-step]
+  uint4 bl[4];     // B-lo, kept from P0 to P3
+  uint4 bh[4];     // B-hi, kept from P1 to P2
+};
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// ---- epilogue helpers ---------------------------------------------------------------------------
+// Every global LOAD of the epilogue is hand-issued too (buffer_load in inline asm, bounds-checked): with
+// LDS-DMA of the NEXT tile in flight, a compiler-counted vmcnt would drain the DMA queue at every use.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+__device__ __forceinline__ void ldg16(u32x4_t& dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+// counted wait that also pins the destinations: nothing may read them above this statement
+template <int N>
+__device__ __forceinline__ void wait_vm4(u32x4_t& a, u32x4_t& b, u32x4_t& c, u32x4_t& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm2(u32x4_t& a, u32x4_t& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
+__device__ __forceinline__ void unpack8(const u32x4_t& c, float (&v)[8]) {
+  v[0] = __uint_as_float(c.x << 16); v[1] = __uint_as_float(c.x & 0xffff0000u);
+  v[2] = __uint_as_float(c.y << 16); v[3] = __uint_as_float(c.y & 0xffff0000u);
+  v[4] = __uint_as_float(c.z << 16); v[5] = __uint_as_float(c.z & 0xffff0000u);
+  v[6] = __uint_as_float(c.w << 16); v[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+
+
+// ---- row-coalesced epilogue -------------------------------------------------------------------------------------
+struct EpiCtx {
+  uint32_t ldc_b, ldr_b, ldu_b;
+  i32x4_t srdR, srdU, srdBias;
+  __amdgpu_buffer_rsrc_t rsC, rsC2;
+  float scale;
+  int M;
+};
+
+template <bool HAS_R, bool HAS_U, bool HAS_C2>
+__device__ __forceinline__ EpiCtx make_epi_ctx(const GemmArgs& p) {
+  EpiCtx e;
+  e.ldc_b = (uint32_t)p.ldc * 2u; e.ldr_b = (uint32_t)p.ldr * 2u; e.ldu_b = (uint32_t)p.ldu * 2u;
+  e.srdR = make_srd(p.R, HAS_R ? (uint32_t)p.M * e.ldr_b : 0u);
+  e.srdU = make_srd(p.U, HAS_U ? (uint32_t)p.M * e.ldu_b : 0u);
+  e.srdBias = make_srd(p.bias, p.bias ? (uint32_t)p.N * 4u : 0u);   // no bias: reads return 0
+  e.rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((uint32_t)p.M * e.ldc_b), 0x00020000);
+  e.rsC2 = __builtin_amdgcn_make_buffer_rsrc(HAS_C2 ? p.C2 : p.C, 0, (int)((uint32_t)p.M * e.ldc_b), 0x00020000);
+  e.scale = p.alpha;
+  e.M = p.M;
+  return e;
+}
+
+// Epilogue of one 128 x 64 wave tile (4 x 2 MFMA 32x32 accumulators, lane = row l31, 4 consecutive columns per
+// register quad).  One 32-row block at a time: its 32 x 64 fp32 accumulators go through the wave-private 8 KiB LDS
+// image W (16-byte chunk index XORed with row & 7: conflict-free both ways) and come back row-coalesced: lane
+// (crow = lane >> 3, g = lane & 7) holds 8 consecutive columns of row it*8 + crow.  All epilogue math (alpha, bias,
+// activation or act'(U), residual) runs in that layout in fp32 with one rounding; every global access is 16 B per
+// lane = 8 full 128-byte rows per wave instruction.  The accumulators are re-zeroed on the way out.
+// Every global LOAD is hand-issued (buffer_load asm) with counted waits, because the caller may have D LDS-DMA
+// loads of its next tile in flight (issued by issue_dma() right after the epilogue's own loads): a compiler-counted
+// vmcnt would drain them.  VMEM stream (all counts static; Lb: NL loads, Sb: NS stores):
+//   bias(2) L0 L1 L2 [D x DMA] | S0 L3 | S1 | S2 | S3
+// Three of the four residual / u blocks are requested up front and the fourth as soon as block 0's accumulators are
+// gone, so that only block 0 can see HBM latency.  On return 4*NS stores (and the D DMAs) may still be in flight.
+template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, int D, typename IssueDma>
+__device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[4][2], int mw, int nw, char* W, int act,
+                                              IssueDma&& issue_dma) {
+  constexpr int NL = 4 * ((HAS_R ? 1 : 0) + (HAS_U ? 1 : 0));   // loads per 32-row block
+  constexpr int NS = 4 * (HAS_C2 ? 2 : 1);                       // stores per 32-row block
+  const int eln = lane_id_now();
+  const int crow = eln >> 3, g = eln & 7, eh = eln >> 5, el31 = eln & 31;
+  const uint32_t lane_c = (uint32_t)crow * ec.ldc_b + (uint32_t)g * 16u;
+  const uint32_t lane_r = (uint32_t)crow * ec.ldr_b + (uint32_t)g * 16u;
+  const uint32_t lane_u = (uint32_t)crow * ec.ldu_b + (uint32_t)g * 16u;
+    const uint32_t wr_row = (uint32_t)el31 * 256u, wr_sw = (uint32_t)(el31 & 7);
+  u32x4_t bq[2];
+  u32x4_t ld_r[4][4], ld_u[4][4];
+  ldg16(bq[0], (uint32_t)g * 32u, ec.srdBias, (uint32_t)nw * 4u);
+  ldg16(bq[1], (uint32_t)g * 32u + 16u, ec.srdBias, (uint32_t)nw * 4u);
+  auto issue_loads = [&](auto bc, auto ic) {
+    constexpr int b = decltype(bc)::value, i = decltype(ic)::value;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const uint32_t row = (uint32_t)(mw + i * 32 + it * 8);
+      if constexpr (HAS_R) ldg16(ld_r[b][it], lane_r, ec.srdR, row * ec.ldr_b + (uint32_t)nw * 2u);
+      if constexpr (HAS_U) ldg16(ld_u[b][it], lane_u, ec.srdU, row * ec.ldu_b + (uint32_t)nw * 2u);
+    }
+  };
+  if constexpr (NL > 0) {
+    issue_loads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    issue_loads(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    issue_loads(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+  }
+  issue_dma();
+  float bv[8];
+
+  static_for<4>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int b = i;
+    // accumulators -> LDS (MFMA layout: row l31, columns j*32 + q*8 + h*4 .. +3); zero them for the next tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t ch = (uint32_t)(j * 8 + q * 2 + eh) ^ wr_sw;
+        *reinterpret_cast<float4*>(W + wr_row + (ch << 4)) =
+            make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    float x[4][8];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = it * 8 + crow;
+      const uint32_t sw = (uint32_t)(rr & 7);
+      const float4 x0 = *reinterpret_cast<const float4*>(W + rr * 256 + (((uint32_t)(2 * g) ^ sw) << 4));
+      const float4 x1 = *reinterpret_cast<const float4*>(W + rr * 256 + (((uint32_t)(2 * g + 1) ^ sw) << 4));
+      x[it][0] = x0.x; x[it][1] = x0.y; x[it][2] = x0.z; x[it][3] = x0.w;
+      x[it][4] = x1.x; x[it][5] = x1.y; x[it][6] = x1.z; x[it][7] = x1.w;
+    }
+    // wait for this block's loads (block 0: also the bias)
+    if constexpr (i == 0) {
+      wait_vm2<2 * NL + D>(bq[0], bq[1]);
+      bv[0] = __uint_as_float(bq[0].x); bv[1] = __uint_as_float(bq[0].y);
+      bv[2] = __uint_as_float(bq[0].z); bv[3] = __uint_as_float(bq[0].w);
+      bv[4] = __uint_as_float(bq[1].x); bv[5] = __uint_as_float(bq[1].y);
+      bv[6] = __uint_as_float(bq[1].z); bv[7] = __uint_as_float(bq[1].w);
+    }
+    if constexpr (NL > 0) {
+      // newer than block i's loads:  0: L1 L2 D   1: L2 D S0 L3   2: D S0 L3 S1   3: S1 S2
+      constexpr int cnt = (i == 0) ? 2 * NL + D : (i == 1) ? 2 * NL + D + NS : (i == 2) ? NL + D + 2 * NS : 2 * NS;
+      if constexpr (HAS_R) wait_vm4<cnt>(ld_r[b][0], ld_r[b][1], ld_r[b][2], ld_r[b][3]);
+      if constexpr (HAS_U) wait_vm4<cnt>(ld_u[b][0], ld_u[b][1], ld_u[b][2], ld_u[b][3]);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      float (&y)[8] = x[it];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = y[e] * ec.scale + bv[e];
+      const uint32_t soff = (uint32_t)(mw + i * 32 + it * 8) * ec.ldc_b + (uint32_t)nw * 2u;
+      if constexpr (HAS_C2) {
+        const u32x4_t o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
+                           pack_bf16x2(y[6], y[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(o, ec.rsC2, lane_c, soff, 0);
+      }
+      if constexpr (HAS_U) {
+        float uf[8];
+        unpack8(ld_u[b][it], uf);
+        if (act == ACT_QUICKGELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] *= act_grad<FAST>(uf[e], ACT_QUICKGELU);
+        } else if (act == ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] *= act_grad<FAST>(uf[e], ACT_GELU_ERF);
+        }
+      } else if (act == ACT_QUICKGELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = act_apply<FAST>(y[e], ACT_QUICKGELU);
+      } else if (act == ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = act_apply<FAST>(y[e], ACT_GELU_ERF);
+      }
+      if constexpr (HAS_R) {
+        float rf[8];
+        unpack8(ld_r[b][it], rf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] += rf[e];
+      }
+      const u32x4_t o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
+                         pack_bf16x2(y[6], y[7])};
+      __builtin_amdgcn_raw_buffer_store_b128(o, ec.rsC, lane_c, soff, 0);
+    }
+    if constexpr (NL > 0 && i == 0) issue_loads(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
+  });
+}
+
+}  // namespace
+}  // namespace ezclip

@@ -32,6 +32,9 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream);
 // 256x256x64 8-phase bf16 kernel (gemm8p.hip): large M, N % 256 == 0, K % 128 == 0, bf16 output
 bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype);
 int gemm_nt_8p(const GemmArgs& p, hipStream_t stream);
+// 256x128x64 four-wave kernel, two workgroups per CU (gemm4w.hip): same constraints; hides the epilogue of short-K products
+bool gemm_nt_4w_eligible(const GemmArgs& p, int dtype);
+int gemm_nt_4w(const GemmArgs& p, hipStream_t stream);
 void set_gemm_variant(int v);   // debugging / sweeps: -1 heuristic, 0 = 128x128 tile, 1 = 256x256 tile
 
 // C[N,K] (+)= A[M,N]^T . B[M,K]   (weight gradients; contraction over rows)

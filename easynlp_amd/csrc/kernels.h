@@ -65,6 +65,10 @@ struct AttnArgs {
   float scale = 0.125f;
 };
 int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream);
+// short-sequence bf16 kernels (attention_short.hip): L <= 256, one-pass online softmax, LDS transpose reads
+bool attention_short_eligible(const AttnArgs& a, int dtype);
+int attention_fwd_short(const AttnArgs& a, hipStream_t stream);
+void set_attention_variant(int v);   // -1 auto, 0: attention.hip kernels only
 
 struct AttnBwdArgs {
   AttnArgs f;                     // forward tensors (q, k, v, key_bias, lse; ctx = forward output)

@@ -87,6 +87,7 @@ struct Shape { const char* name; int M, N, K, act; bool res, c2; bool u = false;
 
 int main(int argc, char** argv) {
   const int batch = argc > 1 ? atoi(argv[1]) : 1024;
+  const bool only_attn = getenv("ONLY_ATTN") != nullptr;
   const int iters = argc > 2 ? atoi(argv[2]) : 20;
   std::vector<int> variants;
   {
@@ -117,6 +118,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_bad, 8));
   printf("batch %d iters %d\n", batch, iters);
   for (const Shape& s : shapes) {
+    if (only_attn) break;
     const size_t nA = (size_t)s.M * s.K, nB = (size_t)s.N * s.K, nC = (size_t)s.M * s.N;
     uint16_t *A, *B, *R = nullptr, *C0, *C1, *P0 = nullptr, *P1 = nullptr, *Uu = nullptr;
     float* bias;
@@ -199,6 +201,7 @@ int main(int argc, char** argv) {
     const TN tns[] = {{"wgrad.out", Mv, 768, 768},   {"wgrad.qkv", Mv, 2304, 768}, {"wgrad.fc", Mv, 3072, 768},
                       {"wgrad.proj", Mv, 768, 3072}, {"wgrad.bert.ffn1", Mt, 3072, 768}, {"wgrad.ragged", Mv - 77, 768, 768}};
     for (const TN& t : tns) {
+      if (only_attn) break;
       const size_t nA = (size_t)t.M * t.N, nB = (size_t)t.M * t.K, nC = (size_t)t.N * t.K;
       uint16_t *A, *B; float *C0, *C1;
       std::vector<float> h0;
@@ -240,6 +243,45 @@ int main(int argc, char** argv) {
       fflush(stdout);
       hipFree(A); hipFree(B); hipFree(C0); hipFree(C1);
     }
+  }
+  // ---- attention (packed qkv [B*L, 3*H*64] bf16): old two-pass kernels (variant 0) vs the short-sequence kernels ----
+  {
+    struct AT { const char* name; int B, L, H; };
+    const AT ats[] = {{"attn.vit", batch, 197, 12}, {"attn.bert", batch, 64, 12}};
+    for (const AT& t : ats) {
+      const size_t rows = (size_t)t.B * t.L, W = (size_t)t.H * 64;
+      uint16_t *qkv, *ctx0, *ctx1; float* lse;
+      CK(hipMalloc(&qkv, rows * 3 * W * 2)); CK(hipMalloc(&ctx0, rows * W * 2)); CK(hipMalloc(&ctx1, rows * W * 2));
+      CK(hipMalloc(&lse, (size_t)t.B * t.H * t.L * 4));
+      fill_bf16<<<2048, 256, 0, st>>>(qkv, rows * 3 * W, 21u, 1.5f);
+      printf("%-15s B=%5d L=%4d H=%3d :", t.name, t.B, t.L, t.H);
+      for (int v = 0; v < 2; ++v) {
+        ezclip::set_attention_variant(v == 0 ? 0 : -1);
+        ezclip::AttnArgs a;
+        a.q = qkv; a.k = qkv + W; a.v = qkv + 2 * W; a.row_stride = 3 * W;
+        a.ctx = v == 0 ? ctx0 : ctx1; a.ctx_stride = W; a.lse = lse; a.B = t.B; a.L = t.L; a.H = t.H; a.scale = 0.125f;
+        if (ezclip::attention_fwd(a, EZCLIP_BF16, st) != 0) { printf(" ERROR %s", ezclip::last_error()); continue; }
+        CK(hipStreamSynchronize(st));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, st));
+        for (int it = 0; it < iters; ++it) ezclip::attention_fwd(a, EZCLIP_BF16, st);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= iters;
+        const double gb = (double)rows * W * 2 * 4 / 1e9;
+        printf("  %s %.3f ms (%.0f TF, %.2f TB/s)", v == 0 ? "two-pass" : "short", ms,
+               4.0 * t.B * t.H * (double)t.L * t.L * 64 / ms / 1e9, gb / ms);
+      }
+      CK(hipMemsetAsync(d_md, 0, 4, st)); CK(hipMemsetAsync(d_bad, 0, 8, st));
+      maxdiff_bf16<<<1024, 256, 0, st>>>(ctx0, ctx1, rows * W, d_md, d_bad);
+      float md; CK(hipMemcpyAsync(&md, d_md, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+      printf("  [max |ctx diff| %.3g]\n", md);
+      hipFree(qkv); hipFree(ctx0); hipFree(ctx1); hipFree(lse);
+    }
+    ezclip::set_attention_variant(-1);
   }
   ezclip::set_gemm_variant(-1);
   return 0;

@@ -151,6 +151,8 @@ def main():
     from easynlp_amd import lib as L
     from easynlp_amd.appzoo.clip import CLIPApp
 
+    if os.environ.get("EZCLIP_NO_LNFOLD"):      # A/B switch: separate LayerNorm kernels in the inference path too
+        L.check(L.load().ezclip_debug_set(2, 0))
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["batch"] = args.batch

@@ -220,7 +220,9 @@ __global__ __launch_bounds__(kThreads4, 2) void gemm_nt_4w_kernel(GemmArgs p) {
   __builtin_amdgcn_sched_barrier(0);
 
   const EpiCtx ep = make_epi_ctx<HAS_R, HAS_U, HAS_C2>(p);
-  epilogue_rows<FAST, HAS_R, HAS_U, HAS_C2, 0>(ep, acc, m0 + wm * 128, n0 + wn * 64, smem + wave * 8192, p.act, []() {});
+  EpiLoads eld;
+  if constexpr (HAS_R || HAS_U) epilogue_issue_block<HAS_R, HAS_U, false, 0, 0>(ep, m0 + wm * 128, n0 + wn * 64, eld);
+  epilogue_rows<FAST, HAS_R, HAS_U, HAS_C2, 0>(ep, acc, m0 + wm * 128, n0 + wn * 64, smem + wave * 8192, p.act, eld, []() {});
 }
 
 int g_num_cus4 = 0;
@@ -241,7 +243,7 @@ int launch_4w(const GemmArgs& p, int tiles, hipStream_t stream) {
 
 bool gemm_nt_4w_eligible(const GemmArgs& p, int dtype) {
   if (!gemm_nt_8p_eligible(p, dtype)) return false;   // same operand / epilogue constraints (N % 256 included)
-  return p.K >= 128;
+  return p.K >= 128 && p.ln_stats == nullptr;
 }
 
 int gemm_nt_4w(const GemmArgs& p, hipStream_t stream) {

@@ -132,7 +132,8 @@ __device__ __forceinline__ void phase(const Ctx& c, Frags& f, f32x16_t (&acc)[4]
 // 1 = second-to-last tile (P0,P1 issue; then 6, 4); 2 = last tile (2, 0, -, -).
 // VMR (with relaxed = true): the count for the first K-tile of a tile whose predecessor's stores are still in the
 // queue (they sit between this tile's half-tiles 0..5 and 6.. in issue order).
-template <int PAR, int TAIL, int VMR = 8>
+// XL (TAIL == 2 only): loads of the epilogue's block 0 issued right before this last K-tile (newer than every DMA).
+template <int PAR, int TAIL, int VMR = 8, int XL = 0>
 __device__ __forceinline__ void ktile(const Ctx& c, Frags& f, f32x16_t (&acc)[4][2], uint32_t kb1, uint32_t kb2,
                                       bool relaxed = false) {
   if constexpr (TAIL == 0) {
@@ -146,8 +147,8 @@ __device__ __forceinline__ void ktile(const Ctx& c, Frags& f, f32x16_t (&acc)[4]
     phase<2, PAR, false, 6>(c, f, acc, kb1, kb2);
     phase<3, PAR, false, 4>(c, f, acc, kb1, kb2);
   } else {
-    phase<0, PAR, false, 2>(c, f, acc, kb1, kb2);
-    phase<1, PAR, false, 0>(c, f, acc, kb1, kb2);
+    phase<0, PAR, false, 2 + XL>(c, f, acc, kb1, kb2);
+    phase<1, PAR, false, 0 + XL>(c, f, acc, kb1, kb2);
     phase<2, PAR, false, -1>(c, f, acc, kb1, kb2);
     phase<3, PAR, false, -1>(c, f, acc, kb1, kb2);
   }
@@ -157,7 +158,7 @@ constexpr int kStage = 6 * kSlot;      // epilogue staging lives in [96 KiB, 160
 constexpr int kLds = 160 * 1024;
 
 // Persistent kernel: workgroup b walks tiles b, b + grid, b + 2*grid, ... (XCD-aware order).
-template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2>
+template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, bool HAS_LN>
 __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
     dma16(d + 5 * kSlot + 1024, c.voffB[1], c.srdB, 128);
   };
 
-  const EpiCtx ep = make_epi_ctx<HAS_R, HAS_U, HAS_C2>(p);
+  const EpiCtx ep = make_epi_ctx<HAS_R, HAS_U, HAS_C2, HAS_LN>(p);
   constexpr int NS = 4 * (HAS_C2 ? 2 : 1);                       // stores per 32-row block
   int v = blockIdx.x, m0, n0;
   tile_origin(v, m0, n0);
@@ -254,7 +255,11 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
       kb += 256;
     }
     ktile<0, 1>(c, f, acc, kb + 128, kb + 256);
-    ktile<1, 2>(c, f, acc, 0, 0);
+    // residual / u / row-stat loads of the epilogue's first 32-row block: one K-tile of MFMAs to hide their latency
+    EpiLoads eld;
+    constexpr int NL0 = 4 * ((HAS_R ? 1 : 0) + (HAS_U ? 1 : 0) + (HAS_LN ? 1 : 0));
+    if constexpr (NL0 > 0) epilogue_issue_block<HAS_R, HAS_U, HAS_LN, 0, 0>(ep, m0 + wm * 128, n0 + wn * 64, eld);
+    ktile<1, 2, 8, NL0>(c, f, acc, 0, 0);
     if (wm == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // every wave is past its last LDS read and no DMA is in flight: the ring is free
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
     // same twelve DMAs are issued anyway (re-reading this tile's first half-tiles into the dead ring): every counted
     // wait of the epilogue is then a single unconditional statement -- a branch around two asm waits made hipcc copy
     // load destinations before the wait that guards them.
-    epilogue_rows<FAST, HAS_R, HAS_U, HAS_C2, 12>(ep, acc, m0 + wm * 128, n0 + wn * 64, smem + kStage + wave * 8192, p.act,
+    epilogue_rows<FAST, HAS_R, HAS_U, HAS_C2, 12, HAS_LN>(ep, acc, m0 + wm * 128, n0 + wn * 64, smem + kStage + wave * 8192, p.act, eld,
                                                   [&]() {
                                                     if (has_next) set_tile(m0n, n0n);
                                                     issue_prologue();
@@ -559,9 +564,12 @@ bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype) {
   if (p.R && ((p.ldr & 7) || ((uintptr_t)p.R & 15))) return false;
   if (p.U && ((p.ldu & 7) || ((uintptr_t)p.U & 15))) return false;
   if (p.bias && ((uintptr_t)p.bias & 15)) return false;
-  // instantiated epilogue combinations: plain, +R, +C2, +U
-  const int combo = (p.R ? 1 : 0) + (p.U ? 2 : 0) + (p.C2 ? 4 : 0);
-  if (!(combo == 0 || combo == 1 || combo == 2 || combo == 4)) return false;
+  // instantiated epilogue combinations: plain, +R, +C2, +U, folded LN (alone)
+  const int combo = (p.R ? 1 : 0) + (p.U ? 2 : 0) + (p.C2 ? 4 : 0) + (p.ln_stats ? 8 : 0);
+  if (!(combo == 0 || combo == 1 || combo == 2 || combo == 4 || combo == 8)) return false;
+  if (p.ln_stats && (p.bias || !p.ln_c1 || !p.ln_c2 || ((uintptr_t)p.ln_c1 & 15) || ((uintptr_t)p.ln_c2 & 15) ||
+                     ((uintptr_t)p.ln_stats & 7)))
+    return false;
   // 32-bit buffer offsets
   const uint64_t lim = 0xffff0000ull;
   if ((uint64_t)p.M * (uint64_t)p.lda * 2u >= lim || (uint64_t)p.N * (uint64_t)p.ldb * 2u >= lim ||
@@ -578,10 +586,10 @@ void set_gemm8p_ablate(int v) { g_gemm8p_ablate = v; }
 namespace {
 int g_num_cus = 0;
 
-template <bool R, bool U, bool C2>
+template <bool R, bool U, bool C2, bool LN = false>
 int launch_8p(const GemmArgs& p, int tiles, int grid, hipStream_t stream) {
   static bool attr_set = false;
-  auto* kern = &gemm_nt_8p_kernel<true, R, U, C2>;
+  auto* kern = &gemm_nt_8p_kernel<true, R, U, C2, LN>;
   if (!attr_set) {
     EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     attr_set = true;
@@ -608,7 +616,8 @@ int gemm_nt_8p(const GemmArgs& p_in, hipStream_t stream) {
   int rc;
   {
     ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);
-    if (p.U) rc = launch_8p<false, true, false>(p, tiles, grid, stream);
+    if (p.ln_stats) rc = launch_8p<false, false, false, true>(p, tiles, grid, stream);
+    else if (p.U) rc = launch_8p<false, true, false>(p, tiles, grid, stream);
     else if (p.C2) rc = launch_8p<false, false, true>(p, tiles, grid, stream);
     else if (p.R) rc = launch_8p<true, false, false>(p, tiles, grid, stream);
     else rc = launch_8p<false, false, false>(p, tiles, grid, stream);

@@ -96,20 +96,24 @@ __device__ __forceinline__ void unpack8(const u32x4_t& c, float (&v)[8]) {
 struct EpiCtx {
   uint32_t ldc_b, ldr_b, ldu_b;
   i32x4_t srdR, srdU, srdBias;
-  __amdgpu_buffer_rsrc_t rsC, rsC2;
+  i32x4_t srdStats, srdLn1, srdLn2;   // folded LayerNorm: row stats, c1, c2
+  i32x4_t srdC, srdC2;
   float scale;
   int M;
 };
 
-template <bool HAS_R, bool HAS_U, bool HAS_C2>
+template <bool HAS_R, bool HAS_U, bool HAS_C2, bool HAS_LN = false>
 __device__ __forceinline__ EpiCtx make_epi_ctx(const GemmArgs& p) {
   EpiCtx e;
   e.ldc_b = (uint32_t)p.ldc * 2u; e.ldr_b = (uint32_t)p.ldr * 2u; e.ldu_b = (uint32_t)p.ldu * 2u;
   e.srdR = make_srd(p.R, HAS_R ? (uint32_t)p.M * e.ldr_b : 0u);
   e.srdU = make_srd(p.U, HAS_U ? (uint32_t)p.M * e.ldu_b : 0u);
   e.srdBias = make_srd(p.bias, p.bias ? (uint32_t)p.N * 4u : 0u);   // no bias: reads return 0
-  e.rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((uint32_t)p.M * e.ldc_b), 0x00020000);
-  e.rsC2 = __builtin_amdgcn_make_buffer_rsrc(HAS_C2 ? p.C2 : p.C, 0, (int)((uint32_t)p.M * e.ldc_b), 0x00020000);
+  e.srdStats = make_srd(p.ln_stats, HAS_LN ? (uint32_t)p.M * 8u : 0u);
+  e.srdLn1 = make_srd(p.ln_c1, HAS_LN ? (uint32_t)p.N * 4u : 0u);
+  e.srdLn2 = make_srd(p.ln_c2, HAS_LN ? (uint32_t)p.N * 4u : 0u);
+  e.srdC = make_srd(p.C, (uint32_t)p.M * e.ldc_b);
+  e.srdC2 = make_srd(HAS_C2 ? p.C2 : p.C, (uint32_t)p.M * e.ldc_b);
   e.scale = p.alpha;
   e.M = p.M;
   return e;
@@ -124,13 +128,51 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const GemmArgs& p) {
 // Every global LOAD is hand-issued (buffer_load asm) with counted waits, because the caller may have D LDS-DMA
 // loads of its next tile in flight (issued by issue_dma() right after the epilogue's own loads): a compiler-counted
 // vmcnt would drain them.  VMEM stream (all counts static; Lb: NL loads, Sb: NS stores):
-//   bias(2) L0 L1 L2 [D x DMA] | S0 L3 | S1 | S2 | S3
-// Three of the four residual / u blocks are requested up front and the fourth as soon as block 0's accumulators are
-// gone, so that only block 0 can see HBM latency.  On return 4*NS stores (and the D DMAs) may still be in flight.
-template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, int D, typename IssueDma>
+//   L0 (by the caller, one K-tile earlier) ... bias(2) L1 L2 [D x DMA] | S0 L3 | S1 | S2 | S3
+// Blocks 1 and 2 are requested up front and block 3 as soon as block 0's accumulators are gone.  On return 4*NS stores (and the D DMAs) may still be in flight.
+// 16-byte buffer store, hand-issued WITH its wait states: the data registers of a dwordx3/x4 store must not be
+// written by the next VALU instruction(s).  hipcc pads that hazard for flat/global stores but exempts MUBUF stores
+// that carry an SGPR soffset -- on gfx950 the exemption does not hold (seen as corrupted second dwords in the last
+// lanes of each 16 when a v_pk_fma_f32 reused the data registers right after the builtin's store).
+__device__ __forceinline__ void stg16(const u32x4_t& data, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+__device__ __forceinline__ void ldg8(u32x2_t& dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
+  asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm4s(u32x2_t& a, u32x2_t& b, u32x2_t& c, u32x2_t& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+
+// Destination registers of the epilogue's per-block loads (residual / pre-activation / LayerNorm row stats).  Owned by
+// the kernel so that block 0 can be requested BEFORE the last K-tile of the main loop (epilogue_issue_block0): its
+// HBM latency then hides under the last 32 MFMAs instead of stalling the first block of the epilogue.
+struct EpiLoads {
+  u32x4_t r[4][4], u[4][4];
+  u32x2_t s[4][4];
+};
+
+template <bool HAS_R, bool HAS_U, bool HAS_LN, int B, int I>
+__device__ __forceinline__ void epilogue_issue_block(const EpiCtx& ec, int mw, int nw, EpiLoads& ld) {
+  const int eln = lane_id_now();
+  const int crow = eln >> 3, g = eln & 7;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const uint32_t row = (uint32_t)(mw + I * 32 + it * 8);
+    if constexpr (HAS_R) ldg16(ld.r[B][it], (uint32_t)crow * ec.ldr_b + (uint32_t)g * 16u, ec.srdR, row * ec.ldr_b + (uint32_t)nw * 2u);
+    if constexpr (HAS_U) ldg16(ld.u[B][it], (uint32_t)crow * ec.ldu_b + (uint32_t)g * 16u, ec.srdU, row * ec.ldu_b + (uint32_t)nw * 2u);
+    if constexpr (HAS_LN) ldg8(ld.s[B][it], (uint32_t)crow * 8u, ec.srdStats, row * 8u);
+  }
+}
+
+// HAS_LN: folded LayerNorm -- y = acc * rstd_m + (-mean_m rstd_m) * c1[n] + c2[n]  (see GemmArgs::ln_stats)
+template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, int D, bool HAS_LN = false, typename IssueDma>
 __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[4][2], int mw, int nw, char* W, int act,
-                                              IssueDma&& issue_dma) {
-  constexpr int NL = 4 * ((HAS_R ? 1 : 0) + (HAS_U ? 1 : 0));   // loads per 32-row block
+                                              EpiLoads& ld, IssueDma&& issue_dma) {
+  constexpr int NL = 4 * ((HAS_R ? 1 : 0) + (HAS_U ? 1 : 0) + (HAS_LN ? 1 : 0));   // loads per 32-row block
   constexpr int NS = 4 * (HAS_C2 ? 2 : 1);                       // stores per 32-row block
   const int eln = lane_id_now();
   const int crow = eln >> 3, g = eln & 7, eh = eln >> 5, el31 = eln & 31;
@@ -138,26 +180,21 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
   const uint32_t lane_r = (uint32_t)crow * ec.ldr_b + (uint32_t)g * 16u;
   const uint32_t lane_u = (uint32_t)crow * ec.ldu_b + (uint32_t)g * 16u;
     const uint32_t wr_row = (uint32_t)el31 * 256u, wr_sw = (uint32_t)(el31 & 7);
-  u32x4_t bq[2];
-  u32x4_t ld_r[4][4], ld_u[4][4];
+  u32x4_t bq[2], c1q[2], c2q[2];
   ldg16(bq[0], (uint32_t)g * 32u, ec.srdBias, (uint32_t)nw * 4u);
   ldg16(bq[1], (uint32_t)g * 32u + 16u, ec.srdBias, (uint32_t)nw * 4u);
-  auto issue_loads = [&](auto bc, auto ic) {
-    constexpr int b = decltype(bc)::value, i = decltype(ic)::value;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const uint32_t row = (uint32_t)(mw + i * 32 + it * 8);
-      if constexpr (HAS_R) ldg16(ld_r[b][it], lane_r, ec.srdR, row * ec.ldr_b + (uint32_t)nw * 2u);
-      if constexpr (HAS_U) ldg16(ld_u[b][it], lane_u, ec.srdU, row * ec.ldu_b + (uint32_t)nw * 2u);
-    }
-  };
-  if constexpr (NL > 0) {
-    issue_loads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-    issue_loads(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-    issue_loads(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+  if constexpr (HAS_LN) {
+    ldg16(c1q[0], (uint32_t)g * 32u, ec.srdLn1, (uint32_t)nw * 4u);
+    ldg16(c1q[1], (uint32_t)g * 32u + 16u, ec.srdLn1, (uint32_t)nw * 4u);
+    ldg16(c2q[0], (uint32_t)g * 32u, ec.srdLn2, (uint32_t)nw * 4u);
+    ldg16(c2q[1], (uint32_t)g * 32u + 16u, ec.srdLn2, (uint32_t)nw * 4u);
+  }
+  if constexpr (NL > 0) {     // (block 0 was requested by the caller, before its last K-tile)
+    epilogue_issue_block<HAS_R, HAS_U, HAS_LN, 1, 1>(ec, mw, nw, ld);
+    epilogue_issue_block<HAS_R, HAS_U, HAS_LN, 2, 2>(ec, mw, nw, ld);
   }
   issue_dma();
-  float bv[8];
+  float bv[8], c1v[8];
 
   static_for<4>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -191,27 +228,46 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
       bv[2] = __uint_as_float(bq[0].z); bv[3] = __uint_as_float(bq[0].w);
       bv[4] = __uint_as_float(bq[1].x); bv[5] = __uint_as_float(bq[1].y);
       bv[6] = __uint_as_float(bq[1].z); bv[7] = __uint_as_float(bq[1].w);
+      if constexpr (HAS_LN) {     // (bias is null here: bv = 0 + c2)
+        wait_vm4<2 * NL + D>(c1q[0], c1q[1], c2q[0], c2q[1]);
+        c1v[0] = __uint_as_float(c1q[0].x); c1v[1] = __uint_as_float(c1q[0].y);
+        c1v[2] = __uint_as_float(c1q[0].z); c1v[3] = __uint_as_float(c1q[0].w);
+        c1v[4] = __uint_as_float(c1q[1].x); c1v[5] = __uint_as_float(c1q[1].y);
+        c1v[6] = __uint_as_float(c1q[1].z); c1v[7] = __uint_as_float(c1q[1].w);
+        bv[0] += __uint_as_float(c2q[0].x); bv[1] += __uint_as_float(c2q[0].y);
+        bv[2] += __uint_as_float(c2q[0].z); bv[3] += __uint_as_float(c2q[0].w);
+        bv[4] += __uint_as_float(c2q[1].x); bv[5] += __uint_as_float(c2q[1].y);
+        bv[6] += __uint_as_float(c2q[1].z); bv[7] += __uint_as_float(c2q[1].w);
+      }
     }
     if constexpr (NL > 0) {
-      // newer than block i's loads:  0: L1 L2 D   1: L2 D S0 L3   2: D S0 L3 S1   3: S1 S2
+      // newer than block i's loads:  0: (bias) L1 L2 D   1: L2 D S0 L3   2: D S0 L3 S1   3: S1 S2
       constexpr int cnt = (i == 0) ? 2 * NL + D : (i == 1) ? 2 * NL + D + NS : (i == 2) ? NL + D + 2 * NS : 2 * NS;
-      if constexpr (HAS_R) wait_vm4<cnt>(ld_r[b][0], ld_r[b][1], ld_r[b][2], ld_r[b][3]);
-      if constexpr (HAS_U) wait_vm4<cnt>(ld_u[b][0], ld_u[b][1], ld_u[b][2], ld_u[b][3]);
+      if constexpr (HAS_R) wait_vm4<cnt>(ld.r[b][0], ld.r[b][1], ld.r[b][2], ld.r[b][3]);
+      if constexpr (HAS_U) wait_vm4<cnt>(ld.u[b][0], ld.u[b][1], ld.u[b][2], ld.u[b][3]);
+      if constexpr (HAS_LN) wait_vm4s<cnt>(ld.s[b][0], ld.s[b][1], ld.s[b][2], ld.s[b][3]);
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       float (&y)[8] = x[it];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = y[e] * ec.scale + bv[e];
+      for (int e = 0; e < 8; ++e) {
+        if constexpr (HAS_LN) {
+          const float ra = __uint_as_float(ld.s[b][it].x), rb = __uint_as_float(ld.s[b][it].y);
+          y[e] = fmaf(y[e], ra, fmaf(rb, c1v[e], bv[e]));
+        } else {
+          y[e] = y[e] * ec.scale + bv[e];
+        }
+      }
       const uint32_t soff = (uint32_t)(mw + i * 32 + it * 8) * ec.ldc_b + (uint32_t)nw * 2u;
       if constexpr (HAS_C2) {
         const u32x4_t o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
                            pack_bf16x2(y[6], y[7])};
-        __builtin_amdgcn_raw_buffer_store_b128(o, ec.rsC2, lane_c, soff, 0);
+        stg16(o, lane_c, ec.srdC2, soff);
       }
       if constexpr (HAS_U) {
         float uf[8];
-        unpack8(ld_u[b][it], uf);
+        unpack8(ld.u[b][it], uf);
         if (act == ACT_QUICKGELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) y[e] *= act_grad<FAST>(uf[e], ACT_QUICKGELU);
@@ -228,15 +284,15 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
       }
       if constexpr (HAS_R) {
         float rf[8];
-        unpack8(ld_r[b][it], rf);
+        unpack8(ld.r[b][it], rf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] += rf[e];
       }
       const u32x4_t o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
                          pack_bf16x2(y[6], y[7])};
-      __builtin_amdgcn_raw_buffer_store_b128(o, ec.rsC, lane_c, soff, 0);
+      stg16(o, lane_c, ec.srdC, soff);
     }
-    if constexpr (NL > 0 && i == 0) issue_loads(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
+    if constexpr (NL > 0 && i == 0) epilogue_issue_block<HAS_R, HAS_U, HAS_LN, 3, 3>(ec, mw, nw, ld);
   });
 }
 

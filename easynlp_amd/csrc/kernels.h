@@ -21,6 +21,12 @@ struct GemmArgs {
   const void* R = nullptr; int64_t ldr = 0;   // optional residual [M, N], dtype T
   const void* U = nullptr; int64_t ldu = 0;   // optional pre-activation [M, N] (T): result *= act'(U) (backward)
   const float* scale_log = nullptr;           // optional device scalar s: acc *= exp(s)
+  // Folded LayerNorm (8-phase bf16 kernel only): A holds the RAW rows x, B the weights pre-multiplied by the LN gain
+  // (W' = W o g), and the epilogue finishes  LN(x) W^T + bias = rstd (x W'^T) - rstd mean c1 + c2  with
+  //   ln_stats[m] = (rstd_m, -mean_m rstd_m),  c1[n] = sum_k W'[n][k],  c2[n] = sum_k b[k] W[n][k] + bias[n].
+  const float* ln_stats = nullptr;            // [M][2] f32
+  const float* ln_c1 = nullptr;               // [N] f32
+  const float* ln_c2 = nullptr;               // [N] f32 (bias folded in; `bias` must be null)
   float alpha = 1.0f;                         // acc *= alpha
   int M = 0, N = 0, K = 0;
   int act = 0;                                // ezclip::Act
@@ -93,6 +99,13 @@ int layernorm_bwd(const void* x, int64_t x_stride, const void* dy, int64_t dy_st
                   int64_t dres_stride, float* dg, float* db, int rows, int D, int dtype, hipStream_t stream,
                   float* dsum = nullptr);
 
+// stats[row] = (rstd, -mean * rstd) of LayerNorm over the last dim (consumed by the GEMM's folded-LN epilogue)
+int layernorm_row_stats(const void* x, int64_t x_stride, float eps, int rows, int D, int dtype, float* stats,
+                        hipStream_t stream);
+// W [N, K] f32, LN gain g / shift b [K], bias [N] (may be null)  ->  Wf [N, ldk] (compute dtype) = W o g,
+// c1[n] = sum_k Wf[n][k] (of the ROUNDED values), c2[n] = sum_k b[k] W[n][k] + bias[n]
+int fold_ln_weight(const float* W, const float* g, const float* b, const float* bias, int N, int K, void* Wf, int64_t ldk,
+                   float* c1, float* c2, int dtype, hipStream_t stream);
 int cast_from_f32(const float* src, void* dst, int64_t n, int dtype, hipStream_t stream);
 int cast_to_f32(const void* src, float* dst, int64_t n, int dtype, hipStream_t stream);
 // dst[c][r] = src[r][c]; src [R, C] f32 (row stride src_ld) -> dst [C, ld] T (ld >= R, pad zero-filled)

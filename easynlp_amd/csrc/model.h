@@ -35,6 +35,10 @@ struct ezclip_model {
     void* s = nullptr;      // packed [N, ldk] in compute dtype (== master for plain f32)
     void* st = nullptr;     // packed transposed [K(ld N), N] for input gradients (with_backward only)
     int ldn = 0;            // leading dim of st ([K, ldn])
+    // folded-LayerNorm copy (bf16 inference path): W o g, c1 = row sums of it, c2 = W b + bias
+    int fold_g = -1, fold_b = -1, fold_bias = -1;   // param indices of the LN gain / shift and the Linear bias
+    void* sf = nullptr;
+    float *c1 = nullptr, *c2 = nullptr;
   };
   struct VitLayer {
     Weight in_w, out_w, fc_w, proj_w;
@@ -64,6 +68,7 @@ namespace ezclip {
 int model_create(const ezclip_config* cfg, ezclip_model** out);
 size_t model_shadow_layout(ezclip_model* m, char* base, bool with_backward);  // returns bytes; assigns when base != null
 int model_refresh_weights(ezclip_model* m, hipStream_t stream);
+void set_fold_layernorm(int on);   // debugging: 0 = separate LayerNorm kernels in the bf16 inference path too
 
 size_t image_workspace_bytes(const ezclip_model* m, int B, bool save);
 size_t text_workspace_bytes(const ezclip_model* m, int B, int L, bool save);

@@ -128,6 +128,9 @@ int model_create(const ezclip_config* c, ezclip_model** out) {
     L.proj_b = add_param(m, p + "mlp.c_proj.bias", {W});
     L.ln2_w = add_param(m, p + "ln_2.weight", {W});
     L.ln2_b = add_param(m, p + "ln_2.bias", {W});
+    // bf16 inference: ln_1 / ln_2 are folded into the in_proj / c_fc products (GemmArgs::ln_stats)
+    L.in_w.fold_g = L.ln1_w; L.in_w.fold_b = L.ln1_b; L.in_w.fold_bias = L.in_b;
+    L.fc_w.fold_g = L.ln2_w; L.fc_w.fold_b = L.ln2_b; L.fc_w.fold_bias = L.fc_b;
     m->vit.push_back(L);
   }
   m->lnpost_w = add_param(m, "visual.ln_post.weight", {W});
@@ -188,7 +191,13 @@ size_t model_shadow_layout(ezclip_model* m, char* base, bool with_backward) {
     void* st = nullptr;
     // conv1 needs no input gradient (pixels are data)
     if (with_backward && &w != &m->conv_w) st = a.take((size_t)w.K * w.ldn * esz);
-    if (base) { w.s = s; w.st = st; }
+    void* sf = nullptr; float *c1 = nullptr, *c2 = nullptr;
+    if (w.fold_g >= 0 && m->dtype == EZCLIP_BF16) {
+      sf = a.take((size_t)w.N * w.ldk * esz);
+      c1 = a.takef(w.N);
+      c2 = a.takef(w.N);
+    }
+    if (base) { w.s = s; w.st = st; w.sf = sf; w.c1 = c1; w.c2 = c2; }
   });
   a.take(0);
   return a.off + 256;
@@ -207,6 +216,11 @@ int model_refresh_weights(ezclip_model* m, hipStream_t stream) {
       // master [N, K] -> [N, ldk]   or master [K, N] -> [N, ldk]
       rc = w.transposed_src ? transpose_cast(src, w.N, w.K, w.N, w.s, w.ldk, m->dtype, stream)
                             : pad_cast(src, w.N, w.K, w.s, w.ldk, m->dtype, stream);
+      if (rc != EZ_OK) return;
+    }
+    if (w.sf != nullptr) {
+      rc = fold_ln_weight(src, m->P(w.fold_g), m->P(w.fold_b), w.fold_bias >= 0 ? m->P(w.fold_bias) : nullptr, w.N, w.K,
+                          w.sf, w.ldk, w.c1, w.c2, m->dtype, stream);
       if (rc != EZ_OK) return;
     }
     if (w.st != nullptr) {
@@ -235,6 +249,32 @@ static int linear(const ezclip_model* m, const void* A, int64_t lda, const ezcli
   return gemm_nt(g, m->dtype, stream);
 }
 
+// C = act(LayerNorm(X) . W^T + bias) with the LayerNorm folded into the product (bf16 inference): X is read raw.
+static int linear_folded_ln(const ezclip_model* m, const void* X, int64_t ldx, const ezclip_model::Weight& w, float eps,
+                            float* stats, void* C, int64_t ldc, int M, int act, hipStream_t stream) {
+  int rc = layernorm_row_stats(X, ldx, eps, M, w.K, m->dtype, stats, stream);
+  if (rc != EZ_OK) return rc;
+  GemmArgs g;
+  g.A = X; g.lda = ldx;
+  g.B = w.sf; g.ldb = w.ldk;
+  g.C = C; g.ldc = ldc;
+  g.M = M; g.N = w.N; g.K = w.ldk;
+  g.act = act;
+  g.ln_stats = stats; g.ln_c1 = w.c1; g.ln_c2 = w.c2;
+  return gemm_nt(g, m->dtype, stream);
+}
+
+static bool g_fold_ln = true;
+void set_fold_layernorm(int on) { g_fold_ln = on != 0; }
+
+static bool can_fold_ln(const ezclip_model* m, const ezclip_model::Weight& w, int M) {
+  if (!g_fold_ln || m->dtype != EZCLIP_BF16 || w.sf == nullptr) return false;
+  GemmArgs g;   // the shape constraints of the 8-phase kernel
+  g.M = M; g.N = w.N; g.K = w.ldk; g.lda = w.ldk; g.ldb = w.ldk; g.ldc = w.N;
+  g.A = w.sf; g.B = w.sf; g.C = w.sf; g.ln_stats = w.c1; g.ln_c1 = w.c1; g.ln_c2 = w.c2;
+  return gemm_nt_8p_eligible(g, m->dtype);
+}
+
 #define EZ_TRY(expr)                 \
   do {                               \
     int _rc = (expr);                \
@@ -247,6 +287,7 @@ namespace {
 struct VitBufs {
   void *x_in, *ln1, *qkv, *ctx, *x_mid, *ln2, *u, *h, *x_out;
   float *m1, *r1, *m2, *r2, *lse;
+  float* stat;   // inference only: (rstd, -mean rstd) per row for the folded-LayerNorm products
 };
 struct ImgWS {
   void *patches, *pemb, *x0;
@@ -280,6 +321,7 @@ size_t layout_image(const ezclip_model* m, int B, bool save, void* base, ImgWS* 
     b.ctx = a.take(M * W * esz);
     b.u = nullptr;
     b.h = a.take(M * 4 * W * esz);
+    b.stat = a.takef(2 * M);
     b.m1 = b.r1 = b.m2 = b.r2 = b.lse = nullptr;
     for (int i = 0; i < nl; ++i) w.layers[i] = b;
   } else {
@@ -297,6 +339,7 @@ size_t layout_image(const ezclip_model* m, int B, bool save, void* base, ImgWS* 
       b.x_out = a.take(M * W * esz);
       b.m1 = a.takef(M); b.r1 = a.takef(M); b.m2 = a.takef(M); b.r2 = a.takef(M);
       b.lse = a.takef((size_t)B * m->vheads * m->Lv);
+      b.stat = nullptr;
       x = b.x_out;
     }
   }
@@ -422,8 +465,13 @@ int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* 
     const auto& Lw = m->vit[i];
     const VitBufs& b = ws.layers[i];
     // x = x + attn(ln_1(x))                                          :203
-    EZ_TRY(layernorm_fwd(b.x_in, W, b.ln1, W, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, M, W, dt, b.m1, b.r1, stream));
-    EZ_TRY(linear(m, b.ln1, W, Lw.in_w, Lw.in_b, b.qkv, 3 * W, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+    const bool fold = !save && can_fold_ln(m, Lw.in_w, M) && can_fold_ln(m, Lw.fc_w, M);
+    if (fold) {
+      EZ_TRY(linear_folded_ln(m, b.x_in, W, Lw.in_w, eps, b.stat, b.qkv, 3 * W, M, ACT_NONE, stream));
+    } else {
+      EZ_TRY(layernorm_fwd(b.x_in, W, b.ln1, W, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, M, W, dt, b.m1, b.r1, stream));
+      EZ_TRY(linear(m, b.ln1, W, Lw.in_w, Lw.in_b, b.qkv, 3 * W, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+    }
     AttnArgs at;
     at.q = b.qkv;
     at.k = (const char*)b.qkv + (size_t)W * dtype_size(dt);
@@ -435,8 +483,12 @@ int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* 
     EZ_TRY(attention_fwd(at, dt, stream));
     EZ_TRY(linear(m, b.ctx, W, Lw.out_w, Lw.out_b, b.x_mid, W, M, ACT_NONE, b.x_in, W, nullptr, false, stream));
     // x = x + c_proj(QuickGELU(c_fc(ln_2(x))))                      :204
-    EZ_TRY(layernorm_fwd(b.x_mid, W, b.ln2, W, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, M, W, dt, b.m2, b.r2, stream));
-    EZ_TRY(linear(m, b.ln2, W, Lw.fc_w, Lw.fc_b, b.h, 4 * W, M, ACT_QUICKGELU, nullptr, 0, b.u, false, stream));
+    if (fold) {
+      EZ_TRY(linear_folded_ln(m, b.x_mid, W, Lw.fc_w, eps, b.stat, b.h, 4 * W, M, ACT_QUICKGELU, stream));
+    } else {
+      EZ_TRY(layernorm_fwd(b.x_mid, W, b.ln2, W, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, M, W, dt, b.m2, b.r2, stream));
+      EZ_TRY(linear(m, b.ln2, W, Lw.fc_w, Lw.fc_b, b.h, 4 * W, M, ACT_QUICKGELU, nullptr, 0, b.u, false, stream));
+    }
     EZ_TRY(linear(m, b.h, 4 * W, Lw.proj_w, Lw.proj_b, b.x_out, W, M, ACT_NONE, b.x_mid, W, nullptr, false, stream));
   }
   // ln_post(x[:, 0, :]) @ proj                                        :248-251

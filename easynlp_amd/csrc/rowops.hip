@@ -76,6 +76,44 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, int64_t xs, T* 
   if (mean_o != nullptr && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
 
+// stats[row] = (rstd, -mean * rstd): what the GEMM's folded-LayerNorm epilogue needs (GemmArgs::ln_stats)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const T* x, int64_t xs, float eps, int rows, int D, float* stats) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[kMaxChunks][4];
+  load_row(x + (int64_t)row * xs, D, lane, v);
+  float mean, rstd;
+  row_stats(v, D, lane, eps, mean, rstd);
+  if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * (int64_t)row) = make_float2(rstd, -mean * rstd);
+}
+
+// One wave per output row n:  Wf[n][k] = W[n][k] * g[k] (rounded to T),  c1[n] = sum_k Wf[n][k] (rounded values),
+// c2[n] = sum_k b[k] * W[n][k] + bias[n].  Columns K..ldk-1 of Wf are zero.
+template <typename T>
+__global__ __launch_bounds__(256) void fold_ln_weight_kernel(const float* W, const float* g, const float* b,
+                                                              const float* bias, int N, int K, T* Wf, int64_t ldk,
+                                                              float* c1, float* c2) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = lane; k < (int)ldk; k += 64) {
+    float wf = 0.f;
+    if (k < K) {
+      const float w = W[(int64_t)n * K + k];
+      wf = w * g[k];
+      s2 += b[k] * w;
+    }
+    Elem<T>::st(Wf + (int64_t)n * ldk + k, wf);
+    s1 += Elem<T>::ld(Wf + (int64_t)n * ldk + k);     // the value the MFMA will see
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) { c1[n] = s1; c2[n] = s2 + (bias ? bias[n] : 0.f); }
+}
+
 // LayerNorm backward, one row per wave at a time, two rows in flight per wave (loads of the second row are issued
 // before the first is reduced), rows interleaved across ~16 waves per CU:
 //   xhat = (x - mean) * rstd;  gy = dy * g
@@ -485,6 +523,26 @@ int layernorm_bwd(const void* x, int64_t xs, const void* dy, int64_t dys, const 
                                           dsum, rows, D))
   if (nc == 1) EZ_LNB(1); else if (nc == 2) EZ_LNB(2); else if (nc == 3) EZ_LNB(3); else EZ_LNB(4);
 #undef EZ_LNB
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int layernorm_row_stats(const void* x, int64_t xs, float eps, int rows, int D, int dtype, float* stats,
+                        hipStream_t stream) {
+  EZ_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * kMaxChunks && xs % 4 == 0, "layernorm_row_stats: D=%d unsupported", D);
+  const int blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+  ProfScope ps(PROF_ROWOP, 1.0 * rows * (double)D * dtype_size(dtype), stream);   // bytes: one read
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((ln_stats_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)x, xs, eps,
+                                          rows, D, stats));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int fold_ln_weight(const float* W, const float* g, const float* b, const float* bias, int N, int K, void* Wf, int64_t ldk,
+                   float* c1, float* c2, int dtype, hipStream_t stream) {
+  EZ_REQUIRE(N > 0 && K > 0 && ldk >= K, "fold_ln_weight: bad shape");
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((fold_ln_weight_kernel<T>), dim3((N + 3) / 4), dim3(256), 0, stream, W, g, b, bias,
+                                          N, K, (T*)Wf, ldk, c1, c2));
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

@@ -99,6 +99,31 @@ def test_all_padding_rows_and_pad_id_inside_sequence(tmp_path):
     assert float((got - ref).abs().max()) < 2e-5
 
 
+def test_folded_layernorm_inference_path(tmp_path):
+    """bf16 inference folds ln_1 / ln_2 of every ViT block into the in_proj / c_fc products
+    (LN(x) W^T + b = rstd (x (W o g)^T) - rstd mean c1 + c2, GemmArgs::ln_stats): same embeddings as the path with
+    separate LayerNorm kernels to bf16 accuracy, and at least as close to the fp32 reference."""
+    from easynlp_amd import lib as L
+    z, cfg, B, Lq, wseed, iseed = load_gold("vitb16_bertbase_b4_l64")
+    app, _ = make_app(tmp_path, cfg, wseed, "bf16")
+    app.eval()
+    px, ids = O.make_inputs(cfg, B, Lq, iseed)
+    lib = L.load()
+    outs = {}
+    for fold in (1, 0):
+        L.check(lib.ezclip_debug_set(2, fold))
+        try:
+            with torch.no_grad():
+                outs[fold] = app({"pixel_values": px, "input_ids": None}, feat=True)["image_embeds"].cpu().clone()
+        finally:
+            L.check(lib.ezclip_debug_set(2, 1))
+    gi = torch.from_numpy(z["image_embeds"])
+    e_fold, e_sep = float((outs[1] - gi).abs().max()), float((outs[0] - gi).abs().max())
+    assert float((outs[1] - outs[0]).abs().max()) < 1e-2
+    assert e_fold < 1e-2 and e_sep < 1e-2
+    assert e_fold < 1.5 * e_sep + 1e-3, (e_fold, e_sep)
+
+
 class _DS(torch.utils.data.Dataset):
     def __init__(self, px, ids):
         self.px, self.ids = px, ids

@@ -1,5 +1,8 @@
 #!/usr/bin/env python
-"""Audit hand-issued VMEM loads in a hipcc .s file: between an inline-asm `buffer_load_dwordx4 v[a:b] ... offen`
+"""Audit hand-issued VMEM in a hipcc .s file.
+(2) After a buffer_store_dwordx3/x4 the data registers must survive 2 wait states before a VALU overwrites them
+    (hipcc exempts MUBUF stores with an SGPR soffset from this padding; gfx950 does not).
+(1) Loads: between an inline-asm `buffer_load_dwordx4 v[a:b] ... offen`
 (VGPR destination, i.e. not an LDS-DMA) and the next `s_waitcnt vmcnt`, no instruction may touch v[a:b]
 (hipcc treats the destination as written at the asm statement and may copy / reuse it before the data lands:
 cdna_hip_programming.md 5.7).  usage: audit_asm_loads.py file.s   -> exit 1 if a violation is found"""
@@ -30,6 +33,20 @@ def main():
             k = int(m.group(1))
             ops = ops[len(ops) - k:] if k > 0 and k < len(ops) else ([] if k == 0 else ops)
             continue
+        # (2) store-data hazard
+        if 'store_guard' not in globals():
+            globals()['store_guard'] = []
+        sg = globals()['store_guard']
+        mnop = re.match(r"s_nop\s+(\d+)", s)
+        step = int(mnop.group(1)) + 1 if mnop else 1
+        if s.startswith("v_") and sg:
+            dst = regs(s.split(",")[0])
+            for (ln, d, left) in sg:
+                if left > 0 and dst & d:
+                    print("%s line %d overwrites data of the store at line %d too early: %s" % (kern, n, ln, s)); bad += 1
+        sg[:] = [(ln, d, left - step) for (ln, d, left) in sg if left - step > 0]
+        if re.match(r"buffer_store_dwordx[34]\b", s):
+            sg.append((n, regs(s.split(",")[0]), 2))
         pend = {}
         for ln, d in ops:
             for r in d:

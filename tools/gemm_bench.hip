@@ -244,6 +244,58 @@ int main(int argc, char** argv) {
       hipFree(A); hipFree(B); hipFree(C0); hipFree(C1);
     }
   }
+  // ---- folded-LayerNorm epilogue:  C = bf16( acc * s0[m] + s1[m] * c1[n] + c2[n] )  against the fp32 product of the
+  //      128x128 kernel finished on the host -------------------------------------------------------------------------
+  if (!only_attn) {
+    const int M = 4000, N = 768, K = 768;
+    uint16_t *A, *B, *C; float *Cf, *st2, *c1, *c2;
+    CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 2));
+    CK(hipMalloc(&Cf, (size_t)M * N * 4)); CK(hipMalloc(&st2, (size_t)M * 8)); CK(hipMalloc(&c1, N * 4)); CK(hipMalloc(&c2, N * 4));
+    fill_bf16<<<2048, 256, 0, st>>>(A, (size_t)M * K, 31u, 1.0f);
+    fill_bf16<<<2048, 256, 0, st>>>(B, (size_t)N * K, 32u, 0.05f);
+    fill_f32<<<(2 * M + 255) / 256, 256, 0, st>>>(st2, 2 * M, 33u);
+    fill_f32<<<(N + 255) / 256, 256, 0, st>>>(c1, N, 34u);
+    fill_f32<<<(N + 255) / 256, 256, 0, st>>>(c2, N, 35u);
+    ezclip::GemmArgs g;
+    g.A = A; g.lda = K; g.B = B; g.ldb = K; g.C = Cf; g.ldc = N; g.M = M; g.N = N; g.K = K; g.out_f32 = 1;
+    ezclip::set_gemm_variant(0);
+    int rc0 = ezclip::gemm_nt(g, EZCLIP_BF16, st);
+    ezclip::set_gemm_variant(2);
+    g.C = C; g.out_f32 = 0; g.ln_stats = st2; g.ln_c1 = c1; g.ln_c2 = c2;
+    int rc1 = ezclip::gemm_nt(g, EZCLIP_BF16, st);
+    CK(hipStreamSynchronize(st));
+    if (rc0 || rc1) printf("ln.fold ERROR %s\n", ezclip::last_error());
+    else {
+      std::vector<float> hcf((size_t)M * N), hs(2 * M), h1(N), h2(N);
+      std::vector<uint16_t> hc((size_t)M * N);
+      CK(hipMemcpy(hcf.data(), Cf, hcf.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hc.data(), C, hc.size() * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hs.data(), st2, hs.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(h1.data(), c1, N * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), c2, N * 4, hipMemcpyDeviceToHost));
+      double md = 0; size_t nan = 0;
+      size_t hb_i[4] = {0}, hb_it[4] = {0}, hb_crow[8] = {0}, hb_g[8] = {0}, hb_e[8] = {0}, hb_tile[16] = {0}, nbad = 0;
+      for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) {
+          const float ref = fmaf(hcf[(size_t)m * N + n], hs[2 * m], fmaf(hs[2 * m + 1], h1[n], h2[n]));
+          const uint32_t u = (uint32_t)hc[(size_t)m * N + n] << 16;
+          float got; memcpy(&got, &u, 4);
+          const bool bad = (got != got) || fabsf(got - ref) / (fabs(ref) + 1.0) > 0.02;
+          if (bad) { ++nbad; ++hb_i[(m % 128) / 32]; ++hb_it[(m % 32) / 8]; ++hb_crow[m % 8]; ++hb_g[(n % 64) / 8]; ++hb_e[n % 8]; ++hb_tile[(m / 256) % 16]; }
+          if (got != got) { ++nan; continue; }
+          md = std::max(md, (double)fabsf(got - ref) / (fabs(ref) + 1.0));
+        }
+      printf("ln.fold         M=%7d N=%5d K=%5d : max rel err %.3g (bf16 ulp = 3.9e-3), NaNs %zu, bad %zu\n", M, N, K, md, nan, nbad);
+      if (nbad) {
+        printf("   by i:"); for (size_t v : hb_i) printf(" %zu", v);
+        printf("  by it:"); for (size_t v : hb_it) printf(" %zu", v);
+        printf("  by crow:"); for (size_t v : hb_crow) printf(" %zu", v);
+        printf("\n   by g:"); for (size_t v : hb_g) printf(" %zu", v);
+        printf("  by e:"); for (size_t v : hb_e) printf(" %zu", v);
+        printf("  by m-tile:"); for (size_t v : hb_tile) printf(" %zu", v);
+        printf("\n");
+      }
+    }
+    hipFree(A); hipFree(B); hipFree(C); hipFree(Cf); hipFree(st2); hipFree(c1); hipFree(c2);
+  }
   // ---- attention (packed qkv [B*L, 3*H*64] bf16): old two-pass kernels (variant 0) vs the short-sequence kernels ----
   {
     struct AT { const char* name; int B, L, H; };

@@ -40,15 +40,22 @@ VITB16_BERTBASE = dict(
     text_hidden_dropout_prob=0.0, text_hidden_size=768, text_initializer_range=0.02, text_intermediate_size=3072,
     text_max_position_embeddings=512, text_num_attention_heads=12, text_num_hidden_layers=12, text_type_vocab_size=2)
 
+# BASELINE.json config 5: ViT-L/14 + hfl/chinese-roberta-wwm-ext (BERT-base architecture), 512 pairs per GPU
+VITL14_ROBERTA = dict(VITB16_BERTBASE, embed_dim=768, vision_layers=24, vision_width=1024, vision_patch_size=14)
+
 WORKLOADS = {
     "bf16_b1024_fwd_loss": dict(dtype="bf16", batch=1024, seq=64, backward=False),
     "bf16_b1024_train": dict(dtype="bf16", batch=1024, seq=64, backward=True),
     "fp32_b256_fwd_sim": dict(dtype="fp32", batch=256, seq=64, backward=False),
+    "bf16_vitl14_b512_fwd_loss": dict(dtype="bf16", batch=512, seq=64, backward=False, model="vitl14"),
+    "bf16_vitl14_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="vitl14"),
 }
 
 # algorithmic GFLOP per pair (multiply-add = 2; padded tiles and softmax/LN excluded)
 GFLOP_FWD_PER_PAIR = 46.152
 GFLOP_TRAIN_PER_PAIR = 138.46
+GFLOP_FWD_PER_PAIR_VITL14 = 173.05      # ViT-L/14 (L = 257) + BERT-base text tower, 64 tokens
+GFLOP_TRAIN_PER_PAIR_VITL14 = 519.2
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 
 # launches of the dominant kernel in one forward step at 1024 pairs (shape names of tools/gemm_bench):
@@ -157,7 +164,10 @@ def main():
     if args.batch:
         wl["batch"] = args.batch
     B, S = wl["batch"], wl["seq"]
-    app = CLIPApp.from_config(VITB16_BERTBASE, seed=1234, device=device, compute_dtype=wl["dtype"])
+    model_cfg = VITL14_ROBERTA if wl.get("model") == "vitl14" else VITB16_BERTBASE
+    model_name = ("ViT-L/14 + chinese-roberta-wwm-ext (BERT-base arch)" if wl.get("model") == "vitl14"
+                  else "ViT-B/16 + BERT-base") + " (chinese_clip), random init"
+    app = CLIPApp.from_config(model_cfg, seed=1234, device=device, compute_dtype=wl["dtype"])
     app.eval()
     px, ids = synth_batch(B, S, VITB16_BERTBASE["vocab_size"], device, seed=1000 + rank)
     pg = True if world > 1 else False
@@ -226,14 +236,18 @@ def main():
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / elapsed
-        gflop = GFLOP_TRAIN_PER_PAIR if wl["backward"] else GFLOP_FWD_PER_PAIR
+        if wl.get("model") == "vitl14":
+            gflop = GFLOP_TRAIN_PER_PAIR_VITL14 if wl["backward"] else GFLOP_FWD_PER_PAIR_VITL14
+        else:
+            gflop = GFLOP_TRAIN_PER_PAIR if wl["backward"] else GFLOP_FWD_PER_PAIR
         out = {
-            "metric": "image-text pairs/sec (fwd+loss) ViT-B/16+BERT-base",
+            "metric": "image-text pairs/sec (fwd+loss) " + ("ViT-L/14+roberta-wwm-ext" if wl.get("model") == "vitl14"
+                                                            else "ViT-B/16+BERT-base"),
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": wl["dtype"], "data": "synthetic",
-            "config": {"workload": args.workload, "model": "ViT-B/16 + BERT-base (chinese_clip), random init",
+            "config": {"workload": args.workload, "model": model_name,
                        "pairs_per_gpu": B, "global_batch": world * B, "image": "224x224", "seq_len": S,
                        "stages": "encode_image+encode_text" + ("+allgather" if world > 1 else "")
                                  + "+similarity(2 dirs)+InfoNCE" + ("+backward" if wl["backward"] else ""),

@@ -137,6 +137,8 @@ int vit_gather_patch_rows(const void* dx0, void* dpemb, int B, int Lv, int W, in
 int bert_word_grad(const int64_t* ids, const void* dx0, float* dword, int64_t rows, int Hd, int vocab, int dtype,
                    hipStream_t stream);
 int add_inplace_f32(float* dst, const float* src, int64_t n, hipStream_t stream);
+// dst[r][c] += src[r][c] for c < cols (row strides ldd / lds): un-pads a K-padded weight gradient
+int add_cols_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int rows, int cols, hipStream_t stream);
 
 // ---- InfoNCE (loss.hip) -----------------------------------------------------------
 // Row-wise cross entropy against the diagonal: for local row i (global column diag0 + i):

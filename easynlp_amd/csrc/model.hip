@@ -298,6 +298,7 @@ struct ImgWS {
   // backward scratch
   void *gx, *gx2, *gqkv, *gbig, *gtmp, *gfeatT, *gcls;
   float *gfeat;
+  float* gconv;   // [W, Kpad] scratch for the patch-embedding weight gradient when K is padded (ViT-L/14: 588 -> 640)
 };
 
 size_t layout_image(const ezclip_model* m, int B, bool save, void* base, ImgWS* ws) {
@@ -357,8 +358,9 @@ size_t layout_image(const ezclip_model* m, int B, bool save, void* base, ImgWS* 
     w.gfeat = a.takef((size_t)B * E);
     w.gfeatT = a.take((size_t)B * E * esz);
     w.gcls = a.take((size_t)B * W * esz);
+    w.gconv = m->Kpad != m->Kpatch ? a.takef((size_t)W * m->Kpad) : nullptr;
   } else {
-    w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = w.gfeatT = w.gcls = nullptr; w.gfeat = nullptr;
+    w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = w.gfeatT = w.gcls = nullptr; w.gfeat = nullptr; w.gconv = nullptr;
   }
   if (ws) *ws = w;
   return a.off + 256;
@@ -600,8 +602,6 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
                    hipStream_t stream) {
   EZ_REQUIRE(B > 0 && d_emb && wsp, "backward_image: null/empty argument");
   EZ_REQUIRE(m->weights_fresh && m->shadow_backward, "backward_image: weights not packed for backward");
-  EZ_REQUIRE(m->Kpad == m->Kpatch, "backward_image: patch size %d (K=%d not a tile multiple) not supported in backward yet",
-             m->cfg.vision_patch_size, m->Kpatch);
   ImgWS ws;
   const size_t need = layout_image(m, B, true, wsp, &ws);
   EZ_REQUIRE(ws_bytes >= need, "backward_image: workspace too small (%zu < %zu): was the forward run with save_for_backward?", ws_bytes, need);
@@ -663,9 +663,16 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
   if (m->Gp(m->conv_w.p)) {
     EZ_TRY(vit_gather_patch_rows(ws.gx2, ws.gtmp, B, Lv, W, dt, stream));
     GemmTNArgs g;
-    g.A = ws.gtmp; g.lda = W; g.B = ws.patches; g.ldb = m->Kpad; g.C = m->Gp(m->conv_w.p); g.ldc = m->Kpatch;
-    g.M = Mp; g.N = W; g.K = m->Kpatch; g.accumulate = 1;
-    EZ_TRY(gemm_tn(g, dt, stream));
+    g.A = ws.gtmp; g.lda = W; g.B = ws.patches; g.ldb = m->Kpad;
+    g.M = Mp; g.N = W;
+    if (m->Kpad == m->Kpatch) {
+      g.C = m->Gp(m->conv_w.p); g.ldc = m->Kpatch; g.K = m->Kpatch; g.accumulate = 1;
+      EZ_TRY(gemm_tn(g, dt, stream));
+    } else {   // K padded to the tile multiple (zero columns in `patches`): gradient into scratch, then un-pad
+      g.C = ws.gconv; g.ldc = m->Kpad; g.K = m->Kpad; g.accumulate = 0;
+      EZ_TRY(gemm_tn(g, dt, stream));
+      EZ_TRY(add_cols_f32(m->Gp(m->conv_w.p), m->Kpatch, ws.gconv, m->Kpad, W, m->Kpatch, stream));
+    }
   }
   return EZ_OK;
 }

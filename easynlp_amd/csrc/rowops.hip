@@ -672,6 +672,21 @@ int bert_word_grad(const int64_t* ids, const void* dx0, float* dword, int64_t ro
   return EZ_OK;
 }
 
+__global__ void add_cols_kernel(float* dst, int64_t ldd, const float* src, int64_t lds, int rows, int cols) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    dst[(int64_t)r * ldd + c] += src[(int64_t)r * lds + c];
+  }
+}
+
+int add_cols_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int rows, int cols, hipStream_t stream) {
+  hipLaunchKernelGGL(add_cols_kernel, dim3(grid_for((int64_t)rows * cols, 256)), dim3(256), 0, stream, dst, ldd, src, lds, rows,
+                     cols);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
 int add_inplace_f32(float* dst, const float* src, int64_t n, hipStream_t stream) {
   hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, dst, src, n);
   EZ_LAUNCH_CHECK();

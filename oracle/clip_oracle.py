@@ -55,6 +55,17 @@ CONFIGS: Dict[str, dict] = {
         text_intermediate_size=768, text_max_position_embeddings=128,
         text_num_attention_heads=3, text_num_hidden_layers=3,
         text_type_vocab_size=2),
+    # a scaled-down ViT-L/14-style tower: patch 14 (3*14*14 = 588 is not a tile multiple: K is padded to 640 and the
+    # conv gradient un-padded), widths that are multiples of 256 so that batch 16 reaches the 8-phase GEMM kernels
+    "p14_w256": dict(
+        model_type="chinese_clip", embed_dim=128, image_resolution=56,
+        vision_layers=2, vision_width=256, vision_patch_size=14,
+        vocab_size=523, text_attention_probs_dropout_prob=0.0,
+        text_hidden_act="gelu", text_hidden_dropout_prob=0.0,
+        text_hidden_size=256, text_initializer_range=0.02,
+        text_intermediate_size=1024, text_max_position_embeddings=64,
+        text_num_attention_heads=4, text_num_hidden_layers=2,
+        text_type_vocab_size=2),
     # BASELINE.json configs 1-4: ViT-B/16 + BERT-base
     "vitb16_bertbase": dict(
         model_type="chinese_clip", embed_dim=512, image_resolution=224,

@@ -32,6 +32,7 @@ CASES = [
     # name, config, batch, seq_len, weight seed, input seed, full grads?
     ("tiny_b6_l24", "tiny", 6, 24, 1234, 3, True),
     ("small_b5_l40", "small", 5, 40, 99, 7, False),
+    ("p14_w256_b16_l32", "p14_w256", 16, 32, 77, 5, False),
     ("vitb16_bertbase_b4_l64", "vitb16_bertbase", 4, 64, 1234, 0, False),
 ]
 

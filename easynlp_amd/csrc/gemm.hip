@@ -258,6 +258,13 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
   p.vec_ok = vec ? 1 : 0;
   if (g_gemm_variant == 3 && gemm_nt_4w_eligible(p, dtype)) return gemm_nt_4w(p, stream);
   if ((g_gemm_variant < 0 || g_gemm_variant == 2) && gemm_nt_8p_eligible(p, dtype)) return gemm_nt_8p(p, stream);
+  if (p.colsum != nullptr) {   // not the 8-phase kernel: separate column-sum pass after the GEMM
+    float* cs = p.colsum;
+    p.colsum = nullptr;
+    int rc = gemm_nt(p, dtype, stream);
+    if (rc != EZ_OK) return rc;
+    return colsum_add(p.C, p.ldc, p.M, p.N, cs, p.out_f32 ? EZCLIP_F32 : dtype, stream);
+  }
   EZ_REQUIRE(p.ln_stats == nullptr, "gemm_nt: the folded-LayerNorm epilogue needs the 8-phase bf16 kernel (M >= 256, N %% 256 == 0, K %% 128 == 0)");
   if (dtype == EZCLIP_F32) return launch_nt<float, float>(p, stream);
   if (dtype == EZCLIP_BF16) {

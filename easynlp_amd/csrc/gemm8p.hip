@@ -577,6 +577,7 @@ bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype) {
     return false;
   if (p.R && (uint64_t)p.M * (uint64_t)p.ldr * 2u >= lim) return false;
   if (p.U && (uint64_t)p.M * (uint64_t)p.ldu * 2u >= lim) return false;
+  if (p.colsum && (!p.U || p.bias)) return false;     // fused column sums: the act'(U) epilogue, no bias
   return true;
 }
 

@@ -98,6 +98,7 @@ struct EpiCtx {
   i32x4_t srdR, srdU, srdBias;
   i32x4_t srdStats, srdLn1, srdLn2;   // folded LayerNorm: row stats, c1, c2
   i32x4_t srdC, srdC2;
+  float* colsum;
   float scale;
   int M;
 };
@@ -116,6 +117,7 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const GemmArgs& p) {
   e.srdC2 = make_srd(HAS_C2 ? p.C2 : p.C, (uint32_t)p.M * e.ldc_b);
   e.scale = p.alpha;
   e.M = p.M;
+  e.colsum = p.colsum;
   return e;
 }
 
@@ -195,6 +197,9 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
   }
   issue_dma();
   float bv[8], c1v[8];
+  float cs[8];                  // HAS_U: column sums of the output (bias gradient)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
 
   static_for<4>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -275,6 +280,8 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
 #pragma unroll
           for (int e = 0; e < 8; ++e) y[e] *= act_grad<FAST>(uf[e], ACT_GELU_ERF);
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] += y[e];     // rows >= M contribute exact zeros (A rows read as 0, no bias)
       } else if (act == ACT_QUICKGELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] = act_apply<FAST>(y[e], ACT_QUICKGELU);
@@ -294,6 +301,18 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
     }
     if constexpr (NL > 0 && i == 0) epilogue_issue_block<HAS_R, HAS_U, HAS_LN, 3, 3>(ec, mw, nw, ld);
   });
+  if constexpr (HAS_U) {
+    if (ec.colsum != nullptr) {      // 8 lanes share a column group: combine over crow, then 64 atomics per wave tile
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = cs[e];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (crow == 0) unsafeAtomicAdd(ec.colsum + nw + g * 8 + e, v);
+      }
+    }
+  }
 }
 
 }  // namespace

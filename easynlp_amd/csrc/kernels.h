@@ -27,6 +27,9 @@ struct GemmArgs {
   const float* ln_stats = nullptr;            // [M][2] f32
   const float* ln_c1 = nullptr;               // [N] f32
   const float* ln_c2 = nullptr;               // [N] f32 (bias folded in; `bias` must be null)
+  // Backward only (with U): colsum[n] += sum_m C[m][n] -- the bias gradient of the Linear whose output gradient C is
+  // (8-phase kernel: accumulated in the epilogue, one hardware atomic per column per wave tile; else a separate pass)
+  float* colsum = nullptr;
   float alpha = 1.0f;                         // acc *= alpha
   int M = 0, N = 0, K = 0;
   int act = 0;                                // ezclip::Act

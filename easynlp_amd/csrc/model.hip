@@ -557,9 +557,10 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
 
 // ------------------------------------------------------------- backward ----
 // dX[M, w.K] = (dY[M, w.N] . W) [* act'(U)] [+ R]      (NT GEMM against the packed W^T copy)
+// bias_p >= 0: dX is itself the output gradient of a Linear with that bias: its column sums are accumulated too
 static int dgrad(const ezclip_model* m, const void* dY, int64_t ldy, const ezclip_model::Weight& w, void* dX,
                  int64_t ldx, int M, const void* U, int64_t ldu, int act, const void* R, int64_t ldr,
-                 hipStream_t stream) {
+                 hipStream_t stream, int bias_p = -1) {
   EZ_REQUIRE(w.st != nullptr, "backward needs ezclip_set_shadow(..., with_backward=1)");
   GemmArgs g;
   g.A = dY; g.lda = ldy;
@@ -568,6 +569,7 @@ static int dgrad(const ezclip_model* m, const void* dY, int64_t ldy, const ezcli
   g.M = M; g.N = w.K; g.K = w.N;
   g.U = U; g.ldu = ldu; g.act = act;
   g.R = R; g.ldr = ldr;
+  g.colsum = bias_p >= 0 ? m->Gp(bias_p) : nullptr;
   return gemm_nt(g, m->dtype, stream);
 }
 
@@ -627,12 +629,12 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
     const auto& Lw = m->vit[i];
     const VitBufs& b = ws.layers[i];
     // x_out = x_mid + c_proj(h);  h = QuickGELU(u);  u = c_fc(ln_2(x_mid))        :204
-    EZ_TRY(dgrad(m, ws.gx, W, Lw.proj_w, ws.gbig, 4 * W, M, b.u, 4 * W, ACT_QUICKGELU, nullptr, 0, stream));   // d u
+    EZ_TRY(dgrad(m, ws.gx, W, Lw.proj_w, ws.gbig, 4 * W, M, b.u, 4 * W, ACT_QUICKGELU, nullptr, 0, stream,
+                 Lw.fc_b));   // d u (+ c_fc bias gradient)
     EZ_TRY(wgrad(m, ws.gx, W, b.h, 4 * W, Lw.proj_w, M, stream));
     // (c_proj bias gradient: accumulated by the ln_bwd that produced gx)
     EZ_TRY(dgrad(m, ws.gbig, 4 * W, Lw.fc_w, ws.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));      // d ln_2
     EZ_TRY(wgrad(m, ws.gbig, 4 * W, b.ln2, W, Lw.fc_w, M, stream));
-    EZ_TRY(bgrad(m, ws.gbig, 4 * W, M, 4 * W, Lw.fc_b, stream));
     EZ_TRY(ln_bwd(m, b.x_mid, W, ws.gtmp, W, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, W, ws.gx, W, M, W, stream,
                   Lw.out_b));   // d x_mid (+ out_proj bias gradient)
     // x_mid = x_in + out_proj(attn(in_proj(ln_1(x_in))))                           :203
@@ -702,11 +704,10 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     const BertBufs& b = ws.layers[i];
     // x_out = LN(z);  z = dense(hh) + a;  hh = gelu(u);  u = dense(a)        modeling_bert.py:330-345
     EZ_TRY(ln_bwd(m, b.z, H, ws.gx, H, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, H, nullptr, 0, M, H, stream, Lw.d_b));  // d z
-    EZ_TRY(dgrad(m, ws.gx2, H, Lw.d_w, ws.gbig, F, M, b.u, F, ACT_GELU_ERF, nullptr, 0, stream));                     // d u
+    EZ_TRY(dgrad(m, ws.gx2, H, Lw.d_w, ws.gbig, F, M, b.u, F, ACT_GELU_ERF, nullptr, 0, stream, Lw.i_b));            // d u
     EZ_TRY(wgrad(m, ws.gx2, H, b.hh, F, Lw.d_w, M, stream));
     EZ_TRY(dgrad(m, ws.gbig, F, Lw.i_w, ws.gtmp, H, M, nullptr, 0, ACT_NONE, ws.gx2, H, stream));                     // d a = d z + d u W_i
     EZ_TRY(wgrad(m, ws.gbig, F, b.a, H, Lw.i_w, M, stream));
-    EZ_TRY(bgrad(m, ws.gbig, F, M, F, Lw.i_b, stream));
     // a = LN(y);  y = dense(ctx) + x_in                                           :264-267
     EZ_TRY(ln_bwd(m, b.y, H, ws.gtmp, H, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx2, H, nullptr, 0, M, H, stream, Lw.o_b)); // d y
     EZ_TRY(dgrad(m, ws.gx2, H, Lw.o_w, ws.gtmp, H, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));                     // d ctx

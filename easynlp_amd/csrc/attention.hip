@@ -645,6 +645,7 @@ int attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream) {
   const int esz = dtype_size(dtype);
   EZ_REQUIRE((f.row_stride * esz) % 16 == 0 && (f.ctx_stride * esz) % 16 == 0, "attention_bwd: strides must be 16-byte multiples");
   EZ_REQUIRE(f.B <= 65535, "attention_bwd: batch %d > 65535", f.B);
+  if (g_attn_variant != 0 && attention_short_eligible(f, dtype)) return attention_bwd_short(a, stream);
   if (dtype == EZCLIP_F32) return launch_bwd<float>(a, stream);
   if (dtype == EZCLIP_BF16) return launch_bwd<bf16_t>(a, stream);
   set_error("attention_bwd: bad dtype %d", dtype);

@@ -168,10 +168,256 @@ __global__ __launch_bounds__(512) void attn_fwd_short_kernel(AttnArgs a, int nt)
   }
 }
 
+
+// =====================================================================================================
+// Fused backward for the same shapes (bf16, L <= 256): ONE kernel, one workgroup per (sample, head).  Q, K, V and dO
+// of the head are brought into LDS once (four row-major 128-byte-row images by LDS-DMA) and serve both halves:
+//   pass A (wave = 32-query block, sweep over key tiles):   S^T = mfma(K, Q), dP^T = mfma(V, dO)   (lane = query)
+//        P = exp(S - lse), dS = P o (dP - D);   dQ^T += mfma(K^T, dS)
+//   pass B (wave = 32-key block, sweep over query tiles):   S = mfma(Q, K), dP = mfma(dO, V)       (lane = key)
+//        dV^T += mfma(dO^T, P),  dK^T += mfma(Q^T, dS)
+// with D_q = <dO_q, O_q> and the log-sum-exp saved by the forward.  Every image is read BOTH as row fragments
+// (ds_read_b128) and as transposed fragments (ds_read_b64_tr_b16); one swizzle serves both: the 16-byte chunk index of
+// row r is XORed with f(r) = ((r>>1)&1)<<2 | (r>>2)&3 -- a bijection of (r>>1)&7, so the 32-row b128 fragment groups
+// stay conflict-free, and its bit 2 flips between rows r and r+2, so the four rows of a transpose block fall on four
+// different bank quarters.  The two-kernel version read q, k, v, dO from HBM twice and staged transposed copies
+// through registers.
+
+__device__ __forceinline__ int swz_f(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+__device__ __forceinline__ void dma_rows_f(char* dst, const char* gbase, int64_t rs, int nrows, int L, int wave, int lane) {
+  const int ninst = nrows / 8;
+  for (int inst = wave; inst < ninst; inst += 8) {
+    const int r = inst * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz_f(r);
+    const int gr = r < L ? r : L - 1;
+    __builtin_amdgcn_global_load_lds((glb_void*)(gbase + gr * rs + c * 16), (lds_void*)(dst + inst * 1024), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int nt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const AttnArgs& f = a.f;
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int L = f.L, LKP = 32 * nt;
+  char* imgQ = smem;
+  char* imgK = smem + LKP * 128;
+  char* imgV = smem + 2 * LKP * 128;
+  char* imgG = smem + 3 * LKP * 128;           // dO
+  float* lseA = reinterpret_cast<float*>(smem + 4 * LKP * 128);
+  float* dA = lseA + LKP;
+  float* kb = dA + LKP;
+  const int64_t rs = f.row_stride * 2, cs = f.ctx_stride * 2;
+  const int64_t base = ((int64_t)b * L * f.row_stride + head * 64) * 2;
+  const int64_t cbase = ((int64_t)b * L * f.ctx_stride + head * 64) * 2;
+
+  dma_rows_f(imgQ, reinterpret_cast<const char*>(f.q) + base, rs, LKP, L, wave, lane);
+  dma_rows_f(imgK, reinterpret_cast<const char*>(f.k) + base, rs, LKP, L, wave, lane);
+  dma_rows_f(imgV, reinterpret_cast<const char*>(f.v) + base, rs, LKP, L, wave, lane);
+  dma_rows_f(imgG, reinterpret_cast<const char*>(a.dctx) + cbase, cs, LKP, L, wave, lane);
+  for (int key = tid; key < LKP; key += 512)
+    kb[key] = key < L ? (f.key_bias ? f.key_bias[(int64_t)b * L + key] : 0.f) : -INFINITY;
+
+  // this wave's 32 rows (queries in pass A, keys in pass B)
+  const int blk = wave;
+  const bool active = blk * 32 < L;
+  const int row = blk * 32 + l31;
+  const int rowc = row < L ? row : L - 1;
+  // D_q = <dO_q, O_q>: each lane of the pair (h = 0, 1) takes half of the 64 columns of O straight from global memory
+  uint4 of[4];
+  float lse_q = INFINITY;
+  if (active) {
+    const char* op = reinterpret_cast<const char*>(f.ctx) + cbase + (int64_t)rowc * cs;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) of[s] = *reinterpret_cast<const uint4*>(op + (2 * s + h) * 16);
+    if (row < L) lse_q = f.lse[((int64_t)b * f.H + head) * L + row];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int fl = swz_f(l31);                     // (32t + l31 has the same f as l31)
+  uint32_t roff[4];                              // row fragments: row l31 of a 32-row tile, chunk (2s+h) ^ f
+#pragma unroll
+  for (int s = 0; s < 4; ++s) roff[s] = (uint32_t)l31 * 128u + ((uint32_t)((2 * s + h) ^ fl) << 4);
+  // transposed fragments: lane supplies row 4h + (t16>>2) (+ 8*part + 16u + 32t), 4 columns at dt*32 + sub*16 + 4*(t16&3)
+  const int t16 = lane & 15, sub = (lane >> 4) & 1;
+  const uint32_t tch = (uint32_t)((((t16 >> 3) & 1) << 2) | (sub << 1) | (((t16 & 3) >> 1) ^ h));   // chunk for dt = 0, part = 0
+  const uint32_t trow = (uint32_t)(4 * h + (t16 >> 2)) * 128u + (uint32_t)(t16 & 1) * 8u;
+  // address(dt, part) = trow + 1024*part + ((tch ^ (dt<<2 | part<<1)) << 4)
+  auto tr_frag = [&](const char* tile, int u, int dt) -> uint4 {     // keys/queries 16u + 4h + {0..3}, + 8 + {0..3}
+    const uint2 lo = tr4(tile + u * 2048 + trow + ((tch ^ (uint32_t)(dt << 2)) << 4));
+    const uint2 hi = tr4(tile + u * 2048 + 1024 + trow + ((tch ^ (uint32_t)((dt << 2) | 2)) << 4));
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+  };
+
+  float d_q = 0.f;
+  uint4 gf[4];        // dO row fragments of this wave's rows (pass A); reused as V fragments in pass B
+  uint4 xf[4];        // Q row fragments (pass A); K row fragments (pass B)
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      gf[s] = *reinterpret_cast<const uint4*>(imgG + blk * 4096 + roff[s]);
+      xf[s] = *reinterpret_cast<const uint4*>(imgQ + blk * 4096 + roff[s]);
+      float gv[8], ov[8];
+      unpack_chunk(gf[s], gv, bf16_t());
+      unpack_chunk(of[s], ov, bf16_t());
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d_q += gv[e] * ov[e];
+    }
+    d_q += __shfl_xor(d_q, 32, 64);
+    if (h == 0) { lseA[row] = lse_q; dA[row] = row < L ? d_q : 0.f; }     // rows >= L: lse = +inf -> P = 0 in pass B
+  }
+  __syncthreads();
+  if (!active) return;
+  const float scale = f.scale;
+
+  // ------------------------------------------------ pass A: dQ for queries 32*blk + l31 ------------------------
+  {
+    f32x16_t dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+      f32x16_t sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = pacc[r] = 0.f;
+      const char* kt = imgK + t * 4096;
+      const char* vt = imgV + t * 4096;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        mma32(sacc, *reinterpret_cast<const uint4*>(kt + roff[s]), xf[s], bf16_t());     // S^T[key][q]
+        mma32(pacc, *reinterpret_cast<const uint4*>(vt + roff[s]), gf[s], bf16_t());     // dP^T[key][q]
+      }
+      float ds[16];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const float4 kb4 = *reinterpret_cast<const float4*>(kb + 32 * t + 8 * qd + 4 * h);
+        const float kbv[4] = {kb4.x, kb4.y, kb4.z, kb4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = __expf(fmaf(sacc[4 * qd + e], scale, kbv[e]) - lse_q);
+          ds[4 * qd + e] = p * (pacc[4 * qd + e] - d_q);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        uint4 dc;
+        dc.x = pack_bf16x2(ds[8 * u + 0], ds[8 * u + 1]);
+        dc.y = pack_bf16x2(ds[8 * u + 2], ds[8 * u + 3]);
+        dc.z = pack_bf16x2(ds[8 * u + 4], ds[8 * u + 5]);
+        dc.w = pack_bf16x2(ds[8 * u + 6], ds[8 * u + 7]);
+        mma32(dq[0], tr_frag(kt, u, 0), dc, bf16_t());      // dQ^T[d][q] += K^T . dS^T
+        mma32(dq[1], tr_frag(kt, u, 1), dc, bf16_t());
+      }
+    }
+    if (row < L) {
+      bf16_t* dqp = reinterpret_cast<bf16_t*>(a.dq) + ((int64_t)b * L + row) * f.row_stride + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = dq[dt][4 * qd + e] * scale;
+          st4(dqp + dt * 32 + 8 * qd + 4 * h, v);
+        }
+    }
+  }
+  // ------------------------------------------------ pass B: dK, dV for keys 32*blk + l31 -----------------------
+  {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      xf[s] = *reinterpret_cast<const uint4*>(imgK + blk * 4096 + roff[s]);
+      gf[s] = *reinterpret_cast<const uint4*>(imgV + blk * 4096 + roff[s]);
+    }
+    const float kb_key = kb[row];
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+      f32x16_t sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = pacc[r] = 0.f;
+      const char* qt = imgQ + t * 4096;
+      const char* gt = imgG + t * 4096;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        mma32(sacc, *reinterpret_cast<const uint4*>(qt + roff[s]), xf[s], bf16_t());     // S[q][key]
+        mma32(pacc, *reinterpret_cast<const uint4*>(gt + roff[s]), gf[s], bf16_t());     // dP[q][key]
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const float4 l4 = *reinterpret_cast<const float4*>(lseA + 32 * t + 8 * qd + 4 * h);
+        const float4 d4 = *reinterpret_cast<const float4*>(dA + 32 * t + 8 * qd + 4 * h);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = __expf(fmaf(sacc[4 * qd + e], scale, kb_key) - lv[e]);
+          p[4 * qd + e] = pe;
+          ds[4 * qd + e] = pe * (pacc[4 * qd + e] - dv4[e]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        uint4 pc, dc;
+        pc.x = pack_bf16x2(p[8 * u + 0], p[8 * u + 1]);   dc.x = pack_bf16x2(ds[8 * u + 0], ds[8 * u + 1]);
+        pc.y = pack_bf16x2(p[8 * u + 2], p[8 * u + 3]);   dc.y = pack_bf16x2(ds[8 * u + 2], ds[8 * u + 3]);
+        pc.z = pack_bf16x2(p[8 * u + 4], p[8 * u + 5]);   dc.z = pack_bf16x2(ds[8 * u + 4], ds[8 * u + 5]);
+        pc.w = pack_bf16x2(p[8 * u + 6], p[8 * u + 7]);   dc.w = pack_bf16x2(ds[8 * u + 6], ds[8 * u + 7]);
+        mma32(dv[0], tr_frag(gt, u, 0), pc, bf16_t());      // dV^T[d][key] += dO^T . P
+        mma32(dv[1], tr_frag(gt, u, 1), pc, bf16_t());
+        mma32(dk[0], tr_frag(qt, u, 0), dc, bf16_t());      // dK^T[d][key] += Q^T . dS
+        mma32(dk[1], tr_frag(qt, u, 1), dc, bf16_t());
+      }
+    }
+    if (row < L) {
+      bf16_t* dkp = reinterpret_cast<bf16_t*>(a.dk) + ((int64_t)b * L + row) * f.row_stride + head * 64;
+      bf16_t* dvp = reinterpret_cast<bf16_t*>(a.dv) + ((int64_t)b * L + row) * f.row_stride + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          float vk[4], vv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vk[e] = dk[dt][4 * qd + e] * scale; vv[e] = dv[dt][4 * qd + e]; }
+          st4(dkp + dt * 32 + 8 * qd + 4 * h, vk);
+          st4(dvp + dt * 32 + 8 * qd + 4 * h, vv);
+        }
+    }
+  }
+}
+
 }  // namespace
 
 bool attention_short_eligible(const AttnArgs& a, int dtype) {
   return dtype == EZCLIP_BF16 && a.L <= 256 && a.B <= 65535;
+}
+
+int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
+  const int nt = (a.f.L + 31) / 32;
+  const int bytes = nt * (4 * 32 * 128 + 3 * 32 * 4);
+  static int attr_max = 0;
+  if (bytes > attr_max) {
+    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_short_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_max = bytes;
+  }
+  {
+    ProfScope ps(PROF_ATTN, 10.0 * a.f.B * a.f.H * (double)a.f.L * a.f.L * 64, stream);   // 5 L x L x 64 products
+    hipLaunchKernelGGL(attn_bwd_short_kernel, dim3(a.f.H, a.f.B), dim3(512), bytes, stream, a, nt);
+  }
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
 }
 
 int attention_fwd_short(const AttnArgs& a, hipStream_t stream) {

@@ -87,6 +87,7 @@ struct AttnBwdArgs {
   void* dv = nullptr;
 };
 int attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream);
+int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream);   // fused single kernel, bf16, L <= 256
 
 // ---- row-wise / elementwise kernels (rowops.hip) ------------------------------
 // y = LN(x) * g + b over the last dim D; rows may be strided (x_stride/y_stride in elements).

@@ -331,6 +331,38 @@ int main(int argc, char** argv) {
       maxdiff_bf16<<<1024, 256, 0, st>>>(ctx0, ctx1, rows * W, d_md, d_bad);
       float md; CK(hipMemcpyAsync(&md, d_md, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
       printf("  [max |ctx diff| %.3g]\n", md);
+      // backward: two-kernel version vs the fused short-sequence kernel
+      {
+        uint16_t *dctx, *dq0, *dq1;
+        CK(hipMalloc(&dctx, rows * W * 2)); CK(hipMalloc(&dq0, rows * 3 * W * 2)); CK(hipMalloc(&dq1, rows * 3 * W * 2));
+        fill_bf16<<<2048, 256, 0, st>>>(dctx, rows * W, 22u, 1.0f);
+        printf("%-15s bwd              :", t.name);
+        for (int v = 0; v < 2; ++v) {
+          ezclip::set_attention_variant(v == 0 ? 0 : -1);
+          ezclip::AttnBwdArgs ab;
+          ab.f.q = qkv; ab.f.k = qkv + W; ab.f.v = qkv + 2 * W; ab.f.row_stride = 3 * W;
+          ab.f.ctx = ctx1; ab.f.ctx_stride = W; ab.f.lse = lse; ab.f.B = t.B; ab.f.L = t.L; ab.f.H = t.H; ab.f.scale = 0.125f;
+          uint16_t* dq = v == 0 ? dq0 : dq1;
+          ab.dctx = dctx; ab.dq = dq; ab.dk = dq + W; ab.dv = dq + 2 * W;
+          if (ezclip::attention_bwd(ab, EZCLIP_BF16, st) != 0) { printf(" ERROR %s", ezclip::last_error()); continue; }
+          CK(hipStreamSynchronize(st));
+          hipEvent_t e0, e1;
+          CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+          CK(hipEventRecord(e0, st));
+          for (int it = 0; it < iters; ++it) ezclip::attention_bwd(ab, EZCLIP_BF16, st);
+          CK(hipEventRecord(e1, st));
+          CK(hipEventSynchronize(e1));
+          float ms = 0;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          ms /= iters;
+          printf("  %s %.3f ms (%.0f TF)", v == 0 ? "two kernels" : "fused", ms, 10.0 * t.B * t.H * (double)t.L * t.L * 64 / ms / 1e9);
+        }
+        CK(hipMemsetAsync(d_md, 0, 4, st)); CK(hipMemsetAsync(d_bad, 0, 8, st));
+        maxdiff_bf16<<<1024, 256, 0, st>>>(dq0, dq1, rows * 3 * W, d_md, d_bad);
+        float md2; CK(hipMemcpyAsync(&md2, d_md, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+        printf("  [max |dqkv diff| %.3g]\n", md2);
+        hipFree(dctx); hipFree(dq0); hipFree(dq1);
+      }
       hipFree(qkv); hipFree(ctx0); hipFree(ctx1); hipFree(lse);
     }
     ezclip::set_attention_variant(-1);

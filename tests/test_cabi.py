@@ -5,6 +5,7 @@ calls here -- there is no GPU in the build container)."""
 import ctypes as C
 import os
 import re
+import sys
 
 import pytest
 
@@ -113,3 +114,27 @@ def test_no_cpu_fallback_in_host_module(tmp_path):
     px, ids = O.make_inputs(cfg, 2, 8, 0)
     with pytest.raises(L.EzclipError):
         app({"pixel_values": px, "input_ids": ids})
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_pipelined_gemm_isa_audit(tmp_path):
+    """The 8-phase GEMM kernels issue their VMEM by hand (inline asm) and count their own waits; hipcc knows nothing
+    about those loads and stores.  Compile the two kernel files for gfx950 and audit the ISA: no register spills (a
+    spill reload carries a compiler-counted vmcnt that drains the DMA pipeline), no instruction touching an asm-load
+    destination before the counted wait that guards it, no VALU overwriting the data of a 16-byte buffer store within
+    its wait states (tools/audit_asm_loads.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "easynlp_amd", "csrc")
+    for src in ("gemm8p.hip", "gemm4w.hip"):
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps",
+                              "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(csrc, src), "-I", csrc,
+                              "-o", str(tmp_path / (src + ".o"))], cwd=str(tmp_path), capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        spills = [l for l in out.stderr.splitlines() if "VGPRs Spill" in l and not l.rstrip().endswith("Spill: 0 [-Rpass-analysis=kernel-resource-usage]")]
+        assert not spills, spills
+        asm = str(tmp_path / (src.replace(".hip", "") + "-hip-amdgcn-amd-amdhsa-gfx950.s"))
+        assert os.path.exists(asm)
+        audit = subprocess.run([sys.executable, os.path.join(root, "tools", "audit_asm_loads.py"), asm],
+                               capture_output=True, text=True)
+        assert audit.returncode == 0 and "audit: ok" in audit.stdout, audit.stdout[-2000:]

@@ -219,8 +219,12 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
     dma16(d + 5 * kSlot + 1024, c.voffB[1], c.srdB, 128);
   };
 
+#ifdef EZ_DEPHASE
+  // experiment: spread the workgroups' tile boundaries (and with them the store bursts) over a tile period
+  for (int d = (int)((blockIdx.x >> 3) % 32u) * EZ_DEPHASE; d > 0; --d) __builtin_amdgcn_s_sleep(16);
+#endif
   const EpiCtx ep = make_epi_ctx<HAS_R, HAS_U, HAS_C2, HAS_LN>(p);
-  constexpr int NS = 4 * (HAS_C2 ? 2 : 1);                       // stores per 32-row block
+  constexpr int NS = kStoresPerBlock * (HAS_C2 ? 2 : 1);         // stores per 32-row block
   int v = blockIdx.x, m0, n0;
   tile_origin(v, m0, n0);
   set_tile(m0, n0);

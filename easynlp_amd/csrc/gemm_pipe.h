@@ -136,8 +136,28 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const GemmArgs& p) {
 // written by the next VALU instruction(s).  hipcc pads that hazard for flat/global stores but exempts MUBUF stores
 // that carry an SGPR soffset -- on gfx950 the exemption does not hold (seen as corrupted second dwords in the last
 // lanes of each 16 when a v_pk_fma_f32 reused the data registers right after the builtin's store).
+// EZ_STG_MOD / EZ_STG_SAMEADDR: experiment hooks of tools/build_variants.py (cache-policy bits on the store; all stores
+// of a wave aimed at one 1 KiB region = same instruction stream without the DRAM write traffic).
+// EZ_ABL_NOSTORE / EZ_ABL_NOLDS / EZ_ABL_NOEPI: timing ablations (results are wrong by construction).
+// Default " nt": C is a write-once stream; the non-temporal hint measured +2 % on the K=768 products and +0.9 % on the
+// forward step (profiles/README.md, store experiments); sc1 / sc0 sc1 made no difference.
+#ifndef EZ_STG_MOD
+#define EZ_STG_MOD " nt"
+#endif
+#if defined(EZ_ABL_NOSTORE) || defined(EZ_ABL_NOEPI)
+constexpr int kStoresPerBlock = 0;
+#else
+constexpr int kStoresPerBlock = 4;
+#endif
 __device__ __forceinline__ void stg16(const u32x4_t& data, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(srd), "s"(soff) : "memory");
+#if defined(EZ_ABL_NOSTORE) || defined(EZ_ABL_NOEPI)
+  asm volatile("" ::"v"(data), "v"(voff), "s"(soff));
+  return;
+#endif
+#ifdef EZ_STG_SAMEADDR
+  voff = (voff & 0x70u) | ((threadIdx.x & 0x1f8u) << 4); soff = 0;
+#endif
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" EZ_STG_MOD "\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
@@ -175,7 +195,19 @@ template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, int D, bool HAS_LN = f
 __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[4][2], int mw, int nw, char* W, int act,
                                               EpiLoads& ld, IssueDma&& issue_dma) {
   constexpr int NL = 4 * ((HAS_R ? 1 : 0) + (HAS_U ? 1 : 0) + (HAS_LN ? 1 : 0));   // loads per 32-row block
-  constexpr int NS = 4 * (HAS_C2 ? 2 : 1);                       // stores per 32-row block
+  constexpr int NS = kStoresPerBlock * (HAS_C2 ? 2 : 1);         // stores per 32-row block
+#ifdef EZ_ABL_NOEPI
+  issue_dma();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      asm volatile("" ::"v"(acc[i][j]));       // keep the MFMAs alive
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+  return;
+#endif
   const int eln = lane_id_now();
   const int crow = eln >> 3, g = eln & 7, eh = eln >> 5, el31 = eln & 31;
   const uint32_t lane_c = (uint32_t)crow * ec.ldc_b + (uint32_t)g * 16u;
@@ -204,6 +236,17 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
   static_for<4>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     constexpr int b = i;
+#ifdef EZ_ABL_NOLDS
+    float x[4][8];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[it][e] = acc[i][e >> 2][it * 4 + (e & 3)];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#else
     // accumulators -> LDS (MFMA layout: row l31, columns j*32 + q*8 + h*4 .. +3); zero them for the next tile
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -226,6 +269,7 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
       x[it][0] = x0.x; x[it][1] = x0.y; x[it][2] = x0.z; x[it][3] = x0.w;
       x[it][4] = x1.x; x[it][5] = x1.y; x[it][6] = x1.z; x[it][7] = x1.w;
     }
+#endif
     // wait for this block's loads (block 0: also the bias)
     if constexpr (i == 0) {
       wait_vm2<2 * NL + D>(bq[0], bq[1]);

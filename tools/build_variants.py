@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Build experiment variants of libezclip_hip.so under tools/bin/var_<name>/ (same objects, gemm8p.hip recompiled
+with extra -D flags).  Run a tool against one with LD_LIBRARY_PATH=tools/bin/var_<name>.
+
+    python tools/build_variants.py name1:-DFOO=1 name2:"-DBAR -DBAZ=2" ...
+"""
+import os
+import shlex
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from easynlp_amd.csrc import build as B  # noqa: E402
+
+
+def main():
+    B.build(verbose=True)
+    csrc = B.HERE
+    for spec in sys.argv[1:]:
+        name, _, defs = spec.partition(":")
+        d = os.path.join(HERE, "bin", "var_" + name)
+        os.makedirs(d, exist_ok=True)
+        objs = []
+        for src in B.SOURCES:
+            o = os.path.join(csrc, "build", src.replace(".hip", ".o"))
+            if src == "gemm8p.hip":
+                o = os.path.join(d, "gemm8p.o")
+                subprocess.check_call([B.hipcc()] + B.FLAGS + shlex.split(defs) + ["-c", os.path.join(csrc, src), "-o", o])
+            objs.append(o)
+        subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(d, "libezclip_hip.so")] + objs)
+        print("built", d)
+
+
+if __name__ == "__main__":
+    main()

@@ -117,8 +117,11 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_md, 4));
   CK(hipMalloc(&d_bad, 8));
   printf("batch %d iters %d\n", batch, iters);
+  const int nt_shapes = getenv("NT_SHAPES") ? atoi(getenv("NT_SHAPES")) : -1;   // run only the first n NT shapes, then exit
+  int shape_no = 0;
   for (const Shape& s : shapes) {
     if (only_attn) break;
+    if (nt_shapes >= 0 && shape_no++ >= nt_shapes) return 0;
     const size_t nA = (size_t)s.M * s.K, nB = (size_t)s.N * s.K, nC = (size_t)s.M * s.N;
     uint16_t *A, *B, *R = nullptr, *C0, *C1, *P0 = nullptr, *P1 = nullptr, *Uu = nullptr;
     float* bias;

@@ -24,7 +24,6 @@ from __future__ import annotations
 
 import json
 import os
-import warnings
 from typing import Dict, List, Optional
 
 import torch
@@ -190,6 +189,11 @@ class HipClipEngine:
                                             1 if save else 0, L.stream_ptr()), "encode_text")
         return out, ws
 
+    def set_text_dropout(self, hidden_p: float, attn_p: float, seed: int) -> None:
+        """Arm (or, with zeros, disarm) the BERT train-mode dropout for the next encode_text / backward_text."""
+        L.check(self.lib.ezclip_set_text_dropout(self.handle, float(hidden_p), float(attn_p), int(seed)),
+                "set_text_dropout")
+
     def backward_image(self, pixels, d_emb, ws):
         L.check(self.lib.ezclip_backward_image(self.handle, L.ptr(pixels), pixels.shape[0], L.ptr(d_emb.contiguous()),
                                                L.ptr(ws), ws.numel(), L.stream_ptr()), "backward_image")
@@ -216,6 +220,8 @@ class _EncodeFn(torch.autograd.Function):
             img, ctx.ws_img = eng.encode_image(pixels, need_grad)
         if ids is not None:
             ids = ids.contiguous().long()
+            ctx.drop = app._next_dropout()          # (hidden_p, attn_p, seed); zeros in eval mode
+            eng.set_text_dropout(*ctx.drop)
             txt, ctx.ws_txt = eng.encode_text(ids, need_grad)
         ctx.app, ctx.pixels, ctx.ids = app, pixels, ids
         ctx.n_params = len(params)
@@ -243,6 +249,7 @@ class _EncodeFn(torch.autograd.Function):
         if ctx.has[0]:
             eng.backward_image(ctx.pixels, d_img, ctx.ws_img)
         if ctx.has[1]:
+            eng.set_text_dropout(*ctx.drop)         # the masks of the matching forward
             eng.backward_text(ctx.ids, d_txt, ctx.ws_txt)
         out = [grads[n] if params[n].requires_grad else None for n in eng.names]
         return (None, None, None, None) + tuple(out)
@@ -328,9 +335,6 @@ class CLIPApp(Application):
                                 "huggingface_clip are listed as next in SURVEY.md 8f" % self.raw_config.get("model_type"))
         self.model_type = "chinese_clip"
         self.config = Config_Wrapper(self.raw_config)
-        for k in ("text_hidden_dropout_prob", "text_attention_probs_dropout_prob"):
-            if float(self.raw_config.get(k, 0.0)) != 0.0:
-                warnings.warn("%s=%s: dropout is not applied on the HIP path (treated as 0)" % (k, self.raw_config[k]))
         self._build(self.raw_config)
         ckpt = os.path.join(path, "pytorch_model.bin")
         if os.path.exists(ckpt):
@@ -418,6 +422,8 @@ class CLIPApp(Application):
         pixel_values = pixel_values.contiguous()
         input_ids = input_ids.contiguous()
         img, ws_i = eng.encode_image(pixel_values, backward)
+        drop = self._next_dropout()
+        eng.set_text_dropout(*drop)
         txt, ws_t = eng.encode_text(input_ids, backward)
         n = img.shape[0]
         e = img.shape[1]
@@ -453,8 +459,25 @@ class CLIPApp(Application):
             d_img_l, d_txt_l = d_img, d_txt
         self.logit_scale.grad.add_(d_ls)
         eng.backward_image(pixel_values, d_img_l, ws_i)
+        eng.set_text_dropout(*drop)
         eng.backward_text(input_ids, d_txt_l, ws_t)
         return loss
+
+    def _next_dropout(self):
+        """(hidden_p, attention_p, seed) of the next text-tower pass.  Like the reference, dropout is active only in
+        train mode (nn.Dropout in BertEmbeddings / BertSelfAttention / BertSelfOutput / BertOutput,
+        modeling_bert.py:128,238,266,344) with the probabilities of config.json; the seed of each pass is drawn from
+        torch's global CPU generator, so ``torch.manual_seed`` makes a run reproducible.  ``self.dropout_seed`` (an
+        int) pins the seed instead (tests)."""
+        cfg = getattr(self, "raw_config", None) or {}
+        hp = float(cfg.get("text_hidden_dropout_prob", 0.0) or 0.0)
+        ap = float(cfg.get("text_attention_probs_dropout_prob", 0.0) or 0.0)
+        if not self.training or (hp == 0.0 and ap == 0.0):
+            return (0.0, 0.0, 0)
+        seed = getattr(self, "dropout_seed", None)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        return (hp, ap, int(seed))
 
     @property
     def logit_scale(self):

@@ -128,6 +128,29 @@ __device__ __forceinline__ void score_tile(const char* kt, const float* kb, cons
   }
 }
 
+// Dropout on a 32-key tile held query-major (lane = one query `row`, element r <-> key 32t + (r&3) + 8(r>>2) + 4h):
+// v[r] <- keep ? v[r] / (1 - p) : 0.  One Philox call per aligned key quad.
+__device__ __forceinline__ void drop_tile_qmajor(const DropCfg& d, uint32_t row, int t, int h, float (&v)[16]) {
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const uint4 w = drop_words(d, row, (uint32_t)(8 * t + 2 * qd + h));
+    v[4 * qd + 0] = w.x >= d.thr ? v[4 * qd + 0] * d.scale : 0.f;
+    v[4 * qd + 1] = w.y >= d.thr ? v[4 * qd + 1] * d.scale : 0.f;
+    v[4 * qd + 2] = w.z >= d.thr ? v[4 * qd + 2] * d.scale : 0.f;
+    v[4 * qd + 3] = w.w >= d.thr ? v[4 * qd + 3] * d.scale : 0.f;
+  }
+}
+// The same decisions seen key-major (lane = one key `col`, element r <-> query row0 + (r&3) + 8(r>>2) + 4h):
+// m[r] = 1 / (1 - p) or 0.
+__device__ __forceinline__ void drop_factors_kmajor(const DropCfg& d, uint32_t row_base, int q0, int h, uint32_t col,
+                                                    float (&m)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t q = (uint32_t)(q0 + (r & 3) + 8 * (r >> 2) + 4 * h);
+    m[r] = drop_word(d, row_base + q, col) >= d.thr ? d.scale : 0.f;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a, int nt) {
   using G = Geo<T>;
@@ -186,6 +209,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a, int nt) {
         x[r] = kFast ? __expf(x[r] - mx) : expf(x[r] - mx);
         sum += x[r];
       }
+      if (a.drop.thr != 0) drop_tile_qmajor(a.drop, ((uint32_t)b * a.H + head) * L + qc, t, h, x);   // bert :238
       if constexpr (G::SZ == 2) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -268,7 +292,7 @@ int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream) {
   EZ_REQUIRE(((uintptr_t)a.q % 16) == 0 && ((uintptr_t)a.k % 16) == 0 && ((uintptr_t)a.v % 16) == 0 &&
              ((uintptr_t)a.ctx % 16) == 0, "attention_fwd: pointers must be 16-byte aligned");
   EZ_REQUIRE(a.B <= 65535, "attention_fwd: batch %d > 65535", a.B);
-  if (g_attn_variant != 0 && attention_short_eligible(a, dtype)) return attention_fwd_short(a, stream);
+  if (g_attn_variant != 0 && a.drop.thr == 0 && attention_short_eligible(a, dtype)) return attention_fwd_short(a, stream);
   if (dtype == EZCLIP_F32) return launch_fwd<float>(a, stream);
   if (dtype == EZCLIP_BF16) return launch_fwd<bf16_t>(a, stream);
   set_error("attention_fwd: bad dtype %d", dtype);
@@ -477,10 +501,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnBwdArgs a, int nt,
         score_tile<T>(smem, kb, qf, t, l31, h, f.scale, x);                 // S^T[key][q]
         f32x16_t dp;
         tile_rows_x_frag<T>(smem + S.vOff, dof, t, l31, h, dp);              // dP^T[key][q] = V . dO^T
+        float dpm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dpm[r] = dp[r];
+        // dropout: dP = mask/(1-p) o (dO V^T)   (D = <dO, O> already contains the mask through O)
+        if (f.drop.thr != 0) drop_tile_qmajor(f.drop, ((uint32_t)b * f.H + head) * L + qc, c0 + t, h, dpm);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float p = kFast ? __expf(x[r] - lse_q) : expf(x[r] - lse_q);
-          x[r] = p * (dp[r] - dq_delta);                                      // dS^T
+          x[r] = p * (dpm[r] - dq_delta);                                     // dS^T
         }
         mma_T<T>(acc, smem + S.ktOff, S.LP, t, l31, h, x);                    // dQ^T[d][q] += K^T . dS
       }
@@ -574,7 +603,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnBwdArgs a, int nt
         f32x16_t sacc, dp;
         tile_rows_x_frag<T>(smem, kf, t, l31, h, sacc);                      // S[q][key]   = Q . K^T
         tile_rows_x_frag<T>(smem + S.doOff, vf, t, l31, h, dp);              // dP[q][key]  = dO . V^T
-        float p[16], ds[16];
+        float p[16], ds[16], dm[16];
+        const bool dropping = f.drop.thr != 0;
+        if (dropping) drop_factors_kmajor(f.drop, ((uint32_t)b * f.H + head) * L, row0 + 32 * t, h, (uint32_t)kc, dm);
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 32 * t + 8 * qd + 4 * h);
@@ -586,7 +617,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnBwdArgs a, int nt
             const int r = 4 * qd + e;
             const float x = fmaf(sacc[r], f.scale, kbias) - lv[e];
             p[r] = kFast ? __expf(x) : expf(x);
-            ds[r] = p[r] * (dp[r] - dv[e]);
+            if (dropping) {
+              ds[r] = p[r] * (dp[r] * dm[r] - dv[e]);
+              p[r] *= dm[r];                                                   // dV takes the dropped probabilities
+            } else {
+              ds[r] = p[r] * (dp[r] - dv[e]);
+            }
           }
         }
         mma_T<T>(accv, smem + S.dotOff, S.LP, t, l31, h, p);                  // dV^T[d][key] += dO^T . P
@@ -645,7 +681,7 @@ int attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream) {
   const int esz = dtype_size(dtype);
   EZ_REQUIRE((f.row_stride * esz) % 16 == 0 && (f.ctx_stride * esz) % 16 == 0, "attention_bwd: strides must be 16-byte multiples");
   EZ_REQUIRE(f.B <= 65535, "attention_bwd: batch %d > 65535", f.B);
-  if (g_attn_variant != 0 && attention_short_eligible(f, dtype)) return attention_bwd_short(a, stream);
+  if (g_attn_variant != 0 && f.drop.thr == 0 && attention_short_eligible(f, dtype)) return attention_bwd_short(a, stream);
   if (dtype == EZCLIP_F32) return launch_bwd<float>(a, stream);
   if (dtype == EZCLIP_BF16) return launch_bwd<bf16_t>(a, stream);
   set_error("attention_bwd: bad dtype %d", dtype);

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemm.hip", "gemm8p.hip", "gemm4w.hip", "attention.hip", "attention_short.hip", "rowops.hip", "loss.hip", "profile.hip", "model.hip", "capi.hip"]
-HEADERS = ["ezclip_common.h", "kernels.h", "model.h", "gemm_pipe.h", "../../include/ezclip.h"]
+HEADERS = ["ezclip_common.h", "kernels.h", "model.h", "gemm_pipe.h", "dropout.h", "../../include/ezclip.h"]
 LIB = os.path.join(HERE, "libezclip_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

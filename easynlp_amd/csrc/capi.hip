@@ -227,6 +227,16 @@ int ezclip_backward_text(ezclip_handle h, const int64_t* ids, int batch, int seq
   return backward_text(h, ids, batch, seq_len, d_emb, ws, ws_bytes, S(stream));
 }
 
+int ezclip_set_text_dropout(ezclip_handle h, float hidden_p, float attention_p, uint64_t seed) {
+  EZ_REQUIRE(h, "ezclip_set_text_dropout: null handle");
+  EZ_REQUIRE(hidden_p >= 0.f && hidden_p < 1.f && attention_p >= 0.f && attention_p < 1.f,
+             "ezclip_set_text_dropout: probabilities must be in [0, 1) (got %g, %g)", (double)hidden_p, (double)attention_p);
+  h->drop_hidden = hidden_p;
+  h->drop_attn = attention_p;
+  h->drop_seed = seed;
+  return EZ_OK;
+}
+
 int ezclip_recall_ranks(const float* text, const float* image, int n, int e, int32_t* rank_out, float* scratch,
                         void* stream) {
   EZ_REQUIRE(text && image && rank_out && scratch && n > 0, "ezclip_recall_ranks: null/empty argument");
@@ -275,9 +285,27 @@ int ezclip_op_layernorm_bwd(const void* x, const void* dy, const float* g, const
   return layernorm_bwd(x, d, dy, d, g, mean, rstd, dx, d, nullptr, 0, dg, db, rows, d, dtype, S(stream));
 }
 
+static DropCfg g_op_attn_drop;   // ezclip_op_set_attention_dropout
+int ezclip_op_set_attention_dropout(float p, uint64_t seed, uint32_t site) {
+  if (!(p >= 0.f && p < 1.f)) { set_error("dropout probability %g outside [0, 1)", (double)p); return EZ_ERR_INVALID; }
+  g_op_attn_drop = make_drop(p, seed, site);
+  return EZ_OK;
+}
+int ezclip_op_dropout(const void* x, const void* residual, void* y, int rows, int d, float p, uint64_t seed,
+                      uint32_t site, int dtype, void* stream) {
+  if (!(p > 0.f && p < 1.f)) { set_error("dropout probability %g outside (0, 1)", (double)p); return EZ_ERR_INVALID; }
+  return dropout_rows(x, d, residual, d, y, d, rows, d, make_drop(p, seed, site), dtype, S(stream));
+}
+int ezclip_op_dropout_mask(float p, uint64_t seed, uint32_t site, int rows, int cols, uint8_t* keep, uint32_t* words,
+                           void* stream) {
+  if (!(p > 0.f && p < 1.f)) { set_error("dropout probability %g outside (0, 1)", (double)p); return EZ_ERR_INVALID; }
+  return dropout_mask(keep, words, rows, cols, make_drop(p, seed, site), S(stream));
+}
+
 int ezclip_op_attention(const void* q, const void* k, const void* v, int64_t row_stride, void* ctx, int64_t ctx_stride,
                         const float* key_bias, float* lse, int batch, int seq_len, int heads, int dtype, void* stream) {
   AttnArgs a;
+  a.drop = g_op_attn_drop;
   a.q = q; a.k = k; a.v = v; a.row_stride = row_stride; a.ctx = ctx; a.ctx_stride = ctx_stride;
   a.key_bias = key_bias; a.lse = lse; a.B = batch; a.L = seq_len; a.H = heads; a.scale = 0.125f;
   return attention_fwd(a, dtype, S(stream));
@@ -287,6 +315,7 @@ int ezclip_op_attention_bwd(const void* q, const void* k, const void* v, int64_t
                             const void* dctx, int64_t ctx_stride, const float* key_bias, const float* lse, void* dq,
                             void* dk, void* dv, int batch, int seq_len, int heads, int dtype, void* stream) {
   AttnBwdArgs b;
+  b.f.drop = g_op_attn_drop;
   b.f.q = q; b.f.k = k; b.f.v = v; b.f.row_stride = row_stride; b.f.ctx = const_cast<void*>(ctx);
   b.f.ctx_stride = ctx_stride; b.f.key_bias = key_bias; b.f.lse = const_cast<float*>(lse);
   b.f.B = batch; b.f.L = seq_len; b.f.H = heads; b.f.scale = 0.125f;

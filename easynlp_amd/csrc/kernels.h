@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dropout.h"
+
 #define EZCLIP_F32 0
 #define EZCLIP_BF16 1
 
@@ -72,6 +74,7 @@ struct AttnArgs {
   float* lse = nullptr;           // optional [B, H, L] log-sum-exp of the scaled scores
   int B = 0, L = 0, H = 0;
   float scale = 0.125f;
+  DropCfg drop;                   // dropout on the probabilities (BERT train mode); row = (b*H + h)*L + query, col = key
 };
 int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream);
 // short-sequence bf16 kernels (attention_short.hip): L <= 256, one-pass online softmax, LDS transpose reads
@@ -142,6 +145,9 @@ int bert_word_grad(const int64_t* ids, const void* dx0, float* dword, int64_t ro
                    hipStream_t stream);
 int add_inplace_f32(float* dst, const float* src, int64_t n, hipStream_t stream);
 // dst[r][c] += src[r][c] for c < cols (row strides ldd / lds): un-pads a K-padded weight gradient
+int dropout_rows(const void* x, int64_t xs, const void* res, int64_t rs, void* y, int64_t ys, int rows, int D,
+                 const DropCfg& d, int dtype, hipStream_t stream);
+int dropout_mask(uint8_t* keep, uint32_t* words, int rows, int cols, const DropCfg& d, hipStream_t stream);
 int add_cols_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int rows, int cols, hipStream_t stream);
 
 // ---- InfoNCE (loss.hip) -----------------------------------------------------------

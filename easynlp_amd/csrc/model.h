@@ -54,6 +54,10 @@ struct ezclip_model {
   std::vector<VitLayer> vit;
   std::vector<BertLayer> bert;
 
+  // BERT train-mode dropout (ezclip_set_text_dropout): probabilities + the seed of the next forward / backward pair
+  float drop_hidden = 0.f, drop_attn = 0.f;
+  uint64_t drop_seed = 0;
+
   void* shadow = nullptr;
   size_t shadow_bytes = 0;
   bool shadow_backward = false;

@@ -375,7 +375,7 @@ struct TxtWS {
   float *m0, *r0, *key_bias;
   std::vector<BertBufs> layers;
   float *feat, *emb, *inv_norm;
-  void *gx, *gx2, *gtmp, *gqkv, *gbig, *gfeatT;
+  void *gx, *gx2, *gx3, *gtmp, *gqkv, *gbig, *gfeatT;
   float *gfeat;
 };
 
@@ -426,13 +426,14 @@ size_t layout_text(const ezclip_model* m, int B, int L, bool save, void* base, T
   if (save) {
     w.gx = a.take(M * H * esz);
     w.gx2 = a.take(M * H * esz);
+    w.gx3 = a.take(M * H * esz);     // dropout-masked copy of a residual-branch gradient (train mode with p > 0)
     w.gtmp = a.take(M * H * esz);
     w.gqkv = a.take(M * 3 * H * esz);
     w.gbig = a.take(M * F * esz);
     w.gfeat = a.takef((size_t)B * E);
     w.gfeatT = a.take((size_t)B * E * esz);
   } else {
-    w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = w.gfeatT = nullptr; w.gfeat = nullptr;
+    w.gx = w.gx2 = w.gx3 = w.gtmp = w.gqkv = w.gbig = w.gfeatT = nullptr; w.gfeat = nullptr;
   }
   if (ws) *ws = w;
   return a.off + 256;
@@ -524,6 +525,11 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
   // BertEmbeddings.forward                                   modeling_bert.py:95-129
   EZ_TRY(bert_embed_ln(ids, m->P(m->word_p), m->P(m->tpos_p), m->P(m->type_p), m->P(m->eln_w), m->P(m->eln_b), eps,
                        ws.x0, ws.layers[0].x_in, ws.m0, ws.r0, ws.key_bias, B, L, H, m->cfg.vocab_size, dt, stream));
+  // train-mode dropout (set per call by ezclip_set_text_dropout; masks are regenerated from the seed in the backward)
+  const float hp = m->drop_hidden, ap = m->drop_attn;
+  const uint64_t seed = m->drop_seed;
+  if (hp > 0.f)                                                                                    // :128
+    EZ_TRY(dropout_rows(ws.layers[0].x_in, H, nullptr, 0, ws.layers[0].x_in, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream));
   for (int i = 0; i < m->cfg.text_num_hidden_layers; ++i) {
     const auto& Lw = m->bert[i];
     const BertBufs& b = ws.layers[i];
@@ -538,13 +544,24 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
     at.ctx = b.ctx; at.ctx_stride = H;
     at.key_bias = ws.key_bias; at.lse = b.lse;
     at.B = B; at.L = L; at.H = m->theads; at.scale = 0.125f;
+    at.drop = make_drop(ap, seed, drop_sid_attn(i));                // :238
     EZ_TRY(attention_fwd(at, dt, stream));                          // :210-248
-    // BertSelfOutput: LN(dense(ctx) + x)                              :264-267
-    EZ_TRY(linear(m, b.ctx, H, Lw.o_w, Lw.o_b, b.y, H, M, ACT_NONE, b.x_in, H, nullptr, false, stream));
+    // BertSelfOutput: LN(dropout(dense(ctx)) + x)                     :264-267
+    if (hp > 0.f) {
+      EZ_TRY(linear(m, b.ctx, H, Lw.o_w, Lw.o_b, b.y, H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+      EZ_TRY(dropout_rows(b.y, H, b.x_in, H, b.y, H, M, H, make_drop(hp, seed, drop_sid_self_out(i)), dt, stream));
+    } else {
+      EZ_TRY(linear(m, b.ctx, H, Lw.o_w, Lw.o_b, b.y, H, M, ACT_NONE, b.x_in, H, nullptr, false, stream));
+    }
     EZ_TRY(layernorm_fwd(b.y, H, b.a, H, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, M, H, dt, b.m1, b.r1, stream));
-    // BertIntermediate (erf GELU) + BertOutput                        :330-345
+    // BertIntermediate (erf GELU) + BertOutput: LN(dropout(dense(h)) + a)   :330-345
     EZ_TRY(linear(m, b.a, H, Lw.i_w, Lw.i_b, b.hh, F, M, ACT_GELU_ERF, nullptr, 0, b.u, false, stream));
-    EZ_TRY(linear(m, b.hh, F, Lw.d_w, Lw.d_b, b.z, H, M, ACT_NONE, b.a, H, nullptr, false, stream));
+    if (hp > 0.f) {
+      EZ_TRY(linear(m, b.hh, F, Lw.d_w, Lw.d_b, b.z, H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+      EZ_TRY(dropout_rows(b.z, H, b.a, H, b.z, H, M, H, make_drop(hp, seed, drop_sid_out(i)), dt, stream));
+    } else {
+      EZ_TRY(linear(m, b.hh, F, Lw.d_w, Lw.d_b, b.z, H, M, ACT_NONE, b.a, H, nullptr, false, stream));
+    }
     EZ_TRY(layernorm_fwd(b.z, H, b.x_out, H, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, M, H, dt, b.m2, b.r2, stream));
   }
   // x[:, 0, :] @ text_projection  (pooler skipped: unused)    modeling_chineseclip.py:349-350
@@ -690,6 +707,9 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
   const int M = B * L;
   const int dt = m->dtype;
   const size_t esz = dtype_size(dt);
+  // the dropout state of the matching forward (the caller re-arms ezclip_set_text_dropout with the same seed)
+  const float hp = m->drop_hidden, ap = m->drop_attn;
+  const uint64_t seed = m->drop_seed;
 
   EZ_TRY(l2_normalize_bwd(ws.emb, d_emb, ws.inv_norm, ws.gfeat, B, E, stream));                     // chineseclip:363
   const void* gfeatT = ws.gfeat;
@@ -703,15 +723,31 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     const auto& Lw = m->bert[i];
     const BertBufs& b = ws.layers[i];
     // x_out = LN(z);  z = dense(hh) + a;  hh = gelu(u);  u = dense(a)        modeling_bert.py:330-345
-    EZ_TRY(ln_bwd(m, b.z, H, ws.gx, H, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, H, nullptr, 0, M, H, stream, Lw.d_b));  // d z
-    EZ_TRY(dgrad(m, ws.gx2, H, Lw.d_w, ws.gbig, F, M, b.u, F, ACT_GELU_ERF, nullptr, 0, stream, Lw.i_b));            // d u
-    EZ_TRY(wgrad(m, ws.gx2, H, b.hh, F, Lw.d_w, M, stream));
+    const void* gd = ws.gx2;      // gradient of the dense output (= d z, or its dropout-masked copy)
+    if (hp > 0.f) {
+      EZ_TRY(ln_bwd(m, b.z, H, ws.gx, H, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, H, nullptr, 0, M, H, stream));          // d z
+      EZ_TRY(dropout_rows(ws.gx2, H, nullptr, 0, ws.gx3, H, M, H, make_drop(hp, seed, drop_sid_out(i)), dt, stream));
+      EZ_TRY(bgrad(m, ws.gx3, H, M, H, Lw.d_b, stream));
+      gd = ws.gx3;
+    } else {
+      EZ_TRY(ln_bwd(m, b.z, H, ws.gx, H, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, H, nullptr, 0, M, H, stream, Lw.d_b));  // d z
+    }
+    EZ_TRY(dgrad(m, gd, H, Lw.d_w, ws.gbig, F, M, b.u, F, ACT_GELU_ERF, nullptr, 0, stream, Lw.i_b));                // d u
+    EZ_TRY(wgrad(m, gd, H, b.hh, F, Lw.d_w, M, stream));
     EZ_TRY(dgrad(m, ws.gbig, F, Lw.i_w, ws.gtmp, H, M, nullptr, 0, ACT_NONE, ws.gx2, H, stream));                     // d a = d z + d u W_i
     EZ_TRY(wgrad(m, ws.gbig, F, b.a, H, Lw.i_w, M, stream));
     // a = LN(y);  y = dense(ctx) + x_in                                           :264-267
-    EZ_TRY(ln_bwd(m, b.y, H, ws.gtmp, H, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx2, H, nullptr, 0, M, H, stream, Lw.o_b)); // d y
-    EZ_TRY(dgrad(m, ws.gx2, H, Lw.o_w, ws.gtmp, H, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));                     // d ctx
-    EZ_TRY(wgrad(m, ws.gx2, H, b.ctx, H, Lw.o_w, M, stream));
+    gd = ws.gx2;
+    if (hp > 0.f) {
+      EZ_TRY(ln_bwd(m, b.y, H, ws.gtmp, H, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx2, H, nullptr, 0, M, H, stream));       // d y
+      EZ_TRY(dropout_rows(ws.gx2, H, nullptr, 0, ws.gx3, H, M, H, make_drop(hp, seed, drop_sid_self_out(i)), dt, stream));
+      EZ_TRY(bgrad(m, ws.gx3, H, M, H, Lw.o_b, stream));
+      gd = ws.gx3;
+    } else {
+      EZ_TRY(ln_bwd(m, b.y, H, ws.gtmp, H, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx2, H, nullptr, 0, M, H, stream, Lw.o_b)); // d y
+    }
+    EZ_TRY(dgrad(m, gd, H, Lw.o_w, ws.gtmp, H, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));                         // d ctx
+    EZ_TRY(wgrad(m, gd, H, b.ctx, H, Lw.o_w, M, stream));
     char* qkv = (char*)b.qkv;
     char* gq = (char*)ws.gqkv;
     AttnBwdArgs ab;
@@ -719,6 +755,7 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     ab.f.row_stride = 3 * H;
     ab.f.ctx = b.ctx; ab.f.ctx_stride = H; ab.f.key_bias = ws.key_bias; ab.f.lse = b.lse;
     ab.f.B = B; ab.f.L = L; ab.f.H = m->theads; ab.f.scale = 0.125f;
+    ab.f.drop = make_drop(ap, seed, drop_sid_attn(i));
     ab.dctx = ws.gtmp;
     ab.dq = gq; ab.dk = gq + H * esz; ab.dv = gq + 2 * H * esz;
     EZ_TRY(attention_bwd(ab, dt, stream));                                                                           // :210-248
@@ -733,7 +770,8 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     EZ_TRY(bgrad(m, gq + H * esz, 3 * H, M, H, Lw.k_b, stream));
     EZ_TRY(bgrad(m, gq + 2 * H * esz, 3 * H, M, H, Lw.v_b, stream));
   }
-  // embeddings: LN(word[ids] + type[0] + pos[t])                                modeling_bert.py:117-127
+  // embeddings: dropout(LN(word[ids] + type[0] + pos[t]))                       modeling_bert.py:117-128
+  if (hp > 0.f) EZ_TRY(dropout_rows(ws.gx, H, nullptr, 0, ws.gx, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream));
   EZ_TRY(ln_bwd(m, ws.x0, H, ws.gx, H, m->eln_w, m->eln_b, ws.m0, ws.r0, ws.gx2, H, nullptr, 0, M, H, stream, m->type_p));
   if (m->Gp(m->word_p)) EZ_TRY(bert_word_grad(ids, ws.gx2, m->Gp(m->word_p), M, H, m->cfg.vocab_size, dt, stream));
   if (m->Gp(m->tpos_p)) EZ_TRY(batch_sum_add(ws.gx2, B, L, L, H, m->Gp(m->tpos_p), dt, stream));

@@ -687,6 +687,73 @@ int add_cols_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int row
   return EZ_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// y = dropout(x) [+ res]   (BertSelfOutput / BertOutput: LayerNorm(dropout(dense(.)) + input), modeling_bert.py:264-267,
+// 342-345; embeddings: dropout(LayerNorm(.)) :127-128; the same kernel masks the gradients in the backward pass).
+// One thread = 4 consecutive columns of one row = one Philox call (dropout.h).  In-place use (y == x) is fine.
+template <typename T>
+__global__ void dropout_rows_kernel(const T* x, int64_t xs, const T* res, int64_t rs, T* y, int64_t ys, int rows, int D,
+                                    DropCfg d) {
+  const int dq = D >> 2;
+  const int64_t n = (int64_t)rows * dq;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / dq), cq = (int)(i - (int64_t)r * dq);
+    float v[4];
+    ld4(x + (int64_t)r * xs + 4 * cq, v);
+    const uint4 w = drop_words(d, (uint32_t)r, (uint32_t)cq);
+    v[0] = w.x >= d.thr ? v[0] * d.scale : 0.f;
+    v[1] = w.y >= d.thr ? v[1] * d.scale : 0.f;
+    v[2] = w.z >= d.thr ? v[2] * d.scale : 0.f;
+    v[3] = w.w >= d.thr ? v[3] * d.scale : 0.f;
+    if (res != nullptr) {
+      float q[4];
+      ld4(res + (int64_t)r * rs + 4 * cq, q);
+      // (the reference rounds dropout's output to the tensor dtype before the residual add)
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += q[e];
+    }
+    st4(y + (int64_t)r * ys + 4 * cq, v);
+  }
+}
+
+int dropout_rows(const void* x, int64_t xs, const void* res, int64_t rs, void* y, int64_t ys, int rows, int D,
+                 const DropCfg& d, int dtype, hipStream_t stream) {
+  EZ_REQUIRE(D % 4 == 0 && xs % 4 == 0 && ys % 4 == 0 && (res == nullptr || rs % 4 == 0), "dropout_rows: D and strides must be multiples of 4");
+  EZ_REQUIRE(d.thr != 0, "dropout_rows: called with dropout off");
+  const int64_t n = (int64_t)rows * (D >> 2);
+  if (dtype == EZCLIP_F32)
+    hipLaunchKernelGGL((dropout_rows_kernel<float>), dim3(grid_for(n, 256)), dim3(256), 0, stream, (const float*)x, xs,
+                       (const float*)res, rs, (float*)y, ys, rows, D, d);
+  else
+    hipLaunchKernelGGL((dropout_rows_kernel<bf16_t>), dim3(grid_for(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, xs,
+                       (const bf16_t*)res, rs, (bf16_t*)y, ys, rows, D, d);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+// keep[r][c] = 1 / 0 for an arbitrary [rows, cols] site (tests feed these masks to the oracle); words (optional):
+// the raw 32-bit Philox outputs (known-answer check of the generator).
+__global__ void dropout_mask_kernel(uint8_t* keep, uint32_t* words, int rows, int cols, DropCfg d) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    const uint32_t w = drop_word(d, (uint32_t)r, (uint32_t)c);
+    if (keep) keep[i] = w >= d.thr ? 1 : 0;
+    if (words) words[i] = w;
+  }
+}
+
+int dropout_mask(uint8_t* keep, uint32_t* words, int rows, int cols, const DropCfg& d, hipStream_t stream) {
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((int64_t)rows * cols, 256)), dim3(256), 0, stream, keep, words, rows,
+                     cols, d);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
 int add_inplace_f32(float* dst, const float* src, int64_t n, hipStream_t stream) {
   hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, dst, src, n);
   EZ_LAUNCH_CHECK();

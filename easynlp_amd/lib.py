@@ -67,6 +67,10 @@ SIGNATURES = {
     "ezclip_op_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ezclip_op_attention": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ezclip_op_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ezclip_set_text_dropout": (_i, [_vp, _f, _f, C.c_uint64]),
+    "ezclip_op_dropout": (_i, [_vp, _vp, _vp, _i, _i, _f, C.c_uint64, C.c_uint32, _i, _vp]),
+    "ezclip_op_dropout_mask": (_i, [_f, C.c_uint64, C.c_uint32, _i, _i, _vp, _vp, _vp]),
+    "ezclip_op_set_attention_dropout": (_i, [_f, C.c_uint64, C.c_uint32]),
     "ezclip_op_cast_from_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
     "ezclip_op_cast_to_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
 }
@@ -179,6 +183,47 @@ def op_attention(qkv: torch.Tensor, batch: int, seq_len: int, heads: int, key_bi
     check(lib.ezclip_op_attention(base, base + D * esz, base + 2 * D * esz, 3 * D, ptr(ctx), D, ptr(key_bias),
                                   ptr(lse), batch, seq_len, heads, dt, stream_ptr()), "op_attention")
     return (ctx, lse) if want_lse else ctx
+
+
+def op_attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, lse: torch.Tensor, batch: int, seq_len: int,
+                     heads: int, key_bias=None) -> torch.Tensor:
+    """Gradient of op_attention w.r.t. the packed qkv (same [batch*seq_len, 3*heads*64] layout)."""
+    lib = load()
+    dt = DTYPE_BF16 if qkv.dtype == torch.bfloat16 else DTYPE_F32
+    D = heads * 64
+    esz = qkv.element_size()
+    dqkv = torch.zeros_like(qkv)
+    base, dbase = ptr(qkv), ptr(dqkv)
+    check(lib.ezclip_op_attention_bwd(base, base + D * esz, base + 2 * D * esz, 3 * D, ptr(ctx), ptr(dctx), D,
+                                      ptr(key_bias), ptr(lse), dbase, dbase + D * esz, dbase + 2 * D * esz, batch,
+                                      seq_len, heads, dt, stream_ptr()), "op_attention_bwd")
+    return dqkv
+
+
+def op_dropout(x: torch.Tensor, p: float, seed: int, site: int, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = dropout(x) [+ residual] with the library's counter-based mask (x: [rows, d])."""
+    lib = load()
+    dt = DTYPE_BF16 if x.dtype == torch.bfloat16 else DTYPE_F32
+    y = torch.empty_like(x)
+    check(lib.ezclip_op_dropout(ptr(x), ptr(residual), ptr(y), x.shape[0], x.shape[1], float(p), int(seed), int(site),
+                                dt, stream_ptr()), "op_dropout")
+    return y
+
+
+def op_dropout_mask(p: float, seed: int, site: int, rows: int, cols: int, device, want_words=False):
+    """keep[rows, cols] (uint8) of a dropout site -- and the raw Philox words (int64 holding uint32) if asked."""
+    lib = load()
+    keep = torch.empty((rows, cols), dtype=torch.uint8, device=device)
+    words = torch.empty((rows, cols), dtype=torch.int32, device=device) if want_words else None
+    check(lib.ezclip_op_dropout_mask(float(p), int(seed), int(site), rows, cols, ptr(keep), ptr(words), stream_ptr()),
+          "op_dropout_mask")
+    if want_words:
+        return keep, words.to(torch.int64) & 0xFFFFFFFF
+    return keep
+
+
+def op_set_attention_dropout(p: float, seed: int = 0, site: int = 0) -> None:
+    check(load().ezclip_op_set_attention_dropout(float(p), int(seed), int(site)), "op_set_attention_dropout")
 
 
 def similarity(a: torch.Tensor, b: torch.Tensor, logit_scale: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -93,6 +93,15 @@ size_t ezclip_shadow_bytes(ezclip_handle h, int with_backward);
 int ezclip_set_shadow(ezclip_handle h, void* shadow_dev, size_t bytes, int with_backward);
 int ezclip_refresh_weights(ezclip_handle h, void* stream);
 
+/* Train-mode dropout of the BERT text tower: nn.Dropout(hidden_dropout_prob) after the embedding LayerNorm, after
+ * BertSelfOutput.dense and BertOutput.dense, nn.Dropout(attention_probs_dropout_prob) on the attention probabilities
+ * (easynlp/modelzoo/models/bert/modeling_bert.py:128,238,266,344; probabilities from CHINESE_CLIP's
+ * text_hidden_dropout_prob / text_attention_probs_dropout_prob, modeling_chineseclip.py:266-268,306-307).
+ * The setting applies to every following ezclip_encode_text / ezclip_backward_text on this handle; masks are
+ * counter-based (Philox-4x32-10 keyed by `seed`, never stored), so a backward call must see the same seed as its
+ * forward.  Eval mode = (0, 0, any).  The ViT tower has no dropout (nn.MultiheadAttention dropout 0). */
+int ezclip_set_text_dropout(ezclip_handle h, float hidden_p, float attention_p, uint64_t seed);
+
 /* ---- forward ------------------------------------------------------------------ */
 /* Workspace (activations; with save_for_backward != 0 also everything backward needs). */
 size_t ezclip_image_workspace_bytes(ezclip_handle h, int batch, int save_for_backward);
@@ -180,6 +189,16 @@ int ezclip_op_attention_bwd(const void* q_dev, const void* k_dev, const void* v_
                             const void* ctx_dev, const void* dctx_dev, int64_t ctx_stride, const float* key_bias_dev,
                             const float* lse_dev, void* dq_dev, void* dk_dev, void* dv_dev, int batch, int seq_len,
                             int heads, int dtype, void* stream);
+/* Dropout building blocks (parity tests feed the library's own masks to the oracle).
+ * Element (row, col) of site `site` is kept iff philox4x32_10(ctr = (col>>2, row, site, 0), key = seed)[col&3] >=
+ * round(p * 2^32); survivors are scaled by 1/(1-p).  Text-tower sites: 0 = embeddings; layer i: 1+3i attention
+ * probabilities (row = (b*heads + h)*L + query, col = key), 2+3i BertSelfOutput, 3+3i BertOutput (row = token). */
+int ezclip_op_dropout(const void* x_dev, const void* residual_dev, void* y_dev, int rows, int d, float p, uint64_t seed,
+                      uint32_t site, int dtype, void* stream);                    /* y = dropout(x) [+ residual] */
+int ezclip_op_dropout_mask(float p, uint64_t seed, uint32_t site, int rows, int cols, uint8_t* keep_dev,
+                           uint32_t* words_dev, void* stream);                    /* either output may be NULL */
+/* dropout applied by the following ezclip_op_attention / ezclip_op_attention_bwd calls (p = 0: off) */
+int ezclip_op_set_attention_dropout(float p, uint64_t seed, uint32_t site);
 int ezclip_op_cast_from_f32(const float* src_dev, void* dst_dev, int64_t n, int dtype, void* stream);
 int ezclip_op_cast_to_f32(const void* src_dev, float* dst_dev, int64_t n, int dtype, void* stream);
 

@@ -314,8 +314,18 @@ def vit_forward(sd, cfg, pixels, taps: Optional[dict] = None):
 # text tower
 # --------------------------------------------------------------------------
 
-def bert_forward(sd, cfg, input_ids, taps: Optional[dict] = None):
-    """``BertModel.forward`` bert/modeling_bert.py:792-920 as driven by
+def apply_dropout(x, keep, p):
+    """``nn.Dropout`` in train mode with an explicit keep mask: ``x * keep / (1 - p)``
+    (torch.nn.functional.dropout: survivors are scaled by 1/(1-p))."""
+    return x * keep.to(x.dtype) * (1.0 / (1.0 - p))
+
+
+def bert_forward(sd, cfg, input_ids, taps: Optional[dict] = None, dropout: Optional[dict] = None):
+    """``dropout`` (train mode, modeling_bert.py:128,238,266,344): ``{"p_hidden", "p_attn", "masks"}`` with keep masks
+    ``masks["emb"]`` [B,L,H], ``masks[f"{i}.attn"]`` [B,heads,L,L], ``masks[f"{i}.self_out"]`` / ``masks[f"{i}.out"]``
+    [B,L,H] -- explicit masks instead of an RNG stream, so that any implementation's masks can be replayed here.
+
+    ``BertModel.forward`` bert/modeling_bert.py:792-920 as driven by
     ``CHINESE_CLIP.encode_text`` (modeling_chineseclip.py:346-350): mask =
     ids != 0, token types all 0, positions 0..L-1, post-LN layers, erf-GELU,
     additive mask -10000 (modeling_utils.py:438-439), scores scaled *after*
@@ -332,6 +342,11 @@ def bert_forward(sd, cfg, input_ids, taps: Optional[dict] = None):
          + sd["bert.embeddings.token_type_embeddings.weight"][0]
          + sd["bert.embeddings.position_embeddings.weight"][:L])   # modeling_bert.py:117-125
     x = layer_norm(x, sd["bert.embeddings.LayerNorm.weight"], sd["bert.embeddings.LayerNorm.bias"], BERT_LN_EPS)
+    dm = dropout["masks"] if dropout is not None else None
+    ph = dropout["p_hidden"] if dropout is not None else 0.0
+    pa = dropout["p_attn"] if dropout is not None else 0.0
+    if dm is not None and ph > 0:
+        x = apply_dropout(x, dm["emb"], ph)                      # modeling_bert.py:128
     if taps is not None:
         taps["bert.emb"] = x
     for i in range(cfg["text_num_hidden_layers"]):
@@ -344,12 +359,20 @@ def bert_forward(sd, cfg, input_ids, taps: Optional[dict] = None):
         v = v.reshape(B, L, heads, hd).transpose(1, 2)
         s = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + key_bias[:, None, None, :]   # :210,228,231
         pr = torch.softmax(s, dim=-1)                                               # :234
+        if dm is not None and pa > 0:
+            pr = apply_dropout(pr, dm[f"{i}.attn"], pa)                              # :238
         ctx = (pr @ v).transpose(1, 2).reshape(B, L, H)                              # :244-248
-        a = layer_norm(linear(ctx, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"]) + x,
+        so = linear(ctx, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
+        if dm is not None and ph > 0:
+            so = apply_dropout(so, dm[f"{i}.self_out"], ph)                          # :266
+        a = layer_norm(so + x,
                        sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"],
                        BERT_LN_EPS)                                                  # :264-267
         h = gelu_erf(linear(a, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))  # :330-331
-        x = layer_norm(linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"]) + a,
+        o = linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+        if dm is not None and ph > 0:
+            o = apply_dropout(o, dm[f"{i}.out"], ph)                                 # :344
+        x = layer_norm(o + a,
                        sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], BERT_LN_EPS)  # :342-345
         if taps is not None:
             taps[f"bert.{i}.ctx"] = ctx
@@ -370,16 +393,16 @@ def encode_image(sd, cfg, pixels, taps=None):
     return l2_normalize(vit_forward(sd, cfg, pixels, taps))
 
 
-def encode_text(sd, cfg, input_ids, taps=None):
-    x = bert_forward(sd, cfg, input_ids, taps)
+def encode_text(sd, cfg, input_ids, taps=None, dropout=None):
+    x = bert_forward(sd, cfg, input_ids, taps, dropout)
     return l2_normalize(x[:, 0, :] @ sd["text_projection"])    # chineseclip:349-350,363
 
 
-def clip_forward(sd, cfg, pixels, input_ids, taps=None):
+def clip_forward(sd, cfg, pixels, input_ids, taps=None, dropout=None):
     """``CLIPApp.forward`` easynlp/appzoo/clip/model.py:106-150 (chinese_clip
     branch): logits_per_text = T @ I^T * exp(logit_scale)."""
     img = encode_image(sd, cfg, pixels, taps)
-    txt = encode_text(sd, cfg, input_ids, taps)
+    txt = encode_text(sd, cfg, input_ids, taps, dropout)
     lpt = (txt @ img.t()) * sd["logit_scale"].exp()              # model.py:148
     return {"logits_per_text": lpt, "logits_per_image": lpt.t(),
             "image_embeds": img, "text_embeds": txt}
@@ -433,12 +456,12 @@ def to_dtype(sd, dtype):
     return {k: v.to(dtype) for k, v in sd.items()}
 
 
-def forward_loss_backward(sd, cfg, pixels, input_ids, dtype=torch.float32):
+def forward_loss_backward(sd, cfg, pixels, input_ids, dtype=torch.float32, dropout=None):
     """fwd + InfoNCE + autograd backward of the restatement; returns
     (outputs, loss, grads by reference parameter name).  ``bert.pooler.*``
     gets no gradient, as in the reference."""
     sdd = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in sd.items()}
-    out = clip_forward(sdd, cfg, pixels.to(dtype), input_ids)
+    out = clip_forward(sdd, cfg, pixels.to(dtype), input_ids, dropout=dropout)
     loss = clip_loss(out["logits_per_text"])
     loss.backward()
     grads = {k: (v.grad.detach() if v.grad is not None else None) for k, v in sdd.items()}

@@ -59,6 +59,44 @@ def test_oracle_backward_matches_reference_golden(name):
             assert err <= 1e-4 * float(ref.norm()) + 1e-7, (n, err)
 
 
+def golden_dropout(z, cfg):
+    """dropout argument of the oracle rebuilt from a fixture's packed keep masks."""
+    masks = {}
+    for key in z.files:
+        if key.startswith("mask/"):
+            n = key[len("mask/"):]
+            shape = tuple(int(x) for x in z["mshape/" + n])
+            bits = np.unpackbits(z[key])[:int(np.prod(shape))]
+            masks[n] = torch.from_numpy(bits.reshape(shape).astype(np.bool_))
+    return {"p_hidden": float(z["p_hidden"]), "p_attn": float(z["p_attn"]), "masks": masks}
+
+
+def test_oracle_train_mode_dropout_matches_reference_golden():
+    """The reference in train mode with BERT dropout 0.1 / 0.15 (masks recorded from its own F.dropout calls,
+    tools/make_golden.py:run_dropout_case): replaying the masks, the oracle reproduces embeddings, loss and every
+    gradient -- i.e. the four dropout sites sit where modeling_bert.py:128,238,266,344 put them."""
+    z, cfg, B, L, wseed, iseed = load("tiny_dropout_b6_l24")
+    sd = O.make_state_dict(cfg, wseed)
+    px, ids = O.make_inputs(cfg, B, L, iseed)
+    drop = golden_dropout(z, cfg)
+    assert len(drop["masks"]) == 1 + 3 * cfg["text_num_hidden_layers"]
+    keep = np.mean([float(m.float().mean()) for n, m in drop["masks"].items() if not n.endswith("attn")])
+    assert abs(keep - 0.9) < 0.02
+    out, loss, grads = O.forward_loss_backward(sd, cfg, px, ids, dropout=drop)
+    np.testing.assert_allclose(out["text_embeds"].numpy(), z["text_embeds"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(out["image_embeds"].numpy(), z["image_embeds"], atol=2e-6, rtol=0)
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    # and the eval-mode output differs (the masks matter)
+    z0 = np.load(os.path.join(GOLD, "tiny_b6_l24.npz"))
+    assert np.abs(z["text_embeds"] - z0["text_embeds"]).max() > 1e-3
+    for key in z.files:
+        if key.startswith("grad/"):
+            n = key[len("grad/"):]
+            ref = torch.from_numpy(z[key])
+            err = float((grads[n] - ref).norm())
+            assert err <= 1e-4 * float(ref.norm()) + 1e-7, (n, err)
+
+
 def test_oracle_recall_matches_bruteforce():
     g = torch.Generator().manual_seed(5)
     t = torch.nn.functional.normalize(torch.randn(40, 16, generator=g), dim=-1)

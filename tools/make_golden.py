@@ -86,6 +86,59 @@ def run_case(name, cfg_name, B, L, wseed, iseed, full):
     print(name, "loss", loss.item(), "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def run_dropout_case(name="tiny_dropout_b6_l24", cfg_name="tiny", B=6, L=24, wseed=1234, iseed=3, p_hidden=0.1, p_attn=0.15):
+    """Train-mode pass of the reference with BERT dropout on.  ``torch.nn.functional.dropout`` is wrapped so that the
+    keep mask of every active call is recorded (mask = output != 0; positions whose input is exactly 0 are irrelevant
+    to values and gradients alike) -- the arithmetic stays the reference's own.  The oracle must reproduce outputs
+    and all gradients when it replays those masks (tests/test_oracle.py)."""
+    torch.manual_seed(0)
+    cfg = dict(O.CONFIGS[cfg_name], text_hidden_dropout_prob=p_hidden, text_attention_probs_dropout_prob=p_attn)
+    sd = O.make_state_dict(cfg, wseed)
+    model = R.reference_chinese_clip(cfg, sd)
+    model.train()
+    px, ids = O.make_inputs(cfg, B, L, iseed)
+    calls = []
+    real = torch.nn.functional.dropout
+
+    def recording_dropout(input, p=0.5, training=True, inplace=False):
+        out = real(input, p, training, False)
+        if training and p > 0:
+            calls.append((float(p), ((out != 0) | (input == 0)).detach().clone()))
+        return out
+
+    torch.nn.functional.dropout = recording_dropout
+    try:
+        torch.manual_seed(4321)
+        img, txt = model(px, ids)
+    finally:
+        torch.nn.functional.dropout = real
+    nl = cfg["text_num_hidden_layers"]
+    assert len(calls) == 1 + 3 * nl, len(calls)                 # emb, then (attn, self_out, out) per layer
+    lpt = torch.matmul(txt, img.t()) * model.logit_scale.exp()
+    ar = torch.arange(B)
+    loss = (torch.nn.functional.cross_entropy(lpt, ar) + torch.nn.functional.cross_entropy(lpt.T, ar)) / 2.0
+    loss.backward()
+    out = {
+        "meta": np.array([cfg_name, str(B), str(L), str(wseed), str(iseed), torch.__version__, np.__version__]),
+        "p_hidden": np.float32(p_hidden), "p_attn": np.float32(p_attn),
+        "image_embeds": img.detach().numpy(), "text_embeds": txt.detach().numpy(),
+        "logits_per_text": lpt.detach().numpy(), "loss": np.float32(loss.item()),
+    }
+    names = ["emb"] + [f"{i}.{k}" for i in range(nl) for k in ("attn", "self_out", "out")]
+    for n, (p, m) in zip(names, calls):
+        assert abs(p - (p_attn if n.endswith("attn") else p_hidden)) < 1e-9, (n, p)
+        out["mask/" + n] = np.packbits(m.numpy().reshape(-1))
+        out["mshape/" + n] = np.array(m.shape, np.int64)
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            out["nograd/" + n] = np.zeros(0, np.float32)
+        else:
+            out["grad/" + n] = p.grad.numpy()
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "loss", loss.item(), "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     only = sys.argv[1:]
@@ -93,3 +146,5 @@ if __name__ == "__main__":
         if only and case[0] not in only:
             continue
         run_case(*case)
+    if not only or "tiny_dropout_b6_l24" in only:
+        run_dropout_case()

@@ -160,6 +160,8 @@ def main():
 
     if os.environ.get("EZCLIP_NO_LNFOLD"):      # A/B switch: separate LayerNorm kernels in the inference path too
         L.check(L.load().ezclip_debug_set(2, 0))
+    if os.environ.get("EZCLIP_LNFOLD_MODE"):    # A/B switch: 2 = folded LayerNorm with a separate statistics pass
+        L.check(L.load().ezclip_debug_set(2, int(os.environ["EZCLIP_LNFOLD_MODE"])))
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["batch"] = args.batch

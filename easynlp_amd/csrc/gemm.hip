@@ -244,6 +244,12 @@ void set_gemm_variant(int v) {   // 2x = 8-phase kernel with ablation code x (ti
   g_gemm_variant = v;
 }
 
+// true when gemm_nt would run this product on the 8-phase kernel (callers that want its optional extras -- folded
+// LayerNorm, row-stat partials -- ask first)
+bool gemm_nt_uses_8p(const GemmArgs& p, int dtype) {
+  return (g_gemm_variant < 0 || g_gemm_variant == 2) && gemm_nt_8p_eligible(p, dtype);
+}
+
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
   EZ_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   const int esz = dtype == EZCLIP_BF16 ? 2 : 4;
@@ -265,6 +271,7 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
     if (rc != EZ_OK) return rc;
     return colsum_add(p.C, p.ldc, p.M, p.N, cs, p.out_f32 ? EZCLIP_F32 : dtype, stream);
   }
+  EZ_REQUIRE(p.rowstat_part == nullptr, "gemm_nt: row-stat partials need the 8-phase bf16 kernel with a residual");
   EZ_REQUIRE(p.ln_stats == nullptr, "gemm_nt: the folded-LayerNorm epilogue needs the 8-phase bf16 kernel (M >= 256, N %% 256 == 0, K %% 128 == 0)");
   if (dtype == EZCLIP_F32) return launch_nt<float, float>(p, stream);
   if (dtype == EZCLIP_BF16) {

@@ -158,7 +158,7 @@ constexpr int kStage = 6 * kSlot;      // epilogue staging lives in [96 KiB, 160
 constexpr int kLds = 160 * 1024;
 
 // Persistent kernel: workgroup b walks tiles b, b + grid, b + 2*grid, ... (XCD-aware order).
-template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, bool HAS_LN>
+template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, bool HAS_LN, bool HAS_PS>
 __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
   // experiment: spread the workgroups' tile boundaries (and with them the store bursts) over a tile period
   for (int d = (int)((blockIdx.x >> 3) % 32u) * EZ_DEPHASE; d > 0; --d) __builtin_amdgcn_s_sleep(16);
 #endif
-  const EpiCtx ep = make_epi_ctx<HAS_R, HAS_U, HAS_C2, HAS_LN>(p);
-  constexpr int NS = kStoresPerBlock * (HAS_C2 ? 2 : 1);         // stores per 32-row block
+  const EpiCtx ep = make_epi_ctx<HAS_R, HAS_U, HAS_C2, HAS_LN, HAS_PS>(p);
+  constexpr int NS = kStoresPerBlock * (1 + (HAS_C2 ? 1 : 0) + (HAS_PS ? 1 : 0));   // stores per 32-row block
   int v = blockIdx.x, m0, n0;
   tile_origin(v, m0, n0);
   set_tile(m0, n0);
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
     // same twelve DMAs are issued anyway (re-reading this tile's first half-tiles into the dead ring): every counted
     // wait of the epilogue is then a single unconditional statement -- a branch around two asm waits made hipcc copy
     // load destinations before the wait that guards them.
-    epilogue_rows<FAST, HAS_R, HAS_U, HAS_C2, 12, HAS_LN>(ep, acc, m0 + wm * 128, n0 + wn * 64, smem + kStage + wave * 8192, p.act, eld,
+    epilogue_rows<FAST, HAS_R, HAS_U, HAS_C2, 12, HAS_LN, HAS_PS>(ep, acc, m0 + wm * 128, n0 + wn * 64, smem + kStage + wave * 8192, p.act, eld,
                                                   [&]() {
                                                     if (has_next) set_tile(m0n, n0n);
                                                     issue_prologue();
@@ -582,6 +582,8 @@ bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype) {
   if (p.R && (uint64_t)p.M * (uint64_t)p.ldr * 2u >= lim) return false;
   if (p.U && (uint64_t)p.M * (uint64_t)p.ldu * 2u >= lim) return false;
   if (p.colsum && (!p.U || p.bias)) return false;     // fused column sums: the act'(U) epilogue, no bias
+  if (p.rowstat_part && (combo != 1 || ((uintptr_t)p.rowstat_part & 7) || (uint64_t)p.M * (uint64_t)(p.N >> 6) * 8u >= lim))
+    return false;                                     // row-stat partials: the residual epilogue only
   return true;
 }
 
@@ -591,10 +593,10 @@ void set_gemm8p_ablate(int v) { g_gemm8p_ablate = v; }
 namespace {
 int g_num_cus = 0;
 
-template <bool R, bool U, bool C2, bool LN = false>
+template <bool R, bool U, bool C2, bool LN = false, bool PS = false>
 int launch_8p(const GemmArgs& p, int tiles, int grid, hipStream_t stream) {
   static bool attr_set = false;
-  auto* kern = &gemm_nt_8p_kernel<true, R, U, C2, LN>;
+  auto* kern = &gemm_nt_8p_kernel<true, R, U, C2, LN, PS>;
   if (!attr_set) {
     EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     attr_set = true;
@@ -624,6 +626,7 @@ int gemm_nt_8p(const GemmArgs& p_in, hipStream_t stream) {
     if (p.ln_stats) rc = launch_8p<false, false, false, true>(p, tiles, grid, stream);
     else if (p.U) rc = launch_8p<false, true, false>(p, tiles, grid, stream);
     else if (p.C2) rc = launch_8p<false, false, true>(p, tiles, grid, stream);
+    else if (p.R && p.rowstat_part) rc = launch_8p<true, false, false, false, true>(p, tiles, grid, stream);
     else if (p.R) rc = launch_8p<true, false, false>(p, tiles, grid, stream);
     else rc = launch_8p<false, false, false>(p, tiles, grid, stream);
   }

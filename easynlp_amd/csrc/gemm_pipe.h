@@ -98,14 +98,18 @@ struct EpiCtx {
   i32x4_t srdR, srdU, srdBias;
   i32x4_t srdStats, srdLn1, srdLn2;   // folded LayerNorm: row stats, c1, c2
   i32x4_t srdC, srdC2;
+  i32x4_t srdPS;                      // row-stat partials [M][N/64][2] f32 (HAS_PS)
+  uint32_t ps_row_b;                  // bytes per row of it
   float* colsum;
   float scale;
   int M;
 };
 
-template <bool HAS_R, bool HAS_U, bool HAS_C2, bool HAS_LN = false>
+template <bool HAS_R, bool HAS_U, bool HAS_C2, bool HAS_LN = false, bool HAS_PS = false>
 __device__ __forceinline__ EpiCtx make_epi_ctx(const GemmArgs& p) {
   EpiCtx e;
+  e.ps_row_b = (uint32_t)(p.N >> 6) * 8u;
+  e.srdPS = make_srd(p.rowstat_part, HAS_PS ? (uint32_t)p.M * e.ps_row_b : 0u);
   e.ldc_b = (uint32_t)p.ldc * 2u; e.ldr_b = (uint32_t)p.ldr * 2u; e.ldu_b = (uint32_t)p.ldu * 2u;
   e.srdR = make_srd(p.R, HAS_R ? (uint32_t)p.M * e.ldr_b : 0u);
   e.srdU = make_srd(p.U, HAS_U ? (uint32_t)p.M * e.ldu_b : 0u);
@@ -161,6 +165,14 @@ __device__ __forceinline__ void stg16(const u32x4_t& data, uint32_t voff, const 
 }
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+// 8-byte store; lanes that must not store pass voff = 0xFFFFFFF0 (out of range: dropped by the descriptor)
+__device__ __forceinline__ void stg8(const u32x2_t& data, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
+#if defined(EZ_ABL_NOSTORE) || defined(EZ_ABL_NOEPI)
+  asm volatile("" ::"v"(data), "v"(voff), "s"(soff));
+  return;
+#endif
+  asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen\n\ts_nop 0" ::"v"(data), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
 __device__ __forceinline__ void ldg8(u32x2_t& dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
   asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
@@ -191,11 +203,12 @@ __device__ __forceinline__ void epilogue_issue_block(const EpiCtx& ec, int mw, i
 }
 
 // HAS_LN: folded LayerNorm -- y = acc * rstd_m + (-mean_m rstd_m) * c1[n] + c2[n]  (see GemmArgs::ln_stats)
-template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, int D, bool HAS_LN = false, typename IssueDma>
+// HAS_PS: also emit the per-row (sum, sum of squares) of this wave's 64 rounded output columns (GemmArgs::rowstat_part)
+template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, int D, bool HAS_LN = false, bool HAS_PS = false, typename IssueDma>
 __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[4][2], int mw, int nw, char* W, int act,
                                               EpiLoads& ld, IssueDma&& issue_dma) {
   constexpr int NL = 4 * ((HAS_R ? 1 : 0) + (HAS_U ? 1 : 0) + (HAS_LN ? 1 : 0));   // loads per 32-row block
-  constexpr int NS = kStoresPerBlock * (HAS_C2 ? 2 : 1);         // stores per 32-row block
+  constexpr int NS = kStoresPerBlock * (1 + (HAS_C2 ? 1 : 0) + (HAS_PS ? 1 : 0));   // stores per 32-row block
 #ifdef EZ_ABL_NOEPI
   issue_dma();
 #pragma unroll
@@ -342,6 +355,19 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
       const u32x4_t o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
                          pack_bf16x2(y[6], y[7])};
       stg16(o, lane_c, ec.srdC, soff);
+      if constexpr (HAS_PS) {
+        float v[8];
+        unpack8(o, v);             // statistics of what the consumer will read (the rounded values)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+        s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+        s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+        s1 += __shfl_xor(s1, 4, 64); s2 += __shfl_xor(s2, 4, 64);
+        const u32x2_t pv = {__float_as_uint(s1), __float_as_uint(s2)};
+        stg8(pv, g == 0 ? (uint32_t)crow * ec.ps_row_b : 0xFFFFFFF0u, ec.srdPS,
+             (uint32_t)(mw + i * 32 + it * 8) * ec.ps_row_b + (uint32_t)(nw >> 6) * 8u);
+      }
     }
     if constexpr (NL > 0 && i == 0) epilogue_issue_block<HAS_R, HAS_U, HAS_LN, 3, 3>(ec, mw, nw, ld);
   });

@@ -29,6 +29,11 @@ struct GemmArgs {
   const float* ln_stats = nullptr;            // [M][2] f32
   const float* ln_c1 = nullptr;               // [N] f32
   const float* ln_c2 = nullptr;               // [N] f32 (bias folded in; `bias` must be null)
+  // Producer side of the same trick (8-phase kernel, with R): the epilogue also writes, for every row and every
+  // 64-column slab s = n / 64, rowstat_part[m][s] = (sum, sum of squares) of the ROUNDED outputs C[m][64 s .. 64 s + 63]
+  // -- N / 64 partials per row that ln_stats_finalize turns into the next LayerNorm's (rstd, -mean rstd) without
+  // re-reading C.  Layout [M][N / 64][2] f32.
+  float* rowstat_part = nullptr;
   // Backward only (with U): colsum[n] += sum_m C[m][n] -- the bias gradient of the Linear whose output gradient C is
   // (8-phase kernel: accumulated in the epilogue, one hardware atomic per column per wave tile; else a separate pass)
   float* colsum = nullptr;
@@ -41,6 +46,7 @@ struct GemmArgs {
 // C = act(alpha * exp(scale) * A.B^T + bias) + R
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream);
 // 256x256x64 8-phase bf16 kernel (gemm8p.hip): large M, N % 256 == 0, K % 128 == 0, bf16 output
+bool gemm_nt_uses_8p(const GemmArgs& p, int dtype);
 bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype);
 int gemm_nt_8p(const GemmArgs& p, hipStream_t stream);
 // 256x128x64 four-wave kernel, two workgroups per CU (gemm4w.hip): same constraints; hides the epilogue of short-K products
@@ -148,6 +154,7 @@ int add_inplace_f32(float* dst, const float* src, int64_t n, hipStream_t stream)
 int dropout_rows(const void* x, int64_t xs, const void* res, int64_t rs, void* y, int64_t ys, int rows, int D,
                  const DropCfg& d, int dtype, hipStream_t stream);
 int dropout_mask(uint8_t* keep, uint32_t* words, int rows, int cols, const DropCfg& d, hipStream_t stream);
+int layernorm_stats_finalize(const float* part, int slabs, int D, float eps, int rows, float* stats, hipStream_t stream);
 int add_cols_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int rows, int cols, hipStream_t stream);
 
 // ---- InfoNCE (loss.hip) -----------------------------------------------------------

@@ -72,7 +72,7 @@ namespace ezclip {
 int model_create(const ezclip_config* cfg, ezclip_model** out);
 size_t model_shadow_layout(ezclip_model* m, char* base, bool with_backward);  // returns bytes; assigns when base != null
 int model_refresh_weights(ezclip_model* m, hipStream_t stream);
-void set_fold_layernorm(int on);   // debugging: 0 = separate LayerNorm kernels in the bf16 inference path too
+void set_fold_layernorm(int mode);   // 0: separate LayerNorm kernels; 1: folded + row statistics from the producing GEMM; 2: folded + separate statistics pass
 
 size_t image_workspace_bytes(const ezclip_model* m, int B, bool save);
 size_t text_workspace_bytes(const ezclip_model* m, int B, int L, bool save);

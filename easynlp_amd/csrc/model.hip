@@ -234,9 +234,8 @@ int model_refresh_weights(ezclip_model* m, hipStream_t stream) {
 }
 
 // --------------------------------------------------------------- helpers ---
-static int linear(const ezclip_model* m, const void* A, int64_t lda, const ezclip_model::Weight& w, int bias_p,
-                  void* C, int64_t ldc, int M, int act, const void* R, int64_t ldr, void* C2, bool out_f32,
-                  hipStream_t stream) {
+static GemmArgs linear_args(const ezclip_model* m, const void* A, int64_t lda, const ezclip_model::Weight& w, int bias_p,
+                            void* C, int64_t ldc, int M, int act, const void* R, int64_t ldr, void* C2, bool out_f32) {
   GemmArgs g;
   g.A = A; g.lda = lda;
   g.B = w.s; g.ldb = w.ldk;
@@ -246,14 +245,28 @@ static int linear(const ezclip_model* m, const void* A, int64_t lda, const ezcli
   g.M = M; g.N = w.N; g.K = w.ldk;
   g.act = act;
   g.out_f32 = (out_f32 && m->dtype == EZCLIP_BF16) ? 1 : 0;
+  return g;
+}
+
+// rowstat_part: also leave the per-row (sum, sum of squares) partials of the output behind (GemmArgs::rowstat_part;
+// the caller checked can_emit_rowstats)
+static int linear(const ezclip_model* m, const void* A, int64_t lda, const ezclip_model::Weight& w, int bias_p,
+                  void* C, int64_t ldc, int M, int act, const void* R, int64_t ldr, void* C2, bool out_f32,
+                  hipStream_t stream, float* rowstat_part = nullptr) {
+  GemmArgs g = linear_args(m, A, lda, w, bias_p, C, ldc, M, act, R, ldr, C2, out_f32);
+  g.rowstat_part = rowstat_part;
   return gemm_nt(g, m->dtype, stream);
 }
 
 // C = act(LayerNorm(X) . W^T + bias) with the LayerNorm folded into the product (bf16 inference): X is read raw.
+// stats_ready: `stats` already holds (rstd, -mean rstd) of X's rows (left behind by the GEMM that produced X).
 static int linear_folded_ln(const ezclip_model* m, const void* X, int64_t ldx, const ezclip_model::Weight& w, float eps,
-                            float* stats, void* C, int64_t ldc, int M, int act, hipStream_t stream) {
-  int rc = layernorm_row_stats(X, ldx, eps, M, w.K, m->dtype, stats, stream);
-  if (rc != EZ_OK) return rc;
+                            float* stats, void* C, int64_t ldc, int M, int act, hipStream_t stream,
+                            bool stats_ready = false) {
+  if (!stats_ready) {
+    int rc = layernorm_row_stats(X, ldx, eps, M, w.K, m->dtype, stats, stream);
+    if (rc != EZ_OK) return rc;
+  }
   GemmArgs g;
   g.A = X; g.lda = ldx;
   g.B = w.sf; g.ldb = w.ldk;
@@ -264,15 +277,26 @@ static int linear_folded_ln(const ezclip_model* m, const void* X, int64_t ldx, c
   return gemm_nt(g, m->dtype, stream);
 }
 
-static bool g_fold_ln = true;
-void set_fold_layernorm(int on) { g_fold_ln = on != 0; }
+// 0: separate LayerNorm kernels; 1: folded, row statistics produced by the epilogue of the GEMM that writes the
+// residual stream; 2: folded, statistics by a separate pass over the stream (ezclip_debug_set(2, v))
+static int g_fold_ln = 1;
+void set_fold_layernorm(int mode) { g_fold_ln = mode; }
 
 static bool can_fold_ln(const ezclip_model* m, const ezclip_model::Weight& w, int M) {
-  if (!g_fold_ln || m->dtype != EZCLIP_BF16 || w.sf == nullptr) return false;
+  if (g_fold_ln == 0 || m->dtype != EZCLIP_BF16 || w.sf == nullptr) return false;
   GemmArgs g;   // the shape constraints of the 8-phase kernel
   g.M = M; g.N = w.N; g.K = w.ldk; g.lda = w.ldk; g.ldb = w.ldk; g.ldc = w.N;
   g.A = w.sf; g.B = w.sf; g.C = w.sf; g.ln_stats = w.c1; g.ln_c1 = w.c1; g.ln_c2 = w.c2;
-  return gemm_nt_8p_eligible(g, m->dtype);
+  return gemm_nt_uses_8p(g, m->dtype);
+}
+
+// can the residual GEMM  C = A W^T + b + R  leave row-stat partials of C behind?
+static bool can_emit_rowstats(const ezclip_model* m, const void* A, int64_t lda, const ezclip_model::Weight& w, int bias_p,
+                              void* C, int M, const void* R, float* part) {
+  if (g_fold_ln != 1 || part == nullptr) return false;
+  GemmArgs g = linear_args(m, A, lda, w, bias_p, C, w.N, M, ACT_NONE, R, w.N, nullptr, false);
+  g.rowstat_part = part;
+  return gemm_nt_uses_8p(g, m->dtype);
 }
 
 #define EZ_TRY(expr)                 \
@@ -288,6 +312,7 @@ struct VitBufs {
   void *x_in, *ln1, *qkv, *ctx, *x_mid, *ln2, *u, *h, *x_out;
   float *m1, *r1, *m2, *r2, *lse;
   float* stat;   // inference only: (rstd, -mean rstd) per row for the folded-LayerNorm products
+  float* part;   // inference only: per-row (sum, sum sq) partials left by the residual GEMMs (GemmArgs::rowstat_part)
 };
 struct ImgWS {
   void *patches, *pemb, *x0;
@@ -323,6 +348,7 @@ size_t layout_image(const ezclip_model* m, int B, bool save, void* base, ImgWS* 
     b.u = nullptr;
     b.h = a.take(M * 4 * W * esz);
     b.stat = a.takef(2 * M);
+    b.part = a.takef(2 * M * (size_t)(W / 64));
     b.m1 = b.r1 = b.m2 = b.r2 = b.lse = nullptr;
     for (int i = 0; i < nl; ++i) w.layers[i] = b;
   } else {
@@ -340,7 +366,7 @@ size_t layout_image(const ezclip_model* m, int B, bool save, void* base, ImgWS* 
       b.x_out = a.take(M * W * esz);
       b.m1 = a.takef(M); b.r1 = a.takef(M); b.m2 = a.takef(M); b.r2 = a.takef(M);
       b.lse = a.takef((size_t)B * m->vheads * m->Lv);
-      b.stat = nullptr;
+      b.stat = nullptr; b.part = nullptr;
       x = b.x_out;
     }
   }
@@ -464,17 +490,19 @@ int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* 
   // cls token, + positional embedding, ln_pre                       :240-242
   EZ_TRY(vit_assemble_ln(ws.pemb, m->P(m->cls_p), m->P(m->pos_p), m->P(m->lnpre_w), m->P(m->lnpre_b), eps, ws.x0,
                          ws.layers[0].x_in, ws.m0, ws.r0, B, Lv, W, dt, stream));
+  bool stats_ready = false;   // b.stat already holds the row statistics of this block's input
   for (int i = 0; i < m->cfg.vision_layers; ++i) {
     const auto& Lw = m->vit[i];
     const VitBufs& b = ws.layers[i];
     // x = x + attn(ln_1(x))                                          :203
     const bool fold = !save && can_fold_ln(m, Lw.in_w, M) && can_fold_ln(m, Lw.fc_w, M);
     if (fold) {
-      EZ_TRY(linear_folded_ln(m, b.x_in, W, Lw.in_w, eps, b.stat, b.qkv, 3 * W, M, ACT_NONE, stream));
+      EZ_TRY(linear_folded_ln(m, b.x_in, W, Lw.in_w, eps, b.stat, b.qkv, 3 * W, M, ACT_NONE, stream, stats_ready));
     } else {
       EZ_TRY(layernorm_fwd(b.x_in, W, b.ln1, W, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, M, W, dt, b.m1, b.r1, stream));
       EZ_TRY(linear(m, b.ln1, W, Lw.in_w, Lw.in_b, b.qkv, 3 * W, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
     }
+    stats_ready = false;
     AttnArgs at;
     at.q = b.qkv;
     at.k = (const char*)b.qkv + (size_t)W * dtype_size(dt);
@@ -484,15 +512,24 @@ int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* 
     at.key_bias = nullptr; at.lse = b.lse;
     at.B = B; at.L = Lv; at.H = m->vheads; at.scale = 0.125f;
     EZ_TRY(attention_fwd(at, dt, stream));
-    EZ_TRY(linear(m, b.ctx, W, Lw.out_w, Lw.out_b, b.x_mid, W, M, ACT_NONE, b.x_in, W, nullptr, false, stream));
+    // (when the next product folds its LayerNorm, the residual GEMM's epilogue leaves that LayerNorm's row sums behind)
+    float* part = fold && can_emit_rowstats(m, b.ctx, W, Lw.out_w, Lw.out_b, b.x_mid, M, b.x_in, b.part) ? b.part : nullptr;
+    EZ_TRY(linear(m, b.ctx, W, Lw.out_w, Lw.out_b, b.x_mid, W, M, ACT_NONE, b.x_in, W, nullptr, false, stream, part));
+    if (part) EZ_TRY(layernorm_stats_finalize(part, W / 64, W, eps, M, b.stat, stream));
     // x = x + c_proj(QuickGELU(c_fc(ln_2(x))))                      :204
     if (fold) {
-      EZ_TRY(linear_folded_ln(m, b.x_mid, W, Lw.fc_w, eps, b.stat, b.h, 4 * W, M, ACT_QUICKGELU, stream));
+      EZ_TRY(linear_folded_ln(m, b.x_mid, W, Lw.fc_w, eps, b.stat, b.h, 4 * W, M, ACT_QUICKGELU, stream, part != nullptr));
     } else {
       EZ_TRY(layernorm_fwd(b.x_mid, W, b.ln2, W, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, M, W, dt, b.m2, b.r2, stream));
       EZ_TRY(linear(m, b.ln2, W, Lw.fc_w, Lw.fc_b, b.h, 4 * W, M, ACT_QUICKGELU, nullptr, 0, b.u, false, stream));
     }
-    EZ_TRY(linear(m, b.h, 4 * W, Lw.proj_w, Lw.proj_b, b.x_out, W, M, ACT_NONE, b.x_mid, W, nullptr, false, stream));
+    part = fold && i + 1 < m->cfg.vision_layers &&
+                   can_emit_rowstats(m, b.h, 4 * W, Lw.proj_w, Lw.proj_b, b.x_out, M, b.x_mid, b.part) ? b.part : nullptr;
+    EZ_TRY(linear(m, b.h, 4 * W, Lw.proj_w, Lw.proj_b, b.x_out, W, M, ACT_NONE, b.x_mid, W, nullptr, false, stream, part));
+    if (part) {    // statistics of the next block's ln_1 (inference: every block shares one buffer set)
+      EZ_TRY(layernorm_stats_finalize(part, W / 64, W, eps, M, ws.layers[i + 1].stat, stream));
+      stats_ready = true;
+    }
   }
   // ln_post(x[:, 0, :]) @ proj                                        :248-251
   const void* xl = ws.layers[m->cfg.vision_layers - 1].x_out;

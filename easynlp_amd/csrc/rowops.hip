@@ -89,6 +89,25 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const T* x, int64_t xs, f
   if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * (int64_t)row) = make_float2(rstd, -mean * rstd);
 }
 
+// stats[row] = (rstd, -mean * rstd) from the per-slab (sum, sum of squares) partials a producing GEMM left behind
+// (GemmArgs::rowstat_part, [rows][slabs][2]); summed in a fixed order, in double (E[x^2] - mean^2 cancels).
+__global__ void ln_stats_finalize_kernel(const float* part, int slabs, int D, float eps, int rows, float* stats) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const float2* p = reinterpret_cast<const float2*>(part) + (int64_t)row * slabs;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < slabs; ++s) {
+    const float2 v = p[s];
+    s1 += (double)v.x;
+    s2 += (double)v.y;
+  }
+  const double mean = s1 / D;
+  double var = s2 / D - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  *reinterpret_cast<float2*>(stats + 2 * (int64_t)row) = make_float2(rstd, (float)(-mean) * rstd);
+}
+
 // One wave per output row n:  Wf[n][k] = W[n][k] * g[k] (rounded to T),  c1[n] = sum_k Wf[n][k] (rounded values),
 // c2[n] = sum_k b[k] * W[n][k] + bias[n].  Columns K..ldk-1 of Wf are zero.
 template <typename T>
@@ -534,6 +553,14 @@ int layernorm_row_stats(const void* x, int64_t xs, float eps, int rows, int D, i
   ProfScope ps(PROF_ROWOP, 1.0 * rows * (double)D * dtype_size(dtype), stream);   // bytes: one read
   EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((ln_stats_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)x, xs, eps,
                                           rows, D, stats));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int layernorm_stats_finalize(const float* part, int slabs, int D, float eps, int rows, float* stats, hipStream_t stream) {
+  EZ_REQUIRE(rows > 0 && slabs > 0 && D == 64 * slabs, "layernorm_stats_finalize: D=%d must be 64 * slabs (%d)", D, slabs);
+  ProfScope ps(PROF_ROWOP, 8.0 * rows * (double)slabs, stream);
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, part, slabs, D, eps, rows, stats);
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

@@ -179,7 +179,11 @@ def main():
             for p in app.parameters():
                 if p.grad is not None:
                     p.grad.zero_()
-            return app.contrastive_step(px, ids, process_group=pg, backward=True)
+            loss = app.contrastive_step(px, ids, process_group=pg, backward=True)
+            if world > 1:       # DDP-style gradient averaging belongs to a training step (trainer.py:101-108)
+                from easynlp_amd import parallel as P
+                P.average_gradients(list(app.parameters()))
+            return loss
         with torch.no_grad():
             return app.contrastive_step(px, ids, process_group=pg, backward=False)
 

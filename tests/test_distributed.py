@@ -76,3 +76,45 @@ def test_global_contrastive_exchange_world2_gloo(n, e):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+_RCCL_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["EZ_ROOT"])
+lr = int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(lr)
+dev = torch.device("cuda", lr)
+dist.init_process_group(backend="nccl", device_id=dev)     # exactly what bench.py does for N > 1
+w, r = dist.get_world_size(), dist.get_rank()
+x = torch.arange(8, dtype=torch.float32, device=dev).reshape(2, 4) + r
+g = torch.empty((w * 2, 4), dtype=torch.float32, device=dev)
+dist.all_gather_into_tensor(g, x)
+assert torch.equal(g[2 * r:2 * r + 2], x)
+m = torch.empty((2, 4), dtype=torch.float32, device=dev)
+dist.reduce_scatter_tensor(m, g.clone(), op=dist.ReduceOp.SUM)
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+from easynlp_amd import parallel as P
+p = torch.nn.Parameter(torch.zeros(5, device=dev)); p.grad = torch.ones(5, device=dev)
+P.average_gradients([p])
+dist.destroy_process_group()
+print("RCCL_OK", w)
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_backend_single_rank_launch(tmp_path):
+    """The launch line the driver uses for N > 1 (python -m torch.distributed.run ... one rank per GPU, backend nccl =
+    RCCL), on the one GPU a test box has: process-group creation with device_id, the two collectives of the exchange
+    step, the barrier / MAX all-reduce of bench.py's timing fence."""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_smoke.py"
+    script.write_text(_RCCL_SCRIPT)
+    env = dict(os.environ, EZ_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "RCCL_OK 1" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

@@ -4,14 +4,23 @@ postprocess(predict(preprocess(x)))``, easynlp/core/predictor.py:69-70).
 
 ``predict`` / ``postprocess`` keep the reference's I/O: one modality per call,
 ``model(output, feat=True)``, embeddings written as tab-joined ``str(float)``.
-Pre-processing (tokenizer / PIL image decode) is the caller's data format and is
-out of this path's scope: ``preprocess`` accepts records
-that already carry ``input_ids`` / ``pixel_values`` tensors, as the reference's
-own ``preprocess`` emits them (predictor.py:77-116).
+``preprocess`` takes the reference's records (predictor.py:77-116): ``first_sequence``
+text is tokenised with the checkpoint's WordPiece vocabulary (CPU, as in the
+reference), ``second_sequence`` urlsafe-base64 images are decoded by PIL (CPU, as in
+the reference) and then resized / cropped / normalised ON THE GPU
+(``ezclip_preprocess_images``: bit-identical to ``_resize`` / ``_center_crop`` /
+``_normalize`` of appzoo/clip/data.py running on Pillow).  Records that already
+carry ``input_ids`` / ``pixel_values`` tensors pass through.
 """
 from __future__ import annotations
 
+import base64
+import os
+from io import BytesIO
+
 import torch
+
+from ... import lib as L
 
 
 class Predictor(object):
@@ -37,18 +46,59 @@ class CLIPPredictor(Predictor):
             from .model import CLIPApp as model_cls
         self.multi_modal = model_cls.from_pretrained(model_dir, user_defined_parameters=user_defined_parameters or {}).cuda()
         self.multi_modal.eval()
-        self.first_sequence = first_sequence
-        self.second_sequence = second_sequence
+        self.first_sequence = first_sequence or "first_sequence"
+        self.second_sequence = second_sequence or "second_sequence"
         self.sequence_length = sequence_length
+        self.model_dir = model_dir
+        self._tokenizer = None
+        cfg = getattr(self.multi_modal, "raw_config", {}) or {}
+        self.size = self.crop_size = int(cfg.get("image_resolution", 224))      # reference: 224 (predictor.py:66-70)
+
+    @property
+    def tokenizer(self):
+        if self._tokenizer is None:
+            from transformers import BertTokenizer
+            self._tokenizer = BertTokenizer(vocab_file=os.path.join(self.model_dir, "vocab.txt"))   # predictor.py:52
+        return self._tokenizer
 
     def preprocess(self, in_data):
         if not in_data:
             raise RuntimeError("Input data should not be None.")
         if not isinstance(in_data, list):
             in_data = [in_data]
+        max_seq_length = -1
+        for record in in_data:                                            # predictor.py:83-87
+            if "sequence_length" not in record:
+                break
+            max_seq_length = max(max_seq_length, record["sequence_length"])
+        max_seq_length = self.sequence_length if max_seq_length == -1 else max_seq_length
+        images, owners = [], []
+        for record in in_data:
+            text = record.get(self.first_sequence, None)
+            if text is not None and "input_ids" not in record:            # predictor.py:95-101
+                tked = self.tokenizer(text, padding="max_length", truncation=True, max_length=max_seq_length,
+                                      return_tensors="pt")
+                record["input_ids"] = tked["input_ids"]
+                record["token_type_ids"] = tked["token_type_ids"]
+                record["attention_mask"] = tked["attention_mask"]
+            blob = record.get(self.second_sequence, None)
+            if blob is not None and "pixel_values" not in record:         # predictor.py:102-103
+                from PIL import Image
+                img = Image.open(BytesIO(base64.urlsafe_b64decode(blob)))
+                if img.mode not in ("RGB", "L"):
+                    # palette / alpha / CMYK images: the reference resizes them in their own mode (nearest for 'P',
+                    # premultiplied for alpha) before convert('RGB'); off this path
+                    raise L.EzclipError("image mode %r is not on the GPU pre-processing path; convert('RGB') upstream" % img.mode)
+                images.append(img)
+                owners.append(record)
+        if images:                                                        # predictor.py:104-113, batched on the GPU
+            px = L.preprocess_images(images, size=self.size, crop=self.crop_size)
+            for i, record in enumerate(owners):
+                record["pixel_values"] = px[i:i + 1]
         for record in in_data:
             if "input_ids" not in record and "pixel_values" not in record:
-                raise RuntimeError("records must carry tokenised 'input_ids' or decoded 'pixel_values' tensors")
+                raise RuntimeError("records must carry text (%r), an image (%r), or ready 'input_ids' / 'pixel_values'"
+                                   % (self.first_sequence, self.second_sequence))
         return in_data
 
     def predict(self, in_data):

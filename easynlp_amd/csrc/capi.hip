@@ -237,6 +237,19 @@ int ezclip_set_text_dropout(ezclip_handle h, float hidden_p, float attention_p, 
   return EZ_OK;
 }
 
+size_t ezclip_preprocess_workspace_bytes(const ezclip_image_desc* desc, int n, int size, int crop) {
+  return preprocess_workspace_bytes(desc, n, size, crop);
+}
+int ezclip_op_resample_table(int in_size, int out_size, int first, int count, int* ksize, int* bounds_host, int* kk_host,
+                             int kk_capacity) {
+  return resample_table(in_size, out_size, first, count, ksize, bounds_host, kk_host, kk_capacity);
+}
+int ezclip_preprocess_images(const uint8_t* packed, const ezclip_image_desc* desc, int n, int size, int crop, const float* mean,
+                             const float* stdv, float* out, void* ws, size_t ws_bytes, void* stream) {
+  EZ_REQUIRE(mean && stdv, "ezclip_preprocess_images: null mean / std");
+  return preprocess_images(packed, desc, n, size, crop, mean, stdv, out, ws, ws_bytes, S(stream));
+}
+
 int ezclip_recall_ranks(const float* text, const float* image, int n, int e, int32_t* rank_out, float* scratch,
                         void* stream) {
   EZ_REQUIRE(text && image && rank_out && scratch && n > 0, "ezclip_recall_ranks: null/empty argument");

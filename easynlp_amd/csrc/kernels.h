@@ -179,6 +179,15 @@ const char* last_error();
 
 // ---- optional per-launch timing (profile.hip) --------------------------------------
 enum ProfClass { PROF_GEMM = 0, PROF_ATTN = 1, PROF_ROWOP = 2 };
+// GPU image pre-processing (preprocess.hip); ezclip_image_desc is declared in include/ezclip.h
+}  // namespace ezclip
+struct ezclip_image_desc;
+namespace ezclip {
+size_t preprocess_workspace_bytes(const ::ezclip_image_desc* desc, int n, int size, int crop);
+int resample_table(int in_size, int out_size, int first, int count, int* ksize, int* bounds, int* kk, int kk_capacity);
+int preprocess_images(const uint8_t* packed, const ::ezclip_image_desc* desc, int n, int size, int crop, const float* mean,
+                      const float* stdv, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
+
 struct ProfScope {   // RAII: records HIP events around the launches issued in its lifetime
   ProfScope(int cls, double work, hipStream_t stream);
   ~ProfScope();

@@ -32,6 +32,10 @@ class EzclipConfig(C.Structure):
         "text_num_attention_heads", "text_num_hidden_layers", "text_type_vocab_size", "compute_dtype")]
 
 
+class EzclipImageDesc(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("width", C.c_int32), ("height", C.c_int32)]
+
+
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 
 # name -> (restype, argtypes): every symbol include/ezclip.h declares
@@ -67,6 +71,10 @@ SIGNATURES = {
     "ezclip_op_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ezclip_op_attention": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ezclip_op_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ezclip_preprocess_workspace_bytes": (_sz, [C.POINTER(EzclipImageDesc), _i, _i, _i]),
+    "ezclip_preprocess_images": (_i, [_vp, C.POINTER(EzclipImageDesc), _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp,
+                                      _sz, _vp]),
+    "ezclip_op_resample_table": (_i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i]),
     "ezclip_set_text_dropout": (_i, [_vp, _f, _f, C.c_uint64]),
     "ezclip_op_dropout": (_i, [_vp, _vp, _vp, _i, _i, _f, C.c_uint64, C.c_uint32, _i, _vp]),
     "ezclip_op_dropout_mask": (_i, [_f, C.c_uint64, C.c_uint32, _i, _i, _vp, _vp, _vp]),
@@ -224,6 +232,55 @@ def op_dropout_mask(p: float, seed: int, site: int, rows: int, cols: int, device
 
 def op_set_attention_dropout(p: float, seed: int = 0, site: int = 0) -> None:
     check(load().ezclip_op_set_attention_dropout(float(p), int(seed), int(site)), "op_set_attention_dropout")
+
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)      # easynlp/appzoo/clip/data.py:101
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def preprocess_images(images, size: int = 224, crop: int = 224, mean=CLIP_MEAN, std=CLIP_STD, device="cuda") -> torch.Tensor:
+    """Decoded images -> float32 ``pixel_values`` [n, 3, crop, crop] on the GPU (ezclip_preprocess_images: Pillow-exact
+    bicubic resize of the shorter side to ``size``, centre crop, /255, normalise).  ``images``: uint8 HWC RGB numpy
+    arrays ([H, W] / [H, W, 1] greyscale is replicated, as ``convert('RGB')`` does after the reference's resize)."""
+    import numpy as np
+    lib = load()
+    arrs = []
+    for im in images:
+        a = np.asarray(im)
+        if a.dtype != np.uint8:
+            raise EzclipError("preprocess_images needs uint8 pixels (got %s)" % a.dtype)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        if a.ndim != 3 or a.shape[2] not in (1, 3):
+            raise EzclipError("preprocess_images needs RGB or greyscale images [H, W, 3]; got shape %s -- convert('RGB') "
+                              "first (palette / alpha images resize differently in the reference)" % (a.shape,))
+        if a.shape[2] == 1:
+            a = np.repeat(a, 3, axis=2)
+        arrs.append(np.ascontiguousarray(a))
+    n = len(arrs)
+    if n == 0:
+        raise EzclipError("preprocess_images: empty batch")
+    desc = (EzclipImageDesc * n)()
+    off = 0
+    for i, a in enumerate(arrs):
+        desc[i].offset, desc[i].width, desc[i].height = off, a.shape[1], a.shape[0]
+        off += (a.size + 15) // 16 * 16
+    host = torch.empty(off + 16, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else torch.empty(off + 16, dtype=torch.uint8)
+    hv = host.numpy()
+    for i, a in enumerate(arrs):
+        hv[desc[i].offset:desc[i].offset + a.size] = a.reshape(-1)
+    packed = host.to(device, non_blocking=True)
+    nbytes = lib.ezclip_preprocess_workspace_bytes(desc, n, size, crop)
+    if nbytes == 0:
+        raise EzclipError("preprocess_images: %s" % last_error())
+    ws = alloc_bytes(nbytes, packed.device)
+    out = torch.empty((n, 3, crop, crop), dtype=torch.float32, device=packed.device)
+    m3, s3 = (_f * 3)(*mean), (_f * 3)(*std)
+    check(lib.ezclip_preprocess_images(ptr(packed), desc, n, size, crop, m3, s3, ptr(out), ptr(ws), ws.numel(), stream_ptr()),
+          "preprocess_images")
+    # the pinned host copy and the workspace must outlive the enqueued work
+    out._ezclip_keepalive = (host, packed, ws)
+    return out
 
 
 def similarity(a: torch.Tensor, b: torch.Tensor, logit_scale: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -152,6 +152,31 @@ int ezclip_backward_text(ezclip_handle h, const int64_t* input_ids_dev, int batc
                          const float* d_embeds_dev, void* workspace_dev, size_t workspace_bytes,
                          void* stream);
 
+/* ---- input pipeline (image half) ---------------------------------------------------- */
+/* CLIPDataset.convert_single_row_to_example's image branch on the GPU (easynlp/appzoo/clip/data.py:256-262):
+ * _resize (:52-72, PIL BICUBIC, shorter side -> size) -> _center_crop (:29-50) -> _normalize (:101-135: /255,
+ * (x - mean) / std in float32, CHW).  Bit-identical to the reference running on Pillow (Resample.c 8-bit path).
+ *   packed_dev : decoded RGB8 pixels (HWC, rows tightly packed) of all n images in one device buffer
+ *   desc_host  : per image byte offset into packed_dev, width, height (HOST array; read during the call)
+ *   out_dev    : float32 [n, 3, crop, crop] -- the pixel_values of ezclip_encode_image
+ * Resampling windows are computed on the host inside the call (double precision, as Pillow does) and uploaded through
+ * a library-owned pinned buffer; the device work is enqueued on `stream`.  Images whose resized size is smaller than
+ * the crop (never the case with size >= crop) are rejected. */
+typedef struct ezclip_image_desc {
+  uint64_t offset;
+  int32_t width, height;
+} ezclip_image_desc;
+size_t ezclip_preprocess_workspace_bytes(const ezclip_image_desc* desc_host, int n, int size, int crop);
+int ezclip_preprocess_images(const uint8_t* packed_dev, const ezclip_image_desc* desc_host, int n, int size, int crop,
+                             const float* mean3_host, const float* std3_host, float* out_dev, void* workspace_dev,
+                             size_t workspace_bytes, void* stream);
+
+/* Host-only: the resampling windows of one axis for outputs [first, first + count) -- ksize taps per output,
+ * bounds[o] = (first source index, taps), kk[o][ksize] int32 with 22 fractional bits (Pillow Resample.c
+ * precompute_coeffs + normalize_coeffs_8bpc, BICUBIC).  No device work: lets CPU-only tests pin the tables. */
+int ezclip_op_resample_table(int in_size, int out_size, int first, int count, int* ksize, int* bounds_host, int* kk_host,
+                             int kk_capacity);
+
 /* ---- retrieval metric -------------------------------------------------------------- */
 /* rank_out[i] = number of images j with sim(text i, image j) > sim(text i, image i)
  * (+ ties with j < i, matching a stable descending sort); text/image: float32 [n, e]. */

@@ -681,11 +681,19 @@ int attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream) {
   const int esz = dtype_size(dtype);
   EZ_REQUIRE((f.row_stride * esz) % 16 == 0 && (f.ctx_stride * esz) % 16 == 0, "attention_bwd: strides must be 16-byte multiples");
   EZ_REQUIRE(f.B <= 65535, "attention_bwd: batch %d > 65535", f.B);
-  if (g_attn_variant != 0 && f.drop.thr == 0 && attention_short_eligible(f, dtype)) return attention_bwd_short(a, stream);
-  if (dtype == EZCLIP_F32) return launch_bwd<float>(a, stream);
-  if (dtype == EZCLIP_BF16) return launch_bwd<bf16_t>(a, stream);
-  set_error("attention_bwd: bad dtype %d", dtype);
-  return EZ_ERR_INVALID;
+  EZ_REQUIRE((a.dbq == nullptr) == (a.dbk == nullptr) && (a.dbq == nullptr) == (a.dbv == nullptr), "attention_bwd: dbq/dbk/dbv must be given together");
+  if (g_attn_variant != 0 && f.drop.thr == 0 && attention_short_eligible(f, dtype) && (a.dbq == nullptr || a.db_part != nullptr))
+    return attention_bwd_short(a, stream);
+  int rc;
+  if (dtype == EZCLIP_F32) rc = launch_bwd<float>(a, stream);
+  else if (dtype == EZCLIP_BF16) rc = launch_bwd<bf16_t>(a, stream);
+  else { set_error("attention_bwd: bad dtype %d", dtype); return EZ_ERR_INVALID; }
+  if (rc != EZ_OK || a.dbq == nullptr) return rc;
+  // general kernels: the bias gradients are a separate column-sum pass over dq / dk / dv
+  const int D = f.H * 64, M = f.B * f.L;
+  if ((rc = colsum_add(a.dq, f.row_stride, M, D, a.dbq, dtype, stream)) != EZ_OK) return rc;
+  if ((rc = colsum_add(a.dk, f.row_stride, M, D, a.dbk, dtype, stream)) != EZ_OK) return rc;
+  return colsum_add(a.dv, f.row_stride, M, D, a.dbv, dtype, stream);
 }
 
 }  // namespace ezclip

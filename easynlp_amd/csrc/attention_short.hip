@@ -195,6 +195,45 @@ __device__ __forceinline__ void dma_rows_f(char* dst, const char* gbase, int64_t
   }
 }
 
+// sum over the 16 lanes of a DPP row (every lane ends up with it): quad butterflies, then the 8- and 16-lane mirrors.
+// (Crossing rows would take a ds_bpermute round trip per value; the two rows of each half-wave are added later, from LDS.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sum16(float v) {
+  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);    // row_half_mirror
+  return dpp_add<0x140>(v); // row_mirror
+}
+// column sums (over this wave's 32 rows, as two 16-row halves) of a [64 d][32 rows] accumulator pair:
+// red[half][d], half = (lane >> 4) & 1, stride kRedHalf floats
+constexpr int kRedHalf = 192;
+__device__ __forceinline__ void reduce_cols(const f32x16_t (&acc)[2], float mul, float* red, int lane) {
+  const int h = lane >> 5;
+  float* dst = red + ((lane >> 4) & 1) * kRedHalf + 4 * h;
+  // every lane of a row holds the row's sum and stores it (16 identical writes to one address: no exec juggling, and
+  // the four DPP chains of a register quad interleave instead of waiting out each other's hazard slots)
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[dt][4 * qd + e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = dpp_add<0xB1>(v[e]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = dpp_add<0x4E>(v[e]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = dpp_add<0x141>(v[e]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = dpp_add<0x140>(v[e]) * mul;
+      *reinterpret_cast<float4*>(dst + dt * 32 + 8 * qd) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const AttnArgs& f = a.f;
@@ -211,6 +250,8 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
   float* lseA = reinterpret_cast<float*>(smem + 4 * LKP * 128);
   float* dA = lseA + LKP;
   float* kb = dA + LKP;
+  float* red = kb + LKP;                       // [8 waves][2 halves][3][64]: column sums of dq / dk / dv (bias gradients)
+  const bool want_db = a.db_part != nullptr;
   const int64_t rs = f.row_stride * 2, cs = f.ctx_stride * 2;
   const int64_t base = ((int64_t)b * L * f.row_stride + head * 64) * 2;
   const int64_t cbase = ((int64_t)b * L * f.ctx_stride + head * 64) * 2;
@@ -272,11 +313,10 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
     if (h == 0) { lseA[row] = lse_q; dA[row] = row < L ? d_q : 0.f; }     // rows >= L: lse = +inf -> P = 0 in pass B
   }
   __syncthreads();
-  if (!active) return;
   const float scale = f.scale;
 
   // ------------------------------------------------ pass A: dQ for queries 32*blk + l31 ------------------------
-  {
+  if (active) {
     f32x16_t dq[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -328,9 +368,10 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
           st4(dqp + dt * 32 + 8 * qd + 4 * h, v);
         }
     }
+    if (want_db) reduce_cols(dq, scale, red + wave * 2 * kRedHalf, lane);     // (rows >= L hold exact zeros)
   }
   // ------------------------------------------------ pass B: dK, dV for keys 32*blk + l31 -----------------------
-  {
+  if (active) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       xf[s] = *reinterpret_cast<const uint4*>(imgK + blk * 4096 + roff[s]);
@@ -394,6 +435,18 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
           st4(dvp + dt * 32 + 8 * qd + 4 * h, vv);
         }
     }
+    if (want_db) {
+      reduce_cols(dk, scale, red + wave * 2 * kRedHalf + 64, lane);
+      reduce_cols(dv, 1.0f, red + wave * 2 * kRedHalf + 128, lane);
+    }
+  }
+  if (want_db) {      // combine the waves in a fixed order; per-sample partials (12k workgroups hammering 2304 addresses
+    __syncthreads();  // with atomics cost more than the pass over dqkv this replaces), summed over the batch afterwards
+    if (tid < 192) {
+      float s = 0.f;
+      for (int w = 0; w < 2 * nt; ++w) s += red[w * kRedHalf + tid];
+      a.db_part[((int64_t)b * 3 + (tid >> 6)) * (f.H * 64) + head * 64 + (tid & 63)] = s;
+    }
   }
 }
 
@@ -405,7 +458,7 @@ bool attention_short_eligible(const AttnArgs& a, int dtype) {
 
 int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
   const int nt = (a.f.L + 31) / 32;
-  const int bytes = nt * (4 * 32 * 128 + 3 * 32 * 4);
+  const int bytes = nt * (4 * 32 * 128 + 3 * 32 * 4) + 8 * 2 * 192 * 4;
   static int attr_max = 0;
   if (bytes > attr_max) {
     EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_short_kernel),
@@ -417,6 +470,13 @@ int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(attn_bwd_short_kernel, dim3(a.f.H, a.f.B), dim3(512), bytes, stream, a, nt);
   }
   EZ_LAUNCH_CHECK();
+  if (a.dbq != nullptr) {      // batch sum of the per-sample partials [B][3][D] -> the three bias gradients
+    const int D = a.f.H * 64;
+    int rc;
+    if ((rc = colsum_add(a.db_part, 3 * D, a.f.B, D, a.dbq, EZCLIP_F32, stream)) != EZ_OK) return rc;
+    if ((rc = colsum_add(a.db_part + D, 3 * D, a.f.B, D, a.dbk, EZCLIP_F32, stream)) != EZ_OK) return rc;
+    if ((rc = colsum_add(a.db_part + 2 * D, 3 * D, a.f.B, D, a.dbv, EZCLIP_F32, stream)) != EZ_OK) return rc;
+  }
   return EZ_OK;
 }
 

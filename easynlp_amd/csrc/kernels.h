@@ -94,6 +94,12 @@ struct AttnBwdArgs {
   void* dq = nullptr;             // same addressing as q/k/v (row_stride)
   void* dk = nullptr;
   void* dv = nullptr;
+  // optional: gradients of the q / k / v projection biases, [H*64] f32 each, ACCUMULATED: db[h*64 + d] += sum over
+  // (batch, token) of dq/dk/dv -- the fused kernel reduces them on the way out instead of a separate pass over dqkv
+  float* dbq = nullptr;
+  float* dbk = nullptr;
+  float* dbv = nullptr;
+  float* db_part = nullptr;       // scratch [B][3][H*64] f32 for the fused kernel's per-sample partial sums (required with dbq)
 };
 int attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream);
 int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream);   // fused single kernel, bf16, L <= 256

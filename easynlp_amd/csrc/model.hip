@@ -322,6 +322,7 @@ struct ImgWS {
   float *mpost, *rpost, *feat, *emb, *inv_norm;
   // backward scratch
   void *gx, *gx2, *gqkv, *gbig, *gtmp, *gfeatT, *gcls;
+  float* gbpart;   // [B][3][W] per-sample partial sums of the qkv bias gradient (fused attention backward)
   float *gfeat;
   float* gconv;   // [W, Kpad] scratch for the patch-embedding weight gradient when K is padded (ViT-L/14: 588 -> 640)
 };
@@ -380,13 +381,14 @@ size_t layout_image(const ezclip_model* m, int B, bool save, void* base, ImgWS* 
     w.gx2 = a.take(M * W * esz);
     w.gtmp = a.take(M * W * esz);
     w.gqkv = a.take(M * 3 * W * esz);
+    w.gbpart = a.takef((size_t)B * 3 * W);
     w.gbig = a.take(M * 4 * W * esz);
     w.gfeat = a.takef((size_t)B * E);
     w.gfeatT = a.take((size_t)B * E * esz);
     w.gcls = a.take((size_t)B * W * esz);
     w.gconv = m->Kpad != m->Kpatch ? a.takef((size_t)W * m->Kpad) : nullptr;
   } else {
-    w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = w.gfeatT = w.gcls = nullptr; w.gfeat = nullptr; w.gconv = nullptr;
+    w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = w.gfeatT = w.gcls = nullptr; w.gfeat = nullptr; w.gconv = nullptr; w.gbpart = nullptr;
   }
   if (ws) *ws = w;
   return a.off + 256;
@@ -402,7 +404,7 @@ struct TxtWS {
   std::vector<BertBufs> layers;
   float *feat, *emb, *inv_norm;
   void *gx, *gx2, *gx3, *gtmp, *gqkv, *gbig, *gfeatT;
-  float *gfeat;
+  float *gfeat, *gbpart;
 };
 
 size_t layout_text(const ezclip_model* m, int B, int L, bool save, void* base, TxtWS* ws) {
@@ -455,11 +457,12 @@ size_t layout_text(const ezclip_model* m, int B, int L, bool save, void* base, T
     w.gx3 = a.take(M * H * esz);     // dropout-masked copy of a residual-branch gradient (train mode with p > 0)
     w.gtmp = a.take(M * H * esz);
     w.gqkv = a.take(M * 3 * H * esz);
+    w.gbpart = a.takef((size_t)B * 3 * H);
     w.gbig = a.take(M * F * esz);
     w.gfeat = a.takef((size_t)B * E);
     w.gfeatT = a.take((size_t)B * E * esz);
   } else {
-    w.gx = w.gx2 = w.gx3 = w.gtmp = w.gqkv = w.gbig = w.gfeatT = nullptr; w.gfeat = nullptr;
+    w.gx = w.gx2 = w.gx3 = w.gtmp = w.gqkv = w.gbig = w.gfeatT = nullptr; w.gfeat = nullptr; w.gbpart = nullptr;
   }
   if (ws) *ws = w;
   return a.off + 256;
@@ -705,10 +708,10 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
     ab.dq = ws.gqkv;
     ab.dk = (char*)ws.gqkv + (size_t)W * esz;
     ab.dv = (char*)ws.gqkv + (size_t)2 * W * esz;
+    if (float* gb = m->Gp(Lw.in_b)) { ab.dbq = gb; ab.dbk = gb + W; ab.dbv = gb + 2 * W; ab.db_part = ws.gbpart; }   // in_proj_bias gradient
     EZ_TRY(attention_bwd(ab, dt, stream));
     EZ_TRY(dgrad(m, ws.gqkv, 3 * W, Lw.in_w, ws.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));      // d ln_1
     EZ_TRY(wgrad(m, ws.gqkv, 3 * W, b.ln1, W, Lw.in_w, M, stream));
-    EZ_TRY(bgrad(m, ws.gqkv, 3 * W, M, 3 * W, Lw.in_b, stream));
     EZ_TRY(ln_bwd(m, b.x_in, W, ws.gtmp, W, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx, W, ws.gx2, W, M, W, stream,
                   i > 0 ? m->vit[i - 1].proj_b : -1));    // d x_in (+ the previous block's c_proj bias gradient)
   }
@@ -795,6 +798,8 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     ab.f.drop = make_drop(ap, seed, drop_sid_attn(i));
     ab.dctx = ws.gtmp;
     ab.dq = gq; ab.dk = gq + H * esz; ab.dv = gq + 2 * H * esz;
+    const bool qkv_bias_grads = m->Gp(Lw.q_b) && m->Gp(Lw.k_b) && m->Gp(Lw.v_b);
+    if (qkv_bias_grads) { ab.dbq = m->Gp(Lw.q_b); ab.dbk = m->Gp(Lw.k_b); ab.dbv = m->Gp(Lw.v_b); ab.db_part = ws.gbpart; }
     EZ_TRY(attention_bwd(ab, dt, stream));                                                                           // :210-248
     // d x_in = d y + d q W_q + d k W_k + d v W_v                                  :172-200
     EZ_TRY(dgrad(m, gq, 3 * H, Lw.q_w, ws.gx, H, M, nullptr, 0, ACT_NONE, ws.gx2, H, stream));
@@ -803,9 +808,11 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     EZ_TRY(wgrad(m, gq, 3 * H, b.x_in, H, Lw.q_w, M, stream));
     EZ_TRY(wgrad(m, gq + H * esz, 3 * H, b.x_in, H, Lw.k_w, M, stream));
     EZ_TRY(wgrad(m, gq + 2 * H * esz, 3 * H, b.x_in, H, Lw.v_w, M, stream));
-    EZ_TRY(bgrad(m, gq, 3 * H, M, H, Lw.q_b, stream));
-    EZ_TRY(bgrad(m, gq + H * esz, 3 * H, M, H, Lw.k_b, stream));
-    EZ_TRY(bgrad(m, gq + 2 * H * esz, 3 * H, M, H, Lw.v_b, stream));
+    if (!qkv_bias_grads) {
+      EZ_TRY(bgrad(m, gq, 3 * H, M, H, Lw.q_b, stream));
+      EZ_TRY(bgrad(m, gq + H * esz, 3 * H, M, H, Lw.k_b, stream));
+      EZ_TRY(bgrad(m, gq + 2 * H * esz, 3 * H, M, H, Lw.v_b, stream));
+    }
   }
   // embeddings: dropout(LN(word[ids] + type[0] + pos[t]))                       modeling_bert.py:117-128
   if (hp > 0.f) EZ_TRY(dropout_rows(ws.gx, H, nullptr, 0, ws.gx, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream));

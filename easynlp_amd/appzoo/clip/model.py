@@ -78,7 +78,10 @@ class HipClipEngine:
     """Owns the C handle, the packed-weight shadow and the workspaces for one
     module instance on one device."""
 
-    def __init__(self, cfg: dict, dtype_code: int):
+    # parameters only the huggingface_clip branch has (include/ezclip.h); never created / bound for chinese_clip
+    HF_ONLY_PARAMS = ("visual.proj_bias", "text_projection_bias")
+
+    def __init__(self, cfg: dict, dtype_code: int, hf_branch: bool = False):
         self.lib = L.load()
         self.cfg = cfg
         self.dtype_code = dtype_code
@@ -94,6 +97,8 @@ class HipClipEngine:
         for i in range(self.lib.ezclip_num_params(h)):
             L.check(self.lib.ezclip_param_info(h, i, L.C.byref(name), shape, L.C.byref(ndim)), "param_info")
             n = name.value.decode()
+            if n in self.HF_ONLY_PARAMS and not hf_branch:
+                continue
             self.names.append(n)
             self.shapes[n] = tuple(int(shape[j]) for j in range(ndim.value))
         self._shadow = None

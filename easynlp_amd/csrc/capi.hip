@@ -227,6 +227,39 @@ int ezclip_backward_text(ezclip_handle h, const int64_t* ids, int batch, int seq
   return backward_text(h, ids, batch, seq_len, d_emb, ws, ws_bytes, S(stream));
 }
 
+int ezclip_set_option(ezclip_handle h, int key, double value) {
+  EZ_REQUIRE(h, "ezclip_set_option: null handle");
+  switch (key) {
+    case EZCLIP_OPT_TEXT_POOLER: h->opt_text_pooler = value != 0.0; return EZ_OK;
+    case EZCLIP_OPT_VISION_FROZEN: h->opt_vision_frozen = value != 0.0; return EZ_OK;
+    case EZCLIP_OPT_TEXT_LN_EPS:
+      EZ_REQUIRE(value > 0.0 && value < 1.0, "ezclip_set_option: layer_norm_eps %g", value);
+      h->text_ln_eps = (float)value;
+      return EZ_OK;
+    case EZCLIP_OPT_TEXT_PAD_ID: h->text_pad_id = (int64_t)value; return EZ_OK;
+    default: break;
+  }
+  set_error("ezclip_set_option: unknown key %d", key);
+  return EZ_ERR_INVALID;
+}
+
+int ezclip_encode_text_ex(ezclip_handle h, const int64_t* ids, const int64_t* position_ids, const int64_t* token_type_ids,
+                          const int64_t* attention_mask, int batch, int seq_len, float* out, void* ws, size_t ws_bytes,
+                          int save, void* stream) {
+  EZ_REQUIRE(h, "ezclip_encode_text_ex: null handle");
+  TextExtras ex;
+  ex.pos_ids = position_ids; ex.type_ids = token_type_ids; ex.attn_mask = attention_mask;
+  return encode_text(h, ids, batch, seq_len, out, ws, ws_bytes, save != 0, S(stream), &ex);
+}
+int ezclip_backward_text_ex(ezclip_handle h, const int64_t* ids, const int64_t* position_ids, const int64_t* token_type_ids,
+                            const int64_t* attention_mask, int batch, int seq_len, const float* d_emb, void* ws,
+                            size_t ws_bytes, void* stream) {
+  EZ_REQUIRE(h, "ezclip_backward_text_ex: null handle");
+  TextExtras ex;
+  ex.pos_ids = position_ids; ex.type_ids = token_type_ids; ex.attn_mask = attention_mask;
+  return backward_text(h, ids, batch, seq_len, d_emb, ws, ws_bytes, S(stream), &ex);
+}
+
 int ezclip_set_text_dropout(ezclip_handle h, float hidden_p, float attention_p, uint64_t seed) {
   EZ_REQUIRE(h, "ezclip_set_text_dropout: null handle");
   EZ_REQUIRE(hidden_p >= 0.f && hidden_p < 1.f && attention_p >= 0.f && attention_p < 1.f,

@@ -13,7 +13,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int kWave = 64;  // CDNA wavefront
 
-enum Act { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2 };
+enum Act { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2, ACT_TANH = 3 };   // TANH: 128x128 kernels only (pooler)
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
@@ -96,6 +96,7 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     const float z = x * 0.70710678118654752440f;
     return 0.5f * x * (1.0f + (FAST ? erf_fast(z) : erff(z)));
   }
+  if (act == ACT_TANH) return tanhf(x);     // BertPooler / RobertaPooler (B rows per step: never hot)
   return x;
 }
 
@@ -112,6 +113,10 @@ __device__ __forceinline__ float act_grad(float x, int act) {
     const float cdf = 0.5f * (1.0f + (FAST ? erf_fast(z) : erff(z)));
     const float pdf = 0.39894228040143267794f * (FAST ? __expf(-0.5f * x * x) : expf(-0.5f * x * x));
     return cdf + x * pdf;
+  }
+  if (act == ACT_TANH) {
+    const float t = tanhf(x);
+    return 1.0f - t * t;
   }
   return 1.0f;
 }

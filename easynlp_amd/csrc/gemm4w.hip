@@ -243,7 +243,7 @@ int launch_4w(const GemmArgs& p, int tiles, hipStream_t stream) {
 
 bool gemm_nt_4w_eligible(const GemmArgs& p, int dtype) {
   if (!gemm_nt_8p_eligible(p, dtype)) return false;   // same operand / epilogue constraints (N % 256 included)
-  return p.K >= 128 && p.ln_stats == nullptr && p.rowstat_part == nullptr;
+  return p.K >= 128 && p.ln_stats == nullptr && p.rowstat_part == nullptr && p.act <= ACT_GELU_ERF;
 }
 
 int gemm_nt_4w(const GemmArgs& p, hipStream_t stream) {

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* part, int s
 }  // namespace
 
 bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype) {
-  if (dtype != EZCLIP_BF16 || p.out_f32 || p.scale_log != nullptr) return false;
+  if (dtype != EZCLIP_BF16 || p.out_f32 || p.scale_log != nullptr || p.act > ACT_GELU_ERF) return false;
   if (p.M < 256 || (p.N & 255) || (p.K & 127) || p.K < 256) return false;
   if ((p.lda & 7) || (p.ldb & 7) || (p.ldc & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15) ||
       ((uintptr_t)p.C & 15))

@@ -141,7 +141,9 @@ int vit_assemble_ln(const void* patch, const float* cls, const float* pos, const
 // BERT embeddings (word + type[0] + pos[t]) -> LN; also key_bias[b*L+t] = ids==0 ? -10000 : 0.
 int bert_embed_ln(const int64_t* ids, const float* word, const float* pos, const float* type, const float* g,
                   const float* b, float eps, void* x0, void* y, float* mean, float* rstd, float* key_bias,
-                  int B, int L, int Hd, int vocab, int dtype, hipStream_t stream);
+                  int B, int L, int Hd, int vocab, int dtype, hipStream_t stream, const int64_t* pos_ids = nullptr,
+                  const int64_t* type_ids = nullptr, const int64_t* attn_mask = nullptr, int max_pos = 1 << 30,
+                  int type_vocab = 1);
 // out[b] = x[b] / ||x[b]||_2 (no eps: reference modeling_chineseclip.py:360,363); inv_norm optional.
 int l2_normalize_fwd(const float* x, float* out, float* inv_norm, int B, int E, hipStream_t stream);
 // dx = (dy - y * <dy, y>) * inv_norm
@@ -153,8 +155,9 @@ int colsum_add(const void* x, int64_t ld, int rows, int cols, float* out, int dt
 // out[t][c] += sum_b x[b][t][c] for t < t_count (x is [B, Tn, W])
 int batch_sum_add(const void* x, int B, int Tn, int t_count, int W, float* out, int dtype, hipStream_t stream);
 int vit_gather_patch_rows(const void* dx0, void* dpemb, int B, int Lv, int W, int dtype, hipStream_t stream);
+// table[ids[r]] += dx0[r] (embedding index-add); rows whose id == pad_id (nn.Embedding padding_idx) or out of range are skipped
 int bert_word_grad(const int64_t* ids, const void* dx0, float* dword, int64_t rows, int Hd, int vocab, int dtype,
-                   hipStream_t stream);
+                   hipStream_t stream, int64_t pad_id = 0);
 int add_inplace_f32(float* dst, const float* src, int64_t n, hipStream_t stream);
 // dst[r][c] += src[r][c] for c < cols (row strides ldd / lds): un-pads a K-padded weight gradient
 int dropout_rows(const void* x, int64_t xs, const void* res, int64_t rs, void* y, int64_t ys, int rows, int D,

@@ -48,11 +48,18 @@ struct ezclip_model {
     Weight q_w, k_w, v_w, o_w, i_w, d_w;
     int q_b, k_b, v_b, o_b, i_b, d_b, ln1_w, ln1_b, ln2_w, ln2_b;
   };
-  Weight conv_w, vproj_w, tproj_w;
+  Weight conv_w, vproj_w, tproj_w, pool_w;
+  int vproj_b = -1, tproj_b = -1, pool_b = -1;    // optional parameters (huggingface_clip branch): projection biases, pooler
   int cls_p, pos_p, lnpre_w, lnpre_b, lnpost_w, lnpost_b;
   int word_p, tpos_p, type_p, eln_w, eln_b, logit_scale_p;
   std::vector<VitLayer> vit;
   std::vector<BertLayer> bert;
+
+  // huggingface_clip branch of CLIPApp (appzoo/clip/model.py:73-104,128-144): ezclip_set_option
+  bool opt_text_pooler = false;      // text feature = projection(tanh(pooler.dense(x[:, 0])))  (RobertaModel pooled output)
+  bool opt_vision_frozen = false;    // image_embeds = vision_outputs[1].detach(): only the projection gets gradients
+  float text_ln_eps = 1e-12f;        // BertConfig / CLIPTextConfig layer_norm_eps
+  int64_t text_pad_id = 0;           // padding_idx of the word / position embeddings (no gradient for that row)
 
   // BERT train-mode dropout (ezclip_set_text_dropout): probabilities + the seed of the next forward / backward pair
   float drop_hidden = 0.f, drop_attn = 0.f;
@@ -78,11 +85,18 @@ size_t image_workspace_bytes(const ezclip_model* m, int B, bool save);
 size_t text_workspace_bytes(const ezclip_model* m, int B, int L, bool save);
 int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* ws, size_t ws_bytes, bool save,
                  hipStream_t stream);
+// optional per-token inputs of the text tower (RobertaModel(input_ids, token_type_ids, attention_mask); position ids are
+// RobertaEmbeddings' pad-aware ones, computed by the caller); any may be null: position t, type 0, mask = ids != 0
+struct TextExtras {
+  const int64_t* pos_ids = nullptr;
+  const int64_t* type_ids = nullptr;
+  const int64_t* attn_mask = nullptr;
+};
 int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, void* ws, size_t ws_bytes, bool save,
-                hipStream_t stream);
+                hipStream_t stream, const TextExtras* ex = nullptr);
 int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_emb, void* ws, size_t ws_bytes,
                    hipStream_t stream);
 int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float* d_emb, void* ws, size_t ws_bytes,
-                  hipStream_t stream);
+                  hipStream_t stream, const TextExtras* ex = nullptr);
 
 }  // namespace ezclip

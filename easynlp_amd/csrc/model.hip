@@ -113,6 +113,8 @@ int model_create(const ezclip_config* c, ezclip_model** out) {
   m->lnpre_b = add_param(m, "visual.ln_pre.bias", {W});
   m->conv_w = make_weight(m, conv, W, m->Kpatch);
   m->vproj_w = make_weight(m, vproj, E, W, true);
+  // optional (huggingface_clip: vision_projection is an nn.Linear with a bias, appzoo/clip/model.py:96-101)
+  m->vproj_b = add_param(m, "visual.proj_bias", {E});
   for (int i = 0; i < c->vision_layers; ++i) {
     const std::string p = "visual.transformer.resblocks." + std::to_string(i) + ".";
     ezclip_model::VitLayer L;
@@ -161,10 +163,12 @@ int model_create(const ezclip_config* c, ezclip_model** out) {
     L.ln2_b = add_param(m, p + "output.LayerNorm.bias", {H});
     m->bert.push_back(L);
   }
-  // computed by the reference but unused on this path (kept for the checkpoint contract)
-  add_param(m, "bert.pooler.dense.weight", {H, H});
-  add_param(m, "bert.pooler.dense.bias", {H});
+  // chinese_clip: computed by the reference but unused (kept for the checkpoint contract).  huggingface_clip: the text
+  // feature IS the pooled output (text_outputs[1], appzoo/clip/model.py:134) -- opt_text_pooler
+  m->pool_w = make_weight(m, add_param(m, "bert.pooler.dense.weight", {H, H}), H, H);
+  m->pool_b = add_param(m, "bert.pooler.dense.bias", {H});
   m->tproj_w = make_weight(m, add_param(m, "text_projection", {H, E}), E, H, true);
+  m->tproj_b = add_param(m, "text_projection_bias", {E});
   m->logit_scale_p = add_param(m, "logit_scale", {});
   *out = m;
   return EZ_OK;
@@ -175,6 +179,7 @@ static void for_each_weight(ezclip_model* m, const std::function<void(ezclip_mod
   f(m->conv_w);
   f(m->vproj_w);
   f(m->tproj_w);
+  f(m->pool_w);
   for (auto& L : m->vit) { f(L.in_w); f(L.out_w); f(L.fc_w); f(L.proj_w); }
   for (auto& L : m->bert) { f(L.q_w); f(L.k_w); f(L.v_w); f(L.o_w); f(L.i_w); f(L.d_w); }
 }
@@ -203,13 +208,18 @@ size_t model_shadow_layout(ezclip_model* m, char* base, bool with_backward) {
   return a.off + 256;
 }
 
+static bool is_optional_param(const std::string& n) {
+  return n.find("pooler") != std::string::npos || n == "visual.proj_bias" || n == "text_projection_bias";
+}
+
 int model_refresh_weights(ezclip_model* m, hipStream_t stream) {
   for (auto& p : m->params)
-    EZ_REQUIRE(p.w != nullptr || p.name.find("pooler") != std::string::npos, "parameter %s is not bound", p.name.c_str());
+    EZ_REQUIRE(p.w != nullptr || is_optional_param(p.name), "parameter %s is not bound", p.name.c_str());
   int rc = EZ_OK;
   for_each_weight(m, [&](ezclip_model::Weight& w) {
     if (rc != EZ_OK) return;
     const float* src = m->P(w.p);
+    if (src == nullptr) return;      // unbound optional weight (pooler): never used
     if (!needs_pack(m, w)) { w.s = const_cast<float*>(src); }
     else {
       if (w.s == nullptr) { set_error("weight shadow not set (call ezclip_set_shadow first)"); rc = EZ_ERR_STATE; return; }
@@ -403,6 +413,7 @@ struct TxtWS {
   float *m0, *r0, *key_bias;
   std::vector<BertBufs> layers;
   float *feat, *emb, *inv_norm;
+  void *pool, *pool_u, *gpool;     // pooled output tanh(u), its pre-activation u, d u   [B, H] (opt_text_pooler)
   void *gx, *gx2, *gx3, *gtmp, *gqkv, *gbig, *gfeatT;
   float *gfeat, *gbpart;
 };
@@ -451,6 +462,9 @@ size_t layout_text(const ezclip_model* m, int B, int L, bool save, void* base, T
   w.feat = a.takef((size_t)B * E);
   w.emb = a.takef((size_t)B * E);
   w.inv_norm = a.takef(B);
+  w.pool = a.take((size_t)B * H * esz);
+  w.pool_u = a.take((size_t)B * H * esz);
+  w.gpool = a.take((size_t)B * H * esz);
   if (save) {
     w.gx = a.take(M * H * esz);
     w.gx2 = a.take(M * H * esz);
@@ -538,7 +552,7 @@ int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* 
   const void* xl = ws.layers[m->cfg.vision_layers - 1].x_out;
   EZ_TRY(layernorm_fwd(xl, (int64_t)Lv * W, ws.cls_ln, W, m->P(m->lnpost_w), m->P(m->lnpost_b), eps, B, W, dt,
                        ws.mpost, ws.rpost, stream));
-  EZ_TRY(linear(m, ws.cls_ln, W, m->vproj_w, -1, ws.feat, E, B, ACT_NONE, nullptr, 0, nullptr, true, stream));
+  EZ_TRY(linear(m, ws.cls_ln, W, m->vproj_w, m->vproj_b, ws.feat, E, B, ACT_NONE, nullptr, 0, nullptr, true, stream));
   // image_features / image_features.norm(dim=-1, keepdim=True)       :360
   EZ_TRY(l2_normalize_fwd(ws.feat, ws.emb, ws.inv_norm, B, E, stream));
   EZ_HIP(hipMemcpyAsync(out, ws.emb, (size_t)B * E * 4, hipMemcpyDeviceToDevice, stream));
@@ -547,7 +561,7 @@ int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* 
 
 // ------------------------------------------------------------- text fwd ----
 int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, void* wsp, size_t ws_bytes, bool save,
-                hipStream_t stream) {
+                hipStream_t stream, const TextExtras* ex) {
   EZ_REQUIRE(B > 0 && L > 0 && ids && out && wsp, "encode_text: null/empty argument");
   EZ_REQUIRE(L <= m->cfg.text_max_position_embeddings, "encode_text: seq_len %d > max_position_embeddings %d", L,
              m->cfg.text_max_position_embeddings);
@@ -560,11 +574,15 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
   const int M = B * L;
   const int dt = m->dtype;
   const size_t esz = dtype_size(dt);
-  const float eps = 1e-12f;  // layer_norm_eps (modeling_chineseclip.py:311)
+  const float eps = m->text_ln_eps;  // layer_norm_eps (1e-12: modeling_chineseclip.py:311, CLIPTextConfig default)
+  const TextExtras none;
+  if (ex == nullptr) ex = &none;
 
-  // BertEmbeddings.forward                                   modeling_bert.py:95-129
+  // BertEmbeddings.forward modeling_bert.py:95-129 / RobertaEmbeddings.forward roberta/modeling_roberta.py:98-134
   EZ_TRY(bert_embed_ln(ids, m->P(m->word_p), m->P(m->tpos_p), m->P(m->type_p), m->P(m->eln_w), m->P(m->eln_b), eps,
-                       ws.x0, ws.layers[0].x_in, ws.m0, ws.r0, ws.key_bias, B, L, H, m->cfg.vocab_size, dt, stream));
+                       ws.x0, ws.layers[0].x_in, ws.m0, ws.r0, ws.key_bias, B, L, H, m->cfg.vocab_size, dt, stream,
+                       ex->pos_ids, ex->type_ids, ex->attn_mask, m->cfg.text_max_position_embeddings,
+                       m->cfg.text_type_vocab_size));
   // train-mode dropout (set per call by ezclip_set_text_dropout; masks are regenerated from the seed in the backward)
   const float hp = m->drop_hidden, ap = m->drop_attn;
   const uint64_t seed = m->drop_seed;
@@ -604,9 +622,18 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
     }
     EZ_TRY(layernorm_fwd(b.z, H, b.x_out, H, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, M, H, dt, b.m2, b.r2, stream));
   }
-  // x[:, 0, :] @ text_projection  (pooler skipped: unused)    modeling_chineseclip.py:349-350
+  // chinese_clip: x[:, 0, :] @ text_projection (pooler unused)  modeling_chineseclip.py:349-350
+  // huggingface_clip: text_projection(tanh(pooler.dense(x[:, 0])))  appzoo/clip/model.py:134-135, RobertaPooler :550-562
   const void* xl = ws.layers[m->cfg.text_num_hidden_layers - 1].x_out;
-  EZ_TRY(linear(m, xl, (int64_t)L * H, m->tproj_w, -1, ws.feat, E, B, ACT_NONE, nullptr, 0, nullptr, true, stream));
+  const void* fa = xl;
+  int64_t fa_ld = (int64_t)L * H;
+  if (m->opt_text_pooler) {
+    EZ_REQUIRE(m->P(m->pool_w.p) && m->P(m->pool_b), "encode_text: the pooler is enabled but bert.pooler.dense.* is not bound");
+    EZ_TRY(linear(m, xl, (int64_t)L * H, m->pool_w, m->pool_b, ws.pool, H, B, ACT_TANH, nullptr, 0, ws.pool_u, false, stream));
+    fa = ws.pool;
+    fa_ld = H;
+  }
+  EZ_TRY(linear(m, fa, fa_ld, m->tproj_w, m->tproj_b, ws.feat, E, B, ACT_NONE, nullptr, 0, nullptr, true, stream));
   EZ_TRY(l2_normalize_fwd(ws.feat, ws.emb, ws.inv_norm, B, E, stream));   // :363
   EZ_HIP(hipMemcpyAsync(out, ws.emb, (size_t)B * E * 4, hipMemcpyDeviceToDevice, stream));
   return EZ_OK;
@@ -675,8 +702,10 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
   const void* gfeatT = ws.gfeat;
   if (dt != EZCLIP_F32) { EZ_TRY(cast_from_f32(ws.gfeat, ws.gfeatT, (int64_t)B * E, dt, stream)); gfeatT = ws.gfeatT; }
   // feat = ln_post(x[:,0]) @ proj                                         :248-251
-  EZ_TRY(dgrad(m, gfeatT, E, m->vproj_w, ws.gcls, W, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
   EZ_TRY(wgrad(m, gfeatT, E, ws.cls_ln, W, m->vproj_w, B, stream));
+  if (m->Gp(m->vproj_b)) EZ_TRY(colsum_add(ws.gfeat, E, B, E, m->Gp(m->vproj_b), EZCLIP_F32, stream));
+  if (m->opt_vision_frozen) return EZ_OK;      // image_embeds = vision_outputs[1].detach()   appzoo/clip/model.py:140
+  EZ_TRY(dgrad(m, gfeatT, E, m->vproj_w, ws.gcls, W, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
   EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * W * esz, stream));
   const void* xl = ws.layers[m->cfg.vision_layers - 1].x_out;
   // (gx is zero outside the CLS rows: its column sums are the last block's c_proj bias gradient)
@@ -737,7 +766,7 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
 }
 
 int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float* d_emb, void* wsp, size_t ws_bytes,
-                  hipStream_t stream) {
+                  hipStream_t stream, const TextExtras* ex) {
   EZ_REQUIRE(B > 0 && L > 0 && ids && d_emb && wsp, "backward_text: null/empty argument");
   EZ_REQUIRE(m->weights_fresh && m->shadow_backward, "backward_text: weights not packed for backward");
   TxtWS ws;
@@ -756,9 +785,20 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
   if (dt != EZCLIP_F32) { EZ_TRY(cast_from_f32(ws.gfeat, ws.gfeatT, (int64_t)B * E, dt, stream)); gfeatT = ws.gfeatT; }
   // feat = x[:, 0, :] @ text_projection                                                               :349-350
   const void* xl = ws.layers[m->cfg.text_num_hidden_layers - 1].x_out;
+  const TextExtras none;
+  if (ex == nullptr) ex = &none;
   EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * H * esz, stream));
-  EZ_TRY(dgrad(m, gfeatT, E, m->tproj_w, ws.gx, (int64_t)L * H, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
-  EZ_TRY(wgrad(m, gfeatT, E, xl, (int64_t)L * H, m->tproj_w, B, stream));
+  if (m->Gp(m->tproj_b)) EZ_TRY(colsum_add(ws.gfeat, E, B, E, m->Gp(m->tproj_b), EZCLIP_F32, stream));
+  if (m->opt_text_pooler) {
+    // feat = proj(tanh(u)), u = pooler.dense(x[:, 0]):  d u = (d feat . W_proj) o tanh'(u)  (+ pooler bias gradient)
+    EZ_TRY(dgrad(m, gfeatT, E, m->tproj_w, ws.gpool, H, B, ws.pool_u, H, ACT_TANH, nullptr, 0, stream, m->pool_b));
+    EZ_TRY(wgrad(m, gfeatT, E, ws.pool, H, m->tproj_w, B, stream));
+    EZ_TRY(dgrad(m, ws.gpool, H, m->pool_w, ws.gx, (int64_t)L * H, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
+    EZ_TRY(wgrad(m, ws.gpool, H, xl, (int64_t)L * H, m->pool_w, B, stream));
+  } else {
+    EZ_TRY(dgrad(m, gfeatT, E, m->tproj_w, ws.gx, (int64_t)L * H, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
+    EZ_TRY(wgrad(m, gfeatT, E, xl, (int64_t)L * H, m->tproj_w, B, stream));
+  }
   for (int i = m->cfg.text_num_hidden_layers - 1; i >= 0; --i) {
     const auto& Lw = m->bert[i];
     const BertBufs& b = ws.layers[i];
@@ -816,10 +856,20 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
   }
   // embeddings: dropout(LN(word[ids] + type[0] + pos[t]))                       modeling_bert.py:117-128
   if (hp > 0.f) EZ_TRY(dropout_rows(ws.gx, H, nullptr, 0, ws.gx, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream));
-  EZ_TRY(ln_bwd(m, ws.x0, H, ws.gx, H, m->eln_w, m->eln_b, ws.m0, ws.r0, ws.gx2, H, nullptr, 0, M, H, stream, m->type_p));
-  if (m->Gp(m->word_p)) EZ_TRY(bert_word_grad(ids, ws.gx2, m->Gp(m->word_p), M, H, m->cfg.vocab_size, dt, stream));
-  if (m->Gp(m->tpos_p)) EZ_TRY(batch_sum_add(ws.gx2, B, L, L, H, m->Gp(m->tpos_p), dt, stream));
-  // (token-type embedding gradient = column sums of gx2: accumulated by the ln_bwd above; only type 0 is used)
+  // token-type gradient: with the default all-zero types it is the column sum of gx2 into row 0 (fused into ln_bwd)
+  EZ_TRY(ln_bwd(m, ws.x0, H, ws.gx, H, m->eln_w, m->eln_b, ws.m0, ws.r0, ws.gx2, H, nullptr, 0, M, H, stream,
+                ex->type_ids ? -1 : m->type_p));
+  if (ex->type_ids && m->Gp(m->type_p))
+    EZ_TRY(bert_word_grad(ex->type_ids, ws.gx2, m->Gp(m->type_p), M, H, m->cfg.text_type_vocab_size, dt, stream, -1));
+  if (m->Gp(m->word_p))
+    EZ_TRY(bert_word_grad(ids, ws.gx2, m->Gp(m->word_p), M, H, m->cfg.vocab_size, dt, stream, m->text_pad_id));
+  if (m->Gp(m->tpos_p)) {
+    if (ex->pos_ids)    // RobertaEmbeddings: nn.Embedding(max_pos, H, padding_idx=pad_token_id)
+      EZ_TRY(bert_word_grad(ex->pos_ids, ws.gx2, m->Gp(m->tpos_p), M, H, m->cfg.text_max_position_embeddings, dt, stream,
+                            m->text_pad_id));
+    else
+      EZ_TRY(batch_sum_add(ws.gx2, B, L, L, H, m->Gp(m->tpos_p), dt, stream));
+  }
   return EZ_OK;
 }
 

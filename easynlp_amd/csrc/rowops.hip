@@ -332,17 +332,26 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const T* patch, co
   if (mean_o != nullptr && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
 
+// pos_ids / type_ids / attn_mask: optional [B, L] int64 (RobertaEmbeddings: pad-aware position ids, roberta/modeling_roberta.py:
+// 1497-1510; explicit token types and mask as the huggingface_clip branch passes them, appzoo/clip/model.py:131-133).
+// Defaults: position t, type 0, mask = ids != 0 (chinese_clip, modeling_chineseclip.py:347).
 template <typename T>
-__global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int64_t* ids, const float* word, const float* pos,
+__global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                                                             const int64_t* attn_mask, const float* word, const float* pos,
                                                              const float* type, const float* g, const float* b,
                                                              float eps, T* x0, T* y, float* mean_o, float* rstd_o,
-                                                             float* key_bias, int B, int L, int Hd, int vocab) {
+                                                             float* key_bias, int B, int L, int Hd, int vocab, int max_pos,
+                                                             int type_vocab) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
   if (row >= (int64_t)B * L) return;
-  const int t = (int)(row % L);
+  int64_t t = pos_ids ? pos_ids[row] : row % L;
+  t = t < 0 ? 0 : (t >= max_pos ? max_pos - 1 : t);
+  int64_t ty = type_ids ? type_ids[row] : 0;
+  ty = ty < 0 ? 0 : (ty >= type_vocab ? type_vocab - 1 : ty);
   int64_t id = ids[row];
-  if (lane == 0) key_bias[row] = (id == 0) ? -10000.0f : 0.0f;
+  const bool masked = attn_mask ? attn_mask[row] == 0 : id == 0;
+  if (lane == 0) key_bias[row] = masked ? -10000.0f : 0.0f;
   if (id < 0) id = 0;
   if (id >= vocab) id = vocab - 1;
   float v[kMaxChunks][4];
@@ -352,8 +361,8 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int64_t* ids, 
     if (col < Hd) {
       float wv[4], pv[4], tv[4];
       ld4(word + id * Hd + col, wv);
-      ld4(type + col, tv);
-      ld4(pos + (int64_t)t * Hd + col, pv);
+      ld4(type + ty * Hd + col, tv);
+      ld4(pos + t * Hd + col, pv);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[c][e] = (wv[e] + tv[e]) + pv[e];
       if (x0 != nullptr) st4(x0 + row * Hd + col, v[c]);
@@ -478,12 +487,12 @@ __global__ void vit_gather_patch_rows_kernel(const T* dx0, T* dpemb, int B, int 
 // (nn.Embedding(padding_idx=0), bert/modeling_bert.py:77)
 template <typename T>
 __global__ __launch_bounds__(256) void bert_word_grad_kernel(const int64_t* ids, const T* dx0, float* dword, int64_t rows,
-                                                              int Hd, int vocab) {
+                                                              int Hd, int vocab, int64_t pad_id) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int64_t id = ids[row];
-  if (id <= 0 || id >= vocab) return;
+  if (id < 0 || id >= vocab || id == pad_id) return;     // nn.Embedding(padding_idx=pad_id): no gradient for that row
 #pragma unroll
   for (int c = 0; c < kMaxChunks; ++c) {
     const int col = (lane + c * 64) * 4;
@@ -633,12 +642,14 @@ int vit_assemble_ln(const void* patch, const float* cls, const float* pos, const
 
 int bert_embed_ln(const int64_t* ids, const float* word, const float* pos, const float* type, const float* g,
                   const float* b, float eps, void* x0, void* y, float* mean, float* rstd, float* key_bias, int B,
-                  int L, int Hd, int vocab, int dtype, hipStream_t stream) {
+                  int L, int Hd, int vocab, int dtype, hipStream_t stream, const int64_t* pos_ids, const int64_t* type_ids,
+                  const int64_t* attn_mask, int max_pos, int type_vocab) {
   EZ_REQUIRE(Hd % 4 == 0 && Hd <= 256 * kMaxChunks, "bert_embed_ln: hidden %d unsupported", Hd);
   const int64_t rows = (int64_t)B * L;
   const int blocks = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
-  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((bert_embed_ln_kernel<T>), dim3(blocks), dim3(256), 0, stream, ids, word, pos,
-                                          type, g, b, eps, (T*)x0, (T*)y, mean, rstd, key_bias, B, L, Hd, vocab));
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((bert_embed_ln_kernel<T>), dim3(blocks), dim3(256), 0, stream, ids, pos_ids, type_ids,
+                                          attn_mask, word, pos, type, g, b, eps, (T*)x0, (T*)y, mean, rstd, key_bias, B, L, Hd,
+                                          vocab, max_pos, type_vocab));
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }
@@ -691,10 +702,10 @@ int vit_gather_patch_rows(const void* dx0, void* dpemb, int B, int Lv, int W, in
 }
 
 int bert_word_grad(const int64_t* ids, const void* dx0, float* dword, int64_t rows, int Hd, int vocab, int dtype,
-                   hipStream_t stream) {
+                   hipStream_t stream, int64_t pad_id) {
   const int blocks = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
   EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((bert_word_grad_kernel<T>), dim3(blocks), dim3(256), 0, stream, ids,
-                                          (const T*)dx0, dword, rows, Hd, vocab));
+                                          (const T*)dx0, dword, rows, Hd, vocab, pad_id));
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libezclip_hip.so")
 
 DTYPE_F32 = 0
 DTYPE_BF16 = 1
-ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
+ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF, ACT_TANH = 0, 1, 2, 3
+OPT_TEXT_POOLER, OPT_VISION_FROZEN, OPT_TEXT_LN_EPS, OPT_TEXT_PAD_ID = 1, 2, 3, 4
 
 
 class EzclipError(RuntimeError):
@@ -75,6 +76,9 @@ SIGNATURES = {
     "ezclip_preprocess_images": (_i, [_vp, C.POINTER(EzclipImageDesc), _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp,
                                       _sz, _vp]),
     "ezclip_op_resample_table": (_i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i]),
+    "ezclip_set_option": (_i, [_vp, _i, C.c_double]),
+    "ezclip_encode_text_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _i, _vp]),
+    "ezclip_backward_text_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ezclip_set_text_dropout": (_i, [_vp, _f, _f, C.c_uint64]),
     "ezclip_op_dropout": (_i, [_vp, _vp, _vp, _i, _i, _f, C.c_uint64, C.c_uint32, _i, _vp]),
     "ezclip_op_dropout_mask": (_i, [_f, C.c_uint64, C.c_uint32, _i, _i, _vp, _vp, _vp]),

@@ -52,6 +52,7 @@ extern "C" {
 #define EZCLIP_ACT_NONE 0
 #define EZCLIP_ACT_QUICKGELU 1
 #define EZCLIP_ACT_GELU_ERF 2
+#define EZCLIP_ACT_TANH 3
 
 /* CHINESE_CLIP constructor kwargs (modeling_chineseclip.py:256-276) + compute dtype. */
 typedef struct ezclip_config {
@@ -92,6 +93,33 @@ int ezclip_bind_param(ezclip_handle h, const char* name, void* weight_dev, void*
 size_t ezclip_shadow_bytes(ezclip_handle h, int with_backward);
 int ezclip_set_shadow(ezclip_handle h, void* shadow_dev, size_t bytes, int with_backward);
 int ezclip_refresh_weights(ezclip_handle h, void* stream);
+
+/* ---- huggingface_clip branch of CLIPApp (easynlp/appzoo/clip/model.py:73-104,128-144) -------------------------
+ * The same towers under other parameter names (the host layer maps them) plus four differences handled here:
+ *   EZCLIP_OPT_TEXT_POOLER   1: text feature = text_projection(tanh(bert.pooler.dense(x[:, 0]))) -- RobertaModel's pooled
+ *                               output text_outputs[1] (model.py:134; roberta/modeling_roberta.py:550-562)
+ *   EZCLIP_OPT_VISION_FROZEN 1: image_embeds = vision_outputs[1].detach() (model.py:140): ezclip_backward_image stops
+ *                               after the projection (weight / bias gradients only)
+ *   EZCLIP_OPT_TEXT_LN_EPS      layer_norm_eps of the text tower (default 1e-12)
+ *   EZCLIP_OPT_TEXT_PAD_ID      padding_idx of the word / position embeddings (no gradient for that row; default 0)
+ * and two optional parameters "visual.proj_bias" / "text_projection_bias" [embed_dim] (vision_projection /
+ * text_projection are nn.Linear with bias there); unbound = no bias. */
+#define EZCLIP_OPT_TEXT_POOLER 1
+#define EZCLIP_OPT_VISION_FROZEN 2
+#define EZCLIP_OPT_TEXT_LN_EPS 3
+#define EZCLIP_OPT_TEXT_PAD_ID 4
+int ezclip_set_option(ezclip_handle h, int key, double value);
+/* ezclip_encode_text / ezclip_backward_text with the per-token inputs RobertaModel takes (model.py:131-133): device
+ * int64 [batch, seq_len] each, any may be NULL: position_ids (default 0..L-1; RobertaEmbeddings' pad-aware ids
+ * cumsum(ids != pad) * (ids != pad) + pad are computed by the caller, roberta/modeling_roberta.py:1497-1510),
+ * token_type_ids (default 0), attention_mask (default ids != 0). */
+int ezclip_encode_text_ex(ezclip_handle h, const int64_t* input_ids_dev, const int64_t* position_ids_dev,
+                          const int64_t* token_type_ids_dev, const int64_t* attention_mask_dev, int batch, int seq_len,
+                          float* out_embeds_dev, void* workspace_dev, size_t workspace_bytes, int save_for_backward,
+                          void* stream);
+int ezclip_backward_text_ex(ezclip_handle h, const int64_t* input_ids_dev, const int64_t* position_ids_dev,
+                            const int64_t* token_type_ids_dev, const int64_t* attention_mask_dev, int batch, int seq_len,
+                            const float* d_embeds_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Train-mode dropout of the BERT text tower: nn.Dropout(hidden_dropout_prob) after the embedding LayerNorm, after
  * BertSelfOutput.dense and BertOutput.dense, nn.Dropout(attention_probs_dropout_prob) on the attention probabilities

@@ -53,7 +53,9 @@ def test_param_table_matches_reference_state_dict(cfg_name, dtype):
     for i in range(n):
         assert lib.ezclip_param_info(h, i, C.byref(name), shape, C.byref(ndim)) == 0
         got[name.value.decode()] = tuple(shape[j] for j in range(ndim.value))
-    assert got == shapes
+    # (+ the two optional projection biases of the huggingface_clip branch, include/ezclip.h)
+    E = O.CONFIGS[cfg_name]["embed_dim"]
+    assert got == dict(shapes, **{"visual.proj_bias": (E,), "text_projection_bias": (E,)})
     # workspace sizes are monotone in batch and larger with save_for_backward
     a = lib.ezclip_image_workspace_bytes(h, 2, 0)
     b = lib.ezclip_image_workspace_bytes(h, 4, 0)

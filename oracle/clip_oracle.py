@@ -320,7 +320,8 @@ def apply_dropout(x, keep, p):
     return x * keep.to(x.dtype) * (1.0 / (1.0 - p))
 
 
-def bert_forward(sd, cfg, input_ids, taps: Optional[dict] = None, dropout: Optional[dict] = None):
+def bert_forward(sd, cfg, input_ids, taps: Optional[dict] = None, dropout: Optional[dict] = None,
+                 position_ids=None, token_type_ids=None, attention_mask=None, ln_eps: float = None):
     """``dropout`` (train mode, modeling_bert.py:128,238,266,344): ``{"p_hidden", "p_attn", "masks"}`` with keep masks
     ``masks["emb"]`` [B,L,H], ``masks[f"{i}.attn"]`` [B,heads,L,L], ``masks[f"{i}.self_out"]`` / ``masks[f"{i}.out"]``
     [B,L,H] -- explicit masks instead of an RNG stream, so that any implementation's masks can be replayed here.
@@ -336,12 +337,17 @@ def bert_forward(sd, cfg, input_ids, taps: Optional[dict] = None, dropout: Optio
     H = cfg["text_hidden_size"]
     heads = cfg["text_num_attention_heads"]
     hd = H // heads
-    mask = input_ids.ne(0).to(dt)                               # chineseclip:347-348
+    # (huggingface_clip branch: RobertaModel is called with explicit token types and mask, and RobertaEmbeddings derives
+    #  pad-aware position ids -- the three optional arguments; hf_clip_oracle.py passes them)
+    eps = BERT_LN_EPS if ln_eps is None else ln_eps
+    mask = (input_ids.ne(0) if attention_mask is None else attention_mask.ne(0)).to(dt)    # chineseclip:347-348
     key_bias = (1.0 - mask) * -10000.0                          # modeling_utils.py:438-439
-    x = (sd["bert.embeddings.word_embeddings.weight"][input_ids]
-         + sd["bert.embeddings.token_type_embeddings.weight"][0]
-         + sd["bert.embeddings.position_embeddings.weight"][:L])   # modeling_bert.py:117-125
-    x = layer_norm(x, sd["bert.embeddings.LayerNorm.weight"], sd["bert.embeddings.LayerNorm.bias"], BERT_LN_EPS)
+    tt = (sd["bert.embeddings.token_type_embeddings.weight"][0] if token_type_ids is None
+          else sd["bert.embeddings.token_type_embeddings.weight"][token_type_ids])
+    pe = (sd["bert.embeddings.position_embeddings.weight"][:L] if position_ids is None
+          else sd["bert.embeddings.position_embeddings.weight"][position_ids])
+    x = sd["bert.embeddings.word_embeddings.weight"][input_ids] + tt + pe   # modeling_bert.py:117-125
+    x = layer_norm(x, sd["bert.embeddings.LayerNorm.weight"], sd["bert.embeddings.LayerNorm.bias"], eps)
     dm = dropout["masks"] if dropout is not None else None
     ph = dropout["p_hidden"] if dropout is not None else 0.0
     pa = dropout["p_attn"] if dropout is not None else 0.0
@@ -367,13 +373,13 @@ def bert_forward(sd, cfg, input_ids, taps: Optional[dict] = None, dropout: Optio
             so = apply_dropout(so, dm[f"{i}.self_out"], ph)                          # :266
         a = layer_norm(so + x,
                        sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"],
-                       BERT_LN_EPS)                                                  # :264-267
+                       eps)                                                  # :264-267
         h = gelu_erf(linear(a, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))  # :330-331
         o = linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
         if dm is not None and ph > 0:
             o = apply_dropout(o, dm[f"{i}.out"], ph)                                 # :344
         x = layer_norm(o + a,
-                       sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], BERT_LN_EPS)  # :342-345
+                       sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], eps)  # :342-345
         if taps is not None:
             taps[f"bert.{i}.ctx"] = ctx
             taps[f"bert.{i}.out"] = x

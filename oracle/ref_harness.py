@@ -103,3 +103,17 @@ def reference_clip_app(ckpt_dir: str):
     install_shims()
     from easynlp.appzoo.clip.model import CLIPApp
     return CLIPApp(ckpt_dir)
+
+
+def write_hf_checkpoint_dir(path: str, cfg: dict, state_dict: dict) -> None:
+    """Synthetic checkpoint of the huggingface_clip flavour (appzoo/clip/model.py:73-104): config.json with
+    text_config / vision_config (no model_type), pytorch_model.bin with ``text_encoder.*`` / ``vision_encoder.*`` /
+    ``text_projection.*`` / ``vision_projection.*`` / ``logit_scale`` keys, a toy vocab.txt."""
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    torch.save(dict(state_dict), os.path.join(path, "pytorch_model.bin"))
+    with open(os.path.join(path, "vocab.txt"), "w") as f:
+        toks = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+        toks += ["tok%d" % i for i in range(cfg["text_config"]["vocab_size"] - len(toks))]
+        f.write("\n".join(toks) + "\n")

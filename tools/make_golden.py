@@ -139,6 +139,46 @@ def run_dropout_case(name="tiny_dropout_b6_l24", cfg_name="tiny", B=6, L=24, wse
     print(name, "loss", loss.item(), "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def run_hf_case(name, cfg_name, B, L, wseed, iseed, full):
+    """The REAL reference CLIPApp in huggingface_clip mode (appzoo/clip/model.py:73-104,128-150: RobertaModel pooled
+    output + CLIPVisionModel pooled output detached + biased projections), loaded from a synthetic checkpoint directory:
+    outputs, loss (CLIPApp.compute_loss) and the gradient of every parameter."""
+    import tempfile
+    from oracle import hf_clip_oracle as H
+    R.install_shims()
+    from easynlp.appzoo.clip.model import CLIPApp
+    torch.manual_seed(0)
+    cfg = H.HF_CONFIGS[cfg_name]
+    sd = H.make_state_dict(cfg, wseed)
+    d = tempfile.mkdtemp()
+    R.write_hf_checkpoint_dir(d, cfg, sd)
+    app = CLIPApp(d)
+    assert app.model_type == "huggingface_clip"
+    app.eval()
+    px, ids, tt, am = H.make_inputs(cfg, B, L, iseed)
+    fo = app({"pixel_values": px, "input_ids": ids, "token_type_ids": tt, "attention_mask": am})
+    loss = app.compute_loss(fo, [])["loss"]
+    loss.backward()
+    out = {"meta": np.array([cfg_name, str(B), str(L), str(wseed), str(iseed), torch.__version__, np.__version__]),
+           "image_embeds": fo["image_embeds"].detach().numpy(), "text_embeds": fo["text_embeds"].detach().numpy(),
+           "logits_per_text": fo["logits_per_text"].detach().numpy(), "loss": np.float32(loss.item())}
+    for n, p in app.named_parameters():
+        if p.grad is None:
+            out["nograd/" + n] = np.zeros(0, np.float32)
+        elif full:
+            out["grad/" + n] = p.grad.numpy()
+        else:
+            norm, samp, idx = grad_digest(p.grad)
+            out["gnorm/" + n] = np.float64(norm)
+            out["gsamp/" + n] = samp
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "loss", loss.item(), "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+HF_CASES = [("hf_tiny_b6_l24", "hf_tiny", 6, 24, 1234, 3, True), ("hf_small_b5_l40", "hf_small", 5, 40, 99, 7, False)]
+
+
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     only = sys.argv[1:]
@@ -148,3 +188,6 @@ if __name__ == "__main__":
         run_case(*case)
     if not only or "tiny_dropout_b6_l24" in only:
         run_dropout_case()
+    for case in HF_CASES:
+        if not only or case[0] in only:
+            run_hf_case(*case)

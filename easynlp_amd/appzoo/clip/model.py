@@ -125,7 +125,7 @@ class HipClipEngine:
         load_state_dict bump ``_version``)."""
         plist = [params[n] for n in self.names]
         bind_sig = (tuple(p.data_ptr() for p in plist),
-                    None if grads is None else tuple(grads[n].data_ptr() for n in self.names))
+                    None if grads is None else tuple((grads[n].data_ptr() if grads.get(n) is not None else 0) for n in self.names))
         dev = plist[0].device
         rebound = False
         if bind_sig != self._bind_sig:
@@ -183,15 +183,21 @@ class HipClipEngine:
                                              1 if save else 0, L.stream_ptr()), "encode_image")
         return out, ws
 
-    def encode_text(self, ids: torch.Tensor, save: bool) -> (torch.Tensor, torch.Tensor):
+    def encode_text(self, ids: torch.Tensor, save: bool, extras=None) -> (torch.Tensor, torch.Tensor):
+        """extras: (position_ids, token_type_ids, attention_mask) int64 [B, S] device tensors (huggingface_clip branch)"""
         ids = ids.contiguous()
         if ids.dtype != torch.int64:
             ids = ids.long()
         B, S = ids.shape
         out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=ids.device)
         ws = self.workspace("text", B, S, save, ids.device)
-        L.check(self.lib.ezclip_encode_text(self.handle, L.ptr(ids), B, S, L.ptr(out), L.ptr(ws), ws.numel(),
-                                            1 if save else 0, L.stream_ptr()), "encode_text")
+        if extras is None:
+            L.check(self.lib.ezclip_encode_text(self.handle, L.ptr(ids), B, S, L.ptr(out), L.ptr(ws), ws.numel(),
+                                                1 if save else 0, L.stream_ptr()), "encode_text")
+        else:
+            pos, tt, am = extras
+            L.check(self.lib.ezclip_encode_text_ex(self.handle, L.ptr(ids), L.ptr(pos), L.ptr(tt), L.ptr(am), B, S, L.ptr(out),
+                                                   L.ptr(ws), ws.numel(), 1 if save else 0, L.stream_ptr()), "encode_text_ex")
         return out, ws
 
     def set_text_dropout(self, hidden_p: float, attn_p: float, seed: int) -> None:
@@ -203,10 +209,19 @@ class HipClipEngine:
         L.check(self.lib.ezclip_backward_image(self.handle, L.ptr(pixels), pixels.shape[0], L.ptr(d_emb.contiguous()),
                                                L.ptr(ws), ws.numel(), L.stream_ptr()), "backward_image")
 
-    def backward_text(self, ids, d_emb, ws):
-        L.check(self.lib.ezclip_backward_text(self.handle, L.ptr(ids), ids.shape[0], ids.shape[1],
-                                              L.ptr(d_emb.contiguous()), L.ptr(ws), ws.numel(), L.stream_ptr()),
-                "backward_text")
+    def backward_text(self, ids, d_emb, ws, extras=None):
+        if extras is None:
+            L.check(self.lib.ezclip_backward_text(self.handle, L.ptr(ids), ids.shape[0], ids.shape[1],
+                                                  L.ptr(d_emb.contiguous()), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                    "backward_text")
+        else:
+            pos, tt, am = extras
+            L.check(self.lib.ezclip_backward_text_ex(self.handle, L.ptr(ids), L.ptr(pos), L.ptr(tt), L.ptr(am), ids.shape[0],
+                                                     ids.shape[1], L.ptr(d_emb.contiguous()), L.ptr(ws), ws.numel(),
+                                                     L.stream_ptr()), "backward_text_ex")
+
+    def set_option(self, key: int, value: float) -> None:
+        L.check(self.lib.ezclip_set_option(self.handle, int(key), float(value)), "set_option")
 
 
 class _EncodeFn(torch.autograd.Function):
@@ -335,9 +350,21 @@ class CLIPApp(Application):
         path = pretrained_model_name_or_path
         with open(os.path.join(path, "config.json"), "r") as f:
             self.raw_config = json.load(f)
+        if self.raw_config.get("model_type") == "open_clip":
+            raise L.EzclipError("model_type 'open_clip' (causal text transformer) is not on the HIP path yet (SURVEY.md 8f)")
         if self.raw_config.get("model_type") != "chinese_clip":
-            raise L.EzclipError("the HIP path implements model_type == 'chinese_clip' (got %r); open_clip / "
-                                "huggingface_clip are listed as next in SURVEY.md 8f" % self.raw_config.get("model_type"))
+            # reference model.py:73: anything else is the huggingface_clip flavour (text_config / vision_config)
+            self.model_type = "huggingface_clip"
+            self._build_hf(self.raw_config)
+            ckpt = os.path.join(path, "pytorch_model.bin")
+            if os.path.exists(ckpt):
+                state = torch.load(ckpt, map_location="cpu")                              # model.py:78
+                own = self.state_dict()
+                missing = [k for k in self._hf_params if k not in state]
+                if missing:
+                    raise L.EzclipError("checkpoint lacks %d parameters, e.g. %s" % (len(missing), missing[:3]))
+                self.load_state_dict({k: v for k, v in state.items() if k in own}, strict=False)
+            return
         self.model_type = "chinese_clip"
         self.config = Config_Wrapper(self.raw_config)
         self._build(self.raw_config)
@@ -364,6 +391,63 @@ class CLIPApp(Application):
         self._engine = eng
         named = dict(tree.named_parameters())
         self._params = {n: named[n] for n in eng.names}
+
+    def _build_hf(self, raw: dict) -> None:
+        """huggingface_clip branch (model.py:73-104): reference-named parameters + the name map of hf_branch.py."""
+        from . import hf_branch as HB
+        ccfg = HB.chinese_style_config(raw)
+        tcfg = dict(raw.get("text_config", {}))
+        # dropout probabilities of the text tower live in text_config there (CLIPTextConfig)
+        self.raw_config = dict(raw, text_hidden_dropout_prob=ccfg["text_hidden_dropout_prob"],
+                               text_attention_probs_dropout_prob=ccfg["text_attention_probs_dropout_prob"],
+                               image_resolution=ccfg["image_resolution"])
+        self.config = Config_Wrapper(raw)
+        eng = HipClipEngine(ccfg, self.compute_dtype, hf_branch=True)
+        eng.set_option(L.OPT_TEXT_POOLER, 1)
+        eng.set_option(L.OPT_VISION_FROZEN, 1)
+        eng.set_option(L.OPT_TEXT_LN_EPS, float(tcfg.get("layer_norm_eps", 1e-12)))
+        self._hf_pad_id = int(tcfg.get("pad_token_id", 0))
+        eng.set_option(L.OPT_TEXT_PAD_ID, self._hf_pad_id)
+        tree_t, tree_v = _ParamTree(), _ParamTree()
+        self.text_projection, self.vision_projection = _ParamTree(), _ParamTree()
+        shapes = HB.reference_param_shapes(ccfg)
+        for n, shp in shapes.items():
+            t = torch.zeros(shp, dtype=torch.float32)
+            if n == "logit_scale":
+                self.logit_scale_param = nn.Parameter(t.fill_(float(torch.log(torch.tensor(1.0 / 0.07)))))   # model.py:104
+            elif n.startswith("text_encoder."):
+                tree_t.add(n[len("text_encoder."):], t)
+            elif n.startswith("vision_encoder."):
+                tree_v.add(n[len("vision_encoder."):], t)
+            elif n.startswith("text_projection."):
+                self.text_projection.add(n[len("text_projection."):], t)
+            else:
+                self.vision_projection.add(n[len("vision_projection."):], t)
+        # persistent buffers of the reference modules' state_dict
+        tree_t.add("embeddings.position_ids", torch.arange(ccfg["text_max_position_embeddings"]).expand((1, -1)).clone(), buffer=True)
+        Lv = (ccfg["image_resolution"] // ccfg["vision_patch_size"]) ** 2 + 1
+        tree_v.add("vision_model.embeddings.position_ids", torch.arange(Lv).expand((1, -1)).clone(), buffer=True)
+        self.text_encoder, self.vision_encoder = tree_t, tree_v
+        self._engine = eng
+        named = dict(self.named_parameters())
+        named["logit_scale"] = named.pop("logit_scale_param")
+        self._hf_params = {n: named[n] for n in shapes}
+        self._hf_param_order = list(shapes)
+        self._hf = HB.HFState(self, ccfg)
+        self._params = {"logit_scale": self._hf_params["logit_scale"], "text_projection": self._hf_params["text_projection.weight"]}
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        if getattr(self, "model_type", None) == "huggingface_clip":      # reference key: 'logit_scale' (model.py:102-104)
+            prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
+            sd = type(sd)((prefix + "logit_scale" if k == prefix + "logit_scale_param" else k, v) for k, v in sd.items())
+        return sd
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kwargs):
+        if getattr(self, "model_type", None) == "huggingface_clip" and "logit_scale" in state_dict:
+            state_dict = dict(state_dict)
+            state_dict["logit_scale_param"] = state_dict.pop("logit_scale").reshape(1)
+        return super().load_state_dict(state_dict, strict=strict, **kwargs)
 
     @classmethod
     def from_config(cls, config: dict, seed: int = 0, device="cuda", compute_dtype="bf16"):
@@ -412,6 +496,8 @@ class CLIPApp(Application):
         with a reduce-scatter.  Returns the (rank-local mean) loss tensor.
         """
         import torch.distributed as dist
+        if getattr(self, "model_type", None) == "huggingface_clip":
+            raise NotImplementedError("contrastive_step is the chinese_clip fast path; use forward / compute_loss")
         eng = self._engine
         lib = eng.lib
         params = self._params
@@ -492,7 +578,13 @@ class CLIPApp(Application):
         return [self._params[n] for n in self._engine.names]
 
     # ------------------------------------------------------------------------------------
-    def encode(self, pixel_values=None, input_ids=None):
+    def encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+        if getattr(self, "model_type", None) == "huggingface_clip":
+            from .hf_branch import HFEncodeFn
+            plist = [self._hf_params[n] for n in self._hf_param_order]
+            need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
+            img, txt = HFEncodeFn.apply(self, need_grad, pixel_values, input_ids, token_type_ids, attention_mask, *plist)
+            return (img if pixel_values is not None else None), (txt if input_ids is not None else None)
         plist = self._plist()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
         img, txt = _EncodeFn.apply(self, need_grad, pixel_values, input_ids, *plist)
@@ -510,7 +602,12 @@ class CLIPApp(Application):
             inputs["input_ids"] = None
         assert inputs["pixel_values"] is not None or inputs["input_ids"] is not None, \
             "text and image cannot both be None!"
-        image_embeds, text_embeds = self.encode(inputs["pixel_values"], inputs["input_ids"])
+        if getattr(self, "model_type", None) == "huggingface_clip" and inputs["input_ids"] is not None:
+            # RobertaModel(input_ids, token_type_ids, attention_mask): the reference requires both keys (model.py:131-133)
+            image_embeds, text_embeds = self.encode(inputs["pixel_values"], inputs["input_ids"],
+                                                    inputs["token_type_ids"].to(_device), inputs["attention_mask"].to(_device))
+        else:
+            image_embeds, text_embeds = self.encode(inputs["pixel_values"], inputs["input_ids"])
         if feat is True:
             return {"image_embeds": image_embeds, "text_embeds": text_embeds}
         logits_per_text = _SimilarityFn.apply(text_embeds, image_embeds, self.logit_scale)

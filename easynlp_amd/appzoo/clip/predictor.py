@@ -108,6 +108,9 @@ class CLIPPredictor(Predictor):
             output = {"pixel_values": torch.cat([d["pixel_values"] for d in in_data], dim=0)}
         if "input_ids" in in_data[0]:
             output = {"input_ids": torch.cat([d["input_ids"] for d in in_data], dim=0)}
+            for k in ("token_type_ids", "attention_mask"):                  # predictor.py:124-134 (huggingface_clip inputs)
+                if all(k in d for d in in_data):
+                    output[k] = torch.cat([d[k] for d in in_data], dim=0)
         with torch.no_grad():
             return self.multi_modal(output, feat=True)
 

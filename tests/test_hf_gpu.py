@@ -1,0 +1,131 @@
+"""huggingface_clip branch of the drop-in CLIPApp on the GPU (reference: appzoo/clip/model.py:73-104,128-150) against
+the fixtures produced by the REAL reference in that mode (tools/make_golden.py:run_hf_case) and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from easynlp_amd import lib as L
+from easynlp_amd.appzoo.clip import CLIPApp
+from oracle import hf_clip_oracle as H
+from oracle import ref_harness as R
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg_name, B, Lq, wseed, iseed = [str(x) for x in z["meta"][:5]]
+    return z, H.HF_CONFIGS[cfg_name], int(B), int(Lq), int(wseed), int(iseed)
+
+
+def make_app(tmp_path, cfg, seed, dtype):
+    sd = H.make_state_dict(cfg, seed)
+    R.write_hf_checkpoint_dir(str(tmp_path), cfg, sd)
+    app = CLIPApp(str(tmp_path), user_defined_parameters={"clip_compute_dtype": dtype}).cuda()
+    assert app.model_type == "huggingface_clip"
+    return app, sd
+
+
+@pytest.mark.parametrize("name", ["hf_tiny_b6_l24", "hf_small_b5_l40"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_hf_forward_and_backward_match_reference_golden(tmp_path, name, dtype):
+    z, cfg, B, Lq, wseed, iseed = load(name)
+    app, sd = make_app(tmp_path, cfg, wseed, dtype)
+    app.eval()      # (dropout probabilities of these fixtures are 0 anyway)
+    px, ids, tt, am = H.make_inputs(cfg, B, Lq, iseed)
+    out = app({"pixel_values": px, "input_ids": ids, "token_type_ids": tt, "attention_mask": am})
+    loss = app.compute_loss(out, [])["loss"]
+    loss.backward()
+    f32 = dtype == "fp32"
+    for k in ("image_embeds", "text_embeds"):
+        err = float((out[k].detach().cpu() - torch.from_numpy(z[k])).abs().max())
+        assert err < (1e-5 if f32 else 1e-2), (k, err)
+    assert float((out["logits_per_text"].detach().cpu() - torch.from_numpy(z["logits_per_text"])).abs().max()) < (4e-4 if f32 else 0.15)
+    assert abs(loss.item() - float(z["loss"])) < (1e-5 if f32 else 1.5e-2)
+    params = dict(app.named_parameters())
+    params["logit_scale"] = params.pop("logit_scale_param")
+    # same-shape scale of the text tower for the bf16 bound
+    scale = {}
+    for key in z.files:
+        if key.startswith(("grad/", "gnorm/")):
+            n = key.split("/", 1)[1]
+            gn = float(np.linalg.norm(z[key].astype(np.float64))) if key.startswith("grad/") else float(z[key])
+            sk = (n.split(".")[0], tuple(params[n].shape))
+            scale[sk] = max(scale.get(sk, 0.0), gn)
+    bad, seen = [], 0
+    for key in z.files:
+        if "/" not in key:
+            continue
+        kind, n = key.split("/", 1)
+        p = params[n]
+        if kind == "nograd":
+            assert n.startswith("vision_encoder.") and p.grad is None, n      # vision_outputs[1].detach()
+            continue
+        if kind not in ("grad", "gnorm"):
+            continue
+        seen += 1
+        assert p.grad is not None, n
+        floor = 0.0 if f32 else 2e-2 * scale[(n.split(".")[0], tuple(p.shape))]
+        if kind == "grad":
+            ref = torch.from_numpy(z[key]).double().reshape(p.shape)
+            err = float((p.grad.detach().cpu().double() - ref).norm())
+            if err > (2e-4 if f32 else 6e-2) * float(ref.norm()) + floor + 1e-7:
+                bad.append((n, err, float(ref.norm())))
+        else:
+            ref, got = float(z[key]), float(p.grad.double().norm())
+            if abs(got - ref) > (2e-4 if f32 else 6e-2) * ref + floor + 1e-7:
+                bad.append((n, got, ref))
+    assert seen > 30 and not bad, bad[:10]
+    pad = cfg["text_config"]["pad_token_id"]
+    assert float(params["text_encoder.embeddings.word_embeddings.weight"].grad[pad].abs().max()) == 0.0
+    assert float(params["text_encoder.embeddings.position_embeddings.weight"].grad[pad].abs().max()) == 0.0
+
+
+def test_hf_parameter_updates_reach_the_packed_copies(tmp_path):
+    """in_proj = [q; k; v] and the transposed projections are derived copies: an in-place update of a source parameter
+    (optimizer step, load_state_dict) must show up in the next forward."""
+    cfg = H.HF_CONFIGS["hf_tiny"]
+    app, sd = make_app(tmp_path, cfg, 7, "fp32")
+    app.eval()
+    px, ids, tt, am = H.make_inputs(cfg, 3, 10, 1)
+    batch = lambda: {"pixel_values": px, "input_ids": ids, "token_type_ids": tt, "attention_mask": am}   # noqa: E731
+    with torch.no_grad():
+        a = app(batch(), feat=True)
+        ref = H.hf_clip_forward(sd, cfg, px, ids, tt, am)
+        assert float((a["image_embeds"].cpu() - ref["image_embeds"]).abs().max()) < 2e-5
+        assert float((a["text_embeds"].cpu() - ref["text_embeds"]).abs().max()) < 2e-5
+        g = torch.Generator().manual_seed(0)
+        sd2 = dict(sd)
+        for k in ("vision_encoder.vision_model.encoder.layers.0.self_attn.k_proj.weight", "vision_projection.weight",
+                  "text_projection.weight", "text_encoder.pooler.dense.bias"):
+            sd2[k] = sd[k] + 0.05 * torch.randn(sd[k].shape, generator=g)
+            dict(app.named_parameters())[k].copy_(sd2[k].cuda())
+        b = app(batch(), feat=True)
+        ref2 = H.hf_clip_forward(sd2, cfg, px, ids, tt, am)
+        assert float((ref2["image_embeds"] - ref["image_embeds"]).abs().max()) > 1e-3
+        assert float((b["image_embeds"].cpu() - ref2["image_embeds"]).abs().max()) < 2e-5
+        assert float((b["text_embeds"].cpu() - ref2["text_embeds"]).abs().max()) < 2e-5
+    # single-modality calls, and the reference's KeyError when the tokenizer outputs are missing
+    with torch.no_grad():
+        only_img = app({"pixel_values": px}, feat=True)
+        assert only_img["text_embeds"] is None
+        with pytest.raises(KeyError):
+            app({"input_ids": ids}, feat=True)
+    sd_out = app.state_dict()
+    assert set(sd_out) == set(H.param_shapes(cfg)) | {"text_encoder.embeddings.position_ids",
+                                                      "vision_encoder.vision_model.embeddings.position_ids"}
+
+
+def test_hf_predictor_and_evaluator_surface(tmp_path):
+    from easynlp_amd.appzoo.clip import CLIPPredictor
+    cfg = H.HF_CONFIGS["hf_tiny"]
+    sd = H.make_state_dict(cfg, 3)
+    R.write_hf_checkpoint_dir(str(tmp_path), cfg, sd)
+    pred = CLIPPredictor(str(tmp_path), first_sequence="text", second_sequence="image", sequence_length=12)
+    out = pred.run([{"text": "tok7 tok9 tok11"}, {"text": "tok8"}])
+    assert len(out) == 2 and "text_feat" in out[0]
+    v = np.array([float(x) for x in out[0]["text_feat"].split("\t")])
+    assert abs(np.linalg.norm(v) - 1.0) < 1e-3

@@ -43,12 +43,23 @@ VITB16_BERTBASE = dict(
 # BASELINE.json config 5: ViT-L/14 + hfl/chinese-roberta-wwm-ext (BERT-base architecture), 512 pairs per GPU
 VITL14_ROBERTA = dict(VITB16_BERTBASE, embed_dim=768, vision_layers=24, vision_width=1024, vision_patch_size=14)
 
+# the same towers as a huggingface_clip checkpoint (pai-clip-commercial-large style, BASELINE.json config 5 as the reference
+# actually runs it: RobertaModel pooled output, CLIPVisionModel DETACHED -- only the text tower and the projections train)
+HF_VITL14_ROBERTA = dict(
+    text_config=dict(vocab_size=21128, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                     max_position_embeddings=512, type_vocab_size=2, pad_token_id=0, layer_norm_eps=1e-12, hidden_act="gelu",
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0),
+    vision_config=dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=224,
+                       patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5),
+    projection_dim=768)
+
 WORKLOADS = {
     "bf16_b1024_fwd_loss": dict(dtype="bf16", batch=1024, seq=64, backward=False),
     "bf16_b1024_train": dict(dtype="bf16", batch=1024, seq=64, backward=True),
     "fp32_b256_fwd_sim": dict(dtype="fp32", batch=256, seq=64, backward=False),
     "bf16_vitl14_b512_fwd_loss": dict(dtype="bf16", batch=512, seq=64, backward=False, model="vitl14"),
     "bf16_vitl14_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="vitl14"),
+    "bf16_hf_vitl14_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="hf_vitl14"),
 }
 
 # algorithmic GFLOP per pair (multiply-add = 2; padded tiles and softmax/LN excluded)
@@ -56,6 +67,7 @@ GFLOP_FWD_PER_PAIR = 46.152
 GFLOP_TRAIN_PER_PAIR = 138.46
 GFLOP_FWD_PER_PAIR_VITL14 = 173.05      # ViT-L/14 (L = 257) + BERT-base text tower, 64 tokens
 GFLOP_TRAIN_PER_PAIR_VITL14 = 519.2
+GFLOP_TRAIN_PER_PAIR_HF_VITL14 = 162.03 + 3 * 11.025      # frozen vision tower: forward only; text tower fwd + bwd
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 
 # launches of the dominant kernel in one forward step at 1024 pairs (shape names of tools/gemm_bench):
@@ -138,6 +150,8 @@ def main():
     ap.add_argument("--workload", default="bf16_b1024_fwd_loss", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--text-dropout", type=float, default=0.0,
+                    help="BERT hidden / attention dropout probability and train() mode (reference default 0.1; BASELINE runs 0)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,8 +183,17 @@ def main():
     model_cfg = VITL14_ROBERTA if wl.get("model") == "vitl14" else VITB16_BERTBASE
     model_name = ("ViT-L/14 + chinese-roberta-wwm-ext (BERT-base arch)" if wl.get("model") == "vitl14"
                   else "ViT-B/16 + BERT-base") + " (chinese_clip), random init"
-    app = CLIPApp.from_config(model_cfg, seed=1234, device=device, compute_dtype=wl["dtype"])
+    if args.text_dropout > 0:
+        model_cfg = dict(model_cfg, text_hidden_dropout_prob=args.text_dropout,
+                         text_attention_probs_dropout_prob=args.text_dropout)
+    if wl.get("model") == "hf_vitl14":
+        app = CLIPApp.from_hf_config(HF_VITL14_ROBERTA, seed=1234, device=device, compute_dtype=wl["dtype"])
+        model_name = "huggingface_clip: frozen ViT-L/14 + chinese-roberta-wwm-ext (BERT-base arch) + pooler, random init"
+    else:
+        app = CLIPApp.from_config(model_cfg, seed=1234, device=device, compute_dtype=wl["dtype"])
     app.eval()
+    if args.text_dropout > 0:
+        app.train()
     px, ids = synth_batch(B, S, VITB16_BERTBASE["vocab_size"], device, seed=1000 + rank)
     pg = True if world > 1 else False
 
@@ -242,12 +265,14 @@ def main():
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / elapsed
-        if wl.get("model") == "vitl14":
+        if wl.get("model") == "hf_vitl14":
+            gflop = GFLOP_TRAIN_PER_PAIR_HF_VITL14
+        elif wl.get("model") == "vitl14":
             gflop = GFLOP_TRAIN_PER_PAIR_VITL14 if wl["backward"] else GFLOP_FWD_PER_PAIR_VITL14
         else:
             gflop = GFLOP_TRAIN_PER_PAIR if wl["backward"] else GFLOP_FWD_PER_PAIR
         out = {
-            "metric": "image-text pairs/sec (fwd+loss) " + ("ViT-L/14+roberta-wwm-ext" if wl.get("model") == "vitl14"
+            "metric": "image-text pairs/sec (fwd+loss) " + ("ViT-L/14+roberta-wwm-ext" if wl.get("model") in ("vitl14", "hf_vitl14")
                                                             else "ViT-B/16+BERT-base"),
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -257,7 +282,8 @@ def main():
                        "pairs_per_gpu": B, "global_batch": world * B, "image": "224x224", "seq_len": S,
                        "stages": "encode_image+encode_text" + ("+allgather" if world > 1 else "")
                                  + "+similarity(2 dirs)+InfoNCE" + ("+backward" if wl["backward"] else ""),
-                       "contrastive_scope": "global" if world > 1 else "local", "parallelism": "dp%d" % world},
+                       "contrastive_scope": "global" if world > 1 else "local", "parallelism": "dp%d" % world,
+                       "text_dropout": args.text_dropout},
             "loss": round(loss_val, 5),
             "model_tflops_per_gpu": round(value / world * gflop / 1e3, 2),
             "model_mfma_frac": round(value / world * gflop / 1e3 / PEAK_TFLOPS[wl["dtype"]], 4),

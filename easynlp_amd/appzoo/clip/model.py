@@ -484,8 +484,35 @@ class CLIPApp(Application):
                     p.copy_(torch.randn(p.shape, generator=g, device=device) * std)
         return app
 
+    @classmethod
+    def from_hf_config(cls, config: dict, seed: int = 0, device="cuda", compute_dtype="bf16"):
+        """Random-init huggingface_clip-flavoured model (config.json schema: text_config / vision_config /
+        projection_dim) directly on the device -- benchmarks and smoke tests."""
+        app = cls(None, compute_dtype=compute_dtype)
+        app.model_type = "huggingface_clip"
+        app._build_hf(dict(config))
+        app.to(device)
+        g = torch.Generator(device=device).manual_seed(seed)
+        with torch.no_grad():
+            for n, p in app._hf_params.items():
+                if n == "logit_scale":
+                    continue
+                if n.endswith("LayerNorm.weight") or n.endswith("layrnorm.weight") or "layer_norm" in n and n.endswith(".weight") \
+                        or n.endswith("post_layernorm.weight"):
+                    p.fill_(1.0)
+                elif n.endswith(".bias"):
+                    p.zero_()
+                elif p.dim() == 1:
+                    p.copy_(torch.randn(p.shape, generator=g, device=device) * p.shape[0] ** -0.5)
+                else:
+                    fan_in = p[0].numel()
+                    std = 0.02 if n.startswith("text_encoder.") else fan_in ** -0.5
+                    p.copy_(torch.randn(p.shape, generator=g, device=device) * std)
+        return app
+
     # ------------------------------------------------------------------------------------
-    def contrastive_step(self, pixel_values, input_ids, process_group=None, backward=False):
+    def contrastive_step(self, pixel_values, input_ids, process_group=None, backward=False, token_type_ids=None,
+                         attention_mask=None):
         """Fast path without autograd bookkeeping: dual-encoder forward + InfoNCE
         (+ full backward into ``.grad`` when ``backward=True``), one C call per stage.
 
@@ -496,26 +523,52 @@ class CLIPApp(Application):
         with a reduce-scatter.  Returns the (rank-local mean) loss tensor.
         """
         import torch.distributed as dist
-        if getattr(self, "model_type", None) == "huggingface_clip":
-            raise NotImplementedError("contrastive_step is the chinese_clip fast path; use forward / compute_loss")
         eng = self._engine
         lib = eng.lib
-        params = self._params
+        hf = getattr(self, "model_type", None) == "huggingface_clip"
+        extras, transposed = None, []
+        pixel_values = pixel_values.contiguous()
+        input_ids = input_ids.contiguous()
+        if hf:
+            # huggingface_clip: the library's parameters are views / derived copies of the reference-named ones
+            # (hf_branch.py); gradients land in the reference parameters' .grad (projections through a transposed scratch)
+            from . import hf_branch as HB
+            st = self._hf
+            params = st.library_tensors(eng.names)
+            pad = self._hf_pad_id
+            am = input_ids.ne(pad).long() if attention_mask is None else attention_mask.to(input_ids.device).long()
+            tt = torch.zeros_like(input_ids) if token_type_ids is None else token_type_ids.to(input_ids.device).long()
+            extras = (HB.position_ids_from_input_ids(input_ids, pad), tt.contiguous(), am.contiguous())
+        else:
+            params = self._params
         if backward:
             grads = {}
-            for n, p in params.items():
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-                grads[n] = p.grad
+            if hf:
+                if self.logit_scale.grad is None:
+                    self.logit_scale.grad = torch.zeros_like(self.logit_scale)
+                for n in st.trainable_library_names(eng.names):
+                    if n in st.map.transposed:
+                        p = self._hf_params[st.map.transposed[n]]
+                        scratch = torch.zeros(params[n].shape, dtype=torch.float32, device=p.device)
+                        grads[n] = scratch
+                        transposed.append((p, scratch))
+                    else:
+                        p = self._hf_params[st.map.reference_name(n)]
+                        if p.grad is None:
+                            p.grad = torch.zeros_like(p)
+                        grads[n] = p.grad
+            else:
+                for n, p in params.items():
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                    grads[n] = p.grad
             eng.sync_params(params, with_backward=True, grads=grads)
         else:
             eng.sync_params(params, with_backward=False)
-        pixel_values = pixel_values.contiguous()
-        input_ids = input_ids.contiguous()
         img, ws_i = eng.encode_image(pixel_values, backward)
         drop = self._next_dropout()
         eng.set_text_dropout(*drop)
-        txt, ws_t = eng.encode_text(input_ids, backward)
+        txt, ws_t = eng.encode_text(input_ids, backward, extras=extras)
         n = img.shape[0]
         e = img.shape[1]
         world, rank, pg = 1, 0, None
@@ -551,7 +604,11 @@ class CLIPApp(Application):
         self.logit_scale.grad.add_(d_ls)
         eng.backward_image(pixel_values, d_img_l, ws_i)
         eng.set_text_dropout(*drop)
-        eng.backward_text(input_ids, d_txt_l, ws_t)
+        eng.backward_text(input_ids, d_txt_l, ws_t, extras=extras)
+        for p, scratch in transposed:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            p.grad.add_(scratch.t())
         return loss
 
     def _next_dropout(self):

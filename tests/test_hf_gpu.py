@@ -129,3 +129,28 @@ def test_hf_predictor_and_evaluator_surface(tmp_path):
     assert len(out) == 2 and "text_feat" in out[0]
     v = np.array([float(x) for x in out[0]["text_feat"].split("\t")])
     assert abs(np.linalg.norm(v) - 1.0) < 1e-3
+
+
+def test_hf_fast_path_contrastive_step_matches_golden(tmp_path):
+    """contrastive_step (no autograd bookkeeping) in huggingface_clip mode: loss and gradients in the reference
+    parameters' .grad, the projections through the transposed scratch."""
+    z, cfg, B, Lq, wseed, iseed = load("hf_tiny_b6_l24")
+    app, _ = make_app(tmp_path, cfg, wseed, "fp32")
+    app.eval()
+    px, ids, tt, am = H.make_inputs(cfg, B, Lq, iseed)
+    loss = app.contrastive_step(px.cuda(), ids.cuda(), process_group=False, backward=True, token_type_ids=tt.cuda(),
+                                attention_mask=am.cuda())
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    params = dict(app.named_parameters())
+    params["logit_scale"] = params.pop("logit_scale_param")
+    n_checked = 0
+    for key in z.files:
+        if key.startswith("grad/"):
+            n = key[len("grad/"):]
+            ref = torch.from_numpy(z[key]).double().reshape(params[n].shape)
+            err = float((params[n].grad.detach().cpu().double() - ref).norm())
+            assert err <= 2e-4 * float(ref.norm()) + 1e-7, (n, err)
+            n_checked += 1
+        elif key.startswith("nograd/"):
+            assert params[key[len("nograd/"):]].grad is None
+    assert n_checked > 30

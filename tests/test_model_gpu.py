@@ -285,3 +285,34 @@ def test_gradient_accumulation_and_optimizer_step(tmp_path):
     with torch.no_grad():
         ref = O.clip_loss(O.clip_forward(sd2, cfg, px, ids)["logits_per_text"])
     assert abs(ref.item() - l1.item()) < 1e-4
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_overfit_fixed_pairs_recall_matches_reference_math(tmp_path, dropout):
+    """BASELINE north star: recall@1 on fixed synthetic pairs within 1e-3 of the reference.  Train the bf16 HIP path
+    (train mode, reference dropout probabilities) on 16 fixed pairs until they are separable, then evaluate in eval mode:
+    R@1/5/10 from CLIPEvaluator equal those of the fp32 CPU oracle run on the TRAINED weights."""
+    cfg = dict(O.CONFIGS["tiny"], text_hidden_dropout_prob=dropout, text_attention_probs_dropout_prob=dropout)
+    app, sd = make_app(tmp_path, cfg, 8, "bf16")
+    px, ids = O.make_inputs(cfg, 16, 12, 5)
+    torch.manual_seed(0)
+    opt = torch.optim.AdamW(app.parameters(), lr=2e-3, weight_decay=0.0)
+    app.train()
+    losses = []
+    for _ in range(60):
+        opt.zero_grad()
+        loss = app.compute_loss(app({"pixel_values": px, "input_ids": ids}), [])["loss"]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(app.parameters(), 1.0)
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+    ev = CLIPEvaluator(_DS(px, ids), eval_batch_size=8)
+    res = ev.evaluate(app)                                     # eval(): dropout off
+    sd2 = {k: app._params[k].detach().cpu() for k in sd}
+    with torch.no_grad():
+        ref = O.clip_forward(sd2, cfg, px, ids)
+    want = O.recall_at_k(ref["text_embeds"], ref["image_embeds"])
+    assert abs(res[0][1] - want[0]) <= 1e-3, (res, want)
+    r1 = O.recall_at_k(ref["text_embeds"], ref["image_embeds"], ks=(1,))
+    assert r1[-1] >= 0.9, r1                                    # the pairs really became separable

@@ -38,6 +38,8 @@
 //   * The kernel is PERSISTENT (one workgroup per CU walks its tiles): the first six half-tiles of the next
 //     tile are DMA'd while the current epilogue runs, bias / residual loads are issued one block ahead, and
 //     there is no workgroup launch, kernarg load or cold pipeline between tiles.
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include "ezclip_common.h"
@@ -637,8 +639,11 @@ int gemm_nt_8p(const GemmArgs& p_in, hipStream_t stream) {
 
 // ---- weight-gradient launcher ---------------------------------------------------------------------------
 namespace {
-float* g_tn_scratch = nullptr;
-size_t g_tn_scratch_bytes = 0;
+// Library-owned scratch for the split partials, ONE PER STREAM (two handles driven on two streams must not share it),
+// grown on first use under a mutex; work on a stream is ordered, so reuse within a stream needs no further sync.
+struct TnScratch { float* ptr = nullptr; size_t bytes = 0; };
+std::mutex g_tn_mutex;
+std::map<hipStream_t, TnScratch> g_tn_scratch;
 }  // namespace
 
 bool gemm_tn_8p_eligible(const GemmTNArgs& p, int dtype) {
@@ -668,11 +673,16 @@ int gemm_tn_8p(const GemmTNArgs& p, hipStream_t stream) {
   kt = (kt + 1) & ~1;                                  // even, >= 4
   splits = (kt_total + kt - 1) / kt;                   // drop splits that would start past M
   const size_t need = (size_t)splits * (size_t)p.N * (size_t)p.K * sizeof(float);
-  if (need > g_tn_scratch_bytes) {
-    // library-owned scratch for the split partials (grown on first use; one stream at a time per handle)
-    if (g_tn_scratch) { EZ_HIP(hipStreamSynchronize(stream)); EZ_HIP(hipFree(g_tn_scratch)); g_tn_scratch = nullptr; }
-    EZ_HIP(hipMalloc(reinterpret_cast<void**>(&g_tn_scratch), need));
-    g_tn_scratch_bytes = need;
+  float* scratch = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_tn_mutex);
+    TnScratch& sc = g_tn_scratch[stream];
+    if (need > sc.bytes) {
+      if (sc.ptr) { EZ_HIP(hipStreamSynchronize(stream)); EZ_HIP(hipFree(sc.ptr)); sc.ptr = nullptr; sc.bytes = 0; }
+      EZ_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ptr), need));
+      sc.bytes = need;
+    }
+    scratch = sc.ptr;
   }
   static bool attr_set = false;
   if (!attr_set) {
@@ -682,11 +692,11 @@ int gemm_tn_8p(const GemmTNArgs& p, hipStream_t stream) {
   }
   {
     ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);
-    hipLaunchKernelGGL(gemm_tn_8p_kernel, dim3(ntiles * splits), dim3(kThreads8), kRing, stream, p, g_tn_scratch, ntiles,
+    hipLaunchKernelGGL(gemm_tn_8p_kernel, dim3(ntiles * splits), dim3(kThreads8), kRing, stream, p, scratch, ntiles,
                        tiles_q, kt);
     const size_t n4 = (size_t)p.N * p.K / 4;
     const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g_tn_scratch, splits, p.N, p.K, p.C, p.ldc,
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, stream, scratch, splits, p.N, p.K, p.C, p.ldc,
                        p.accumulate);
   }
   EZ_LAUNCH_CHECK();

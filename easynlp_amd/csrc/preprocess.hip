@@ -20,6 +20,8 @@
 // Both are HBM-bound: the source is read once, the output written once.
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/ezclip.h"
@@ -267,7 +269,11 @@ int preprocess_images(const uint8_t* packed, const ezclip_image_desc* desc, int 
     }
   // plans + tables + lut go through one library-owned pinned staging buffer (a pageable source would either make the
   // copy synchronous or leave the DMA reading freed vectors); an event guards its reuse by the next call
-  static struct { char* host = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool pending = false; } stg;
+  struct Staging { char* host = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool pending = false; };
+  static std::mutex stg_mutex;
+  static std::map<hipStream_t, Staging> stg_by_stream;          // one staging buffer per stream
+  std::lock_guard<std::mutex> stg_lock(stg_mutex);
+  Staging& stg = stg_by_stream[stream];
   const size_t up_bytes = l.tmp;
   if (stg.pending) { EZ_HIP(hipEventSynchronize(stg.ev)); stg.pending = false; }
   if (stg.bytes < up_bytes) {

@@ -109,7 +109,7 @@ __device__ __forceinline__ void stage_kv(const AttnArgs& a, const Smem<T>& S, in
 // scaled + biased scores of one 32-key tile for this lane's query: x[r], key = 32t + (r&3) + 8(r>>2) + 4h
 template <typename T>
 __device__ __forceinline__ void score_tile(const char* kt, const float* kb, const uint4 (&qf)[Geo<T>::NS], int t, int l31,
-                                           int h, float scale, float (&x)[16]) {
+                                           int h, float scale, float (&x)[16], int causal = 0, int qrow = 0, int key0 = 0) {
   f32x16_t acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -125,6 +125,11 @@ __device__ __forceinline__ void score_tile(const char* kt, const float* kb, cons
     x[4 * qd + 1] = fmaf(acc[4 * qd + 1], scale, kb4.y);
     x[4 * qd + 2] = fmaf(acc[4 * qd + 2], scale, kb4.z);
     x[4 * qd + 3] = fmaf(acc[4 * qd + 3], scale, kb4.w);
+  }
+  if (causal) {      // key0 = index of this tile's first key; keys after the query are masked
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (key0 + (r & 3) + 8 * (r >> 2) + 4 * h > qrow) x[r] = -INFINITY;
   }
 }
 
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a, int nt) {
 #pragma unroll 1
     for (int t = 0; t < nt; ++t) {
       float x[16];
-      score_tile<T>(kt, kb, qf, t, l31, h, a.scale, x);
+      score_tile<T>(kt, kb, qf, t, l31, h, a.scale, x, a.causal, q, 32 * t);
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, x[r]);
     }
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a, int nt) {
 #pragma unroll 1
     for (int t = 0; t < nt; ++t) {
       float x[16];
-      score_tile<T>(kt, kb, qf, t, l31, h, a.scale, x);
+      score_tile<T>(kt, kb, qf, t, l31, h, a.scale, x, a.causal, q, 32 * t);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         x[r] = kFast ? __expf(x[r] - mx) : expf(x[r] - mx);
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnBwdArgs a, int nt,
 #pragma unroll 1
       for (int t = 0; t < cht; ++t) {
         float x[16];
-        score_tile<T>(smem, kb, qf, t, l31, h, f.scale, x);                 // S^T[key][q]
+        score_tile<T>(smem, kb, qf, t, l31, h, f.scale, x, f.causal, q, row0 + 32 * t);   // S^T[key][q]
         f32x16_t dp;
         tile_rows_x_frag<T>(smem + S.vOff, dof, t, l31, h, dp);              // dP^T[key][q] = V . dO^T
         float dpm[16];
@@ -617,6 +622,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnBwdArgs a, int nt
             const int r = 4 * qd + e;
             const float x = fmaf(sacc[r], f.scale, kbias) - lv[e];
             p[r] = kFast ? __expf(x) : expf(x);
+            if (f.causal && key > row0 + 32 * t + 8 * qd + 4 * h + e) p[r] = 0.f;       // (query before this key)
             if (dropping) {
               ds[r] = p[r] * (dp[r] * dm[r] - dv[e]);
               p[r] *= dm[r];                                                   // dV takes the dropped probabilities

@@ -119,6 +119,11 @@ __global__ __launch_bounds__(512) void attn_fwd_short_kernel(AttnArgs a, int nt)
       x[4 * qd + 2] = fmaf(acc[4 * qd + 2], scale, kb4.z);
       x[4 * qd + 3] = fmaf(acc[4 * qd + 3], scale, kb4.w);
     }
+    if (a.causal) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (32 * t + (r & 3) + 8 * (r >> 2) + 4 * h > q) x[r] = -INFINITY;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -341,7 +346,8 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
         const float kbv[4] = {kb4.x, kb4.y, kb4.z, kb4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = __expf(fmaf(sacc[4 * qd + e], scale, kbv[e]) - lse_q);
+          float p = __expf(fmaf(sacc[4 * qd + e], scale, kbv[e]) - lse_q);
+          if (f.causal && 32 * t + 8 * qd + 4 * h + e > row) p = 0.f;
           ds[4 * qd + e] = p * (pacc[4 * qd + e] - d_q);
         }
       }
@@ -403,7 +409,8 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
         const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float pe = __expf(fmaf(sacc[4 * qd + e], scale, kb_key) - lv[e]);
+          float pe = __expf(fmaf(sacc[4 * qd + e], scale, kb_key) - lv[e]);
+          if (f.causal && row > 32 * t + 8 * qd + 4 * h + e) pe = 0.f;      // this key lies after that query
           p[4 * qd + e] = pe;
           ds[4 * qd + e] = pe * (pacc[4 * qd + e] - dv4[e]);
         }

@@ -332,6 +332,8 @@ int ezclip_op_layernorm_bwd(const void* x, const void* dy, const float* g, const
 }
 
 static DropCfg g_op_attn_drop;   // ezclip_op_set_attention_dropout
+static int g_op_attn_causal = 0; // ezclip_op_set_attention_causal
+int ezclip_op_set_attention_causal(int on) { g_op_attn_causal = on != 0; return EZ_OK; }
 int ezclip_op_set_attention_dropout(float p, uint64_t seed, uint32_t site) {
   if (!(p >= 0.f && p < 1.f)) { set_error("dropout probability %g outside [0, 1)", (double)p); return EZ_ERR_INVALID; }
   g_op_attn_drop = make_drop(p, seed, site);
@@ -352,6 +354,7 @@ int ezclip_op_attention(const void* q, const void* k, const void* v, int64_t row
                         const float* key_bias, float* lse, int batch, int seq_len, int heads, int dtype, void* stream) {
   AttnArgs a;
   a.drop = g_op_attn_drop;
+  a.causal = g_op_attn_causal;
   a.q = q; a.k = k; a.v = v; a.row_stride = row_stride; a.ctx = ctx; a.ctx_stride = ctx_stride;
   a.key_bias = key_bias; a.lse = lse; a.B = batch; a.L = seq_len; a.H = heads; a.scale = 0.125f;
   return attention_fwd(a, dtype, S(stream));
@@ -362,6 +365,7 @@ int ezclip_op_attention_bwd(const void* q, const void* k, const void* v, int64_t
                             void* dk, void* dv, int batch, int seq_len, int heads, int dtype, void* stream) {
   AttnBwdArgs b;
   b.f.drop = g_op_attn_drop;
+  b.f.causal = g_op_attn_causal;
   b.f.q = q; b.f.k = k; b.f.v = v; b.f.row_stride = row_stride; b.f.ctx = const_cast<void*>(ctx);
   b.f.ctx_stride = ctx_stride; b.f.key_bias = key_bias; b.f.lse = const_cast<float*>(lse);
   b.f.B = batch; b.f.L = seq_len; b.f.H = heads; b.f.scale = 0.125f;

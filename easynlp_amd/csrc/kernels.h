@@ -80,6 +80,7 @@ struct AttnArgs {
   float* lse = nullptr;           // optional [B, H, L] log-sum-exp of the scaled scores
   int B = 0, L = 0, H = 0;
   float scale = 0.125f;
+  int causal = 0;                 // 1: key j > query i is masked (-inf): CLIP text transformer, build_attention_mask (modeling_openclip.py:343-349)
   DropCfg drop;                   // dropout on the probabilities (BERT train mode); row = (b*H + h)*L + query, col = key
 };
 int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream);

@@ -83,6 +83,7 @@ SIGNATURES = {
     "ezclip_op_dropout": (_i, [_vp, _vp, _vp, _i, _i, _f, C.c_uint64, C.c_uint32, _i, _vp]),
     "ezclip_op_dropout_mask": (_i, [_f, C.c_uint64, C.c_uint32, _i, _i, _vp, _vp, _vp]),
     "ezclip_op_set_attention_dropout": (_i, [_f, C.c_uint64, C.c_uint32]),
+    "ezclip_op_set_attention_causal": (_i, [_i]),
     "ezclip_op_cast_from_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
     "ezclip_op_cast_to_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
 }
@@ -285,6 +286,10 @@ def preprocess_images(images, size: int = 224, crop: int = 224, mean=CLIP_MEAN, 
     # the pinned host copy and the workspace must outlive the enqueued work
     out._ezclip_keepalive = (host, packed, ws)
     return out
+
+
+def op_set_attention_causal(on: bool) -> None:
+    check(load().ezclip_op_set_attention_causal(1 if on else 0), "op_set_attention_causal")
 
 
 def similarity(a: torch.Tensor, b: torch.Tensor, logit_scale: Optional[torch.Tensor] = None) -> torch.Tensor:

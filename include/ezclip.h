@@ -255,6 +255,9 @@ int ezclip_op_dropout_mask(float p, uint64_t seed, uint32_t site, int rows, int 
                            uint32_t* words_dev, void* stream);                    /* either output may be NULL */
 /* dropout applied by the following ezclip_op_attention / ezclip_op_attention_bwd calls (p = 0: off) */
 int ezclip_op_set_attention_dropout(float p, uint64_t seed, uint32_t site);
+/* causal mask (key index > query index -> -inf, OPEN_CLIP.build_attention_mask, modeling_openclip.py:343-349) for the
+ * following ezclip_op_attention / ezclip_op_attention_bwd calls */
+int ezclip_op_set_attention_causal(int on);
 int ezclip_op_cast_from_f32(const float* src_dev, void* dst_dev, int64_t n, int dtype, void* stream);
 int ezclip_op_cast_to_f32(const void* src_dev, float* dst_dev, int64_t n, int dtype, void* stream);
 

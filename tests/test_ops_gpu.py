@@ -421,3 +421,38 @@ def test_gemm_tn_8phase(M, N, K, strided):
                                   L.DTYPE_BF16, L.stream_ptr()))
     torch.cuda.synchronize()
     assert rel_err(c1, prod) < 1e-5
+
+
+@pytest.mark.parametrize("Lq", [26, 77, 197])
+@pytest.mark.parametrize("dtype,variant", [("f32", -1), ("bf16", -1), ("bf16", 0)])
+def test_attention_causal_forward_and_backward(Lq, dtype, variant):
+    """Causal mask of the CLIP text transformer (OPEN_CLIP.build_attention_mask, modeling_openclip.py:343-349: -inf above
+    the diagonal) in every attention kernel: one-pass short kernels (bf16, variant -1), general two-pass kernels
+    (f32, and bf16 with variant 0)."""
+    B_, H = 2, 2
+    g = torch.Generator().manual_seed(Lq)
+    D = H * 64
+    qkv = torch.randn(B_ * Lq, 3 * D, generator=g)
+    dctx = torch.randn(B_ * Lq, D, generator=g)
+    if dtype == "bf16":
+        qkv, dctx = qkv.bfloat16(), dctx.bfloat16()
+    qd = qkv.double().requires_grad_(True)
+    q, k, v = [t.reshape(B_, Lq, H, 64).transpose(1, 2) for t in qd.split(D, dim=-1)]
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    s = s + torch.full((Lq, Lq), float("-inf"), dtype=torch.float64).triu_(1)
+    ref = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B_ * Lq, D)
+    ref.backward(dctx.double())
+    lib = L.load()
+    L.check(lib.ezclip_debug_set(1, variant))
+    L.op_set_attention_causal(True)
+    try:
+        ctx, lse = L.op_attention(qkv.to(DEV), B_, Lq, H, want_lse=True)
+        dqkv = L.op_attention_bwd(qkv.to(DEV), ctx, dctx.to(DEV), lse, B_, Lq, H)
+    finally:
+        L.op_set_attention_causal(False)
+        L.check(lib.ezclip_debug_set(1, -1))
+    assert max_err(ctx.float(), ref.detach()) < (2e-5 if dtype == "f32" else 3e-2)
+    assert rel_err(dqkv.float(), qd.grad) < (1e-5 if dtype == "f32" else 2e-2)
+    # the first token attends only to itself: ctx[0] = v[0]
+    v0 = qkv[0, 2 * D:2 * D + 64].float()
+    assert float((ctx[0, :64].float().cpu() - v0).abs().max()) < (1e-6 if dtype == "f32" else 1e-2)

@@ -487,6 +487,58 @@ size_t layout_text(const ezclip_model* m, int B, int L, bool save, void* base, T
 size_t image_workspace_bytes(const ezclip_model* m, int B, bool save) { return layout_image(m, B, save, nullptr, nullptr); }
 size_t text_workspace_bytes(const ezclip_model* m, int B, int L, bool save) { return layout_text(m, B, L, save, nullptr, nullptr); }
 
+// One pre-LN residual attention block (ResidualAttentionBlock, modeling_chineseclip.py:184-205 == modeling_openclip.py's
+// text / vision blocks): x_mid = x_in + out_proj(attn(in_proj(ln_1(x_in)))), x_out = x_mid + c_proj(QuickGELU(c_fc(ln_2(x_mid)))).
+// Shared by the ViT tower and the CLIP text transformer (causal = 1).  stats_ready / next_stat: the folded-LayerNorm
+// statistics hand-over between consecutive blocks of the bf16 inference path.
+struct BlockDims { int M, W, B, L, heads, causal; };
+
+static int resblock_forward(ezclip_model* m, const ezclip_model::VitLayer& Lw, const VitBufs& b, const BlockDims& d, bool save,
+                            bool& stats_ready, float* next_stat, hipStream_t stream) {
+  const int M = d.M, W = d.W, dt = m->dtype;
+  const float eps = 1e-5f;  // nn.LayerNorm default (modeling_chineseclip.py:170)
+  {
+    // x = x + attn(ln_1(x))                                          :203
+    const bool fold = !save && can_fold_ln(m, Lw.in_w, M) && can_fold_ln(m, Lw.fc_w, M);
+    if (fold) {
+      EZ_TRY(linear_folded_ln(m, b.x_in, W, Lw.in_w, eps, b.stat, b.qkv, 3 * W, M, ACT_NONE, stream, stats_ready));
+    } else {
+      EZ_TRY(layernorm_fwd(b.x_in, W, b.ln1, W, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, M, W, dt, b.m1, b.r1, stream));
+      EZ_TRY(linear(m, b.ln1, W, Lw.in_w, Lw.in_b, b.qkv, 3 * W, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+    }
+    stats_ready = false;
+    AttnArgs at;
+    at.q = b.qkv;
+    at.k = (const char*)b.qkv + (size_t)W * dtype_size(dt);
+    at.v = (const char*)b.qkv + (size_t)2 * W * dtype_size(dt);
+    at.row_stride = 3 * W;
+    at.ctx = b.ctx; at.ctx_stride = W;
+    at.key_bias = nullptr; at.lse = b.lse;
+    at.B = d.B; at.L = d.L; at.H = d.heads; at.scale = 0.125f;
+    at.causal = d.causal;
+    EZ_TRY(attention_fwd(at, dt, stream));
+    // (when the next product folds its LayerNorm, the residual GEMM's epilogue leaves that LayerNorm's row sums behind)
+    float* part = fold && can_emit_rowstats(m, b.ctx, W, Lw.out_w, Lw.out_b, b.x_mid, M, b.x_in, b.part) ? b.part : nullptr;
+    EZ_TRY(linear(m, b.ctx, W, Lw.out_w, Lw.out_b, b.x_mid, W, M, ACT_NONE, b.x_in, W, nullptr, false, stream, part));
+    if (part) EZ_TRY(layernorm_stats_finalize(part, W / 64, W, eps, M, b.stat, stream));
+    // x = x + c_proj(QuickGELU(c_fc(ln_2(x))))                      :204
+    if (fold) {
+      EZ_TRY(linear_folded_ln(m, b.x_mid, W, Lw.fc_w, eps, b.stat, b.h, 4 * W, M, ACT_QUICKGELU, stream, part != nullptr));
+    } else {
+      EZ_TRY(layernorm_fwd(b.x_mid, W, b.ln2, W, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, M, W, dt, b.m2, b.r2, stream));
+      EZ_TRY(linear(m, b.ln2, W, Lw.fc_w, Lw.fc_b, b.h, 4 * W, M, ACT_QUICKGELU, nullptr, 0, b.u, false, stream));
+    }
+    part = fold && next_stat != nullptr &&
+                   can_emit_rowstats(m, b.h, 4 * W, Lw.proj_w, Lw.proj_b, b.x_out, M, b.x_mid, b.part) ? b.part : nullptr;
+    EZ_TRY(linear(m, b.h, 4 * W, Lw.proj_w, Lw.proj_b, b.x_out, W, M, ACT_NONE, b.x_mid, W, nullptr, false, stream, part));
+    if (part) {    // statistics of the next block's ln_1 (inference: every block shares one buffer set)
+      EZ_TRY(layernorm_stats_finalize(part, W / 64, W, eps, M, next_stat, stream));
+      stats_ready = true;
+    }
+  }
+  return EZ_OK;
+}
+
 // ------------------------------------------------------------ image fwd ----
 int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* wsp, size_t ws_bytes, bool save,
                  hipStream_t stream) {
@@ -508,46 +560,10 @@ int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* 
   EZ_TRY(vit_assemble_ln(ws.pemb, m->P(m->cls_p), m->P(m->pos_p), m->P(m->lnpre_w), m->P(m->lnpre_b), eps, ws.x0,
                          ws.layers[0].x_in, ws.m0, ws.r0, B, Lv, W, dt, stream));
   bool stats_ready = false;   // b.stat already holds the row statistics of this block's input
-  for (int i = 0; i < m->cfg.vision_layers; ++i) {
-    const auto& Lw = m->vit[i];
-    const VitBufs& b = ws.layers[i];
-    // x = x + attn(ln_1(x))                                          :203
-    const bool fold = !save && can_fold_ln(m, Lw.in_w, M) && can_fold_ln(m, Lw.fc_w, M);
-    if (fold) {
-      EZ_TRY(linear_folded_ln(m, b.x_in, W, Lw.in_w, eps, b.stat, b.qkv, 3 * W, M, ACT_NONE, stream, stats_ready));
-    } else {
-      EZ_TRY(layernorm_fwd(b.x_in, W, b.ln1, W, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, M, W, dt, b.m1, b.r1, stream));
-      EZ_TRY(linear(m, b.ln1, W, Lw.in_w, Lw.in_b, b.qkv, 3 * W, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
-    }
-    stats_ready = false;
-    AttnArgs at;
-    at.q = b.qkv;
-    at.k = (const char*)b.qkv + (size_t)W * dtype_size(dt);
-    at.v = (const char*)b.qkv + (size_t)2 * W * dtype_size(dt);
-    at.row_stride = 3 * W;
-    at.ctx = b.ctx; at.ctx_stride = W;
-    at.key_bias = nullptr; at.lse = b.lse;
-    at.B = B; at.L = Lv; at.H = m->vheads; at.scale = 0.125f;
-    EZ_TRY(attention_fwd(at, dt, stream));
-    // (when the next product folds its LayerNorm, the residual GEMM's epilogue leaves that LayerNorm's row sums behind)
-    float* part = fold && can_emit_rowstats(m, b.ctx, W, Lw.out_w, Lw.out_b, b.x_mid, M, b.x_in, b.part) ? b.part : nullptr;
-    EZ_TRY(linear(m, b.ctx, W, Lw.out_w, Lw.out_b, b.x_mid, W, M, ACT_NONE, b.x_in, W, nullptr, false, stream, part));
-    if (part) EZ_TRY(layernorm_stats_finalize(part, W / 64, W, eps, M, b.stat, stream));
-    // x = x + c_proj(QuickGELU(c_fc(ln_2(x))))                      :204
-    if (fold) {
-      EZ_TRY(linear_folded_ln(m, b.x_mid, W, Lw.fc_w, eps, b.stat, b.h, 4 * W, M, ACT_QUICKGELU, stream, part != nullptr));
-    } else {
-      EZ_TRY(layernorm_fwd(b.x_mid, W, b.ln2, W, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, M, W, dt, b.m2, b.r2, stream));
-      EZ_TRY(linear(m, b.ln2, W, Lw.fc_w, Lw.fc_b, b.h, 4 * W, M, ACT_QUICKGELU, nullptr, 0, b.u, false, stream));
-    }
-    part = fold && i + 1 < m->cfg.vision_layers &&
-                   can_emit_rowstats(m, b.h, 4 * W, Lw.proj_w, Lw.proj_b, b.x_out, M, b.x_mid, b.part) ? b.part : nullptr;
-    EZ_TRY(linear(m, b.h, 4 * W, Lw.proj_w, Lw.proj_b, b.x_out, W, M, ACT_NONE, b.x_mid, W, nullptr, false, stream, part));
-    if (part) {    // statistics of the next block's ln_1 (inference: every block shares one buffer set)
-      EZ_TRY(layernorm_stats_finalize(part, W / 64, W, eps, M, ws.layers[i + 1].stat, stream));
-      stats_ready = true;
-    }
-  }
+  const BlockDims bd{M, W, B, Lv, m->vheads, 0};
+  for (int i = 0; i < m->cfg.vision_layers; ++i)
+    EZ_TRY(resblock_forward(m, m->vit[i], ws.layers[i], bd, save, stats_ready,
+                            i + 1 < m->cfg.vision_layers ? ws.layers[i + 1].stat : nullptr, stream));
   // ln_post(x[:, 0, :]) @ proj                                        :248-251
   const void* xl = ws.layers[m->cfg.vision_layers - 1].x_out;
   EZ_TRY(layernorm_fwd(xl, (int64_t)Lv * W, ws.cls_ln, W, m->P(m->lnpost_w), m->P(m->lnpost_b), eps, B, W, dt,
@@ -684,6 +700,49 @@ static int ln_bwd(const ezclip_model* m, const void* x, int64_t xs, const void* 
                        D, m->dtype, stream, bias_p >= 0 ? m->Gp(bias_p) : nullptr);
 }
 
+// backward of resblock_forward.  On entry g.gx = d x_out; on exit g.gx = d x_in.  prev_proj_b: bias parameter of the
+// PREVIOUS block's c_proj (its gradient = column sums of d x_in, fused into the last LayerNorm backward), or -1.
+struct BlockGrads { void *gx, *gx2, *gtmp, *gqkv, *gbig; float* gbpart; };
+
+static int resblock_backward(ezclip_model* m, const ezclip_model::VitLayer& Lw, const VitBufs& b, const BlockDims& d,
+                             const BlockGrads& g, int prev_proj_b, hipStream_t stream) {
+  const int M = d.M, W = d.W, dt = m->dtype;
+  const size_t esz = dtype_size(dt);
+  {
+    // x_out = x_mid + c_proj(h);  h = QuickGELU(u);  u = c_fc(ln_2(x_mid))        :204
+    EZ_TRY(dgrad(m, g.gx, W, Lw.proj_w, g.gbig, 4 * W, M, b.u, 4 * W, ACT_QUICKGELU, nullptr, 0, stream,
+                 Lw.fc_b));   // d u (+ c_fc bias gradient)
+    EZ_TRY(wgrad(m, g.gx, W, b.h, 4 * W, Lw.proj_w, M, stream));
+    // (c_proj bias gradient: accumulated by the ln_bwd that produced gx)
+    EZ_TRY(dgrad(m, g.gbig, 4 * W, Lw.fc_w, g.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));      // d ln_2
+    EZ_TRY(wgrad(m, g.gbig, 4 * W, b.ln2, W, Lw.fc_w, M, stream));
+    EZ_TRY(ln_bwd(m, b.x_mid, W, g.gtmp, W, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, g.gx2, W, g.gx, W, M, W, stream,
+                  Lw.out_b));   // d x_mid (+ out_proj bias gradient)
+    // x_mid = x_in + out_proj(attn(in_proj(ln_1(x_in))))                           :203
+    EZ_TRY(dgrad(m, g.gx2, W, Lw.out_w, g.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));          // d ctx
+    EZ_TRY(wgrad(m, g.gx2, W, b.ctx, W, Lw.out_w, M, stream));
+    AttnBwdArgs ab;
+    ab.f.q = b.qkv;
+    ab.f.k = (const char*)b.qkv + (size_t)W * esz;
+    ab.f.v = (const char*)b.qkv + (size_t)2 * W * esz;
+    ab.f.row_stride = 3 * W;
+    ab.f.ctx = b.ctx; ab.f.ctx_stride = W; ab.f.key_bias = nullptr; ab.f.lse = b.lse;
+    ab.f.B = d.B; ab.f.L = d.L; ab.f.H = d.heads; ab.f.scale = 0.125f;
+    ab.f.causal = d.causal;
+    ab.dctx = g.gtmp;
+    ab.dq = g.gqkv;
+    ab.dk = (char*)g.gqkv + (size_t)W * esz;
+    ab.dv = (char*)g.gqkv + (size_t)2 * W * esz;
+    if (float* gb = m->Gp(Lw.in_b)) { ab.dbq = gb; ab.dbk = gb + W; ab.dbv = gb + 2 * W; ab.db_part = g.gbpart; }   // in_proj_bias gradient
+    EZ_TRY(attention_bwd(ab, dt, stream));
+    EZ_TRY(dgrad(m, g.gqkv, 3 * W, Lw.in_w, g.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));      // d ln_1
+    EZ_TRY(wgrad(m, g.gqkv, 3 * W, b.ln1, W, Lw.in_w, M, stream));
+    EZ_TRY(ln_bwd(m, b.x_in, W, g.gtmp, W, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, g.gx, W, g.gx2, W, M, W, stream,
+                  prev_proj_b));    // d x_in (+ the previous block's c_proj bias gradient)
+  }
+  return EZ_OK;
+}
+
 int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_emb, void* wsp, size_t ws_bytes,
                    hipStream_t stream) {
   EZ_REQUIRE(B > 0 && d_emb && wsp, "backward_image: null/empty argument");
@@ -711,39 +770,10 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
   // (gx is zero outside the CLS rows: its column sums are the last block's c_proj bias gradient)
   EZ_TRY(ln_bwd(m, xl, (int64_t)Lv * W, ws.gcls, W, m->lnpost_w, m->lnpost_b, ws.mpost, ws.rpost, ws.gx, (int64_t)Lv * W,
                 nullptr, 0, B, W, stream, m->vit[m->cfg.vision_layers - 1].proj_b));
-  for (int i = m->cfg.vision_layers - 1; i >= 0; --i) {
-    const auto& Lw = m->vit[i];
-    const VitBufs& b = ws.layers[i];
-    // x_out = x_mid + c_proj(h);  h = QuickGELU(u);  u = c_fc(ln_2(x_mid))        :204
-    EZ_TRY(dgrad(m, ws.gx, W, Lw.proj_w, ws.gbig, 4 * W, M, b.u, 4 * W, ACT_QUICKGELU, nullptr, 0, stream,
-                 Lw.fc_b));   // d u (+ c_fc bias gradient)
-    EZ_TRY(wgrad(m, ws.gx, W, b.h, 4 * W, Lw.proj_w, M, stream));
-    // (c_proj bias gradient: accumulated by the ln_bwd that produced gx)
-    EZ_TRY(dgrad(m, ws.gbig, 4 * W, Lw.fc_w, ws.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));      // d ln_2
-    EZ_TRY(wgrad(m, ws.gbig, 4 * W, b.ln2, W, Lw.fc_w, M, stream));
-    EZ_TRY(ln_bwd(m, b.x_mid, W, ws.gtmp, W, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, W, ws.gx, W, M, W, stream,
-                  Lw.out_b));   // d x_mid (+ out_proj bias gradient)
-    // x_mid = x_in + out_proj(attn(in_proj(ln_1(x_in))))                           :203
-    EZ_TRY(dgrad(m, ws.gx2, W, Lw.out_w, ws.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));          // d ctx
-    EZ_TRY(wgrad(m, ws.gx2, W, b.ctx, W, Lw.out_w, M, stream));
-    AttnBwdArgs ab;
-    ab.f.q = b.qkv;
-    ab.f.k = (const char*)b.qkv + (size_t)W * esz;
-    ab.f.v = (const char*)b.qkv + (size_t)2 * W * esz;
-    ab.f.row_stride = 3 * W;
-    ab.f.ctx = b.ctx; ab.f.ctx_stride = W; ab.f.key_bias = nullptr; ab.f.lse = b.lse;
-    ab.f.B = B; ab.f.L = Lv; ab.f.H = m->vheads; ab.f.scale = 0.125f;
-    ab.dctx = ws.gtmp;
-    ab.dq = ws.gqkv;
-    ab.dk = (char*)ws.gqkv + (size_t)W * esz;
-    ab.dv = (char*)ws.gqkv + (size_t)2 * W * esz;
-    if (float* gb = m->Gp(Lw.in_b)) { ab.dbq = gb; ab.dbk = gb + W; ab.dbv = gb + 2 * W; ab.db_part = ws.gbpart; }   // in_proj_bias gradient
-    EZ_TRY(attention_bwd(ab, dt, stream));
-    EZ_TRY(dgrad(m, ws.gqkv, 3 * W, Lw.in_w, ws.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));      // d ln_1
-    EZ_TRY(wgrad(m, ws.gqkv, 3 * W, b.ln1, W, Lw.in_w, M, stream));
-    EZ_TRY(ln_bwd(m, b.x_in, W, ws.gtmp, W, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx, W, ws.gx2, W, M, W, stream,
-                  i > 0 ? m->vit[i - 1].proj_b : -1));    // d x_in (+ the previous block's c_proj bias gradient)
-  }
+  const BlockDims bd{M, W, B, Lv, m->vheads, 0};
+  const BlockGrads bg{ws.gx, ws.gx2, ws.gtmp, ws.gqkv, ws.gbig, ws.gbpart};
+  for (int i = m->cfg.vision_layers - 1; i >= 0; --i)
+    EZ_TRY(resblock_backward(m, m->vit[i], ws.layers[i], bd, bg, i > 0 ? m->vit[i - 1].proj_b : -1, stream));
   // x = ln_pre(cat(cls, conv(patches)) + pos)                                          :237-242
   EZ_TRY(ln_bwd(m, ws.x0, W, ws.gx, W, m->lnpre_w, m->lnpre_b, ws.m0, ws.r0, ws.gx2, W, nullptr, 0, M, W, stream));
   if (m->Gp(m->pos_p)) EZ_TRY(batch_sum_add(ws.gx2, B, Lv, Lv, W, m->Gp(m->pos_p), dt, stream));

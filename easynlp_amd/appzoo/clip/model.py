@@ -81,13 +81,13 @@ class HipClipEngine:
     # parameters only the huggingface_clip branch has (include/ezclip.h); never created / bound for chinese_clip
     HF_ONLY_PARAMS = ("visual.proj_bias", "text_projection_bias")
 
-    def __init__(self, cfg: dict, dtype_code: int, hf_branch: bool = False):
+    def __init__(self, cfg: dict, dtype_code: int, hf_branch: bool = False, text_arch: int = 0):
         self.lib = L.load()
         self.cfg = cfg
         self.dtype_code = dtype_code
         self._cstruct = _cfg_struct(cfg, dtype_code)
         h = L.C.c_void_p()
-        L.check(self.lib.ezclip_create(L.C.byref(self._cstruct), L.C.byref(h)), "ezclip_create")
+        L.check(self.lib.ezclip_create_ex(L.C.byref(self._cstruct), int(text_arch), L.C.byref(h)), "ezclip_create")
         self.handle = h
         self.names: List[str] = []
         self.shapes: Dict[str, tuple] = {}
@@ -351,7 +351,16 @@ class CLIPApp(Application):
         with open(os.path.join(path, "config.json"), "r") as f:
             self.raw_config = json.load(f)
         if self.raw_config.get("model_type") == "open_clip":
-            raise L.EzclipError("model_type 'open_clip' (causal text transformer) is not on the HIP path yet (SURVEY.md 8f)")
+            # reference model.py:56-64: OPEN_CLIP(**config), checkpoint keys prefixed 'open_clip.'
+            self.model_type = "open_clip"
+            self.config = Config_Wrapper(self.raw_config)
+            self._build(self.raw_config)
+            ckpt = os.path.join(path, "pytorch_model.bin")
+            if os.path.exists(ckpt):
+                checkpoint = torch.load(ckpt, map_location="cpu")
+                state = {k.replace("open_clip.", ""): v for k, v in checkpoint.items()}
+                self.open_clip.load_state_dict(state)                                         # strict, as the reference (:64)
+            return
         if self.raw_config.get("model_type") != "chinese_clip":
             # reference model.py:73: anything else is the huggingface_clip flavour (text_config / vision_config)
             self.model_type = "huggingface_clip"
@@ -376,7 +385,21 @@ class CLIPApp(Application):
 
     # ------------------------------------------------------------------------------------
     def _build(self, cfg: dict) -> None:
-        eng = HipClipEngine(cfg, self.compute_dtype)
+        open_clip = cfg.get("model_type") == "open_clip"
+        if open_clip:
+            # OPEN_CLIP ctor kwargs (modeling_openclip.py:256-271) -> the library's config fields (include/ezclip.h)
+            if isinstance(cfg.get("vision_layers"), (list, tuple)):
+                raise L.EzclipError("ModifiedResNet vision towers are not on the HIP path (SURVEY.md 8f)")
+            T = int(cfg["transformer_width"])
+            if int(cfg["transformer_heads"]) * 64 != T:
+                raise L.EzclipError("open_clip: transformer_heads must be transformer_width / 64 on the HIP path")
+            ecfg = dict(cfg, text_hidden_size=T, text_intermediate_size=4 * T,
+                        text_max_position_embeddings=int(cfg["context_length"]),
+                        text_num_attention_heads=int(cfg["transformer_heads"]),
+                        text_num_hidden_layers=int(cfg["transformer_layers"]), text_type_vocab_size=1)
+            eng = HipClipEngine(ecfg, self.compute_dtype, text_arch=1)
+        else:
+            eng = HipClipEngine(cfg, self.compute_dtype)
         tree = _ParamTree()
         for n in eng.names:
             shape = eng.shapes[n]
@@ -384,10 +407,13 @@ class CLIPApp(Application):
             if n == "logit_scale":
                 t.fill_(float(torch.log(torch.tensor(1.0 / 0.07))))       # modeling_chineseclip.py:316
             tree.add(n, t)
-        # persistent buffer the reference BertEmbeddings carries in its state_dict (modeling_bert.py:88)
-        tree.add("bert.embeddings.position_ids",
-                 torch.arange(int(cfg["text_max_position_embeddings"])).expand((1, -1)).clone(), buffer=True)
-        self.chinese_clip = tree
+        if open_clip:
+            self.open_clip = tree
+        else:
+            # persistent buffer the reference BertEmbeddings carries in its state_dict (modeling_bert.py:88)
+            tree.add("bert.embeddings.position_ids",
+                     torch.arange(int(cfg["text_max_position_embeddings"])).expand((1, -1)).clone(), buffer=True)
+            self.chinese_clip = tree
         self._engine = eng
         named = dict(tree.named_parameters())
         self._params = {n: named[n] for n in eng.names}

@@ -75,6 +75,9 @@ class CLIPPredictor(Predictor):
         images, owners = [], []
         for record in in_data:
             text = record.get(self.first_sequence, None)
+            if text is not None and "input_ids" not in record and getattr(self.multi_modal, "model_type", "") == "open_clip":
+                raise L.EzclipError("open_clip checkpoints use the BPE SimpleTokenizer (predictor.py:91-93): pass records with "
+                                    "tokenised 'input_ids' [1, context_length]")
             if text is not None and "input_ids" not in record:            # predictor.py:95-101
                 tked = self.tokenizer(text, padding="max_length", truncation=True, max_length=max_seq_length,
                                       return_tensors="pt")

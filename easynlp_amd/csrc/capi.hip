@@ -64,7 +64,8 @@ extern "C" {
 const char* ezclip_last_error(void) { return ezclip::last_error(); }
 const char* ezclip_version(void) { return "ezclip-hip 0.1 (gfx950)"; }
 
-int ezclip_create(const ezclip_config* cfg, ezclip_handle* out) { return model_create(cfg, out); }
+int ezclip_create(const ezclip_config* cfg, ezclip_handle* out) { return model_create(cfg, out, 0); }
+int ezclip_create_ex(const ezclip_config* cfg, int text_arch, ezclip_handle* out) { return model_create(cfg, out, text_arch); }
 
 void ezclip_destroy(ezclip_handle h) { delete h; }
 

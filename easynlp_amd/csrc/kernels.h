@@ -145,6 +145,11 @@ int bert_embed_ln(const int64_t* ids, const float* word, const float* pos, const
                   int B, int L, int Hd, int vocab, int dtype, hipStream_t stream, const int64_t* pos_ids = nullptr,
                   const int64_t* type_ids = nullptr, const int64_t* attn_mask = nullptr, int max_pos = 1 << 30,
                   int type_vocab = 1);
+// CLIP text transformer (OPEN_CLIP.encode_text): x = token_embedding[ids] + positional_embedding; eot_idx[b] = argmax_t ids[b, t]
+int clip_text_embed(const int64_t* ids, const float* tok, const float* pos, void* x, int* eot_idx, int B, int L, int W, int vocab,
+                    int dtype, hipStream_t stream);
+// scatter = 0: dst[b] = src[b, idx[b]];  scatter = 1: dst[b, idx[b]] = src[b] (other rows untouched)
+int gather_rows(const void* src, const int* idx, void* dst, int B, int L, int W, int scatter, int dtype, hipStream_t stream);
 // out[b] = x[b] / ||x[b]||_2 (no eps: reference modeling_chineseclip.py:360,363); inv_norm optional.
 int l2_normalize_fwd(const float* x, float* out, float* inv_norm, int B, int E, hipStream_t stream);
 // dx = (dy - y * <dy, y>) * inv_norm

@@ -54,6 +54,11 @@ struct ezclip_model {
   int word_p, tpos_p, type_p, eln_w, eln_b, logit_scale_p;
   std::vector<VitLayer> vit;
   std::vector<BertLayer> bert;
+  // text_arch 1 (open_clip, OPEN_CLIP.encode_text modeling_openclip.py:354-368): token + positional embedding, pre-LN
+  // causal residual attention blocks (the ViT's block type), ln_final, feature of the EOT token, text_projection
+  int text_arch = 0;
+  std::vector<VitLayer> ttx;
+  int tok_p = -1, tpos2_p = -1, lnf_w = -1, lnf_b = -1;
 
   // huggingface_clip branch of CLIPApp (appzoo/clip/model.py:73-104,128-144): ezclip_set_option
   bool opt_text_pooler = false;      // text feature = projection(tanh(pooler.dense(x[:, 0])))  (RobertaModel pooled output)
@@ -76,7 +81,7 @@ struct ezclip_model {
 
 namespace ezclip {
 
-int model_create(const ezclip_config* cfg, ezclip_model** out);
+int model_create(const ezclip_config* cfg, ezclip_model** out, int text_arch = 0);
 size_t model_shadow_layout(ezclip_model* m, char* base, bool with_backward);  // returns bytes; assigns when base != null
 int model_refresh_weights(ezclip_model* m, hipStream_t stream);
 void set_fold_layernorm(int mode);   // 0: separate LayerNorm kernels; 1: folded + row statistics from the producing GEMM; 2: folded + separate statistics pass

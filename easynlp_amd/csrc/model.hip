@@ -80,7 +80,7 @@ static ezclip_model::Weight make_weight(ezclip_model* m, int p, int N, int K, bo
   return w;
 }
 
-int model_create(const ezclip_config* c, ezclip_model** out) {
+int model_create(const ezclip_config* c, ezclip_model** out, int text_arch) {
   EZ_REQUIRE(c != nullptr && out != nullptr, "ezclip_create: null argument");
   EZ_REQUIRE(c->compute_dtype == EZCLIP_F32 || c->compute_dtype == EZCLIP_BF16, "ezclip_create: bad compute_dtype %d", c->compute_dtype);
   const int kmult = 128 / dtype_size(c->compute_dtype);
@@ -92,7 +92,10 @@ int model_create(const ezclip_config* c, ezclip_model** out) {
   EZ_REQUIRE(E % 32 == 0 && E <= 1024, "embed_dim %d must be a multiple of 32 and <= 1024", E);
   EZ_REQUIRE(c->vision_patch_size > 0 && c->image_resolution >= c->vision_patch_size, "bad patch/resolution");
   EZ_REQUIRE(c->vision_layers > 0 && c->text_num_hidden_layers > 0, "layer counts must be positive");
-  EZ_REQUIRE(c->vocab_size > 0 && c->text_max_position_embeddings > 0 && c->text_type_vocab_size > 0, "bad text table sizes");
+  EZ_REQUIRE(c->vocab_size > 0 && c->text_max_position_embeddings > 0 && (c->text_type_vocab_size > 0 || text_arch == 1),
+             "bad text table sizes");
+  EZ_REQUIRE(text_arch == 0 || text_arch == 1, "text_arch %d: 0 = BERT / RoBERTa, 1 = CLIP text transformer", text_arch);
+  EZ_REQUIRE(text_arch == 0 || F == 4 * H, "CLIP text transformer: intermediate size must be 4 * width");
 
   ezclip_model* m = new ezclip_model();
   m->cfg = *c;
@@ -103,6 +106,7 @@ int model_create(const ezclip_config* c, ezclip_model** out) {
   m->Kpad = round_up(m->Kpatch, kmult);
   m->vheads = W / 64;
   m->theads = c->text_num_attention_heads;
+  m->text_arch = text_arch;
   const int P = c->vision_patch_size;
 
   m->cls_p = add_param(m, "visual.class_embedding", {W});
@@ -137,38 +141,66 @@ int model_create(const ezclip_config* c, ezclip_model** out) {
   }
   m->lnpost_w = add_param(m, "visual.ln_post.weight", {W});
   m->lnpost_b = add_param(m, "visual.ln_post.bias", {W});
-  m->word_p = add_param(m, "bert.embeddings.word_embeddings.weight", {c->vocab_size, H});
-  m->tpos_p = add_param(m, "bert.embeddings.position_embeddings.weight", {c->text_max_position_embeddings, H});
-  m->type_p = add_param(m, "bert.embeddings.token_type_embeddings.weight", {c->text_type_vocab_size, H});
-  m->eln_w = add_param(m, "bert.embeddings.LayerNorm.weight", {H});
-  m->eln_b = add_param(m, "bert.embeddings.LayerNorm.bias", {H});
-  for (int i = 0; i < c->text_num_hidden_layers; ++i) {
-    const std::string p = "bert.encoder.layer." + std::to_string(i) + ".";
-    ezclip_model::BertLayer L;
-    L.q_w = make_weight(m, add_param(m, p + "attention.self.query.weight", {H, H}), H, H);
-    L.q_b = add_param(m, p + "attention.self.query.bias", {H});
-    L.k_w = make_weight(m, add_param(m, p + "attention.self.key.weight", {H, H}), H, H);
-    L.k_b = add_param(m, p + "attention.self.key.bias", {H});
-    L.v_w = make_weight(m, add_param(m, p + "attention.self.value.weight", {H, H}), H, H);
-    L.v_b = add_param(m, p + "attention.self.value.bias", {H});
-    L.o_w = make_weight(m, add_param(m, p + "attention.output.dense.weight", {H, H}), H, H);
-    L.o_b = add_param(m, p + "attention.output.dense.bias", {H});
-    L.ln1_w = add_param(m, p + "attention.output.LayerNorm.weight", {H});
-    L.ln1_b = add_param(m, p + "attention.output.LayerNorm.bias", {H});
-    L.i_w = make_weight(m, add_param(m, p + "intermediate.dense.weight", {F, H}), F, H);
-    L.i_b = add_param(m, p + "intermediate.dense.bias", {F});
-    L.d_w = make_weight(m, add_param(m, p + "output.dense.weight", {H, F}), H, F);
-    L.d_b = add_param(m, p + "output.dense.bias", {H});
-    L.ln2_w = add_param(m, p + "output.LayerNorm.weight", {H});
-    L.ln2_b = add_param(m, p + "output.LayerNorm.bias", {H});
-    m->bert.push_back(L);
+  if (text_arch == 1) {
+    // OPEN_CLIP state_dict names (modeling_openclip.py:296-311)
+    m->tok_p = add_param(m, "token_embedding.weight", {c->vocab_size, H});
+    m->tpos2_p = add_param(m, "positional_embedding", {c->text_max_position_embeddings, H});
+    for (int i = 0; i < c->text_num_hidden_layers; ++i) {
+      const std::string p = "transformer.resblocks." + std::to_string(i) + ".";
+      ezclip_model::VitLayer L;
+      L.in_w = make_weight(m, add_param(m, p + "attn.in_proj_weight", {3 * H, H}), 3 * H, H);
+      L.in_b = add_param(m, p + "attn.in_proj_bias", {3 * H});
+      L.out_w = make_weight(m, add_param(m, p + "attn.out_proj.weight", {H, H}), H, H);
+      L.out_b = add_param(m, p + "attn.out_proj.bias", {H});
+      L.ln1_w = add_param(m, p + "ln_1.weight", {H});
+      L.ln1_b = add_param(m, p + "ln_1.bias", {H});
+      L.fc_w = make_weight(m, add_param(m, p + "mlp.c_fc.weight", {4 * H, H}), 4 * H, H);
+      L.fc_b = add_param(m, p + "mlp.c_fc.bias", {4 * H});
+      L.proj_w = make_weight(m, add_param(m, p + "mlp.c_proj.weight", {H, 4 * H}), H, 4 * H);
+      L.proj_b = add_param(m, p + "mlp.c_proj.bias", {H});
+      L.ln2_w = add_param(m, p + "ln_2.weight", {H});
+      L.ln2_b = add_param(m, p + "ln_2.bias", {H});
+      L.in_w.fold_g = L.ln1_w; L.in_w.fold_b = L.ln1_b; L.in_w.fold_bias = L.in_b;
+      L.fc_w.fold_g = L.ln2_w; L.fc_w.fold_b = L.ln2_b; L.fc_w.fold_bias = L.fc_b;
+      m->ttx.push_back(L);
+    }
+    m->lnf_w = add_param(m, "ln_final.weight", {H});
+    m->lnf_b = add_param(m, "ln_final.bias", {H});
+    m->tproj_w = make_weight(m, add_param(m, "text_projection", {H, E}), E, H, true);
+  } else {
+    m->word_p = add_param(m, "bert.embeddings.word_embeddings.weight", {c->vocab_size, H});
+    m->tpos_p = add_param(m, "bert.embeddings.position_embeddings.weight", {c->text_max_position_embeddings, H});
+    m->type_p = add_param(m, "bert.embeddings.token_type_embeddings.weight", {c->text_type_vocab_size, H});
+    m->eln_w = add_param(m, "bert.embeddings.LayerNorm.weight", {H});
+    m->eln_b = add_param(m, "bert.embeddings.LayerNorm.bias", {H});
+    for (int i = 0; i < c->text_num_hidden_layers; ++i) {
+      const std::string p = "bert.encoder.layer." + std::to_string(i) + ".";
+      ezclip_model::BertLayer L;
+      L.q_w = make_weight(m, add_param(m, p + "attention.self.query.weight", {H, H}), H, H);
+      L.q_b = add_param(m, p + "attention.self.query.bias", {H});
+      L.k_w = make_weight(m, add_param(m, p + "attention.self.key.weight", {H, H}), H, H);
+      L.k_b = add_param(m, p + "attention.self.key.bias", {H});
+      L.v_w = make_weight(m, add_param(m, p + "attention.self.value.weight", {H, H}), H, H);
+      L.v_b = add_param(m, p + "attention.self.value.bias", {H});
+      L.o_w = make_weight(m, add_param(m, p + "attention.output.dense.weight", {H, H}), H, H);
+      L.o_b = add_param(m, p + "attention.output.dense.bias", {H});
+      L.ln1_w = add_param(m, p + "attention.output.LayerNorm.weight", {H});
+      L.ln1_b = add_param(m, p + "attention.output.LayerNorm.bias", {H});
+      L.i_w = make_weight(m, add_param(m, p + "intermediate.dense.weight", {F, H}), F, H);
+      L.i_b = add_param(m, p + "intermediate.dense.bias", {F});
+      L.d_w = make_weight(m, add_param(m, p + "output.dense.weight", {H, F}), H, F);
+      L.d_b = add_param(m, p + "output.dense.bias", {H});
+      L.ln2_w = add_param(m, p + "output.LayerNorm.weight", {H});
+      L.ln2_b = add_param(m, p + "output.LayerNorm.bias", {H});
+      m->bert.push_back(L);
+    }
+    // chinese_clip: computed by the reference but unused (kept for the checkpoint contract).  huggingface_clip: the text
+    // feature IS the pooled output (text_outputs[1], appzoo/clip/model.py:134) -- opt_text_pooler
+    m->pool_w = make_weight(m, add_param(m, "bert.pooler.dense.weight", {H, H}), H, H);
+    m->pool_b = add_param(m, "bert.pooler.dense.bias", {H});
+    m->tproj_w = make_weight(m, add_param(m, "text_projection", {H, E}), E, H, true);
+    m->tproj_b = add_param(m, "text_projection_bias", {E});
   }
-  // chinese_clip: computed by the reference but unused (kept for the checkpoint contract).  huggingface_clip: the text
-  // feature IS the pooled output (text_outputs[1], appzoo/clip/model.py:134) -- opt_text_pooler
-  m->pool_w = make_weight(m, add_param(m, "bert.pooler.dense.weight", {H, H}), H, H);
-  m->pool_b = add_param(m, "bert.pooler.dense.bias", {H});
-  m->tproj_w = make_weight(m, add_param(m, "text_projection", {H, E}), E, H, true);
-  m->tproj_b = add_param(m, "text_projection_bias", {E});
   m->logit_scale_p = add_param(m, "logit_scale", {});
   *out = m;
   return EZ_OK;
@@ -179,9 +211,10 @@ static void for_each_weight(ezclip_model* m, const std::function<void(ezclip_mod
   f(m->conv_w);
   f(m->vproj_w);
   f(m->tproj_w);
-  f(m->pool_w);
+  if (m->text_arch == 0) f(m->pool_w);
   for (auto& L : m->vit) { f(L.in_w); f(L.out_w); f(L.fc_w); f(L.proj_w); }
   for (auto& L : m->bert) { f(L.q_w); f(L.k_w); f(L.v_w); f(L.o_w); f(L.i_w); f(L.d_w); }
+  for (auto& L : m->ttx) { f(L.in_w); f(L.out_w); f(L.fc_w); f(L.proj_w); }
 }
 
 static bool needs_pack(const ezclip_model* m, const ezclip_model::Weight& w) {
@@ -485,7 +518,7 @@ size_t layout_text(const ezclip_model* m, int B, int L, bool save, void* base, T
 }  // namespace
 
 size_t image_workspace_bytes(const ezclip_model* m, int B, bool save) { return layout_image(m, B, save, nullptr, nullptr); }
-size_t text_workspace_bytes(const ezclip_model* m, int B, int L, bool save) { return layout_text(m, B, L, save, nullptr, nullptr); }
+
 
 // One pre-LN residual attention block (ResidualAttentionBlock, modeling_chineseclip.py:184-205 == modeling_openclip.py's
 // text / vision blocks): x_mid = x_in + out_proj(attn(in_proj(ln_1(x_in)))), x_out = x_mid + c_proj(QuickGELU(c_fc(ln_2(x_mid)))).
@@ -575,6 +608,113 @@ int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* 
   return EZ_OK;
 }
 
+// ---------------------------------------------- CLIP text transformer (open_clip) ----
+namespace {
+
+struct TxtClipWS {
+  std::vector<VitBufs> layers;
+  int* eot;                        // [B] argmax_t ids
+  void *eot_rows, *eot_ln;         // [B, W] gathered EOT rows, ln_final of them
+  float *mpost, *rpost, *feat, *emb, *inv_norm;
+  void *gx, *gx2, *gtmp, *gqkv, *gbig, *gfeatT, *gcls, *geot;
+  float *gfeat, *gbpart;
+};
+
+size_t layout_text_clip(const ezclip_model* m, int B, int L, bool save, void* base, TxtClipWS* ws) {
+  Arena a(base);
+  const size_t esz = dtype_size(m->dtype);
+  const int W = m->cfg.text_hidden_size, E = m->cfg.embed_dim;
+  const size_t M = (size_t)B * L;
+  TxtClipWS w;
+  const int nl = m->cfg.text_num_hidden_layers;
+  w.layers.resize(nl);
+  if (!save) {
+    VitBufs b;
+    b.x_in = b.x_mid = b.x_out = a.take(M * W * esz);
+    b.ln1 = b.ln2 = a.take(M * W * esz);
+    b.qkv = a.take(M * 3 * W * esz);
+    b.ctx = a.take(M * W * esz);
+    b.u = nullptr;
+    b.h = a.take(M * 4 * W * esz);
+    b.stat = a.takef(2 * M);
+    b.part = a.takef(2 * M * (size_t)(W / 64));
+    b.m1 = b.r1 = b.m2 = b.r2 = b.lse = nullptr;
+    for (int i = 0; i < nl; ++i) w.layers[i] = b;
+  } else {
+    void* x = a.take(M * W * esz);
+    for (int i = 0; i < nl; ++i) {
+      VitBufs& b = w.layers[i];
+      b.x_in = x;
+      b.ln1 = a.take(M * W * esz);
+      b.qkv = a.take(M * 3 * W * esz);
+      b.ctx = a.take(M * W * esz);
+      b.x_mid = a.take(M * W * esz);
+      b.ln2 = a.take(M * W * esz);
+      b.u = a.take(M * 4 * W * esz);
+      b.h = a.take(M * 4 * W * esz);
+      b.x_out = a.take(M * W * esz);
+      b.m1 = a.takef(M); b.r1 = a.takef(M); b.m2 = a.takef(M); b.r2 = a.takef(M);
+      b.lse = a.takef((size_t)B * m->theads * L);
+      b.stat = nullptr; b.part = nullptr;
+      x = b.x_out;
+    }
+  }
+  w.eot = reinterpret_cast<int*>(a.takef(B));
+  w.eot_rows = a.take((size_t)B * W * esz);
+  w.eot_ln = a.take((size_t)B * W * esz);
+  w.mpost = a.takef(B); w.rpost = a.takef(B);
+  w.feat = a.takef((size_t)B * E);
+  w.emb = a.takef((size_t)B * E);
+  w.inv_norm = a.takef(B);
+  if (save) {
+    w.gx = a.take(M * W * esz);
+    w.gx2 = a.take(M * W * esz);
+    w.gtmp = a.take(M * W * esz);
+    w.gqkv = a.take(M * 3 * W * esz);
+    w.gbpart = a.takef((size_t)B * 3 * W);
+    w.gbig = a.take(M * 4 * W * esz);
+    w.gfeat = a.takef((size_t)B * E);
+    w.gfeatT = a.take((size_t)B * E * esz);
+    w.gcls = a.take((size_t)B * W * esz);
+    w.geot = a.take((size_t)B * W * esz);
+  } else {
+    w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = w.gfeatT = w.gcls = w.geot = nullptr;
+    w.gfeat = nullptr; w.gbpart = nullptr;
+  }
+  if (ws) *ws = w;
+  return a.off + 256;
+}
+
+// OPEN_CLIP.encode_text (modeling_openclip.py:354-368) + L2 normalise (:383)
+int encode_text_clip(ezclip_model* m, const int64_t* ids, int B, int L, float* out, void* wsp, size_t ws_bytes, bool save,
+                     hipStream_t stream) {
+  TxtClipWS ws;
+  const size_t need = layout_text_clip(m, B, L, save, wsp, &ws);
+  EZ_REQUIRE(ws_bytes >= need, "encode_text: workspace too small (%zu < %zu)", ws_bytes, need);
+  const int W = m->cfg.text_hidden_size, E = m->cfg.embed_dim, M = B * L, dt = m->dtype;
+  const float eps = 1e-5f;
+  // x = token_embedding(text) + positional_embedding                :355-357
+  EZ_TRY(clip_text_embed(ids, m->P(m->tok_p), m->P(m->tpos2_p), ws.layers[0].x_in, ws.eot, B, L, W, m->cfg.vocab_size, dt, stream));
+  bool stats_ready = false;
+  const BlockDims bd{M, W, B, L, m->theads, 1};                     // causal: build_attention_mask :343-349
+  const int nl = m->cfg.text_num_hidden_layers;
+  for (int i = 0; i < nl; ++i)
+    EZ_TRY(resblock_forward(m, m->ttx[i], ws.layers[i], bd, save, stats_ready, i + 1 < nl ? ws.layers[i + 1].stat : nullptr, stream));
+  // ln_final(x)[arange(B), text.argmax(-1)] @ text_projection       :361-366  (LayerNorm is per row: gather first)
+  EZ_TRY(gather_rows(ws.layers[nl - 1].x_out, ws.eot, ws.eot_rows, B, L, W, 0, dt, stream));
+  EZ_TRY(layernorm_fwd(ws.eot_rows, W, ws.eot_ln, W, m->P(m->lnf_w), m->P(m->lnf_b), eps, B, W, dt, ws.mpost, ws.rpost, stream));
+  EZ_TRY(linear(m, ws.eot_ln, W, m->tproj_w, -1, ws.feat, E, B, ACT_NONE, nullptr, 0, nullptr, true, stream));
+  EZ_TRY(l2_normalize_fwd(ws.feat, ws.emb, ws.inv_norm, B, E, stream));
+  EZ_HIP(hipMemcpyAsync(out, ws.emb, (size_t)B * E * 4, hipMemcpyDeviceToDevice, stream));
+  return EZ_OK;
+}
+
+}  // namespace
+
+size_t text_workspace_bytes(const ezclip_model* m, int B, int L, bool save) {
+  return m->text_arch == 1 ? layout_text_clip(m, B, L, save, nullptr, nullptr) : layout_text(m, B, L, save, nullptr, nullptr);
+}
+
 // ------------------------------------------------------------- text fwd ----
 int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, void* wsp, size_t ws_bytes, bool save,
                 hipStream_t stream, const TextExtras* ex) {
@@ -583,6 +723,7 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
              m->cfg.text_max_position_embeddings);
   EZ_REQUIRE(m->weights_fresh, "encode_text: call ezclip_refresh_weights after binding/updating parameters");
   EZ_REQUIRE(((uintptr_t)wsp % 256) == 0, "encode_text: workspace must be 256-byte aligned");
+  if (m->text_arch == 1) return encode_text_clip(m, ids, B, L, out, wsp, ws_bytes, save, stream);
   TxtWS ws;
   const size_t need = layout_text(m, B, L, save, wsp, &ws);
   EZ_REQUIRE(ws_bytes >= need, "encode_text: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -795,10 +936,41 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
   return EZ_OK;
 }
 
+// backward of encode_text_clip
+static int backward_text_clip(ezclip_model* m, const int64_t* ids, int B, int L, const float* d_emb, void* wsp, size_t ws_bytes,
+                              hipStream_t stream) {
+  TxtClipWS ws;
+  const size_t need = layout_text_clip(m, B, L, true, wsp, &ws);
+  EZ_REQUIRE(ws_bytes >= need, "backward_text: workspace too small (%zu < %zu): was the forward run with save_for_backward?", ws_bytes, need);
+  const int W = m->cfg.text_hidden_size, E = m->cfg.embed_dim, M = B * L, dt = m->dtype;
+  const size_t esz = dtype_size(dt);
+  const int nl = m->cfg.text_num_hidden_layers;
+  EZ_TRY(l2_normalize_bwd(ws.emb, d_emb, ws.inv_norm, ws.gfeat, B, E, stream));
+  const void* gfeatT = ws.gfeat;
+  if (dt != EZCLIP_F32) { EZ_TRY(cast_from_f32(ws.gfeat, ws.gfeatT, (int64_t)B * E, dt, stream)); gfeatT = ws.gfeatT; }
+  // feat = ln_final(x_eot) @ text_projection
+  EZ_TRY(dgrad(m, gfeatT, E, m->tproj_w, ws.gcls, W, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
+  EZ_TRY(wgrad(m, gfeatT, E, ws.eot_ln, W, m->tproj_w, B, stream));
+  // d x_eot (+ the last block's c_proj bias gradient = its column sums: every other row of d x is zero)
+  EZ_TRY(ln_bwd(m, ws.eot_rows, W, ws.gcls, W, m->lnf_w, m->lnf_b, ws.mpost, ws.rpost, ws.geot, W, nullptr, 0, B, W, stream,
+                m->ttx[nl - 1].proj_b));
+  EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * W * esz, stream));
+  EZ_TRY(gather_rows(ws.geot, ws.eot, ws.gx, B, L, W, 1, dt, stream));
+  const BlockDims bd{M, W, B, L, m->theads, 1};
+  const BlockGrads bg{ws.gx, ws.gx2, ws.gtmp, ws.gqkv, ws.gbig, ws.gbpart};
+  for (int i = nl - 1; i >= 0; --i)
+    EZ_TRY(resblock_backward(m, m->ttx[i], ws.layers[i], bd, bg, i > 0 ? m->ttx[i - 1].proj_b : -1, stream));
+  // x = token_embedding[ids] + positional_embedding: index-add and batch sum of d x
+  if (m->Gp(m->tok_p)) EZ_TRY(bert_word_grad(ids, ws.gx, m->Gp(m->tok_p), M, W, m->cfg.vocab_size, dt, stream, -1));
+  if (m->Gp(m->tpos2_p)) EZ_TRY(batch_sum_add(ws.gx, B, L, L, W, m->Gp(m->tpos2_p), dt, stream));
+  return EZ_OK;
+}
+
 int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float* d_emb, void* wsp, size_t ws_bytes,
                   hipStream_t stream, const TextExtras* ex) {
   EZ_REQUIRE(B > 0 && L > 0 && ids && d_emb && wsp, "backward_text: null/empty argument");
   EZ_REQUIRE(m->weights_fresh && m->shadow_backward, "backward_text: weights not packed for backward");
+  if (m->text_arch == 1) return backward_text_clip(m, ids, B, L, d_emb, wsp, ws_bytes, stream);
   TxtWS ws;
   const size_t need = layout_text(m, B, L, true, wsp, &ws);
   EZ_REQUIRE(ws_bytes >= need, "backward_text: workspace too small (%zu < %zu): was the forward run with save_for_backward?", ws_bytes, need);

@@ -332,6 +332,57 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const T* patch, co
   if (mean_o != nullptr && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
 
+// CLIP text transformer input (OPEN_CLIP.encode_text, modeling_openclip.py:355-357): x[b, t] = token_embedding[ids[b, t]]
+// + positional_embedding[t], no LayerNorm.  One wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void clip_text_embed_kernel(const int64_t* ids, const float* tok, const float* pos, T* x,
+                                                              int B, int L, int W, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * L) return;
+  const int t = (int)(row % L);
+  int64_t id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int col = (lane + c * 64) * 4;
+    if (col < W) {
+      float tv[4], pv[4], v[4];
+      ld4(tok + id * W + col, tv);
+      ld4(pos + (int64_t)t * W + col, pv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = tv[e] + pv[e];
+      st4(x + row * W + col, v);
+    }
+  }
+}
+
+// idx[b] = argmax_t ids[b, t] (first maximum, as torch.argmax): the EOT position (modeling_openclip.py:364-366)
+__global__ void argmax_rows_kernel(const int64_t* ids, int* idx, int B, int L) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int64_t best = ids[(int64_t)b * L];
+  int bi = 0;
+  for (int t = 1; t < L; ++t) {
+    const int64_t v = ids[(int64_t)b * L + t];
+    if (v > best) { best = v; bi = t; }
+  }
+  idx[b] = bi;
+}
+
+// gather: dst[b] = src[b, idx[b]] ; scatter: dst[b, idx[b]] = src[b] (dst zeroed by the caller)   rows of W elements
+template <typename T>
+__global__ void gather_rows_kernel(const T* src, const int* idx, T* dst, int B, int L, int W, int scatter) {
+  const int64_t n = (int64_t)B * (W >> 2);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / (W >> 2)), c = (int)(i - (int64_t)b * (W >> 2)) * 4;
+    const int64_t big = ((int64_t)b * L + idx[b]) * W + c, small = (int64_t)b * W + c;
+    float v[4];
+    ld4(src + (scatter ? small : big), v);
+    st4(dst + (scatter ? big : small), v);
+  }
+}
+
 // pos_ids / type_ids / attn_mask: optional [B, L] int64 (RobertaEmbeddings: pad-aware position ids, roberta/modeling_roberta.py:
 // 1497-1510; explicit token types and mask as the huggingface_clip branch passes them, appzoo/clip/model.py:131-133).
 // Defaults: position t, type 0, mask = ids != 0 (chinese_clip, modeling_chineseclip.py:347).
@@ -636,6 +687,28 @@ int vit_assemble_ln(const void* patch, const float* cls, const float* pos, const
   const int blocks = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
   EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((vit_assemble_ln_kernel<T>), dim3(blocks), dim3(256), 0, stream,
                                           (const T*)patch, cls, pos, g, b, eps, (T*)x0, (T*)y, mean, rstd, B, Lv, W));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int clip_text_embed(const int64_t* ids, const float* tok, const float* pos, void* x, int* eot_idx, int B, int L, int W, int vocab,
+                    int dtype, hipStream_t stream) {
+  EZ_REQUIRE(W % 4 == 0 && W <= 256 * kMaxChunks, "clip_text_embed: width %d unsupported", W);
+  const int64_t rows = (int64_t)B * L;
+  const int blocks = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((clip_text_embed_kernel<T>), dim3(blocks), dim3(256), 0, stream, ids, tok, pos, (T*)x, B, L,
+                                          W, vocab));
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, ids, eot_idx, B, L);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int gather_rows(const void* src, const int* idx, void* dst, int B, int L, int W, int scatter, int dtype, hipStream_t stream) {
+  EZ_REQUIRE(W % 4 == 0, "gather_rows: width %d must be a multiple of 4", W);
+  const int64_t n = (int64_t)B * (W >> 2);
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)src, idx, (T*)dst, B,
+                                          L, W, scatter));
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

@@ -44,6 +44,7 @@ SIGNATURES = {
     "ezclip_last_error": (C.c_char_p, []),
     "ezclip_version": (C.c_char_p, []),
     "ezclip_create": (_i, [C.POINTER(EzclipConfig), C.POINTER(_vp)]),
+    "ezclip_create_ex": (_i, [C.POINTER(EzclipConfig), _i, C.POINTER(_vp)]),
     "ezclip_destroy": (None, [_vp]),
     "ezclip_num_params": (_i, [_vp]),
     "ezclip_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i)]),

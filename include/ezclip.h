@@ -78,6 +78,17 @@ const char* ezclip_version(void);
 
 /* ---- model lifetime / parameters ------------------------------------------ */
 int ezclip_create(const ezclip_config* cfg, ezclip_handle* out);
+/* text_arch: EZCLIP_TEXT_BERT (ezclip_create; BertModel / RobertaModel) or EZCLIP_TEXT_CLIP -- the open_clip branch's text
+ * tower (OPEN_CLIP.encode_text, easynlp/modelzoo/models/clip/modeling_openclip.py:296-311,354-368): token_embedding +
+ * positional_embedding, pre-LN residual attention blocks with the causal mask of build_attention_mask (:343-349),
+ * ln_final, the feature of the EOT token (argmax of the ids) times text_projection.  Parameter names are OPEN_CLIP's
+ * (token_embedding.weight, positional_embedding, transformer.resblocks.*, ln_final.*, text_projection); config fields:
+ * text_hidden_size = transformer_width, text_num_attention_heads = transformer_heads (width / 64),
+ * text_num_hidden_layers = transformer_layers, text_max_position_embeddings = context_length,
+ * text_intermediate_size = 4 * width, text_type_vocab_size ignored. */
+#define EZCLIP_TEXT_BERT 0
+#define EZCLIP_TEXT_CLIP 1
+int ezclip_create_ex(const ezclip_config* cfg, int text_arch, ezclip_handle* out);
 void ezclip_destroy(ezclip_handle h);
 /* Number of parameters the model expects and the i-th reference name (state_dict key without
  * the "chinese_clip." prefix); shape is written to shape[0..*ndim). */

@@ -250,7 +250,7 @@ def patchify(pixels, patch):
 
 
 def mha_self_attention(x, in_w, in_b, out_w, out_b, heads, key_bias=None,
-                       scale_q_first=True, taps=None, tap_prefix=""):
+                       scale_q_first=True, taps=None, tap_prefix="", attn_mask=None):
     """Multi-head self-attention on batch-first x [B, L, D].
 
     ViT: ``nn.MultiheadAttention(d_model, n_head)`` called with
@@ -273,6 +273,8 @@ def mha_self_attention(x, in_w, in_b, out_w, out_b, heads, key_bias=None,
         s = (q @ k.transpose(-1, -2)) * scale
     if key_bias is not None:
         s = s + key_bias[:, None, None, :]
+    if attn_mask is not None:            # additive [L, L] mask (open_clip text tower: -inf above the diagonal)
+        s = s + attn_mask
     p = torch.softmax(s, dim=-1)
     ctx = (p @ v).transpose(1, 2).reshape(B, L, D)
     if taps is not None:

@@ -176,6 +176,48 @@ def run_hf_case(name, cfg_name, B, L, wseed, iseed, full):
     print(name, "loss", loss.item(), "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def run_openclip_case(name, cfg_name, B, wseed, iseed, full):
+    """The REAL reference CLIPApp in open_clip mode (appzoo/clip/model.py:56-64,124-125: OPEN_CLIP with the causal text
+    transformer), loaded from a synthetic checkpoint directory."""
+    import json
+    import tempfile
+    from oracle import open_clip_oracle as OC
+    R.install_shims()
+    from easynlp.appzoo.clip.model import CLIPApp
+    torch.manual_seed(0)
+    cfg = OC.OPENCLIP_CONFIGS[cfg_name]
+    sd = OC.make_state_dict(cfg, wseed)
+    d = tempfile.mkdtemp()
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    torch.save({"open_clip." + k: v for k, v in sd.items()}, os.path.join(d, "pytorch_model.bin"))
+    app = CLIPApp(d)
+    assert app.model_type == "open_clip"
+    app.eval()
+    px, ids = OC.make_inputs(cfg, B, iseed)
+    fo = app({"pixel_values": px, "input_ids": ids})
+    loss = app.compute_loss(fo, [])["loss"]
+    loss.backward()
+    out = {"meta": np.array([cfg_name, str(B), str(cfg["context_length"]), str(wseed), str(iseed), torch.__version__, np.__version__]),
+           "image_embeds": fo["image_embeds"].detach().numpy(), "text_embeds": fo["text_embeds"].detach().numpy(),
+           "logits_per_text": fo["logits_per_text"].detach().numpy(), "loss": np.float32(loss.item())}
+    for n, p in app.named_parameters():
+        n = n.replace("open_clip.", "", 1)
+        if p.grad is None:
+            out["nograd/" + n] = np.zeros(0, np.float32)
+        elif full:
+            out["grad/" + n] = p.grad.numpy()
+        else:
+            norm, samp, idx = grad_digest(p.grad)
+            out["gnorm/" + n] = np.float64(norm)
+            out["gsamp/" + n] = samp
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "loss", loss.item(), "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+OPENCLIP_CASES = [("openclip_tiny_b6", "oc_tiny", 6, 1234, 3, True), ("openclip_small_b5", "oc_small", 5, 99, 7, False)]
+
 HF_CASES = [("hf_tiny_b6_l24", "hf_tiny", 6, 24, 1234, 3, True), ("hf_small_b5_l40", "hf_small", 5, 40, 99, 7, False)]
 
 
@@ -191,3 +233,6 @@ if __name__ == "__main__":
     for case in HF_CASES:
         if not only or case[0] in only:
             run_hf_case(*case)
+    for case in OPENCLIP_CASES:
+        if not only or case[0] in only:
+            run_openclip_case(*case)

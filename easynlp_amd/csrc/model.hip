@@ -370,7 +370,11 @@ struct ImgWS {
   float* gconv;   // [W, Kpad] scratch for the patch-embedding weight gradient when K is padded (ViT-L/14: 588 -> 640)
 };
 
-size_t layout_image(const ezclip_model* m, int B, bool save, void* base, ImgWS* ws) {
+// save: keep what the backward pass needs.  With a frozen tower (opt_vision_frozen: the huggingface_clip branch detaches the
+// vision output) that is only the projection's input and the embedding scratch: the blocks run on the inference
+// buffer set (one set for all layers, LayerNorms folded).
+size_t layout_image(const ezclip_model* m, int B, bool save_arg, void* base, ImgWS* ws) {
+  const bool save = save_arg && !m->opt_vision_frozen;
   Arena a(base);
   const size_t esz = dtype_size(m->dtype);
   const int W = m->cfg.vision_width, E = m->cfg.embed_dim;
@@ -432,6 +436,10 @@ size_t layout_image(const ezclip_model* m, int B, bool save, void* base, ImgWS* 
     w.gconv = m->Kpad != m->Kpatch ? a.takef((size_t)W * m->Kpad) : nullptr;
   } else {
     w.gx = w.gx2 = w.gtmp = w.gqkv = w.gbig = w.gfeatT = w.gcls = nullptr; w.gfeat = nullptr; w.gconv = nullptr; w.gbpart = nullptr;
+    if (save_arg) {      // frozen tower: the projection's gradients only
+      w.gfeat = a.takef((size_t)B * E);
+      w.gfeatT = a.take((size_t)B * E * esz);
+    }
   }
   if (ws) *ws = w;
   return a.off + 256;
@@ -594,8 +602,9 @@ int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* 
                          ws.layers[0].x_in, ws.m0, ws.r0, B, Lv, W, dt, stream));
   bool stats_ready = false;   // b.stat already holds the row statistics of this block's input
   const BlockDims bd{M, W, B, Lv, m->vheads, 0};
+  const bool save_blocks = save && !m->opt_vision_frozen;     // (see layout_image)
   for (int i = 0; i < m->cfg.vision_layers; ++i)
-    EZ_TRY(resblock_forward(m, m->vit[i], ws.layers[i], bd, save, stats_ready,
+    EZ_TRY(resblock_forward(m, m->vit[i], ws.layers[i], bd, save_blocks, stats_ready,
                             i + 1 < m->cfg.vision_layers ? ws.layers[i + 1].stat : nullptr, stream));
   // ln_post(x[:, 0, :]) @ proj                                        :248-251
   const void* xl = ws.layers[m->cfg.vision_layers - 1].x_out;

@@ -64,6 +64,10 @@ WORKLOADS = {
 
 # algorithmic GFLOP per pair (multiply-add = 2; padded tiles and softmax/LN excluded)
 GFLOP_FWD_PER_PAIR = 46.152
+# Forward-only workloads evaluate the last block of each tower for the CLS rows only (nothing else reaches the embeddings):
+# out_proj + MLP + attention core of one ViT block for 196 of 197 tokens (2.199 G) and query / attention / output / FFN of one
+# BERT layer for 63 of 64 tokens (0.756 G) are not executed.  model_tflops is computed from the EXECUTED figure.
+GFLOP_FWD_EXECUTED_PER_PAIR = 46.152 - 2.199 - 0.756
 GFLOP_TRAIN_PER_PAIR = 138.46
 GFLOP_FWD_PER_PAIR_VITL14 = 173.05      # ViT-L/14 (L = 257) + BERT-base text tower, 64 tokens
 GFLOP_TRAIN_PER_PAIR_VITL14 = 519.2
@@ -174,6 +178,8 @@ def main():
 
     if os.environ.get("EZCLIP_NO_LNFOLD"):      # A/B switch: separate LayerNorm kernels in the inference path too
         L.check(L.load().ezclip_debug_set(2, 0))
+    if os.environ.get("EZCLIP_CLS_LAST"):       # A/B switch: 0 = evaluate the last block of each tower for every token
+        L.check(L.load().ezclip_debug_set(3, int(os.environ["EZCLIP_CLS_LAST"])))
     if os.environ.get("EZCLIP_LNFOLD_MODE"):    # A/B switch: 2 = folded LayerNorm with a separate statistics pass
         L.check(L.load().ezclip_debug_set(2, int(os.environ["EZCLIP_LNFOLD_MODE"])))
     wl = dict(WORKLOADS[args.workload])
@@ -270,7 +276,8 @@ def main():
         elif wl.get("model") == "vitl14":
             gflop = GFLOP_TRAIN_PER_PAIR_VITL14 if wl["backward"] else GFLOP_FWD_PER_PAIR_VITL14
         else:
-            gflop = GFLOP_TRAIN_PER_PAIR if wl["backward"] else GFLOP_FWD_PER_PAIR
+            cls_last = os.environ.get("EZCLIP_CLS_LAST", "1") != "0"
+            gflop = GFLOP_TRAIN_PER_PAIR if wl["backward"] else (GFLOP_FWD_EXECUTED_PER_PAIR if cls_last else GFLOP_FWD_PER_PAIR)
         out = {
             "metric": "image-text pairs/sec (fwd+loss) " + ("ViT-L/14+roberta-wwm-ext" if wl.get("model") in ("vitl14", "hf_vitl14")
                                                             else "ViT-B/16+BERT-base"),
@@ -285,6 +292,8 @@ def main():
                        "contrastive_scope": "global" if world > 1 else "local", "parallelism": "dp%d" % world,
                        "text_dropout": args.text_dropout},
             "loss": round(loss_val, 5),
+            "gflop_per_pair": {"algorithmic_all_tokens": (GFLOP_TRAIN_PER_PAIR if wl["backward"] else GFLOP_FWD_PER_PAIR)
+                               if wl.get("model") is None else None, "executed": round(gflop, 3)},
             "model_tflops_per_gpu": round(value / world * gflop / 1e3, 2),
             "model_mfma_frac": round(value / world * gflop / 1e3 / PEAK_TFLOPS[wl["dtype"]], 4),
             "roofline": roof,

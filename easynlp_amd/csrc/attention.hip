@@ -287,6 +287,89 @@ int launch_fwd(const AttnArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------
+// Attention for ONE query per sample (the CLS token): the last block of either tower only feeds x[:, 0] to the head
+// (ln_post(x[:, 0, :]) @ proj, modeling_chineseclip.py:248-251; bert(...)[0][:, 0, :] @ text_projection :349-350), so its
+// attention output is needed for that row alone.  One wave per (sample, head): lanes split the keys for q.k (a K row is
+// one 128-byte line per lane), a wave softmax, then lane = d accumulates sum_key p_key V[key][d] (V rows read coalesced).
+// HBM traffic: K and V once -- the same bytes the full kernel reads for them; no Q block, no ctx block.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void attn_cls_fwd_kernel(AttnArgs a, const T* q_cls, int64_t q_stride, T* ctx_cls,
+                                                           int64_t ctx_stride) {
+  constexpr int kMaxJ = 8;                     // keys per lane: L <= 512
+  const int lane = threadIdx.x & 63;
+  const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bh >= a.B * a.H) return;
+  const int b = bh / a.H, head = bh - b * a.H;
+  const int L = a.L;
+  const T* q = q_cls + (int64_t)b * q_stride + head * 64;
+  const T* kbase = reinterpret_cast<const T*>(a.k) + (int64_t)b * L * a.row_stride + head * 64;
+  const T* vbase = reinterpret_cast<const T*>(a.v) + (int64_t)b * L * a.row_stride + head * 64;
+  float qv[64];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) ld4(q + 4 * c, *reinterpret_cast<float(*)[4]>(&qv[4 * c]));
+  float sc[kMaxJ];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < kMaxJ; ++j) {
+    const int key = lane + 64 * j;
+    sc[j] = -INFINITY;
+    if (key < L) {
+      const T* kr = kbase + (int64_t)key * a.row_stride;
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        float kv[4];
+        ld4(kr + 4 * c, kv);
+        dot = fmaf(qv[4 * c], kv[0], dot); dot = fmaf(qv[4 * c + 1], kv[1], dot);
+        dot = fmaf(qv[4 * c + 2], kv[2], dot); dot = fmaf(qv[4 * c + 3], kv[3], dot);
+      }
+      sc[j] = fmaf(dot, a.scale, a.key_bias ? a.key_bias[(int64_t)b * L + key] : 0.f);
+    }
+    mx = fmaxf(mx, sc[j]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < kMaxJ; ++j) {
+    sc[j] = lane + 64 * j < L ? expf(sc[j] - mx) : 0.f;
+    sum += sc[j];
+  }
+  sum = wave_sum(sum);
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < kMaxJ; ++j) {
+    if (64 * j >= L) break;
+    const int n = min(64, L - 64 * j);
+    for (int src = 0; src < n; ++src) {
+      const float p = __shfl(sc[j], src, 64);
+      acc = fmaf(p, Elem<T>::ld(vbase + (int64_t)(64 * j + src) * a.row_stride + lane), acc);
+    }
+  }
+  Elem<T>::st(ctx_cls + (int64_t)b * ctx_stride + head * 64 + lane, acc / sum);
+}
+}  // namespace
+
+// q_cls: [B, q_stride] rows holding the CLS queries (heads side by side); k / v of `a` as usual; ctx_cls [B, ctx_stride]
+int attention_cls_fwd(const AttnArgs& a, const void* q_cls, int64_t q_stride, void* ctx_cls, int64_t ctx_stride, int dtype,
+                      hipStream_t stream) {
+  EZ_REQUIRE(a.B > 0 && a.L > 0 && a.L <= 512 && a.H > 0 && a.causal == 0 && a.drop.thr == 0,
+             "attention_cls_fwd: unsupported problem (L=%d)", a.L);
+  const int esz = dtype_size(dtype);
+  EZ_REQUIRE((a.row_stride * esz) % 16 == 0 && (q_stride * esz) % 16 == 0, "attention_cls_fwd: strides must be 16-byte multiples");
+  const int waves = a.B * a.H;
+  ProfScope ps(PROF_ATTN, 4.0 * a.B * a.H * (double)a.L * 64, stream);
+  if (dtype == EZCLIP_F32)
+    hipLaunchKernelGGL((attn_cls_fwd_kernel<float>), dim3((waves + 3) / 4), dim3(256), 0, stream, a, (const float*)q_cls, q_stride,
+                       (float*)ctx_cls, ctx_stride);
+  else
+    hipLaunchKernelGGL((attn_cls_fwd_kernel<bf16_t>), dim3((waves + 3) / 4), dim3(256), 0, stream, a, (const bf16_t*)q_cls, q_stride,
+                       (bf16_t*)ctx_cls, ctx_stride);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
 static int g_attn_variant = -1;
 void set_attention_variant(int v) { g_attn_variant = v; }
 

@@ -295,6 +295,7 @@ int ezclip_debug_set(int key, int value) {
   if (key == 0) { set_gemm_variant(value); return EZ_OK; }
   if (key == 1) { set_attention_variant(value); return EZ_OK; }
   if (key == 2) { set_fold_layernorm(value); return EZ_OK; }
+  if (key == 3) { set_cls_last(value); return EZ_OK; }
   set_error("ezclip_debug_set: unknown key %d", key);
   return EZ_ERR_INVALID;
 }

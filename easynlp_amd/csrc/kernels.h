@@ -84,6 +84,9 @@ struct AttnArgs {
   DropCfg drop;                   // dropout on the probabilities (BERT train mode); row = (b*H + h)*L + query, col = key
 };
 int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream);
+// one query per sample (the CLS row of the last block): q_cls [B, q_stride], ctx_cls [B, ctx_stride]; k / v / key_bias of `a`
+int attention_cls_fwd(const AttnArgs& a, const void* q_cls, int64_t q_stride, void* ctx_cls, int64_t ctx_stride, int dtype,
+                      hipStream_t stream);
 // short-sequence bf16 kernels (attention_short.hip): L <= 256, one-pass online softmax, LDS transpose reads
 bool attention_short_eligible(const AttnArgs& a, int dtype);
 int attention_fwd_short(const AttnArgs& a, hipStream_t stream);

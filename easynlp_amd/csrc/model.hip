@@ -580,6 +580,44 @@ static int resblock_forward(ezclip_model* m, const ezclip_model::VitLayer& Lw, c
   return EZ_OK;
 }
 
+// The LAST block of a tower on the inference path: only x[:, 0] is read afterwards (ln_post(x[:, 0, :]) @ proj,
+// modeling_chineseclip.py:248-251), so after the full-width qkv product everything runs on B rows: attention for the CLS
+// query (attention_cls_fwd), out_proj + residual, ln_2, c_fc, QuickGELU, c_proj + residual.  Same arithmetic per row as
+// resblock_forward (a GEMM row does not depend on M); 72 % of the block's FLOPs are not spent on rows nobody reads.
+// scratch: >= 3 * B * W elements.  Output: x_out_cls = scratch + B * W elements, row stride W.
+static bool g_cls_last = true;
+void set_cls_last(int on) { g_cls_last = on != 0; }
+
+static int resblock_forward_cls(ezclip_model* m, const ezclip_model::VitLayer& Lw, const VitBufs& b, const BlockDims& d,
+                                bool stats_ready, void* scratch, hipStream_t stream) {
+  const int M = d.M, W = d.W, B = d.B, dt = m->dtype;
+  const size_t esz = dtype_size(dt);
+  const float eps = 1e-5f;
+  char* x_mid = static_cast<char*>(scratch);
+  char* x_out = x_mid + (size_t)B * W * esz;
+  char* ln2 = x_out + (size_t)B * W * esz;
+  if (can_fold_ln(m, Lw.in_w, M)) {
+    EZ_TRY(linear_folded_ln(m, b.x_in, W, Lw.in_w, eps, b.stat, b.qkv, 3 * W, M, ACT_NONE, stream, stats_ready));
+  } else {
+    EZ_TRY(layernorm_fwd(b.x_in, W, b.ln1, W, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, M, W, dt, nullptr, nullptr, stream));
+    EZ_TRY(linear(m, b.ln1, W, Lw.in_w, Lw.in_b, b.qkv, 3 * W, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  }
+  AttnArgs at;
+  at.k = (const char*)b.qkv + (size_t)W * esz;
+  at.v = (const char*)b.qkv + (size_t)2 * W * esz;
+  at.row_stride = 3 * W;
+  at.B = B; at.L = d.L; at.H = d.heads; at.scale = 0.125f;
+  EZ_TRY(attention_cls_fwd(at, b.qkv, (int64_t)d.L * 3 * W, b.ctx, W, dt, stream));                 // q of token 0
+  EZ_TRY(linear(m, b.ctx, W, Lw.out_w, Lw.out_b, x_mid, W, B, ACT_NONE, b.x_in, (int64_t)d.L * W, nullptr, false, stream));
+  if (can_fold_ln(m, Lw.fc_w, B)) {
+    EZ_TRY(linear_folded_ln(m, x_mid, W, Lw.fc_w, eps, b.stat, b.h, 4 * W, B, ACT_QUICKGELU, stream));
+  } else {
+    EZ_TRY(layernorm_fwd(x_mid, W, ln2, W, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, B, W, dt, nullptr, nullptr, stream));
+    EZ_TRY(linear(m, ln2, W, Lw.fc_w, Lw.fc_b, b.h, 4 * W, B, ACT_QUICKGELU, nullptr, 0, nullptr, false, stream));
+  }
+  return linear(m, b.h, 4 * W, Lw.proj_w, Lw.proj_b, x_out, W, B, ACT_NONE, x_mid, W, nullptr, false, stream);
+}
+
 // ------------------------------------------------------------ image fwd ----
 int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* wsp, size_t ws_bytes, bool save,
                  hipStream_t stream) {
@@ -603,12 +641,21 @@ int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* 
   bool stats_ready = false;   // b.stat already holds the row statistics of this block's input
   const BlockDims bd{M, W, B, Lv, m->vheads, 0};
   const bool save_blocks = save && !m->opt_vision_frozen;     // (see layout_image)
-  for (int i = 0; i < m->cfg.vision_layers; ++i)
+  const int nl = m->cfg.vision_layers;
+  const bool cls_last = !save_blocks && g_cls_last && Lv >= 4;      // inference: the last block only feeds x[:, 0]
+  for (int i = 0; i < nl - (cls_last ? 1 : 0); ++i)
     EZ_TRY(resblock_forward(m, m->vit[i], ws.layers[i], bd, save_blocks, stats_ready,
-                            i + 1 < m->cfg.vision_layers ? ws.layers[i + 1].stat : nullptr, stream));
+                            i + 1 < nl ? ws.layers[i + 1].stat : nullptr, stream));
   // ln_post(x[:, 0, :]) @ proj                                        :248-251
-  const void* xl = ws.layers[m->cfg.vision_layers - 1].x_out;
-  EZ_TRY(layernorm_fwd(xl, (int64_t)Lv * W, ws.cls_ln, W, m->P(m->lnpost_w), m->P(m->lnpost_b), eps, B, W, dt,
+  const void* xl = ws.layers[nl - 1].x_out;
+  int64_t xl_stride = (int64_t)Lv * W;
+  if (cls_last) {
+    const VitBufs& b = ws.layers[nl - 1];
+    EZ_TRY(resblock_forward_cls(m, m->vit[nl - 1], b, bd, stats_ready, b.ln1, stream));     // (ln1: M * W >= 3 * B * W elements)
+    xl = static_cast<const char*>(b.ln1) + (size_t)B * W * dtype_size(dt);
+    xl_stride = W;
+  }
+  EZ_TRY(layernorm_fwd(xl, xl_stride, ws.cls_ln, W, m->P(m->lnpost_w), m->P(m->lnpost_b), eps, B, W, dt,
                        ws.mpost, ws.rpost, stream));
   EZ_TRY(linear(m, ws.cls_ln, W, m->vproj_w, m->vproj_b, ws.feat, E, B, ACT_NONE, nullptr, 0, nullptr, true, stream));
   // image_features / image_features.norm(dim=-1, keepdim=True)       :360
@@ -725,6 +772,36 @@ size_t text_workspace_bytes(const ezclip_model* m, int B, int L, bool save) {
 }
 
 // ------------------------------------------------------------- text fwd ----
+// Last BERT layer on the inference path, CLS rows only (modeling_chineseclip.py:349-350 reads bert(...)[0][:, 0, :]): key and
+// value projections over all tokens; query, attention, BertSelfOutput, BertIntermediate, BertOutput for token 0 of each
+// sentence.  Scratch: q | ctx in b.ctx, y | a | z | x_out in b.y ([B, H] each; L >= 4).  x_out_cls = b.y + 3 * B * H.
+static int bert_last_layer_cls(ezclip_model* m, const ezclip_model::BertLayer& Lw, const BertBufs& b, const float* key_bias, int B,
+                               int L, float eps, hipStream_t stream) {
+  const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, M = B * L, dt = m->dtype;
+  const size_t esz = dtype_size(dt), blk = (size_t)B * H * esz;
+  char* qkv = (char*)b.qkv;
+  char* q_cls = (char*)b.ctx;
+  char* ctx_cls = q_cls + blk;
+  char* y = (char*)b.y;
+  char* a = y + blk;
+  char* z = a + blk;
+  char* x_out = z + blk;
+  EZ_TRY(linear(m, b.x_in, (int64_t)L * H, Lw.q_w, Lw.q_b, q_cls, H, B, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  EZ_TRY(linear(m, b.x_in, H, Lw.k_w, Lw.k_b, qkv + H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  EZ_TRY(linear(m, b.x_in, H, Lw.v_w, Lw.v_b, qkv + 2 * H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  AttnArgs at;
+  at.k = qkv + H * esz; at.v = qkv + 2 * H * esz;
+  at.row_stride = 3 * H;
+  at.key_bias = key_bias;
+  at.B = B; at.L = L; at.H = m->theads; at.scale = 0.125f;
+  EZ_TRY(attention_cls_fwd(at, q_cls, H, ctx_cls, H, dt, stream));
+  EZ_TRY(linear(m, ctx_cls, H, Lw.o_w, Lw.o_b, y, H, B, ACT_NONE, b.x_in, (int64_t)L * H, nullptr, false, stream));
+  EZ_TRY(layernorm_fwd(y, H, a, H, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, B, H, dt, nullptr, nullptr, stream));
+  EZ_TRY(linear(m, a, H, Lw.i_w, Lw.i_b, b.hh, F, B, ACT_GELU_ERF, nullptr, 0, nullptr, false, stream));
+  EZ_TRY(linear(m, b.hh, F, Lw.d_w, Lw.d_b, z, H, B, ACT_NONE, a, H, nullptr, false, stream));
+  return layernorm_fwd(z, H, x_out, H, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, B, H, dt, nullptr, nullptr, stream);
+}
+
 int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, void* wsp, size_t ws_bytes, bool save,
                 hipStream_t stream, const TextExtras* ex) {
   EZ_REQUIRE(B > 0 && L > 0 && ids && out && wsp, "encode_text: null/empty argument");
@@ -754,7 +831,10 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
   const uint64_t seed = m->drop_seed;
   if (hp > 0.f)                                                                                    // :128
     EZ_TRY(dropout_rows(ws.layers[0].x_in, H, nullptr, 0, ws.layers[0].x_in, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream));
-  for (int i = 0; i < m->cfg.text_num_hidden_layers; ++i) {
+  // inference: the last layer only feeds x[:, 0] to the pooler / projection -- see bert_last_layer_cls
+  const int nlayers = m->cfg.text_num_hidden_layers;
+  const bool cls_last = !save && g_cls_last && hp == 0.f && ap == 0.f && L >= 8;
+  for (int i = 0; i < nlayers - (cls_last ? 1 : 0); ++i) {
     const auto& Lw = m->bert[i];
     const BertBufs& b = ws.layers[i];
     // BertSelfAttention: separate q/k/v Linear                        :172-200
@@ -790,12 +870,19 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
   }
   // chinese_clip: x[:, 0, :] @ text_projection (pooler unused)  modeling_chineseclip.py:349-350
   // huggingface_clip: text_projection(tanh(pooler.dense(x[:, 0])))  appzoo/clip/model.py:134-135, RobertaPooler :550-562
-  const void* xl = ws.layers[m->cfg.text_num_hidden_layers - 1].x_out;
+  const void* xl = ws.layers[nlayers - 1].x_out;
+  int64_t xl_ld = (int64_t)L * H;
+  if (cls_last) {
+    const BertBufs& b = ws.layers[nlayers - 1];
+    EZ_TRY(bert_last_layer_cls(m, m->bert[nlayers - 1], b, ws.key_bias, B, L, eps, stream));
+    xl = static_cast<const char*>(b.y) + (size_t)3 * B * H * esz;      // x_out of the CLS rows, [B, H]
+    xl_ld = H;
+  }
   const void* fa = xl;
-  int64_t fa_ld = (int64_t)L * H;
+  int64_t fa_ld = xl_ld;
   if (m->opt_text_pooler) {
     EZ_REQUIRE(m->P(m->pool_w.p) && m->P(m->pool_b), "encode_text: the pooler is enabled but bert.pooler.dense.* is not bound");
-    EZ_TRY(linear(m, xl, (int64_t)L * H, m->pool_w, m->pool_b, ws.pool, H, B, ACT_TANH, nullptr, 0, ws.pool_u, false, stream));
+    EZ_TRY(linear(m, xl, xl_ld, m->pool_w, m->pool_b, ws.pool, H, B, ACT_TANH, nullptr, 0, ws.pool_u, false, stream));
     fa = ws.pool;
     fa_ld = H;
   }

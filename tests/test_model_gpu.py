@@ -316,3 +316,32 @@ def test_overfit_fixed_pairs_recall_matches_reference_math(tmp_path, dropout):
     assert abs(res[0][1] - want[0]) <= 1e-3, (res, want)
     r1 = O.recall_at_k(ref["text_embeds"], ref["image_embeds"], ks=(1,))
     assert r1[-1] >= 0.9, r1                                    # the pairs really became separable
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("cfg_name,B,Lq", [("small", 5, 40), ("vitb16_bertbase", 4, 64), ("p14_w256", 16, 32)])
+def test_last_block_on_cls_rows_only_equals_full_evaluation(tmp_path, dtype, cfg_name, B, Lq):
+    """Inference path: the last block of each tower is evaluated for the CLS rows only (nothing else is read by
+    ln_post(x[:, 0]) @ proj / bert(...)[0][:, 0] @ text_projection).  Same embeddings as the full evaluation
+    (ezclip_debug_set(3, 0)) up to the rounding of the one-query attention kernel, and as the oracle."""
+    cfg = O.CONFIGS[cfg_name]
+    app, sd = make_app(tmp_path, cfg, 11, dtype)
+    app.eval()
+    px, ids = O.make_inputs(cfg, B, Lq, 2)
+    ids[1, 5] = 0                         # a masked key inside a sentence
+    lib = L.load()
+    outs = {}
+    for mode in (1, 0):
+        L.check(lib.ezclip_debug_set(3, mode))
+        try:
+            with torch.no_grad():
+                o = app({"pixel_values": px, "input_ids": ids}, feat=True)
+                outs[mode] = (o["image_embeds"].cpu().clone(), o["text_embeds"].cpu().clone())
+        finally:
+            L.check(lib.ezclip_debug_set(3, 1))
+    with torch.no_grad():
+        ref = O.clip_forward(sd, cfg, px, ids)
+    tol = 1e-5 if dtype == "fp32" else 1e-2
+    for k, name in ((0, "image_embeds"), (1, "text_embeds")):
+        assert float((outs[1][k] - outs[0][k]).abs().max()) < (2e-6 if dtype == "fp32" else 6e-3), name
+        assert float((outs[1][k] - ref[name]).abs().max()) < tol, name

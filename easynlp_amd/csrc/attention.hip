@@ -294,60 +294,95 @@ int launch_fwd(const AttnArgs& a, hipStream_t stream) {
 // one 128-byte line per lane), a wave softmax, then lane = d accumulates sum_key p_key V[key][d] (V rows read coalesced).
 // HBM traffic: K and V once -- the same bytes the full kernel reads for them; no Q block, no ctx block.
 namespace {
+// 8 of the 64 head dimensions per lane, chunk c = lane & 7: bf16 -> elements 8c .. 8c+7 (one 16-byte load);
+// f32 -> 4c .. 4c+3 and 32+4c .. 32+4c+3 (two 16-byte loads).  A group of 8 lanes covers a whole row in full lines.
+__device__ __forceinline__ void load8(const bf16_t* row, int c, float (&v)[8]) {
+  unpack_chunk(*reinterpret_cast<const uint4*>(row + 8 * c), v, bf16_t());
+}
+__device__ __forceinline__ void load8(const float* row, int c, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(row + 4 * c), b = *reinterpret_cast<const float4*>(row + 32 + 4 * c);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(bf16_t* row, int c, const float (&v)[8]) {
+  *reinterpret_cast<uint4*>(row + 8 * c) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                      pack_bf16x2(v[6], v[7]));
+}
+__device__ __forceinline__ void store8(float* row, int c, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(row + 4 * c) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(row + 32 + 4 * c) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// One wave per (sample, head); lane = (key group g = lane >> 3, chunk c = lane & 7): every load instruction of the wave
+// covers 8 consecutive keys in full 128-byte (bf16) lines.  Scores go through a per-wave LDS row (512 floats).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(AttnArgs a, const T* q_cls, int64_t q_stride, T* ctx_cls,
                                                            int64_t ctx_stride) {
-  constexpr int kMaxJ = 8;                     // keys per lane: L <= 512
-  const int lane = threadIdx.x & 63;
-  const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ float sc_all[4][512];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int bh = blockIdx.x * 4 + w;
   if (bh >= a.B * a.H) return;
+  float* sc = sc_all[w];
   const int b = bh / a.H, head = bh - b * a.H;
-  const int L = a.L;
-  const T* q = q_cls + (int64_t)b * q_stride + head * 64;
+  const int L = a.L, g = lane >> 3, c = lane & 7;
   const T* kbase = reinterpret_cast<const T*>(a.k) + (int64_t)b * L * a.row_stride + head * 64;
   const T* vbase = reinterpret_cast<const T*>(a.v) + (int64_t)b * L * a.row_stride + head * 64;
-  float qv[64];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) ld4(q + 4 * c, *reinterpret_cast<float(*)[4]>(&qv[4 * c]));
-  float sc[kMaxJ];
+  float qv[8];
+  load8(q_cls + (int64_t)b * q_stride + head * 64, c, qv);
+  const int nit = (L + 7) >> 3;
   float mx = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < kMaxJ; ++j) {
-    const int key = lane + 64 * j;
-    sc[j] = -INFINITY;
+#pragma unroll 4
+  for (int i = 0; i < nit; ++i) {
+    const int key = g + 8 * i;
+    float dot = 0.f;
     if (key < L) {
-      const T* kr = kbase + (int64_t)key * a.row_stride;
-      float dot = 0.f;
+      float kv[8];
+      load8(kbase + (int64_t)key * a.row_stride, c, kv);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        float kv[4];
-        ld4(kr + 4 * c, kv);
-        dot = fmaf(qv[4 * c], kv[0], dot); dot = fmaf(qv[4 * c + 1], kv[1], dot);
-        dot = fmaf(qv[4 * c + 2], kv[2], dot); dot = fmaf(qv[4 * c + 3], kv[3], dot);
-      }
-      sc[j] = fmaf(dot, a.scale, a.key_bias ? a.key_bias[(int64_t)b * L + key] : 0.f);
+      for (int e = 0; e < 8; ++e) dot = fmaf(qv[e], kv[e], dot);
     }
-    mx = fmaxf(mx, sc[j]);
+    dot += __shfl_xor(dot, 1, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    dot += __shfl_xor(dot, 4, 64);
+    if (key < L) {
+      const float x = fmaf(dot, a.scale, a.key_bias ? a.key_bias[(int64_t)b * L + key] : 0.f);
+      mx = fmaxf(mx, x);
+      if (c == 0) sc[key] = x;
+    }
   }
   mx = wave_max(mx);
+  __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the scores are in LDS (same wave wrote them)
   float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < kMaxJ; ++j) {
-    sc[j] = lane + 64 * j < L ? expf(sc[j] - mx) : 0.f;
-    sum += sc[j];
+  for (int key = lane; key < L; key += 64) {
+    const float p = expf(sc[key] - mx);
+    sc[key] = p;
+    sum += p;
   }
   sum = wave_sum(sum);
-  float acc = 0.f;
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  float acc[8];
 #pragma unroll
-  for (int j = 0; j < kMaxJ; ++j) {
-    if (64 * j >= L) break;
-    const int n = min(64, L - 64 * j);
-    for (int src = 0; src < n; ++src) {
-      const float p = __shfl(sc[j], src, 64);
-      acc = fmaf(p, Elem<T>::ld(vbase + (int64_t)(64 * j + src) * a.row_stride + lane), acc);
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < nit; ++i) {
+    const int key = g + 8 * i;
+    if (key < L) {
+      float vv[8];
+      load8(vbase + (int64_t)key * a.row_stride, c, vv);
+      const float p = sc[key];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vv[e], acc[e]);
     }
   }
-  Elem<T>::st(ctx_cls + (int64_t)b * ctx_stride + head * 64 + lane, acc / sum);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = acc[e];
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    acc[e] = v * inv;
+  }
+  if (g == 0) store8(ctx_cls + (int64_t)b * ctx_stride + head * 64, c, acc);
 }
 }  // namespace
 
@@ -357,7 +392,10 @@ int attention_cls_fwd(const AttnArgs& a, const void* q_cls, int64_t q_stride, vo
   EZ_REQUIRE(a.B > 0 && a.L > 0 && a.L <= 512 && a.H > 0 && a.causal == 0 && a.drop.thr == 0,
              "attention_cls_fwd: unsupported problem (L=%d)", a.L);
   const int esz = dtype_size(dtype);
-  EZ_REQUIRE((a.row_stride * esz) % 16 == 0 && (q_stride * esz) % 16 == 0, "attention_cls_fwd: strides must be 16-byte multiples");
+  EZ_REQUIRE((a.row_stride * esz) % 16 == 0 && (q_stride * esz) % 16 == 0 && (ctx_stride * esz) % 16 == 0,
+             "attention_cls_fwd: strides must be 16-byte multiples");
+  EZ_REQUIRE(((uintptr_t)a.k % 16) == 0 && ((uintptr_t)a.v % 16) == 0 && ((uintptr_t)q_cls % 16) == 0 && ((uintptr_t)ctx_cls % 16) == 0,
+             "attention_cls_fwd: pointers must be 16-byte aligned");
   const int waves = a.B * a.H;
   ProfScope ps(PROF_ATTN, 4.0 * a.B * a.H * (double)a.L * 64, stream);
   if (dtype == EZCLIP_F32)

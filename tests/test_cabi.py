@@ -140,3 +140,49 @@ def test_pipelined_gemm_isa_audit(tmp_path):
         audit = subprocess.run([sys.executable, os.path.join(root, "tools", "audit_asm_loads.py"), asm],
                                capture_output=True, text=True)
         assert audit.returncode == 0 and "audit: ok" in audit.stdout, audit.stdout[-2000:]
+
+
+def test_all_three_checkpoint_flavours_keep_the_reference_state_dict(tmp_path):
+    """chinese_clip / huggingface_clip / open_clip (appzoo/clip/model.py:52-104): the drop-in CLIPApp exposes exactly the
+    reference's state-dict keys and round-trips the weights (checked here without a GPU: construction and loading are
+    host-side)."""
+    import json
+    import torch
+    from easynlp_amd.appzoo.clip import CLIPApp
+    from oracle import hf_clip_oracle as H
+    from oracle import open_clip_oracle as OC
+    from oracle import ref_harness as R
+    # huggingface_clip
+    d1 = tmp_path / "hf"
+    cfg = H.HF_CONFIGS["hf_small"]
+    sd = H.make_state_dict(cfg, 2)
+    R.write_hf_checkpoint_dir(str(d1), cfg, sd)
+    app = CLIPApp(str(d1))
+    assert app.model_type == "huggingface_clip"
+    got = app.state_dict()
+    assert set(got) == set(H.param_shapes(cfg)) | {"text_encoder.embeddings.position_ids",
+                                                   "vision_encoder.vision_model.embeddings.position_ids"}
+    for k, v in sd.items():
+        assert torch.equal(got[k].reshape(v.shape), v), k
+    assert {n for n, _ in app.named_parameters()} - {"logit_scale_param"} == set(H.param_shapes(cfg)) - {"logit_scale"}
+    # the library-side view: packed in_proj = [q; k; v], transposed projections
+    t = app._hf.library_tensors(app._engine.names)
+    vm = "vision_encoder.vision_model.encoder.layers.1.self_attn."
+    assert torch.equal(t["visual.transformer.resblocks.1.attn.in_proj_weight"],
+                       torch.cat([sd[vm + "q_proj.weight"], sd[vm + "k_proj.weight"], sd[vm + "v_proj.weight"]]))
+    assert torch.equal(t["text_projection"], sd["text_projection.weight"].t())
+    assert t["bert.pooler.dense.bias"].data_ptr() == app._hf_params["text_encoder.pooler.dense.bias"].data_ptr()
+    # open_clip
+    d2 = tmp_path / "oc"
+    os.makedirs(str(d2))
+    ocfg = OC.OPENCLIP_CONFIGS["oc_tiny"]
+    osd = OC.make_state_dict(ocfg, 4)
+    with open(os.path.join(str(d2), "config.json"), "w") as f:
+        json.dump(ocfg, f)
+    torch.save({"open_clip." + k: v for k, v in osd.items()}, os.path.join(str(d2), "pytorch_model.bin"))
+    app2 = CLIPApp(str(d2))
+    assert app2.model_type == "open_clip"
+    got2 = app2.state_dict()
+    assert set(got2) == {"open_clip." + k for k in OC.param_shapes(ocfg)}
+    for k, v in osd.items():
+        assert torch.equal(got2["open_clip." + k], v), k

@@ -180,6 +180,8 @@ def main():
         L.check(L.load().ezclip_debug_set(2, 0))
     if os.environ.get("EZCLIP_CLS_LAST"):       # A/B switch: 0 = evaluate the last block of each tower for every token
         L.check(L.load().ezclip_debug_set(3, int(os.environ["EZCLIP_CLS_LAST"])))
+    if os.environ.get("EZCLIP_CLS_TRAIN"):      # A/B switch: 0 = the training path evaluates the last blocks for every token
+        L.check(L.load().ezclip_debug_set(4, int(os.environ["EZCLIP_CLS_TRAIN"])))
     if os.environ.get("EZCLIP_LNFOLD_MODE"):    # A/B switch: 2 = folded LayerNorm with a separate statistics pass
         L.check(L.load().ezclip_debug_set(2, int(os.environ["EZCLIP_LNFOLD_MODE"])))
     wl = dict(WORKLOADS[args.workload])

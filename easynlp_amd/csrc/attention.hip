@@ -408,6 +408,136 @@ int attention_cls_fwd(const AttnArgs& a, const void* q_cls, int64_t q_stride, vo
   return EZ_OK;
 }
 
+namespace {
+// Backward of attn_cls_fwd_kernel.  One wave per (sample, head), same lane = (key group, chunk) layout.  Writes the FULL
+// dq / dk / dv blocks of the head: dk, dv for every key, dq for the query row (row 0 of the sample) and zeros for the
+// other rows (they have no path to the loss) -- the in_proj gradients then run over all tokens as usual.
+//   p = softmax(scale q.K^T + bias),  D = <dO, O>,  dP_k = <dO, V_k>,  dS_k = p_k (dP_k - D)
+//   dV_k = p_k dO,   dK_k = scale dS_k q,   dq = scale sum_k dS_k K_k
+template <typename T>
+__global__ __launch_bounds__(256) void attn_cls_bwd_kernel(AttnBwdArgs a, const T* q_cls, int64_t q_stride, const T* ctx_cls,
+                                                           const T* dctx_cls, int64_t ctx_stride, T* dq_cls, int64_t dq_stride) {
+  __shared__ float sc_all[4][512];
+  const AttnArgs& f = a.f;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int bh = blockIdx.x * 4 + w;
+  if (bh >= f.B * f.H) return;
+  float* sc = sc_all[w];
+  const int b = bh / f.H, head = bh - b * f.H;
+  const int L = f.L, g = lane >> 3, c = lane & 7;
+  const int64_t hoff = (int64_t)b * L * f.row_stride + head * 64;
+  const T* kbase = reinterpret_cast<const T*>(f.k) + hoff;
+  const T* vbase = reinterpret_cast<const T*>(f.v) + hoff;
+  T* dqb = a.dq ? reinterpret_cast<T*>(a.dq) + hoff : nullptr;
+  T* dkb = reinterpret_cast<T*>(a.dk) + hoff;
+  T* dvb = reinterpret_cast<T*>(a.dv) + hoff;
+  float qv[8], ov[8], gv[8];
+  load8(q_cls + (int64_t)b * q_stride + head * 64, c, qv);
+  load8(ctx_cls + (int64_t)b * ctx_stride + head * 64, c, ov);
+  load8(dctx_cls + (int64_t)b * ctx_stride + head * 64, c, gv);
+  float D = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) D = fmaf(gv[e], ov[e], D);
+  D += __shfl_xor(D, 1, 64);
+  D += __shfl_xor(D, 2, 64);
+  D += __shfl_xor(D, 4, 64);
+  const int nit = (L + 7) >> 3;
+  float mx = -INFINITY;
+#pragma unroll 4
+  for (int i = 0; i < nit; ++i) {
+    const int key = g + 8 * i;
+    float dot = 0.f;
+    if (key < L) {
+      float kv[8];
+      load8(kbase + (int64_t)key * f.row_stride, c, kv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dot = fmaf(qv[e], kv[e], dot);
+    }
+    dot += __shfl_xor(dot, 1, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    dot += __shfl_xor(dot, 4, 64);
+    if (key < L) {
+      const float x = fmaf(dot, f.scale, f.key_bias ? f.key_bias[(int64_t)b * L + key] : 0.f);
+      mx = fmaxf(mx, x);
+      if (c == 0) sc[key] = x;
+    }
+  }
+  mx = wave_max(mx);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  float sum = 0.f;
+  for (int key = lane; key < L; key += 64) {
+    const float p = expf(sc[key] - mx);
+    sc[key] = p;
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  const float inv = 1.0f / sum;
+  float dq[8], zero[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { dq[e] = 0.f; zero[e] = 0.f; }
+#pragma unroll 2
+  for (int i = 0; i < nit; ++i) {
+    const int key = g + 8 * i;
+    float dp = 0.f;
+    float kv[8], vv[8];
+    if (key < L) {
+      load8(vbase + (int64_t)key * f.row_stride, c, vv);
+      load8(kbase + (int64_t)key * f.row_stride, c, kv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dp = fmaf(gv[e], vv[e], dp);
+    }
+    dp += __shfl_xor(dp, 1, 64);
+    dp += __shfl_xor(dp, 2, 64);
+    dp += __shfl_xor(dp, 4, 64);
+    if (key < L) {
+      const float p = sc[key] * inv;
+      const float ds = p * (dp - D) * f.scale;
+      float dk[8], dv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        dv[e] = p * gv[e];
+        dk[e] = ds * qv[e];
+        dq[e] = fmaf(ds, kv[e], dq[e]);
+      }
+      store8(dvb + (int64_t)key * f.row_stride, c, dv);
+      store8(dkb + (int64_t)key * f.row_stride, c, dk);
+      if (key > 0 && dq_cls == nullptr) store8(dqb + (int64_t)key * f.row_stride, c, zero);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = dq[e];
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    dq[e] = v;
+  }
+  // dq_cls given (BERT: the query projection itself ran on the CLS rows): compact [B, dq_stride] output, no zero fill
+  if (g == 0) store8(dq_cls ? dq_cls + (int64_t)b * dq_stride + head * 64 : dqb, c, dq);
+}
+}  // namespace
+
+int attention_cls_bwd(const AttnBwdArgs& a, const void* q_cls, int64_t q_stride, const void* ctx_cls, const void* dctx_cls,
+                      int64_t ctx_stride, int dtype, hipStream_t stream, void* dq_cls, int64_t dq_stride) {
+  const AttnArgs& f = a.f;
+  EZ_REQUIRE(f.B > 0 && f.L > 0 && f.L <= 512 && f.H > 0 && f.causal == 0 && f.drop.thr == 0 && (a.dq || dq_cls) && a.dk && a.dv,
+             "attention_cls_bwd: unsupported problem (L=%d)", f.L);
+  const int esz = dtype_size(dtype);
+  EZ_REQUIRE((f.row_stride * esz) % 16 == 0 && (q_stride * esz) % 16 == 0 && (ctx_stride * esz) % 16 == 0,
+             "attention_cls_bwd: strides must be 16-byte multiples");
+  const int waves = f.B * f.H;
+  ProfScope ps(PROF_ATTN, 10.0 * f.B * f.H * (double)f.L * 64, stream);
+  if (dtype == EZCLIP_F32)
+    hipLaunchKernelGGL((attn_cls_bwd_kernel<float>), dim3((waves + 3) / 4), dim3(256), 0, stream, a, (const float*)q_cls, q_stride,
+                       (const float*)ctx_cls, (const float*)dctx_cls, ctx_stride, (float*)dq_cls, dq_stride);
+  else
+    hipLaunchKernelGGL((attn_cls_bwd_kernel<bf16_t>), dim3((waves + 3) / 4), dim3(256), 0, stream, a, (const bf16_t*)q_cls, q_stride,
+                       (const bf16_t*)ctx_cls, (const bf16_t*)dctx_cls, ctx_stride, (bf16_t*)dq_cls, dq_stride);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
 static int g_attn_variant = -1;
 void set_attention_variant(int v) { g_attn_variant = v; }
 

@@ -296,6 +296,7 @@ int ezclip_debug_set(int key, int value) {
   if (key == 1) { set_attention_variant(value); return EZ_OK; }
   if (key == 2) { set_fold_layernorm(value); return EZ_OK; }
   if (key == 3) { set_cls_last(value); return EZ_OK; }
+  if (key == 4) { set_cls_last_train(value); return EZ_OK; }
   set_error("ezclip_debug_set: unknown key %d", key);
   return EZ_ERR_INVALID;
 }
@@ -375,6 +376,23 @@ int ezclip_op_attention_bwd(const void* q, const void* k, const void* v, int64_t
   return attention_bwd(b, dtype, S(stream));
 }
 
+int ezclip_op_attention_cls(const void* q_cls, int64_t q_stride, const void* k, const void* v, int64_t row_stride,
+                            const float* key_bias, void* ctx_cls, int64_t ctx_stride, int batch, int seq_len, int heads, int dtype,
+                            void* stream) {
+  AttnArgs a;
+  a.k = k; a.v = v; a.row_stride = row_stride; a.key_bias = key_bias; a.B = batch; a.L = seq_len; a.H = heads; a.scale = 0.125f;
+  return attention_cls_fwd(a, q_cls, q_stride, ctx_cls, ctx_stride, dtype, S(stream));
+}
+int ezclip_op_attention_cls_bwd(const void* q_cls, int64_t q_stride, const void* k, const void* v, int64_t row_stride,
+                                const float* key_bias, const void* ctx_cls, const void* dctx_cls, int64_t ctx_stride, void* dq,
+                                void* dk, void* dv, void* dq_cls, int64_t dq_stride, int batch, int seq_len, int heads, int dtype,
+                                void* stream) {
+  AttnBwdArgs b;
+  b.f.k = k; b.f.v = v; b.f.row_stride = row_stride; b.f.key_bias = key_bias;
+  b.f.B = batch; b.f.L = seq_len; b.f.H = heads; b.f.scale = 0.125f;
+  b.dq = dq; b.dk = dk; b.dv = dv;
+  return attention_cls_bwd(b, q_cls, q_stride, ctx_cls, dctx_cls, ctx_stride, dtype, S(stream), dq_cls, dq_stride);
+}
 int ezclip_op_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, void* stream) {
   return cast_from_f32(src, dst, n, dtype, S(stream));
 }

@@ -106,6 +106,10 @@ struct AttnBwdArgs {
   float* db_part = nullptr;       // scratch [B][3][H*64] f32 for the fused kernel's per-sample partial sums (required with dbq)
 };
 int attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream);
+// backward of attention_cls_fwd: writes the full dq / dk / dv blocks (dq: the query row, zeros elsewhere)
+// dq_cls != null: dq goes to that compact [B, dq_stride] buffer instead of (row 0 + zero fill of) a.dq
+int attention_cls_bwd(const AttnBwdArgs& a, const void* q_cls, int64_t q_stride, const void* ctx_cls, const void* dctx_cls,
+                      int64_t ctx_stride, int dtype, hipStream_t stream, void* dq_cls = nullptr, int64_t dq_stride = 0);
 int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream);   // fused single kernel, bf16, L <= 256
 
 // ---- row-wise / elementwise kernels (rowops.hip) ------------------------------
@@ -151,8 +155,8 @@ int bert_embed_ln(const int64_t* ids, const float* word, const float* pos, const
 // CLIP text transformer (OPEN_CLIP.encode_text): x = token_embedding[ids] + positional_embedding; eot_idx[b] = argmax_t ids[b, t]
 int clip_text_embed(const int64_t* ids, const float* tok, const float* pos, void* x, int* eot_idx, int B, int L, int W, int vocab,
                     int dtype, hipStream_t stream);
-// scatter = 0: dst[b] = src[b, idx[b]];  scatter = 1: dst[b, idx[b]] = src[b] (other rows untouched)
-int gather_rows(const void* src, const int* idx, void* dst, int B, int L, int W, int scatter, int dtype, hipStream_t stream);
+// mode 0: dst[b] = src[b, idx[b]];  1: dst[b, idx[b]] = src[b];  2: dst[b, idx[b]] += src[b]  (other rows untouched; idx null: row 0)
+int gather_rows(const void* src, const int* idx, void* dst, int B, int L, int W, int mode, int dtype, hipStream_t stream);
 // out[b] = x[b] / ||x[b]||_2 (no eps: reference modeling_chineseclip.py:360,363); inv_norm optional.
 int l2_normalize_fwd(const float* x, float* out, float* inv_norm, int B, int E, hipStream_t stream);
 // dx = (dy - y * <dy, y>) * inv_norm

@@ -618,6 +618,30 @@ static int resblock_forward_cls(ezclip_model* m, const ezclip_model::VitLayer& L
   return linear(m, b.h, 4 * W, Lw.proj_w, Lw.proj_b, x_out, W, B, ACT_NONE, x_mid, W, nullptr, false, stream);
 }
 
+// Training variant of resblock_forward_cls: the same evaluation (full-width ln_1 + in_proj, everything after it on the CLS
+// rows), every intermediate kept for the backward pass in the block's own buffers (the first B rows of each).
+static bool g_cls_last_train = true;
+void set_cls_last_train(int on) { g_cls_last_train = on != 0; }
+
+static int resblock_forward_cls_save(ezclip_model* m, const ezclip_model::VitLayer& Lw, const VitBufs& b, const BlockDims& d,
+                                     hipStream_t stream) {
+  const int M = d.M, W = d.W, B = d.B, dt = m->dtype;
+  const size_t esz = dtype_size(dt);
+  const float eps = 1e-5f;
+  EZ_TRY(layernorm_fwd(b.x_in, W, b.ln1, W, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, M, W, dt, b.m1, b.r1, stream));
+  EZ_TRY(linear(m, b.ln1, W, Lw.in_w, Lw.in_b, b.qkv, 3 * W, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  AttnArgs at;
+  at.k = (const char*)b.qkv + (size_t)W * esz;
+  at.v = (const char*)b.qkv + (size_t)2 * W * esz;
+  at.row_stride = 3 * W;
+  at.B = B; at.L = d.L; at.H = d.heads; at.scale = 0.125f;
+  EZ_TRY(attention_cls_fwd(at, b.qkv, (int64_t)d.L * 3 * W, b.ctx, W, dt, stream));
+  EZ_TRY(linear(m, b.ctx, W, Lw.out_w, Lw.out_b, b.x_mid, W, B, ACT_NONE, b.x_in, (int64_t)d.L * W, nullptr, false, stream));
+  EZ_TRY(layernorm_fwd(b.x_mid, W, b.ln2, W, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, B, W, dt, b.m2, b.r2, stream));
+  EZ_TRY(linear(m, b.ln2, W, Lw.fc_w, Lw.fc_b, b.h, 4 * W, B, ACT_QUICKGELU, nullptr, 0, b.u, false, stream));
+  return linear(m, b.h, 4 * W, Lw.proj_w, Lw.proj_b, b.x_out, W, B, ACT_NONE, b.x_mid, W, nullptr, false, stream);
+}
+
 // ------------------------------------------------------------ image fwd ----
 int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* wsp, size_t ws_bytes, bool save,
                  hipStream_t stream) {
@@ -642,18 +666,23 @@ int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* 
   const BlockDims bd{M, W, B, Lv, m->vheads, 0};
   const bool save_blocks = save && !m->opt_vision_frozen;     // (see layout_image)
   const int nl = m->cfg.vision_layers;
-  const bool cls_last = !save_blocks && g_cls_last && Lv >= 4;      // inference: the last block only feeds x[:, 0]
+  const bool cls_infer = !save_blocks && g_cls_last && Lv >= 4;     // the last block only feeds x[:, 0]
+  const bool cls_train = save_blocks && g_cls_last_train && Lv >= 4;
+  const bool cls_last = cls_infer || cls_train;
   for (int i = 0; i < nl - (cls_last ? 1 : 0); ++i)
     EZ_TRY(resblock_forward(m, m->vit[i], ws.layers[i], bd, save_blocks, stats_ready,
                             i + 1 < nl ? ws.layers[i + 1].stat : nullptr, stream));
   // ln_post(x[:, 0, :]) @ proj                                        :248-251
   const void* xl = ws.layers[nl - 1].x_out;
   int64_t xl_stride = (int64_t)Lv * W;
-  if (cls_last) {
+  if (cls_infer) {
     const VitBufs& b = ws.layers[nl - 1];
     EZ_TRY(resblock_forward_cls(m, m->vit[nl - 1], b, bd, stats_ready, b.ln1, stream));     // (ln1: M * W >= 3 * B * W elements)
     xl = static_cast<const char*>(b.ln1) + (size_t)B * W * dtype_size(dt);
     xl_stride = W;
+  } else if (cls_train) {
+    EZ_TRY(resblock_forward_cls_save(m, m->vit[nl - 1], ws.layers[nl - 1], bd, stream));
+    xl_stride = W;                                                   // x_out of the last block: [B, W] (CLS rows)
   }
   EZ_TRY(layernorm_fwd(xl, xl_stride, ws.cls_ln, W, m->P(m->lnpost_w), m->P(m->lnpost_b), eps, B, W, dt,
                        ws.mpost, ws.rpost, stream));
@@ -802,6 +831,31 @@ static int bert_last_layer_cls(ezclip_model* m, const ezclip_model::BertLayer& L
   return layernorm_fwd(z, H, x_out, H, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, B, H, dt, nullptr, nullptr, stream);
 }
 
+// Training variant of bert_last_layer_cls: intermediates kept in the layer's own buffers (first B rows of y, a, u, hh, z,
+// x_out, the LayerNorm statistics; ctx rows [0, B) = the CLS context, rows [B, 2B) = the CLS queries).
+static int bert_last_layer_cls_save(ezclip_model* m, const ezclip_model::BertLayer& Lw, const BertBufs& b, const float* key_bias,
+                                    int B, int L, float eps, hipStream_t stream) {
+  const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, M = B * L, dt = m->dtype;
+  const size_t esz = dtype_size(dt), blk = (size_t)B * H * esz;
+  char* qkv = (char*)b.qkv;
+  char* ctx_cls = (char*)b.ctx;
+  char* q_cls = ctx_cls + blk;
+  EZ_TRY(linear(m, b.x_in, (int64_t)L * H, Lw.q_w, Lw.q_b, q_cls, H, B, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  EZ_TRY(linear(m, b.x_in, H, Lw.k_w, Lw.k_b, qkv + H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  EZ_TRY(linear(m, b.x_in, H, Lw.v_w, Lw.v_b, qkv + 2 * H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  AttnArgs at;
+  at.k = qkv + H * esz; at.v = qkv + 2 * H * esz;
+  at.row_stride = 3 * H;
+  at.key_bias = key_bias;
+  at.B = B; at.L = L; at.H = m->theads; at.scale = 0.125f;
+  EZ_TRY(attention_cls_fwd(at, q_cls, H, ctx_cls, H, dt, stream));
+  EZ_TRY(linear(m, ctx_cls, H, Lw.o_w, Lw.o_b, b.y, H, B, ACT_NONE, b.x_in, (int64_t)L * H, nullptr, false, stream));
+  EZ_TRY(layernorm_fwd(b.y, H, b.a, H, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, B, H, dt, b.m1, b.r1, stream));
+  EZ_TRY(linear(m, b.a, H, Lw.i_w, Lw.i_b, b.hh, F, B, ACT_GELU_ERF, nullptr, 0, b.u, false, stream));
+  EZ_TRY(linear(m, b.hh, F, Lw.d_w, Lw.d_b, b.z, H, B, ACT_NONE, b.a, H, nullptr, false, stream));
+  return layernorm_fwd(b.z, H, b.x_out, H, m->P(Lw.ln2_w), m->P(Lw.ln2_b), eps, B, H, dt, b.m2, b.r2, stream);
+}
+
 int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, void* wsp, size_t ws_bytes, bool save,
                 hipStream_t stream, const TextExtras* ex) {
   EZ_REQUIRE(B > 0 && L > 0 && ids && out && wsp, "encode_text: null/empty argument");
@@ -833,7 +887,9 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
     EZ_TRY(dropout_rows(ws.layers[0].x_in, H, nullptr, 0, ws.layers[0].x_in, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream));
   // inference: the last layer only feeds x[:, 0] to the pooler / projection -- see bert_last_layer_cls
   const int nlayers = m->cfg.text_num_hidden_layers;
-  const bool cls_last = !save && g_cls_last && hp == 0.f && ap == 0.f && L >= 8;
+  const bool cls_infer = !save && g_cls_last && hp == 0.f && ap == 0.f && L >= 8;
+  const bool cls_train = save && g_cls_last_train && hp == 0.f && ap == 0.f && L >= 8;
+  const bool cls_last = cls_infer || cls_train;
   for (int i = 0; i < nlayers - (cls_last ? 1 : 0); ++i) {
     const auto& Lw = m->bert[i];
     const BertBufs& b = ws.layers[i];
@@ -872,11 +928,14 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
   // huggingface_clip: text_projection(tanh(pooler.dense(x[:, 0])))  appzoo/clip/model.py:134-135, RobertaPooler :550-562
   const void* xl = ws.layers[nlayers - 1].x_out;
   int64_t xl_ld = (int64_t)L * H;
-  if (cls_last) {
+  if (cls_infer) {
     const BertBufs& b = ws.layers[nlayers - 1];
     EZ_TRY(bert_last_layer_cls(m, m->bert[nlayers - 1], b, ws.key_bias, B, L, eps, stream));
     xl = static_cast<const char*>(b.y) + (size_t)3 * B * H * esz;      // x_out of the CLS rows, [B, H]
     xl_ld = H;
+  } else if (cls_train) {
+    EZ_TRY(bert_last_layer_cls_save(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws.key_bias, B, L, eps, stream));
+    xl_ld = H;                                                         // x_out of the last layer: [B, H] (CLS rows)
   }
   const void* fa = xl;
   int64_t fa_ld = xl_ld;
@@ -980,6 +1039,37 @@ static int resblock_backward(ezclip_model* m, const ezclip_model::VitLayer& Lw, 
   return EZ_OK;
 }
 
+// backward of resblock_forward_cls_save.  On entry g.gx = d x_out of the CLS rows, compact [B, W]; on exit g.gx = d x_in
+// for every row [M, W] (only the CLS query, the keys and the values carry gradient into the rows of ln_1).
+static int resblock_backward_cls(ezclip_model* m, const ezclip_model::VitLayer& Lw, const VitBufs& b, const BlockDims& d,
+                                 const BlockGrads& g, int prev_proj_b, hipStream_t stream) {
+  const int M = d.M, W = d.W, B = d.B, dt = m->dtype;
+  const size_t esz = dtype_size(dt);
+  EZ_TRY(dgrad(m, g.gx, W, Lw.proj_w, g.gbig, 4 * W, B, b.u, 4 * W, ACT_QUICKGELU, nullptr, 0, stream, Lw.fc_b));      // d u
+  EZ_TRY(wgrad(m, g.gx, W, b.h, 4 * W, Lw.proj_w, B, stream));
+  EZ_TRY(dgrad(m, g.gbig, 4 * W, Lw.fc_w, g.gtmp, W, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));                     // d ln_2
+  EZ_TRY(wgrad(m, g.gbig, 4 * W, b.ln2, W, Lw.fc_w, B, stream));
+  EZ_TRY(ln_bwd(m, b.x_mid, W, g.gtmp, W, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, g.gx2, W, g.gx, W, B, W, stream, Lw.out_b)); // d x_mid
+  EZ_TRY(dgrad(m, g.gx2, W, Lw.out_w, g.gtmp, W, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));                         // d ctx
+  EZ_TRY(wgrad(m, g.gx2, W, b.ctx, W, Lw.out_w, B, stream));
+  AttnBwdArgs ab;
+  ab.f.k = (const char*)b.qkv + (size_t)W * esz;
+  ab.f.v = (const char*)b.qkv + (size_t)2 * W * esz;
+  ab.f.row_stride = 3 * W;
+  ab.f.B = B; ab.f.L = d.L; ab.f.H = d.heads; ab.f.scale = 0.125f;
+  ab.dq = g.gqkv;
+  ab.dk = (char*)g.gqkv + (size_t)W * esz;
+  ab.dv = (char*)g.gqkv + (size_t)2 * W * esz;
+  EZ_TRY(attention_cls_bwd(ab, b.qkv, (int64_t)d.L * 3 * W, b.ctx, g.gtmp, W, dt, stream));
+  EZ_TRY(bgrad(m, g.gqkv, 3 * W, M, 3 * W, Lw.in_b, stream));
+  // the residual x_mid = x_in + ... reaches x_in at the CLS rows only: d x_mid scattered into a zeroed block (gbig is free)
+  EZ_HIP(hipMemsetAsync(g.gbig, 0, (size_t)M * W * esz, stream));
+  EZ_TRY(gather_rows(g.gx2, nullptr, g.gbig, B, d.L, W, 1, dt, stream));
+  EZ_TRY(dgrad(m, g.gqkv, 3 * W, Lw.in_w, g.gtmp, W, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));                     // d ln_1
+  EZ_TRY(wgrad(m, g.gqkv, 3 * W, b.ln1, W, Lw.in_w, M, stream));
+  return ln_bwd(m, b.x_in, W, g.gtmp, W, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, g.gx, W, g.gbig, W, M, W, stream, prev_proj_b);
+}
+
 int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_emb, void* wsp, size_t ws_bytes,
                    hipStream_t stream) {
   EZ_REQUIRE(B > 0 && d_emb && wsp, "backward_image: null/empty argument");
@@ -1002,14 +1092,23 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
   if (m->Gp(m->vproj_b)) EZ_TRY(colsum_add(ws.gfeat, E, B, E, m->Gp(m->vproj_b), EZCLIP_F32, stream));
   if (m->opt_vision_frozen) return EZ_OK;      // image_embeds = vision_outputs[1].detach()   appzoo/clip/model.py:140
   EZ_TRY(dgrad(m, gfeatT, E, m->vproj_w, ws.gcls, W, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
-  EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * W * esz, stream));
-  const void* xl = ws.layers[m->cfg.vision_layers - 1].x_out;
-  // (gx is zero outside the CLS rows: its column sums are the last block's c_proj bias gradient)
-  EZ_TRY(ln_bwd(m, xl, (int64_t)Lv * W, ws.gcls, W, m->lnpost_w, m->lnpost_b, ws.mpost, ws.rpost, ws.gx, (int64_t)Lv * W,
-                nullptr, 0, B, W, stream, m->vit[m->cfg.vision_layers - 1].proj_b));
+  const int nl = m->cfg.vision_layers;
+  const void* xl = ws.layers[nl - 1].x_out;
   const BlockDims bd{M, W, B, Lv, m->vheads, 0};
   const BlockGrads bg{ws.gx, ws.gx2, ws.gtmp, ws.gqkv, ws.gbig, ws.gbpart};
-  for (int i = m->cfg.vision_layers - 1; i >= 0; --i)
+  const bool cls_train = g_cls_last_train && Lv >= 4;        // (the forward's choice: encode_image)
+  if (cls_train) {
+    // x_out of the last block is [B, W]; d x_out lands compact in gx (+ the block's c_proj bias gradient)
+    EZ_TRY(ln_bwd(m, xl, W, ws.gcls, W, m->lnpost_w, m->lnpost_b, ws.mpost, ws.rpost, ws.gx, W, nullptr, 0, B, W, stream,
+                  m->vit[nl - 1].proj_b));
+    EZ_TRY(resblock_backward_cls(m, m->vit[nl - 1], ws.layers[nl - 1], bd, bg, nl > 1 ? m->vit[nl - 2].proj_b : -1, stream));
+  } else {
+    EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * W * esz, stream));
+    // (gx is zero outside the CLS rows: its column sums are the last block's c_proj bias gradient)
+    EZ_TRY(ln_bwd(m, xl, (int64_t)Lv * W, ws.gcls, W, m->lnpost_w, m->lnpost_b, ws.mpost, ws.rpost, ws.gx, (int64_t)Lv * W,
+                  nullptr, 0, B, W, stream, m->vit[nl - 1].proj_b));
+  }
+  for (int i = nl - (cls_train ? 2 : 1); i >= 0; --i)
     EZ_TRY(resblock_backward(m, m->vit[i], ws.layers[i], bd, bg, i > 0 ? m->vit[i - 1].proj_b : -1, stream));
   // x = ln_pre(cat(cls, conv(patches)) + pos)                                          :237-242
   EZ_TRY(ln_bwd(m, ws.x0, W, ws.gx, W, m->lnpre_w, m->lnpre_b, ws.m0, ws.r0, ws.gx2, W, nullptr, 0, M, W, stream));
@@ -1030,6 +1129,47 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
     }
   }
   return EZ_OK;
+}
+
+// backward of bert_last_layer_cls_save.  On entry ws.gx = d x_out of the CLS rows, compact [B, H]; on exit ws.gx = d x_in
+// for every row [M, H] (the key / value projections over all tokens; the query projection and the residual at the CLS rows).
+static int bert_last_layer_cls_backward(ezclip_model* m, const ezclip_model::BertLayer& Lw, const BertBufs& b, const TxtWS& ws,
+                                        int B, int L, hipStream_t stream) {
+  const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, M = B * L, dt = m->dtype;
+  const size_t esz = dtype_size(dt), blk = (size_t)B * H * esz;
+  char* qkv = (char*)b.qkv;
+  char* gq = (char*)ws.gqkv;
+  const char* ctx_cls = (const char*)b.ctx;
+  const char* q_cls = ctx_cls + blk;
+  // x_out = LN(z);  z = dense(hh) + a;  hh = gelu(u);  u = dense(a)          (B rows)
+  EZ_TRY(ln_bwd(m, b.z, H, ws.gx, H, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, H, nullptr, 0, B, H, stream, Lw.d_b));        // d z
+  EZ_TRY(dgrad(m, ws.gx2, H, Lw.d_w, ws.gbig, F, B, b.u, F, ACT_GELU_ERF, nullptr, 0, stream, Lw.i_b));                  // d u
+  EZ_TRY(wgrad(m, ws.gx2, H, b.hh, F, Lw.d_w, B, stream));
+  EZ_TRY(dgrad(m, ws.gbig, F, Lw.i_w, ws.gtmp, H, B, nullptr, 0, ACT_NONE, ws.gx2, H, stream));                           // d a
+  EZ_TRY(wgrad(m, ws.gbig, F, b.a, H, Lw.i_w, B, stream));
+  // a = LN(y);  y = dense(ctx) + x_in[:, 0]
+  EZ_TRY(ln_bwd(m, b.y, H, ws.gtmp, H, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx2, H, nullptr, 0, B, H, stream, Lw.o_b));    // d y
+  EZ_TRY(dgrad(m, ws.gx2, H, Lw.o_w, ws.gtmp, H, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));                           // d ctx
+  EZ_TRY(wgrad(m, ws.gx2, H, ctx_cls, H, Lw.o_w, B, stream));
+  AttnBwdArgs ab;
+  ab.f.k = qkv + H * esz; ab.f.v = qkv + 2 * H * esz;
+  ab.f.row_stride = 3 * H;
+  ab.f.key_bias = ws.key_bias;
+  ab.f.B = B; ab.f.L = L; ab.f.H = m->theads; ab.f.scale = 0.125f;
+  ab.dq = nullptr; ab.dk = gq + H * esz; ab.dv = gq + 2 * H * esz;
+  EZ_TRY(attention_cls_bwd(ab, q_cls, H, ctx_cls, ws.gtmp, H, dt, stream, ws.gx3, H));            // d q of the CLS rows -> gx3 [B, H]
+  // d x_in: keys and values over all rows ...
+  EZ_TRY(dgrad(m, gq + H * esz, 3 * H, Lw.k_w, ws.gx, H, M, nullptr, 0, ACT_NONE, nullptr, 0, stream));
+  EZ_TRY(dgrad(m, gq + 2 * H * esz, 3 * H, Lw.v_w, ws.gx, H, M, nullptr, 0, ACT_NONE, ws.gx, H, stream));
+  // ... plus, at the CLS rows, the query projection and the residual of y
+  EZ_TRY(dgrad(m, ws.gx3, H, Lw.q_w, ws.gtmp, H, B, nullptr, 0, ACT_NONE, ws.gx2, H, stream));
+  EZ_TRY(gather_rows(ws.gtmp, nullptr, ws.gx, B, L, H, 2, dt, stream));
+  EZ_TRY(wgrad(m, ws.gx3, H, b.x_in, (int64_t)L * H, Lw.q_w, B, stream));
+  EZ_TRY(wgrad(m, gq + H * esz, 3 * H, b.x_in, H, Lw.k_w, M, stream));
+  EZ_TRY(wgrad(m, gq + 2 * H * esz, 3 * H, b.x_in, H, Lw.v_w, M, stream));
+  EZ_TRY(bgrad(m, ws.gx3, H, B, H, Lw.q_b, stream));
+  EZ_TRY(bgrad(m, gq + H * esz, 3 * H, M, H, Lw.k_b, stream));
+  return bgrad(m, gq + 2 * H * esz, 3 * H, M, H, Lw.v_b, stream);
 }
 
 // backward of encode_text_clip
@@ -1085,19 +1225,24 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
   const void* xl = ws.layers[m->cfg.text_num_hidden_layers - 1].x_out;
   const TextExtras none;
   if (ex == nullptr) ex = &none;
-  EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * H * esz, stream));
+  const int nlayers = m->cfg.text_num_hidden_layers;
+  // (the forward's choice, encode_text: last layer on the CLS rows -> its x_out and the gradient entering it are [B, H])
+  const bool cls_train = g_cls_last_train && hp == 0.f && ap == 0.f && L >= 8;
+  const int64_t xl_ld = cls_train ? H : (int64_t)L * H;
+  if (!cls_train) EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * H * esz, stream));
   if (m->Gp(m->tproj_b)) EZ_TRY(colsum_add(ws.gfeat, E, B, E, m->Gp(m->tproj_b), EZCLIP_F32, stream));
   if (m->opt_text_pooler) {
     // feat = proj(tanh(u)), u = pooler.dense(x[:, 0]):  d u = (d feat . W_proj) o tanh'(u)  (+ pooler bias gradient)
     EZ_TRY(dgrad(m, gfeatT, E, m->tproj_w, ws.gpool, H, B, ws.pool_u, H, ACT_TANH, nullptr, 0, stream, m->pool_b));
     EZ_TRY(wgrad(m, gfeatT, E, ws.pool, H, m->tproj_w, B, stream));
-    EZ_TRY(dgrad(m, ws.gpool, H, m->pool_w, ws.gx, (int64_t)L * H, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
-    EZ_TRY(wgrad(m, ws.gpool, H, xl, (int64_t)L * H, m->pool_w, B, stream));
+    EZ_TRY(dgrad(m, ws.gpool, H, m->pool_w, ws.gx, xl_ld, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
+    EZ_TRY(wgrad(m, ws.gpool, H, xl, xl_ld, m->pool_w, B, stream));
   } else {
-    EZ_TRY(dgrad(m, gfeatT, E, m->tproj_w, ws.gx, (int64_t)L * H, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
-    EZ_TRY(wgrad(m, gfeatT, E, xl, (int64_t)L * H, m->tproj_w, B, stream));
+    EZ_TRY(dgrad(m, gfeatT, E, m->tproj_w, ws.gx, xl_ld, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
+    EZ_TRY(wgrad(m, gfeatT, E, xl, xl_ld, m->tproj_w, B, stream));
   }
-  for (int i = m->cfg.text_num_hidden_layers - 1; i >= 0; --i) {
+  if (cls_train) EZ_TRY(bert_last_layer_cls_backward(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws, B, L, stream));
+  for (int i = nlayers - (cls_train ? 2 : 1); i >= 0; --i) {
     const auto& Lw = m->bert[i];
     const BertBufs& b = ws.layers[i];
     // x_out = LN(z);  z = dense(hh) + a;  hh = gelu(u);  u = dense(a)        modeling_bert.py:330-345

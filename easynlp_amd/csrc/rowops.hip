@@ -370,16 +370,23 @@ __global__ void argmax_rows_kernel(const int64_t* ids, int* idx, int B, int L) {
   idx[b] = bi;
 }
 
-// gather: dst[b] = src[b, idx[b]] ; scatter: dst[b, idx[b]] = src[b] (dst zeroed by the caller)   rows of W elements
+// mode 0 gather: dst[b] = src[b, idx[b]];  1 scatter: dst[b, idx[b]] = src[b];  2 scatter-add: dst[b, idx[b]] += src[b]
+// (rows of W elements; idx == nullptr: row 0 of every sample)
 template <typename T>
-__global__ void gather_rows_kernel(const T* src, const int* idx, T* dst, int B, int L, int W, int scatter) {
+__global__ void gather_rows_kernel(const T* src, const int* idx, T* dst, int B, int L, int W, int mode) {
   const int64_t n = (int64_t)B * (W >> 2);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / (W >> 2)), c = (int)(i - (int64_t)b * (W >> 2)) * 4;
-    const int64_t big = ((int64_t)b * L + idx[b]) * W + c, small = (int64_t)b * W + c;
+    const int64_t big = ((int64_t)b * L + (idx ? idx[b] : 0)) * W + c, small = (int64_t)b * W + c;
     float v[4];
-    ld4(src + (scatter ? small : big), v);
-    st4(dst + (scatter ? big : small), v);
+    ld4(src + (mode ? small : big), v);
+    if (mode == 2) {
+      float o[4];
+      ld4(dst + big, o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += o[e];
+    }
+    st4(dst + (mode ? big : small), v);
   }
 }
 
@@ -703,12 +710,12 @@ int clip_text_embed(const int64_t* ids, const float* tok, const float* pos, void
   return EZ_OK;
 }
 
-int gather_rows(const void* src, const int* idx, void* dst, int B, int L, int W, int scatter, int dtype, hipStream_t stream) {
+int gather_rows(const void* src, const int* idx, void* dst, int B, int L, int W, int mode, int dtype, hipStream_t stream) {
   EZ_REQUIRE(W % 4 == 0, "gather_rows: width %d must be a multiple of 4", W);
   const int64_t n = (int64_t)B * (W >> 2);
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)src, idx, (T*)dst, B,
-                                          L, W, scatter));
+                                          L, W, mode));
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

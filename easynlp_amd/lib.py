@@ -85,6 +85,8 @@ SIGNATURES = {
     "ezclip_op_dropout_mask": (_i, [_f, C.c_uint64, C.c_uint32, _i, _i, _vp, _vp, _vp]),
     "ezclip_op_set_attention_dropout": (_i, [_f, C.c_uint64, C.c_uint32]),
     "ezclip_op_set_attention_causal": (_i, [_i]),
+    "ezclip_op_attention_cls": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "ezclip_op_attention_cls_bwd": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "ezclip_op_cast_from_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
     "ezclip_op_cast_to_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
 }

@@ -269,6 +269,17 @@ int ezclip_op_set_attention_dropout(float p, uint64_t seed, uint32_t site);
 /* causal mask (key index > query index -> -inf, OPEN_CLIP.build_attention_mask, modeling_openclip.py:343-349) for the
  * following ezclip_op_attention / ezclip_op_attention_bwd calls */
 int ezclip_op_set_attention_causal(int on);
+/* One query per sample (the CLS row of a tower's last block): q_cls [batch, q_stride] holds the queries (heads
+ * side by side), k / v as in ezclip_op_attention, ctx_cls / dctx_cls [batch, ctx_stride].  The backward writes dk / dv for every
+ * key and dq either as row 0 of each sample in the full block `dq_dev` (other rows zeroed) or, when dq_cls_dev is given, into
+ * that compact [batch, dq_stride] buffer. */
+int ezclip_op_attention_cls(const void* q_cls_dev, int64_t q_stride, const void* k_dev, const void* v_dev, int64_t row_stride,
+                            const float* key_bias_dev, void* ctx_cls_dev, int64_t ctx_stride, int batch, int seq_len, int heads,
+                            int dtype, void* stream);
+int ezclip_op_attention_cls_bwd(const void* q_cls_dev, int64_t q_stride, const void* k_dev, const void* v_dev, int64_t row_stride,
+                                const float* key_bias_dev, const void* ctx_cls_dev, const void* dctx_cls_dev, int64_t ctx_stride,
+                                void* dq_dev, void* dk_dev, void* dv_dev, void* dq_cls_dev, int64_t dq_stride, int batch,
+                                int seq_len, int heads, int dtype, void* stream);
 int ezclip_op_cast_from_f32(const float* src_dev, void* dst_dev, int64_t n, int dtype, void* stream);
 int ezclip_op_cast_to_f32(const void* src_dev, float* dst_dev, int64_t n, int dtype, void* stream);
 

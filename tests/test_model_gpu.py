@@ -345,3 +345,27 @@ def test_last_block_on_cls_rows_only_equals_full_evaluation(tmp_path, dtype, cfg
     for k, name in ((0, "image_embeds"), (1, "text_embeds")):
         assert float((outs[1][k] - outs[0][k]).abs().max()) < (2e-6 if dtype == "fp32" else 6e-3), name
         assert float((outs[1][k] - ref[name]).abs().max()) < tol, name
+
+
+def test_training_path_last_block_on_cls_rows_equals_full_backward(tmp_path):
+    """Training path: with the last block of each tower evaluated on the CLS rows only (default) the loss and every
+    parameter gradient equal those of the all-token evaluation (ezclip_debug_set(4, 0)) -- fp32, so any slip shows."""
+    cfg = O.CONFIGS["small"]
+    px, ids = O.make_inputs(cfg, 5, 40, 9)
+    lib = L.load()
+    res = {}
+    for mode in (1, 0):
+        L.check(lib.ezclip_debug_set(4, mode))
+        try:
+            app, _ = make_app(tmp_path, cfg, 17, "fp32")
+            app.train()
+            loss = app.compute_loss(app({"pixel_values": px, "input_ids": ids}), [])["loss"]
+            loss.backward()
+            res[mode] = (loss.item(), {n: p.grad.detach().cpu().clone() for n, p in app._params.items() if p.grad is not None})
+        finally:
+            L.check(lib.ezclip_debug_set(4, 1))
+    assert abs(res[1][0] - res[0][0]) < 1e-6
+    assert set(res[1][1]) == set(res[0][1])
+    for n, g0 in res[0][1].items():
+        err = float((res[1][1][n] - g0).norm())
+        assert err <= 2e-5 * float(g0.norm()) + 1e-8, (n, err, float(g0.norm()))

@@ -456,3 +456,50 @@ def test_attention_causal_forward_and_backward(Lq, dtype, variant):
     # the first token attends only to itself: ctx[0] = v[0]
     v0 = qkv[0, 2 * D:2 * D + 64].float()
     assert float((ctx[0, :64].float().cpu() - v0).abs().max()) < (1e-6 if dtype == "f32" else 1e-2)
+
+
+@pytest.mark.parametrize("Lq", [8, 33, 64, 197, 300])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("compact_dq", [False, True])
+def test_attention_cls_query_forward_and_backward(Lq, dtype, compact_dq):
+    """One query per sample (the CLS row of a tower's last block): ctx, and dq / dk / dv for all keys, against torch fp64."""
+    B_, H = 3, 2
+    g = torch.Generator().manual_seed(Lq + 7)
+    D = H * 64
+    qkv = torch.randn(B_ * Lq, 3 * D, generator=g)
+    dctx = torch.randn(B_, D, generator=g)
+    kb = torch.zeros(B_, Lq)
+    kb[1, Lq - 3:] = -10000.0
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    qkv, dctx = qkv.to(tdt), dctx.to(tdt)
+    qd = qkv.double().requires_grad_(True)
+    q, k, v = [t.reshape(B_, Lq, H, 64).transpose(1, 2) for t in qd.split(D, dim=-1)]
+    s = (q[:, :, :1] @ k.transpose(-1, -2)) * 0.125 + kb.double().reshape(B_, 1, 1, Lq)
+    ref = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B_, D)
+    ref.backward(dctx.double())
+    lib = L.load()
+    dt = L.DTYPE_F32 if dtype == "f32" else L.DTYPE_BF16
+    qg, dg_, kbg = qkv.to(DEV), dctx.to(DEV), kb.reshape(-1).to(DEV)
+    esz = qg.element_size()
+    base = qg.data_ptr()
+    ctx = torch.empty((B_, D), dtype=tdt, device=DEV)
+    L.check(lib.ezclip_op_attention_cls(base, Lq * 3 * D, base + D * esz, base + 2 * D * esz, 3 * D, L.ptr(kbg), L.ptr(ctx), D,
+                                        B_, Lq, H, dt, L.stream_ptr()))
+    dqkv = torch.full_like(qg, float("nan"))
+    dq_c = torch.zeros((B_, D), dtype=tdt, device=DEV)
+    db = dqkv.data_ptr()
+    L.check(lib.ezclip_op_attention_cls_bwd(base, Lq * 3 * D, base + D * esz, base + 2 * D * esz, 3 * D, L.ptr(kbg), L.ptr(ctx),
+                                            L.ptr(dg_), D, None if compact_dq else db, db + D * esz, db + 2 * D * esz,
+                                            L.ptr(dq_c) if compact_dq else None, D, B_, Lq, H, dt, L.stream_ptr()))
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == "f32" else 3e-2
+    assert max_err(ctx.float(), ref.detach()) < tol
+    gq, gk, gv = qd.grad.split(D, dim=-1)
+    got = dqkv.float().cpu().double()
+    assert rel_err(got[:, D:2 * D], gk) < (1e-5 if dtype == "f32" else 2e-2)
+    assert rel_err(got[:, 2 * D:], gv) < (1e-5 if dtype == "f32" else 2e-2)
+    if compact_dq:
+        assert rel_err(dq_c.float().cpu().double(), gq.reshape(B_, Lq, D)[:, 0]) < (1e-5 if dtype == "f32" else 2e-2)
+        assert torch.isnan(got[:, :D]).all()          # untouched
+    else:
+        assert rel_err(got[:, :D], gq) < (1e-5 if dtype == "f32" else 2e-2)      # (zeros outside row 0 on both sides)

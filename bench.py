@@ -68,6 +68,7 @@ GFLOP_FWD_PER_PAIR = 46.152
 # out_proj + MLP + attention core of one ViT block for 196 of 197 tokens (2.199 G) and query / attention / output / FFN of one
 # BERT layer for 63 of 64 tokens (0.756 G) are not executed.  model_tflops is computed from the EXECUTED figure.
 GFLOP_FWD_EXECUTED_PER_PAIR = 46.152 - 2.199 - 0.756
+GFLOP_TRAIN_EXECUTED_PER_PAIR = 138.46 - 3 * (2.199 + 0.756)     # the same rows are skipped in the backward pass
 GFLOP_TRAIN_PER_PAIR = 138.46
 GFLOP_FWD_PER_PAIR_VITL14 = 173.05      # ViT-L/14 (L = 257) + BERT-base text tower, 64 tokens
 GFLOP_TRAIN_PER_PAIR_VITL14 = 519.2
@@ -279,7 +280,11 @@ def main():
             gflop = GFLOP_TRAIN_PER_PAIR_VITL14 if wl["backward"] else GFLOP_FWD_PER_PAIR_VITL14
         else:
             cls_last = os.environ.get("EZCLIP_CLS_LAST", "1") != "0"
-            gflop = GFLOP_TRAIN_PER_PAIR if wl["backward"] else (GFLOP_FWD_EXECUTED_PER_PAIR if cls_last else GFLOP_FWD_PER_PAIR)
+            cls_train = os.environ.get("EZCLIP_CLS_TRAIN", "1") != "0"
+            if wl["backward"]:
+                gflop = GFLOP_TRAIN_EXECUTED_PER_PAIR if cls_train else GFLOP_TRAIN_PER_PAIR
+            else:
+                gflop = GFLOP_FWD_EXECUTED_PER_PAIR if cls_last else GFLOP_FWD_PER_PAIR
         out = {
             "metric": "image-text pairs/sec (fwd+loss) " + ("ViT-L/14+roberta-wwm-ext" if wl.get("model") in ("vitl14", "hf_vitl14")
                                                             else "ViT-B/16+BERT-base"),

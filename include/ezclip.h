@@ -232,7 +232,7 @@ int ezclip_recall_ranks(const float* text_dev, const float* image_dev, int n, in
 /* Tuning / A-B switches for sweeps and tests.  key 0: GEMM kernel (-1 heuristic, 0 128x128, 1 256x256 two-phase,
  * 2 8-phase, 3 4-wave 256x128);  key 1: attention kernels (-1 heuristic, 0 general two-pass kernels only);
  * key 2: LayerNorm folding on the bf16 inference path (0 off, 1 folded + statistics from the producing GEMM, 2 folded +
- * separate statistics pass);  key 3: last-block CLS-only evaluation on the inference path (1 on, 0 off). */
+ * separate statistics pass);  key 3: last-block CLS-only evaluation on the inference path (1 on, 0 off);  key 4: the same on the training path. */
 int ezclip_debug_set(int key, int value);
 int ezclip_profile_begin(void);
 int ezclip_profile_end(int kernel_class, double* total_ms, double* total_work, int* launches);

@@ -548,7 +548,7 @@ int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream) {
   EZ_REQUIRE(((uintptr_t)a.q % 16) == 0 && ((uintptr_t)a.k % 16) == 0 && ((uintptr_t)a.v % 16) == 0 &&
              ((uintptr_t)a.ctx % 16) == 0, "attention_fwd: pointers must be 16-byte aligned");
   EZ_REQUIRE(a.B <= 65535, "attention_fwd: batch %d > 65535", a.B);
-  if (g_attn_variant != 0 && a.drop.thr == 0 && attention_short_eligible(a, dtype)) return attention_fwd_short(a, stream);
+  if (g_attn_variant != 0 && a.drop.thr == 0 && attention_short_fwd_eligible(a, dtype)) return attention_fwd_short(a, stream);
   if (dtype == EZCLIP_F32) return launch_fwd<float>(a, stream);
   if (dtype == EZCLIP_BF16) return launch_fwd<bf16_t>(a, stream);
   set_error("attention_fwd: bad dtype %d", dtype);

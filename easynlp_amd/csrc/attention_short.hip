@@ -47,7 +47,8 @@ __device__ __forceinline__ void dma_rows(char* dst, const char* gbase, int64_t r
   }
 }
 
-__global__ __launch_bounds__(512) void attn_fwd_short_kernel(AttnArgs a, int nt) {
+// (up to 9 waves = 288 tokens: ViT-L/14 has 257; 104 VGPRs leave room for three waves on a SIMD)
+__global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int head = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x;
@@ -61,9 +62,10 @@ __global__ __launch_bounds__(512) void attn_fwd_short_kernel(AttnArgs a, int nt)
   const int64_t rs = a.row_stride * 2;
   const int64_t base = ((int64_t)b * L * a.row_stride + head * 64) * 2;
 
-  dma_rows<0>(kimg, reinterpret_cast<const char*>(a.k) + base, rs, LKP, L, wave, 8, lane);
-  dma_rows<1>(vimg, reinterpret_cast<const char*>(a.v) + base, rs, LKP, L, wave, 8, lane);
-  for (int key = tid; key < LKP; key += 512)
+  const int nwaves = (int)(blockDim.x >> 6);
+  dma_rows<0>(kimg, reinterpret_cast<const char*>(a.k) + base, rs, LKP, L, wave, nwaves, lane);
+  dma_rows<1>(vimg, reinterpret_cast<const char*>(a.v) + base, rs, LKP, L, wave, nwaves, lane);
+  for (int key = tid; key < LKP; key += (int)blockDim.x)
     kb[key] = key < L ? (a.key_bias ? a.key_bias[(int64_t)b * L + key] : 0.f) : -INFINITY;
 
   // this wave's 32 queries
@@ -459,8 +461,11 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
 
 }  // namespace
 
-bool attention_short_eligible(const AttnArgs& a, int dtype) {
+bool attention_short_eligible(const AttnArgs& a, int dtype) {       // fused backward: four images of L rows in LDS
   return dtype == EZCLIP_BF16 && a.L <= 256 && a.B <= 65535;
+}
+bool attention_short_fwd_eligible(const AttnArgs& a, int dtype) {   // forward: two images; one wave per 32 queries, <= 9 waves
+  return dtype == EZCLIP_BF16 && a.L <= 288 && a.B <= 65535;
 }
 
 int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
@@ -498,7 +503,7 @@ int attention_fwd_short(const AttnArgs& a, hipStream_t stream) {
   }
   {
     ProfScope ps(PROF_ATTN, 4.0 * a.B * a.H * (double)a.L * a.L * 64, stream);   // QK^T + PV, unpadded
-    hipLaunchKernelGGL(attn_fwd_short_kernel, dim3(a.H, a.B), dim3(512), bytes, stream, a, nt);
+    hipLaunchKernelGGL(attn_fwd_short_kernel, dim3(a.H, a.B), dim3(nt > 8 ? 64 * nt : 512), bytes, stream, a, nt);
   }
   EZ_LAUNCH_CHECK();
   return EZ_OK;

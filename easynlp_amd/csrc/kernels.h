@@ -89,6 +89,7 @@ int attention_cls_fwd(const AttnArgs& a, const void* q_cls, int64_t q_stride, vo
                       hipStream_t stream);
 // short-sequence bf16 kernels (attention_short.hip): L <= 256, one-pass online softmax, LDS transpose reads
 bool attention_short_eligible(const AttnArgs& a, int dtype);
+bool attention_short_fwd_eligible(const AttnArgs& a, int dtype);
 int attention_fwd_short(const AttnArgs& a, hipStream_t stream);
 void set_attention_variant(int v);   // -1 auto, 0: attention.hip kernels only
 

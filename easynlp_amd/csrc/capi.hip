@@ -278,6 +278,9 @@ int ezclip_op_resample_table(int in_size, int out_size, int first, int count, in
                              int kk_capacity) {
   return resample_table(in_size, out_size, first, count, ksize, bounds_host, kk_host, kk_capacity);
 }
+int ezclip_op_resample_table_device(int in_size, int out_size, int first, int count, int* bounds_dev, int* kk_dev, void* stream) {
+  return resample_table_device(in_size, out_size, first, count, bounds_dev, kk_dev, S(stream));
+}
 int ezclip_preprocess_images(const uint8_t* packed, const ezclip_image_desc* desc, int n, int size, int crop, const float* mean,
                              const float* stdv, float* out, void* ws, size_t ws_bytes, void* stream) {
   EZ_REQUIRE(mean && stdv, "ezclip_preprocess_images: null mean / std");
@@ -297,6 +300,7 @@ int ezclip_debug_set(int key, int value) {
   if (key == 2) { set_fold_layernorm(value); return EZ_OK; }
   if (key == 3) { set_cls_last(value); return EZ_OK; }
   if (key == 4) { set_cls_last_train(value); return EZ_OK; }
+  if (key == 5) { set_device_resample_tables(value); return EZ_OK; }
   set_error("ezclip_debug_set: unknown key %d", key);
   return EZ_ERR_INVALID;
 }

@@ -208,6 +208,8 @@ struct ezclip_image_desc;
 namespace ezclip {
 size_t preprocess_workspace_bytes(const ::ezclip_image_desc* desc, int n, int size, int crop);
 int resample_table(int in_size, int out_size, int first, int count, int* ksize, int* bounds, int* kk, int kk_capacity);
+int resample_table_device(int in_size, int out_size, int first, int count, int* bounds_dev, int* kk_dev, hipStream_t stream);
+void set_device_resample_tables(int on);
 int preprocess_images(const uint8_t* packed, const ::ezclip_image_desc* desc, int n, int size, int crop, const float* mean,
                       const float* stdv, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
 

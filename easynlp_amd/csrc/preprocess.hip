@@ -90,6 +90,47 @@ AxisTable axis_table(int in_size, int out_size, int first, int count) {
   return t;
 }
 
+// What the host still computes per axis when the DEVICE fills the tables (O(1) per image): the scalars of
+// precompute_coeffs and the window of the first / last kept output (which source rows / columns are touched at all).
+struct AxisGeom {
+  int in_size, out_size, first, ksize, identity;
+  int lo, hi;                 // source range [lo, hi) touched by outputs first .. first + count - 1
+  double scale, support, ss;
+};
+
+void window_of(const AxisGeom& g, int xx, int* xmin, int* taps) {
+  const double center = 0.0f + (xx + 0.5) * g.scale;
+  int lo = (int)(center - g.support + 0.5);
+  if (lo < 0) lo = 0;
+  int hi = (int)(center + g.support + 0.5);
+  if (hi > g.in_size) hi = g.in_size;
+  *xmin = lo;
+  *taps = hi - lo;
+}
+
+AxisGeom axis_geom(int in_size, int out_size, int first, int count) {
+  AxisGeom g;
+  g.in_size = in_size; g.out_size = out_size; g.first = first;
+  g.identity = in_size == out_size;
+  if (g.identity) {
+    g.ksize = 1; g.scale = 1.0; g.support = 0.0; g.ss = 1.0;
+    g.lo = first; g.hi = first + count;
+    return g;
+  }
+  const float in0 = 0.f, in1 = (float)in_size;
+  g.scale = (double)(in1 - in0) / out_size;
+  const double filterscale = g.scale < 1.0 ? 1.0 : g.scale;
+  g.support = 2.0 * filterscale;
+  g.ksize = (int)std::ceil(g.support) * 2 + 1;
+  g.ss = 1.0 / filterscale;
+  int a, n;
+  window_of(g, first, &a, &n);
+  g.lo = a;
+  window_of(g, first + count - 1, &a, &n);
+  g.hi = a + n;
+  return g;
+}
+
 struct ImgPlan {
   uint64_t src_off;     // byte offset of the image in the packed buffer
   uint64_t tmp_off;     // byte offset of its [nrows][crop][3] intermediate in the workspace
@@ -98,7 +139,95 @@ struct ImgPlan {
   int col0, ncols;      // source columns the horizontal windows touch (staged in LDS)
   int ksize_h, hb, hk;  // horizontal table: taps, int offsets of bounds / coefficients in the table buffer
   int ksize_v, vb, vk;  // vertical table (bounds relative to row0)
+  // device-built tables: per-axis scalars (h, then v)
+  int out_size[2], first[2], identity[2];
+  double scale[2], support[2], ss[2];
 };
+
+// Resample.c bicubic_filter / precompute_coeffs / normalize_coeffs_8bpc on the device.  Every double operation is an
+// explicitly rounded intrinsic in Pillow's operation order (no FMA contraction), so the tables equal the host's bit for bit
+// (tests/test_preprocess.py compares them over many sizes).
+// Plain operators under `#pragma clang fp contract(off)`: hipcc's default for device code is contract(fast), and the
+// __dmul_rn / __dadd_rn wrappers of the HIP headers are plain operators compiled in the HEADER's context -- a product feeding a
+// sum became an FMA (seen as windows off by one where center + support + 0.5 sits one ulp under an integer).
+__device__ __forceinline__ double bicubic_filter_dev(double x) {
+#pragma clang fp contract(off)
+  if (x < 0.0) x = -x;
+  if (x < 1.0) {
+    double t = 1.5 * x;
+    t = t - 2.5;
+    t = t * x;
+    t = t * x;
+    return t + 1.0;
+  }
+  if (x < 2.0) {
+    double t = x - 5.0;
+    t = t * x;
+    t = t + 8.0;
+    t = t * x;
+    t = t - 4.0;
+    return t * -0.5;
+  }
+  return 0.0;
+}
+
+// one thread per kept output of one axis of one image: bounds[o] = (first source index - shift, taps), kk[o][ksize]
+__device__ __forceinline__ void fill_axis_output(int in_size, int xx, double scale, double support, double ss, int ksize,
+                                                 int identity, int shift, int* bounds, int* kk) {
+#pragma clang fp contract(off)
+  if (identity) {
+    bounds[0] = xx - shift; bounds[1] = 1;
+    kk[0] = 1 << kPrecisionBits;
+    return;
+  }
+  double center = (double)xx + 0.5;
+  center = center * scale;
+  double lo = center - support;
+  lo = lo + 0.5;
+  int xmin = (int)lo;
+  if (xmin < 0) xmin = 0;
+  double hi = center + support;
+  hi = hi + 0.5;
+  int xmax = (int)hi;
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  double ww = 0.0;
+  for (int x = 0; x < xmax; ++x) {
+    double a = (double)(x + xmin) - center;
+    a = a + 0.5;
+    a = a * ss;
+    ww = ww + bicubic_filter_dev(a);
+  }
+  for (int x = 0; x < ksize; ++x) {
+    int c = 0;
+    if (x < xmax) {
+      double a = (double)(x + xmin) - center;
+      a = a + 0.5;
+      a = a * ss;
+      const double w = bicubic_filter_dev(a);
+      const double v = ww != 0.0 ? w / ww : w;
+      double sc = v * (double)(1 << kPrecisionBits);
+      sc = v < 0 ? -0.5 + sc : 0.5 + sc;
+      c = (int)sc;
+    }
+    kk[x] = c;
+  }
+  bounds[0] = xmin - shift;
+  bounds[1] = xmax;
+}
+
+__global__ __launch_bounds__(256) void resample_tables_kernel(const ImgPlan* __restrict__ plans, int* __restrict__ tables, int crop) {
+  const ImgPlan p = plans[blockIdx.y];
+  const int axis = blockIdx.x;          // 0 horizontal, 1 vertical
+  const int o = threadIdx.x;
+  if (o >= crop) return;
+  const int in_size = axis == 0 ? p.in_w : p.in_h;
+  const int ksize = axis == 0 ? p.ksize_h : p.ksize_v;
+  int* bounds = tables + (axis == 0 ? p.hb : p.vb) + 2 * o;
+  int* kk = tables + (axis == 0 ? p.hk : p.vk) + o * ksize;
+  fill_axis_output(in_size, p.first[axis] + o, p.scale[axis], p.support[axis], p.ss[axis], ksize, p.identity[axis],
+                   axis == 1 ? p.row0 : 0, bounds, kk);
+}
 
 __device__ __forceinline__ uint8_t clip8(int acc) {
   int v = acc >> kPrecisionBits;
@@ -172,14 +301,25 @@ __global__ __launch_bounds__(256) void resize_v_norm_kernel(const ImgPlan* __res
   o[(uint64_t)2 * crop * crop] = lut[512 + clip8(s2)];
 }
 
+__global__ __launch_bounds__(256) void resample_tables_split_kernel(const ImgPlan* __restrict__ plans, int* bounds, int* kk, int count) {
+  const ImgPlan p = plans[0];
+  const int o = threadIdx.x;
+  if (o >= count) return;
+  fill_axis_output(p.in_w, p.first[0] + o, p.scale[0], p.support[0], p.ss[0], p.ksize_h, p.identity[0], 0, bounds + 2 * o,
+                   kk + o * p.ksize_h);
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BatchPlan {
   std::vector<ImgPlan> plans;
-  std::vector<int> tables;
+  std::vector<int> tables;      // host-built tables (empty when the device builds them)
+  size_t table_ints = 0;        // size of the table buffer either way
   size_t tmp_bytes = 0;
   int max_rows = 0, max_cols = 0;
 };
+
+bool g_device_tables = true;    // ezclip_debug_set(5, v): 0 = window tables computed on the host (the verified fallback)
 
 // data.py:62-71 (resized size) and :43-48 (crop origin)
 int plan_batch(const ezclip_image_desc* desc, int n, int size, int crop, BatchPlan* out) {
@@ -196,20 +336,34 @@ int plan_batch(const ezclip_image_desc* desc, int n, int size, int crop, BatchPl
     EZ_REQUIRE(nw >= crop && nh >= crop, "preprocess: image %d (%d x %d -> %d x %d) is smaller than the %d crop (the reference pads; "
                "not on this path)", i, w, h, nw, nh, crop);
     const int left = (int)((nw - crop + 1) * 0.5), top = (int)((nh - crop + 1) * 0.5);
-    AxisTable th = axis_table(w, nw, left, crop), tv = axis_table(h, nh, top, crop);
     ImgPlan& p = out->plans[(size_t)i];
     p.src_off = desc[i].offset;
     p.in_w = w; p.in_h = h;
-    p.row0 = tv.bounds[0];
-    p.nrows = tv.bounds[2 * (crop - 1)] + tv.bounds[2 * (crop - 1) + 1] - p.row0;
-    p.col0 = th.bounds[0];
-    p.ncols = th.bounds[2 * (crop - 1)] + th.bounds[2 * (crop - 1) + 1] - p.col0;
-    for (int o = 0; o < crop; ++o) tv.bounds[2 * o] -= p.row0;        // vertical windows index the intermediate
-    p.ksize_h = th.ksize; p.ksize_v = tv.ksize;
-    p.hb = (int)out->tables.size(); out->tables.insert(out->tables.end(), th.bounds.begin(), th.bounds.end());
-    p.hk = (int)out->tables.size(); out->tables.insert(out->tables.end(), th.kk.begin(), th.kk.end());
-    p.vb = (int)out->tables.size(); out->tables.insert(out->tables.end(), tv.bounds.begin(), tv.bounds.end());
-    p.vk = (int)out->tables.size(); out->tables.insert(out->tables.end(), tv.kk.begin(), tv.kk.end());
+    const AxisGeom gh = axis_geom(w, nw, left, crop), gv = axis_geom(h, nh, top, crop);
+    p.row0 = gv.lo; p.nrows = gv.hi - gv.lo;
+    p.col0 = gh.lo; p.ncols = gh.hi - gh.lo;
+    p.ksize_h = gh.ksize; p.ksize_v = gv.ksize;
+    const AxisGeom* gs[2] = {&gh, &gv};
+    for (int a = 0; a < 2; ++a) {
+      p.out_size[a] = gs[a]->out_size; p.first[a] = gs[a]->first; p.identity[a] = gs[a]->identity;
+      p.scale[a] = gs[a]->scale; p.support[a] = gs[a]->support; p.ss[a] = gs[a]->ss;
+    }
+    if (g_device_tables) {
+      size_t off = out->table_ints;
+      p.hb = (int)off; off += 2 * (size_t)crop;
+      p.hk = (int)off; off += (size_t)crop * gh.ksize;
+      p.vb = (int)off; off += 2 * (size_t)crop;
+      p.vk = (int)off; off += (size_t)crop * gv.ksize;
+      out->table_ints = off;
+    } else {
+      AxisTable th = axis_table(w, nw, left, crop), tv = axis_table(h, nh, top, crop);
+      for (int o = 0; o < crop; ++o) tv.bounds[2 * o] -= p.row0;        // vertical windows index the intermediate
+      p.hb = (int)out->tables.size(); out->tables.insert(out->tables.end(), th.bounds.begin(), th.bounds.end());
+      p.hk = (int)out->tables.size(); out->tables.insert(out->tables.end(), th.kk.begin(), th.kk.end());
+      p.vb = (int)out->tables.size(); out->tables.insert(out->tables.end(), tv.bounds.begin(), tv.bounds.end());
+      p.vk = (int)out->tables.size(); out->tables.insert(out->tables.end(), tv.kk.begin(), tv.kk.end());
+      out->table_ints = out->tables.size();
+    }
     p.tmp_off = out->tmp_bytes;
     out->tmp_bytes += align_up((size_t)p.nrows * crop * 3, 256);
     if (p.nrows > out->max_rows) out->max_rows = p.nrows;
@@ -221,10 +375,10 @@ int plan_batch(const ezclip_image_desc* desc, int n, int size, int crop, BatchPl
 struct WsLayout { size_t plans, tables, lut, tmp, total; };
 WsLayout ws_layout(const BatchPlan& b) {
   WsLayout l;
-  l.plans = 0;
-  l.tables = align_up(b.plans.size() * sizeof(ImgPlan), 256);
-  l.lut = l.tables + align_up(b.tables.size() * sizeof(int), 256);
-  l.tmp = l.lut + align_up(3 * 256 * sizeof(float), 256);
+  l.plans = 0;                                   // [plans | lut | tables | tmp]: plans + lut (+ host-built tables) are uploaded
+  l.lut = align_up(b.plans.size() * sizeof(ImgPlan), 256);
+  l.tables = l.lut + align_up(3 * 256 * sizeof(float), 256);
+  l.tmp = l.tables + align_up(b.table_ints * sizeof(int), 256);
   l.total = l.tmp + b.tmp_bytes + 256;
   return l;
 }
@@ -240,6 +394,29 @@ int resample_table(int in_size, int out_size, int first, int count, int* ksize, 
   *ksize = t.ksize;
   std::memcpy(bounds, t.bounds.data(), t.bounds.size() * sizeof(int));
   std::memcpy(kk, t.kk.data(), t.kk.size() * sizeof(int));
+  return EZ_OK;
+}
+
+void set_device_resample_tables(int on) { g_device_tables = on != 0; }
+
+// test hook: the same table built by the device kernel (bounds [count][2], kk [count][ksize] device int32 buffers)
+int resample_table_device(int in_size, int out_size, int first, int count, int* bounds_dev, int* kk_dev, hipStream_t stream) {
+  EZ_REQUIRE(in_size > 0 && out_size > 0 && first >= 0 && count > 0 && count <= 256 && first + count <= out_size && bounds_dev && kk_dev,
+             "resample_table_device: bad argument");
+  const AxisGeom g = axis_geom(in_size, out_size, first, count);
+  ImgPlan p;
+  std::memset(&p, 0, sizeof(p));
+  p.in_w = in_size; p.ksize_h = g.ksize;
+  p.first[0] = first; p.identity[0] = g.identity; p.scale[0] = g.scale; p.support[0] = g.support; p.ss[0] = g.ss;
+  p.hb = 0; p.hk = 0;
+  ImgPlan* dp = nullptr;
+  EZ_HIP(hipMalloc(reinterpret_cast<void**>(&dp), sizeof(ImgPlan)));
+  EZ_HIP(hipMemcpyAsync(dp, &p, sizeof(p), hipMemcpyHostToDevice, stream));
+  EZ_HIP(hipStreamSynchronize(stream));
+  hipLaunchKernelGGL(resample_tables_split_kernel, dim3(1), dim3(256), 0, stream, dp, bounds_dev, kk_dev, count);
+  EZ_HIP(hipStreamSynchronize(stream));
+  EZ_HIP(hipFree(dp));
+  EZ_LAUNCH_CHECK();
   return EZ_OK;
 }
 
@@ -274,7 +451,7 @@ int preprocess_images(const uint8_t* packed, const ezclip_image_desc* desc, int 
   static std::map<hipStream_t, Staging> stg_by_stream;          // one staging buffer per stream
   std::lock_guard<std::mutex> stg_lock(stg_mutex);
   Staging& stg = stg_by_stream[stream];
-  const size_t up_bytes = l.tmp;
+  const size_t up_bytes = b.tables.empty() ? l.tables : l.tmp;        // device-built tables are not uploaded
   if (stg.pending) { EZ_HIP(hipEventSynchronize(stg.ev)); stg.pending = false; }
   if (stg.bytes < up_bytes) {
     if (stg.host) EZ_HIP(hipHostFree(stg.host));
@@ -284,14 +461,16 @@ int preprocess_images(const uint8_t* packed, const ezclip_image_desc* desc, int 
   }
   if (stg.ev == nullptr) EZ_HIP(hipEventCreateWithFlags(&stg.ev, hipEventDisableTiming));
   std::memcpy(stg.host + l.plans, b.plans.data(), b.plans.size() * sizeof(ImgPlan));
-  std::memcpy(stg.host + l.tables, b.tables.data(), b.tables.size() * sizeof(int));
   std::memcpy(stg.host + l.lut, lut, sizeof(lut));
+  if (!b.tables.empty()) std::memcpy(stg.host + l.tables, b.tables.data(), b.tables.size() * sizeof(int));
   char* w = static_cast<char*>(ws);
   EZ_HIP(hipMemcpyAsync(w, stg.host, up_bytes, hipMemcpyHostToDevice, stream));
   EZ_HIP(hipEventRecord(stg.ev, stream));
   stg.pending = true;
   const ImgPlan* dplans = reinterpret_cast<const ImgPlan*>(w + l.plans);
-  const int* dtables = reinterpret_cast<const int*>(w + l.tables);
+  int* dtables = reinterpret_cast<int*>(w + l.tables);
+  if (b.tables.empty())      // window tables on the device: 2 x crop threads per image
+    hipLaunchKernelGGL(resample_tables_kernel, dim3(2, n), dim3(256), 0, stream, dplans, dtables, crop);
   const size_t lds = align_up((size_t)b.max_cols * 3 + 8, 16);
   EZ_REQUIRE(lds <= 64 * 1024, "preprocess_images: a source row of %d pixels does not fit the staging buffer", b.max_cols);
   {

@@ -77,6 +77,7 @@ SIGNATURES = {
     "ezclip_preprocess_images": (_i, [_vp, C.POINTER(EzclipImageDesc), _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp,
                                       _sz, _vp]),
     "ezclip_op_resample_table": (_i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i]),
+    "ezclip_op_resample_table_device": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "ezclip_set_option": (_i, [_vp, _i, C.c_double]),
     "ezclip_encode_text_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _i, _vp]),
     "ezclip_backward_text_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),

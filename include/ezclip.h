@@ -216,6 +216,10 @@ int ezclip_preprocess_images(const uint8_t* packed_dev, const ezclip_image_desc*
 int ezclip_op_resample_table(int in_size, int out_size, int first, int count, int* ksize, int* bounds_host, int* kk_host,
                              int kk_capacity);
 
+/* The same table as built by the device kernel ezclip_preprocess_images uses by default (ezclip_debug_set(5, 0) selects the
+ * host tables): device int32 buffers bounds [count][2], kk [count][ksize]; ksize as reported by ezclip_op_resample_table. */
+int ezclip_op_resample_table_device(int in_size, int out_size, int first, int count, int* bounds_dev, int* kk_dev, void* stream);
+
 /* ---- retrieval metric -------------------------------------------------------------- */
 /* rank_out[i] = number of images j with sim(text i, image j) > sim(text i, image i)
  * (+ ties with j < i, matching a stable descending sort); text/image: float32 [n, e]. */
@@ -232,7 +236,8 @@ int ezclip_recall_ranks(const float* text_dev, const float* image_dev, int n, in
 /* Tuning / A-B switches for sweeps and tests.  key 0: GEMM kernel (-1 heuristic, 0 128x128, 1 256x256 two-phase,
  * 2 8-phase, 3 4-wave 256x128);  key 1: attention kernels (-1 heuristic, 0 general two-pass kernels only);
  * key 2: LayerNorm folding on the bf16 inference path (0 off, 1 folded + statistics from the producing GEMM, 2 folded +
- * separate statistics pass);  key 3: last-block CLS-only evaluation on the inference path (1 on, 0 off);  key 4: the same on the training path. */
+ * separate statistics pass);  key 3: last-block CLS-only evaluation on the inference path (1 on, 0 off);  key 4: the same on the training path;  key 5: resampling window
+ * tables of ezclip_preprocess_images built on the device (1, default) or on the host (0). */
 int ezclip_debug_set(int key, int value);
 int ezclip_profile_begin(void);
 int ezclip_profile_end(int kernel_class, double* total_ms, double* total_work, int* launches);

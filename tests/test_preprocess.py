@@ -139,3 +139,42 @@ def test_predictor_preprocess_decodes_and_uses_the_gpu_pipeline(tmp_path):
     assert tuple(trecs[0]["input_ids"].shape) == (1, 16) and int(trecs[0]["attention_mask"].sum()) == 5
     tf = pred.run([{"text": "tok7 tok9 tok11"}, {"text": "tok8"}])
     assert len(tf) == 2 and "text_feat" in tf[0]
+
+
+@pytest.mark.gpu
+def test_device_built_window_tables_equal_host_tables():
+    """ezclip_preprocess_images builds its resampling windows on the device by default (explicitly rounded double
+    arithmetic in Pillow's operation order); they must equal the host tables -- themselves equal to the Pillow-pinned
+    oracle (CPU test above) -- bit for bit, over many size pairs including extreme ratios."""
+    lib = L.load()
+    rs = np.random.RandomState(5)
+    pairs = [(375, 224), (500, 298), (80, 224), (17, 224), (3024, 224), (224, 224), (2000, 1493), (255, 224), (1000, 74666),
+             (4032, 298), (7, 224), (225, 224), (223, 224)]
+    pairs += [(int(rs.randint(8, 5000)), int(rs.randint(224, 2000))) for _ in range(120)]
+    for in_size, out_size in pairs:
+        first = max(0, (out_size - 224 + 1) // 2)
+        count = min(224, out_size - first)
+        ksize = C.c_int()
+        cap = count * 400
+        hb = (C.c_int * (2 * count))()
+        hk = (C.c_int * cap)()
+        L.check(lib.ezclip_op_resample_table(in_size, out_size, first, count, C.byref(ksize), hb, hk, cap))
+        ks = ksize.value
+        db = torch.full((count, 2), -7, dtype=torch.int32, device="cuda")
+        dk = torch.full((count, ks), -7, dtype=torch.int32, device="cuda")
+        L.check(lib.ezclip_op_resample_table_device(in_size, out_size, first, count, L.ptr(db), L.ptr(dk), L.stream_ptr()))
+        assert np.array_equal(db.cpu().numpy(), np.array(hb[:]).reshape(count, 2)), (in_size, out_size)
+        assert np.array_equal(dk.cpu().numpy(), np.array(hk[:count * ks]).reshape(count, ks)), (in_size, out_size)
+
+
+@pytest.mark.gpu
+def test_device_preprocess_with_host_tables_switch():
+    imgs = [_img(w, h, i) for i, (w, h) in enumerate(SIZES[:8])]
+    lib = L.load()
+    dev = L.preprocess_images(imgs).cpu().numpy()
+    L.check(lib.ezclip_debug_set(5, 0))
+    try:
+        host = L.preprocess_images(imgs).cpu().numpy()
+    finally:
+        L.check(lib.ezclip_debug_set(5, 1))
+    assert np.array_equal(dev.view(np.uint32), host.view(np.uint32))

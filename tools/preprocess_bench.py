@@ -65,7 +65,7 @@ def main():
         P.reference_pipeline_pil(pil)
         k += 1
     cpu = k / (time.perf_counter() - t1)
-    print("preprocess %d x (%d x %d): %.3f ms per call incl. host tables = %.0f images/s; device kernels %.3f ms = %.2f TB/s "
+    print("preprocess %d x (%d x %d): %.3f ms per call (host planning + upload + device) = %.0f images/s; device kernels %.3f ms = %.2f TB/s "
           "(src %.0f MB + out %.0f MB); PIL pipeline on one core: %.0f images/s"
           % (n, w, h, dt * 1e3, n / dt, ms.value, (src + dst) / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0, src / 1e6, dst / 1e6, cpu))
 

@@ -247,7 +247,13 @@ void set_gemm_variant(int v) {   // 2x = 8-phase kernel with ablation code x (ti
 // true when gemm_nt would run this product on the 8-phase kernel (callers that want its optional extras -- folded
 // LayerNorm, row-stat partials -- ask first)
 bool gemm_nt_uses_8p(const GemmArgs& p, int dtype) {
-  return (g_gemm_variant < 0 || g_gemm_variant == 2) && gemm_nt_8p_eligible(p, dtype);
+  if (!((g_gemm_variant < 0 || g_gemm_variant == 2) && gemm_nt_8p_eligible(p, dtype))) return false;
+  if (g_gemm_variant == 2) return true;       // forced (tests, sweeps)
+  // A dozen 256 x 256 tiles on 256 CUs (the B-row products of the CLS-only last blocks at N = 768; with K = 3072 each tile is a
+  // full 86 us): the 128 x 128 kernel spreads the same work over four times as many workgroups.  (Below 512 rows both kernels
+  // are launch-bound; those stay on the 8-phase kernel so that small batches run the code large ones do.)
+  const int64_t tiles = (int64_t)((p.M + 255) >> 8) * (p.N >> 8);
+  return tiles >= 16 || p.M < 512;
 }
 
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
@@ -263,7 +269,7 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
              (p.U == nullptr || (p.ldu % 4 == 0 && (uintptr_t)p.U % 16 == 0));
   p.vec_ok = vec ? 1 : 0;
   if (g_gemm_variant == 3 && gemm_nt_4w_eligible(p, dtype)) return gemm_nt_4w(p, stream);
-  if ((g_gemm_variant < 0 || g_gemm_variant == 2) && gemm_nt_8p_eligible(p, dtype)) return gemm_nt_8p(p, stream);
+  if (gemm_nt_uses_8p(p, dtype)) return gemm_nt_8p(p, stream);
   if (p.colsum != nullptr) {   // not the 8-phase kernel: separate column-sum pass after the GEMM
     float* cs = p.colsum;
     p.colsum = nullptr;

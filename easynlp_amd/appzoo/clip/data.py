@@ -1,0 +1,128 @@
+"""Data side of the path -- mirror of ``easynlp.appzoo.clip.data.CLIPDataset`` (easynlp/appzoo/clip/data.py:152-295)
+for the local TSV format ``text \\t urlsafe-base64(encoded image)`` the tutorials use (``input_schema`` such as
+``"text:str:1,image:str:1"``; base class contract easynlp/appzoo/dataset.py:39-215: ``__getitem__`` parses the row by the
+schema and calls ``convert_single_row_to_example``; the DataLoader collates with ``batch_fn``).
+
+What stays where the reference has it (CPU, DataLoader workers): reading the file, WordPiece tokenisation with the
+checkpoint's ``vocab.txt`` (padding='max_length', truncation, max_length=max_seq_length, data.py:250-253), base64 + image
+decode (data.py:240-244).
+
+What moves to the GPU: the per-image ``_resize`` / ``_center_crop`` / ``_normalize`` (data.py:256-262).  ``batch_fn`` emits
+the decoded images under ``'images'`` (plus ``'image_size'``) instead of ``'pixel_values'`` and the drop-in
+``CLIPApp.forward`` turns them into the same float32 ``pixel_values`` with ``ezclip_preprocess_images`` (bit-identical to the
+reference's PIL pipeline) -- no GPU call happens in a DataLoader worker.  There is no CPU resize here: a
+caller who wants CPU-side ``pixel_values`` uses the reference's own CLIPDataset, whose batches ``CLIPApp.forward`` takes
+unchanged.
+"""
+from __future__ import annotations
+
+import base64
+import io
+import json
+import os
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from ... import lib as L
+
+
+def parse_row_by_schema(row: str, input_schema: str) -> Dict[str, object]:
+    """``"text:str:1,image:str:1"`` + one tab-separated line -> {column: value} (easynlp/utils/__init__.py:77-98: columns are
+    zipped with the schema, so surplus columns are ignored; int / float columns of length > 1 are comma lists)."""
+    out: Dict[str, object] = {}
+    for schema, content in zip(input_schema.split(","), row.strip("\n").split("\t")):
+        name, typ, length = schema.split(":")
+        if typ == "str":
+            out[name] = content
+        elif typ in ("int", "float"):
+            conv = int if typ == "int" else float
+            out[name] = conv(content) if int(length) == 1 else [conv(t) for t in content.split(",")]
+        else:
+            raise RuntimeError("Invalid schema: %s" % schema)
+    return out
+
+
+def load_wordpiece_tokenizer(vocab_path: str):
+    """``BertTokenizer.from_pretrained(dir + '/vocab.txt')`` of the reference (data.py:229, predictor.py:52) with the installed
+    ``transformers``: 4.x takes ``vocab_file=``, 5.x takes the token -> id table and silently ignores ``vocab_file`` (every
+    token would come out as [UNK]) -- so build by signature and verify the table landed."""
+    import inspect
+    from transformers import BertTokenizer
+    with io.open(vocab_path, encoding="utf-8") as f:
+        tokens = [t.rstrip("\n") for t in f.readlines()]
+    while tokens and tokens[-1] == "":
+        tokens.pop()
+    table = {t: i for i, t in enumerate(tokens)}
+    if "vocab" in inspect.signature(BertTokenizer.__init__).parameters:
+        tok = BertTokenizer(vocab=table)
+    else:
+        tok = BertTokenizer(vocab_file=vocab_path)
+    probe = tokens[len(tokens) // 2]
+    if tok.convert_tokens_to_ids(probe) != table[probe] or tok.convert_tokens_to_ids("[CLS]") != table.get("[CLS]"):
+        raise L.EzclipError("the installed transformers BertTokenizer did not take the vocabulary of %s" % vocab_path)
+    return tok
+
+
+class CLIPDataset(torch.utils.data.Dataset):
+
+    def __init__(self, pretrained_model_name_or_path, data_file, max_seq_length, input_schema=None, first_sequence=None,
+                 label_name=None, second_sequence=None, label_enumerate_values=None, user_defined_parameters=None,
+                 skip_first_line: bool = False, image_size: int = 224, *args, **kwargs):
+        path = pretrained_model_name_or_path
+        with open(os.path.join(path, "config.json"), "r") as f:
+            self.raw_config = json.load(f)
+        mt = self.raw_config.get("model_type")
+        self.model_type = mt if mt in ("open_clip", "chinese_clip") else "huggingface_clip"          # data.py:196-201
+        if self.model_type == "open_clip":
+            raise L.EzclipError("open_clip checkpoints tokenise with the BPE SimpleTokenizer (data.py:226-227): feed "
+                                "pre-tokenised input_ids; CLIPDataset covers the WordPiece flavours")
+        if str(data_file).endswith("tar"):
+            raise L.EzclipError("webdataset tar input (data.py:203-217) is not covered; use the TSV format")
+        if not input_schema:
+            raise L.EzclipError("CLIPDataset needs input_schema, e.g. 'text:str:1,image:str:1'")
+        self.input_schema = input_schema
+        self.column_names = [t.split(":")[0] for t in input_schema.split(",")]
+        with io.open(data_file) as f:
+            if skip_first_line:
+                f.readline()
+            self.data_rows = f.readlines()
+        self.text_col = first_sequence
+        self.image_col = second_sequence
+        self.tokenizer = load_wordpiece_tokenizer(os.path.join(path, "vocab.txt"))                 # data.py:229
+        self.max_text_length = max_seq_length
+        self.size = self.crop_size = int(image_size)             # data.py:231-236 fixes 224; other resolutions by keyword
+
+    def __len__(self):
+        return len(self.data_rows)
+
+    def __getitem__(self, item):
+        row = parse_row_by_schema(self.data_rows[item].strip("\n"), self.input_schema)          # dataset.py:160-196
+        try:
+            return self.convert_single_row_to_example(row)
+        except L.EzclipError:
+            raise
+        except Exception as e:
+            raise RuntimeError("Failed row %d: %s" % (item, e)) from e
+
+    def convert_single_row_to_example(self, row: Dict[str, str]):
+        from PIL import Image
+        text = row[self.text_col]
+        image = Image.open(io.BytesIO(base64.urlsafe_b64decode(row[self.image_col])))             # data.py:242
+        tk = self.tokenizer([text], padding="max_length", truncation=True, max_length=self.max_text_length,
+                            return_tensors="pt")                                                    # data.py:250-253
+        if image.mode not in ("RGB", "L"):
+            raise L.EzclipError("image mode %r is not on the GPU pre-processing path (the reference resizes palette / alpha "
+                                "images in their own mode); convert('RGB') upstream" % image.mode)
+        return {"text": tk, "image": np.asarray(image)}
+
+    def batch_fn(self, features):
+        """data.py:275-295; the decoded images travel as ``'images'`` (list of uint8 HWC / HW arrays)."""
+        out = {"input_ids": torch.cat([f["text"]["input_ids"] for f in features], dim=0), "label_ids": []}
+        for k in ("token_type_ids", "attention_mask"):
+            if all(k in f["text"] for f in features):
+                out[k] = torch.cat([f["text"][k] for f in features], dim=0)
+        out["images"] = [f["image"] for f in features]
+        out["image_size"] = self.size
+        return out

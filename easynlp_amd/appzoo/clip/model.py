@@ -675,6 +675,11 @@ class CLIPApp(Application):
 
     def forward(self, inputs, feat=None):
         _device = self._params["text_projection"].device
+        if inputs.get("pixel_values") is None and inputs.get("images") is not None:
+            # batches of the drop-in CLIPDataset (gpu_preprocess): decoded uint8 images -> the reference's float32
+            # pixel_values (data.py:256-262) on the GPU, bit for bit
+            R = int(inputs.get("image_size") or self._engine.cfg["image_resolution"])
+            inputs["pixel_values"] = L.preprocess_images(inputs["images"], size=R, crop=R, device=_device)
         if "pixel_values" in inputs and inputs["pixel_values"] is not None:
             inputs["pixel_values"] = inputs["pixel_values"].to(_device)
         else:

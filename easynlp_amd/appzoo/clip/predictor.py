@@ -57,8 +57,8 @@ class CLIPPredictor(Predictor):
     @property
     def tokenizer(self):
         if self._tokenizer is None:
-            from transformers import BertTokenizer
-            self._tokenizer = BertTokenizer(vocab_file=os.path.join(self.model_dir, "vocab.txt"))   # predictor.py:52
+            from .data import load_wordpiece_tokenizer
+            self._tokenizer = load_wordpiece_tokenizer(os.path.join(self.model_dir, "vocab.txt"))   # predictor.py:52
         return self._tokenizer
 
     def preprocess(self, in_data):

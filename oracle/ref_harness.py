@@ -48,7 +48,7 @@ def install_shims() -> None:
             datasets.list_datasets = lambda *a, **k: []
     except Exception:  # pragma: no cover
         pass
-    for name in ("tensorboardX", "rouge", "ftfy"):
+    for name in ("tensorboardX", "rouge", "ftfy", "jieba"):
         if name not in sys.modules:
             try:
                 __import__(name)

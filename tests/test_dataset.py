@@ -1,0 +1,161 @@
+"""Input side of the path (SURVEY.md 8f "next": the caller upstream of CLIPApp.forward) -- the drop-in CLIPDataset against
+the reference's own ``easynlp.appzoo.clip.data.CLIPDataset``.
+
+Fixture tests/golden/dataset_tsv_b7.npz (tools/make_golden.py: run_dataset_case) holds a 7-row TSV in the reference's
+wire format (text \\t urlsafe-base64(PNG)), the vocab, and what the REFERENCE dataset's batch_fn produced from it:
+token tensors verbatim, pixel_values as per-image SHA-256 (+ a strided sample).  CPU tests pin rows / tokens / decode;
+the GPU tests pin the float32 pixel_values bit for bit and run them through CLIPApp.forward."""
+import base64
+import hashlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from easynlp_amd import lib as L
+from easynlp_amd.appzoo.clip.data import CLIPDataset, parse_row_by_schema
+
+PIL = pytest.importorskip("PIL.Image")
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "dataset_tsv_b7.npz")
+SCHEMA = "text:str:1,image:str:1"
+
+
+def _materialise(tmp_path, model_type="chinese_clip"):
+    g = np.load(GOLD)
+    d = str(tmp_path)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump({"model_type": model_type} if model_type else {"text_config": {}, "vision_config": {}}, f)
+    with open(os.path.join(d, "vocab.txt"), "wb") as f:
+        f.write(g["vocab"].tobytes() + b"\n")
+    with open(os.path.join(d, "data.tsv"), "wb") as f:
+        f.write(g["tsv"].tobytes())
+    return g, d
+
+
+def _dataset(d, **kw):
+    return CLIPDataset(d, os.path.join(d, "data.tsv"), 20, input_schema=SCHEMA, first_sequence="text",
+                       second_sequence="image", **kw)
+
+
+def test_parse_row_by_schema_follows_the_reference():
+    assert parse_row_by_schema("hello\tQUJD\n", SCHEMA) == {"text": "hello", "image": "QUJD"}
+    # columns are zipped with the schema: surplus columns are dropped, missing ones simply absent
+    assert parse_row_by_schema("a\tb\tc", SCHEMA) == {"text": "a", "image": "b"}
+    assert parse_row_by_schema("a", SCHEMA) == {"text": "a"}
+    assert parse_row_by_schema("3\t1,2,3\t0.5", "n:int:1,v:int:3,x:float:1") == {"n": 3, "v": [1, 2, 3], "x": 0.5}
+    with pytest.raises(RuntimeError):
+        parse_row_by_schema("a", "text:bytes:1")
+
+
+def test_tokens_equal_the_reference_batch(tmp_path):
+    g, d = _materialise(tmp_path)
+    ds = _dataset(d)
+    assert len(ds) == 7
+    batch = ds.batch_fn([ds[i] for i in range(len(ds))])
+    for k in ("input_ids", "token_type_ids", "attention_mask"):
+        assert batch[k].dtype == torch.int64
+        assert np.array_equal(batch[k].numpy(), g[k]), k
+    assert batch["label_ids"] == [] and "pixel_values" not in batch
+    # rows: truncated to max_seq_length (row 3), empty text = [CLS][SEP] (row 4)
+    assert int(batch["attention_mask"][3].sum()) == 20 and int(batch["attention_mask"][4].sum()) == 2
+
+
+def test_images_are_the_decoded_pixels(tmp_path):
+    g, d = _materialise(tmp_path)
+    ds = _dataset(d)
+    rows = g["tsv"].tobytes().decode("utf-8").split("\n")[:-1]
+    batch = ds.batch_fn([ds[i] for i in range(len(ds))])
+    assert batch["image_size"] == 224 and len(batch["images"]) == 7
+    for row, img in zip(rows, batch["images"]):
+        ref = PIL.open(io.BytesIO(base64.urlsafe_b64decode(row.split("\t")[1])))
+        assert img.dtype == np.uint8 and np.array_equal(img, np.asarray(ref))
+    assert batch["images"][3].ndim == 2 and batch["images"][0].shape == (56, 40, 3)      # 'L' stays one channel
+
+
+def test_dataloader_with_workers_collates_through_batch_fn(tmp_path):
+    g, d = _materialise(tmp_path)
+    ds = _dataset(d)
+    dl = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, collate_fn=ds.batch_fn, num_workers=2)
+    batches = list(dl)
+    assert [len(b["images"]) for b in batches] == [4, 3]
+    assert np.array_equal(torch.cat([b["input_ids"] for b in batches]).numpy(), g["input_ids"])
+
+
+def test_huggingface_flavour_and_what_is_not_covered(tmp_path):
+    g, d = _materialise(tmp_path, model_type=None)
+    ds = _dataset(d)
+    assert ds.model_type == "huggingface_clip"
+    b = ds.batch_fn([ds[0], ds[1]])
+    assert np.array_equal(b["input_ids"].numpy(), g["input_ids"][:2]) and "token_type_ids" in b and "attention_mask" in b
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump({"model_type": "open_clip"}, f)
+    with pytest.raises(L.EzclipError):
+        _dataset(d)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump({"model_type": "chinese_clip"}, f)
+    with pytest.raises(L.EzclipError):
+        CLIPDataset(d, os.path.join(d, "shard-000.tar"), 20, input_schema=SCHEMA, first_sequence="text", second_sequence="image")
+    # a palette image is refused (the reference resizes it in 'P' mode; not on the device path) -- loudly, not silently converted
+    buf = io.BytesIO()
+    PIL.fromarray(np.arange(64, dtype=np.uint8).reshape(8, 8), "P").save(buf, format="PNG")
+    with open(os.path.join(d, "p.tsv"), "w") as f:
+        f.write("a\t" + base64.urlsafe_b64encode(buf.getvalue()).decode() + "\n")
+    dp = CLIPDataset(d, os.path.join(d, "p.tsv"), 20, input_schema=SCHEMA, first_sequence="text", second_sequence="image")
+    with pytest.raises(L.EzclipError):
+        dp[0]
+    # a corrupt row surfaces as the reference's RuntimeError (dataset.py:196-201)
+    with open(os.path.join(d, "bad.tsv"), "w") as f:
+        f.write("a\tnot-an-image\n")
+    db = CLIPDataset(d, os.path.join(d, "bad.tsv"), 20, input_schema=SCHEMA, first_sequence="text", second_sequence="image")
+    with pytest.raises(RuntimeError):
+        db[0]
+
+
+@pytest.mark.gpu
+def test_gpu_pixel_values_equal_the_reference_dataset_bit_for_bit(tmp_path):
+    g, d = _materialise(tmp_path)
+    ds = _dataset(d)
+    batch = ds.batch_fn([ds[i] for i in range(len(ds))])
+    px = L.preprocess_images(batch["images"], size=224, crop=224).cpu().numpy()
+    assert px.shape == (7, 3, 224, 224) and px.dtype == np.float32
+    assert np.array_equal(px[:, :, ::16, ::16].view(np.uint32), g["pixel_sample"].view(np.uint32))
+    for i in range(7):
+        assert hashlib.sha256(np.ascontiguousarray(px[i]).tobytes()).hexdigest() == str(g["pixel_sha256"][i]), i
+
+
+@pytest.mark.gpu
+def test_clipapp_forward_takes_dataset_batches(tmp_path):
+    """DataLoader(CLIPDataset, collate_fn=batch_fn) -> CLIPApp.forward -> compute_loss, as Trainer drives it
+    (core/trainer.py); 'images' and the equivalent 'pixel_values' give identical outputs."""
+    from easynlp_amd.appzoo.clip import CLIPApp
+    from oracle import clip_oracle as O
+    from oracle import ref_harness as R
+    g = np.load(GOLD)
+    cfg = dict(O.CONFIGS["tiny"])
+    vocab = g["vocab"].tobytes().decode("utf-8").split("\n")
+    cfg["vocab_size"] = len(vocab)
+    R.write_checkpoint_dir(str(tmp_path), cfg, O.make_state_dict(cfg, 5))
+    with open(os.path.join(str(tmp_path), "vocab.txt"), "wb") as f:
+        f.write(g["vocab"].tobytes() + b"\n")
+    with open(os.path.join(str(tmp_path), "data.tsv"), "wb") as f:
+        f.write(g["tsv"].tobytes())
+    res = int(cfg["image_resolution"])
+    ds = _dataset(str(tmp_path), image_size=res)
+    app = CLIPApp(str(tmp_path)).cuda()
+    dl = torch.utils.data.DataLoader(ds, batch_size=7, shuffle=False, collate_fn=ds.batch_fn)
+    batch = next(iter(dl))
+    images = list(batch["images"])
+    out = app(batch)
+    assert tuple(out["logits_per_text"].shape) == (7, 7) and tuple(batch["pixel_values"].shape) == (7, 3, res, res)
+    loss = app.compute_loss(out, batch["label_ids"])["loss"]
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None for p in app.parameters() if p.requires_grad)
+    px = L.preprocess_images(images, size=res, crop=res)
+    app.eval()
+    with torch.no_grad():
+        a = app({"images": images, "image_size": res, "input_ids": torch.from_numpy(g["input_ids"])})
+        b = app({"pixel_values": px, "input_ids": torch.from_numpy(g["input_ids"])})
+    assert torch.equal(a["logits_per_text"], b["logits_per_text"]) and torch.equal(a["image_embeds"], b["image_embeds"])

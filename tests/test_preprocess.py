@@ -137,6 +137,7 @@ def test_predictor_preprocess_decodes_and_uses_the_gpu_pipeline(tmp_path):
     # text records: WordPiece ids from the checkpoint's vocab.txt, padded to sequence_length (predictor.py:95-101)
     trecs = pred.preprocess([{"text": "tok7 tok9 tok11"}, {"text": "tok8"}])
     assert tuple(trecs[0]["input_ids"].shape) == (1, 16) and int(trecs[0]["attention_mask"].sum()) == 5
+    assert trecs[0]["input_ids"][0, :6].tolist() == [2, 12, 14, 16, 3, 0]      # [CLS] tok7 tok9 tok11 [SEP] [PAD]: real ids, not [UNK]
     tf = pred.run([{"text": "tok7 tok9 tok11"}, {"text": "tok8"}])
     assert len(tf) == 2 and "text_feat" in tf[0]
 

@@ -17,6 +17,7 @@ deviation) per parameter instead of hand-picked exceptions.
 """
 from __future__ import annotations
 
+import json
 import os
 import sys
 
@@ -221,6 +222,49 @@ OPENCLIP_CASES = [("openclip_tiny_b6", "oc_tiny", 6, 1234, 3, True), ("openclip_
 HF_CASES = [("hf_tiny_b6_l24", "hf_tiny", 6, 24, 1234, 3, True), ("hf_small_b5_l40", "hf_small", 5, 40, 99, 7, False)]
 
 
+def run_dataset_case(name="dataset_tsv_b7"):
+    """The reference's own CLIPDataset (appzoo/clip/data.py:152-295) over a small TSV: text \\t urlsafe-base64(PNG).
+    Fixture: the TSV, vocab.txt, the token tensors of batch_fn, and per-image SHA-256 of the float32 pixel_values (the
+    tensors themselves would be 4 MB of resampled noise) plus a strided sample for diagnostics."""
+    import base64, hashlib, io, tempfile
+    import numpy as np
+    from PIL import Image
+    R.install_shims()
+    from easynlp.appzoo.clip.data import CLIPDataset
+    rng = np.random.RandomState(77)
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list("abcdefghijklmnopqrstuvwxyz") + \
+            ["##" + c for c in "abcdefghijklmnopqrstuvwxyz"] + ["cat", "dog", "photo", "of", "a", "the", "##s", "red", "中", "文", "猫", "狗", "图", ",", "."]
+    texts = ["a photo of a cat", "the red dogs.", "中文猫图", "zzz unknownword " * 12, "", "photo, of THE Dog", "狗 a 图"]
+    sizes = [(40, 56, "RGB"), (64, 33, "RGB"), (224, 224, "RGB"), (300, 231, "L"), (17, 90, "RGB"), (250, 224, "RGB"), (96, 96, "L")]
+    rows = []
+    for t, (w, h, mode) in zip(texts, sizes):
+        shape = (h, w, 3) if mode == "RGB" else (h, w)
+        img = Image.fromarray(rng.randint(0, 256, size=shape).astype(np.uint8), mode)
+        buf = io.BytesIO()
+        img.save(buf, format="PNG")
+        rows.append(t + "\t" + base64.urlsafe_b64encode(buf.getvalue()).decode("ascii"))
+    tsv = "\n".join(rows) + "\n"
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "config.json"), "w") as f:
+            json.dump({"model_type": "chinese_clip"}, f)
+        with open(os.path.join(d, "vocab.txt"), "w") as f:
+            f.write("\n".join(vocab) + "\n")
+        with open(os.path.join(d, "data.tsv"), "w") as f:
+            f.write(tsv)
+        ds = CLIPDataset(d, os.path.join(d, "data.tsv"), 20, input_schema="text:str:1,image:str:1",
+                         first_sequence="text", second_sequence="image")
+        batch = ds.batch_fn([ds[i] for i in range(len(ds))])
+    px = batch["pixel_values"].numpy()
+    assert px.dtype == np.float32 and px.shape == (len(rows), 3, 224, 224)
+    out = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(out, tsv=np.frombuffer(tsv.encode("utf-8"), dtype=np.uint8), vocab=np.frombuffer("\n".join(vocab).encode("utf-8"), dtype=np.uint8),
+                        input_ids=batch["input_ids"].numpy(), token_type_ids=batch["token_type_ids"].numpy(),
+                        attention_mask=batch["attention_mask"].numpy(),
+                        pixel_sha256=np.array([hashlib.sha256(np.ascontiguousarray(px[i]).tobytes()).hexdigest() for i in range(len(rows))]),
+                        pixel_sample=px[:, :, ::16, ::16].copy())
+    print("wrote", out, os.path.getsize(out))
+
+
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     only = sys.argv[1:]
@@ -236,3 +280,5 @@ if __name__ == "__main__":
     for case in OPENCLIP_CASES:
         if not only or case[0] in only:
             run_openclip_case(*case)
+    if not only or "dataset_tsv_b7" in only:
+        run_dataset_case()

@@ -238,6 +238,15 @@ int ezclip_set_option(ezclip_handle h, int key, double value) {
       h->text_ln_eps = (float)value;
       return EZ_OK;
     case EZCLIP_OPT_TEXT_PAD_ID: h->text_pad_id = (int64_t)value; return EZ_OK;
+    case EZCLIP_OPT_BLOCK_LN_EPS:
+      EZ_REQUIRE(value > 0.0 && value < 1.0, "ezclip_set_option: block LayerNorm eps %g", value);
+      h->block_ln_eps = (float)value;
+      return EZ_OK;
+    case EZCLIP_OPT_TEXT_EOT_ID:
+      EZ_REQUIRE(h->text_arch == 1, "ezclip_set_option: EZCLIP_OPT_TEXT_EOT_ID needs a handle created with EZCLIP_TEXT_CLIP");
+      EZ_REQUIRE(value >= -1.0 && value < (double)h->cfg.vocab_size, "ezclip_set_option: token id %g outside the vocabulary", value);
+      h->text_eot_id = (int64_t)value;
+      return EZ_OK;
     default: break;
   }
   set_error("ezclip_set_option: unknown key %d", key);

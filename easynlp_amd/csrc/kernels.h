@@ -155,7 +155,7 @@ int bert_embed_ln(const int64_t* ids, const float* word, const float* pos, const
                   int type_vocab = 1);
 // CLIP text transformer (OPEN_CLIP.encode_text): x = token_embedding[ids] + positional_embedding; eot_idx[b] = argmax_t ids[b, t]
 int clip_text_embed(const int64_t* ids, const float* tok, const float* pos, void* x, int* eot_idx, int B, int L, int W, int vocab,
-                    int dtype, hipStream_t stream);
+                    int64_t eot_id, int dtype, hipStream_t stream);
 // mode 0: dst[b] = src[b, idx[b]];  1: dst[b, idx[b]] = src[b];  2: dst[b, idx[b]] += src[b]  (other rows untouched; idx null: row 0)
 int gather_rows(const void* src, const int* idx, void* dst, int B, int L, int W, int mode, int dtype, hipStream_t stream);
 // out[b] = x[b] / ||x[b]||_2 (no eps: reference modeling_chineseclip.py:360,363); inv_norm optional.

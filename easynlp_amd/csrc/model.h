@@ -65,6 +65,9 @@ struct ezclip_model {
   bool opt_vision_frozen = false;    // image_embeds = vision_outputs[1].detach(): only the projection gets gradients
   float text_ln_eps = 1e-12f;        // BertConfig / CLIPTextConfig layer_norm_eps
   int64_t text_pad_id = 0;           // padding_idx of the word / position embeddings (no gradient for that row)
+  // wukong_clip flavour of the pre-LN towers (modelzoo/models/wukong/modeling_wukong.py:238-361)
+  float block_ln_eps = 1e-5f;        // eps of every LayerNorm of the residual-attention-block towers (wukong: 1e-7)
+  int64_t text_eot_id = -1;          // text_arch 1: pooled row = first position holding this id (wukong: 102); -1: argmax of the ids
 
   // BERT train-mode dropout (ezclip_set_text_dropout): probabilities + the seed of the next forward / backward pair
   float drop_hidden = 0.f, drop_attn = 0.f;

@@ -537,7 +537,7 @@ struct BlockDims { int M, W, B, L, heads, causal; };
 static int resblock_forward(ezclip_model* m, const ezclip_model::VitLayer& Lw, const VitBufs& b, const BlockDims& d, bool save,
                             bool& stats_ready, float* next_stat, hipStream_t stream) {
   const int M = d.M, W = d.W, dt = m->dtype;
-  const float eps = 1e-5f;  // nn.LayerNorm default (modeling_chineseclip.py:170)
+  const float eps = m->block_ln_eps;  // nn.LayerNorm default 1e-5 (modeling_chineseclip.py:170); EZCLIP_OPT_BLOCK_LN_EPS
   {
     // x = x + attn(ln_1(x))                                          :203
     const bool fold = !save && can_fold_ln(m, Lw.in_w, M) && can_fold_ln(m, Lw.fc_w, M);
@@ -592,7 +592,7 @@ static int resblock_forward_cls(ezclip_model* m, const ezclip_model::VitLayer& L
                                 bool stats_ready, void* scratch, hipStream_t stream) {
   const int M = d.M, W = d.W, B = d.B, dt = m->dtype;
   const size_t esz = dtype_size(dt);
-  const float eps = 1e-5f;
+  const float eps = m->block_ln_eps;
   char* x_mid = static_cast<char*>(scratch);
   char* x_out = x_mid + (size_t)B * W * esz;
   char* ln2 = x_out + (size_t)B * W * esz;
@@ -627,7 +627,7 @@ static int resblock_forward_cls_save(ezclip_model* m, const ezclip_model::VitLay
                                      hipStream_t stream) {
   const int M = d.M, W = d.W, B = d.B, dt = m->dtype;
   const size_t esz = dtype_size(dt);
-  const float eps = 1e-5f;
+  const float eps = m->block_ln_eps;
   EZ_TRY(layernorm_fwd(b.x_in, W, b.ln1, W, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, M, W, dt, b.m1, b.r1, stream));
   EZ_TRY(linear(m, b.ln1, W, Lw.in_w, Lw.in_b, b.qkv, 3 * W, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
   AttnArgs at;
@@ -654,7 +654,7 @@ int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* 
   const int W = m->cfg.vision_width, E = m->cfg.embed_dim, Lv = m->Lv;
   const int Mp = B * (Lv - 1), M = B * Lv;
   const int dt = m->dtype;
-  const float eps = 1e-5f;  // nn.LayerNorm default (modeling_chineseclip.py:170)
+  const float eps = m->block_ln_eps;  // nn.LayerNorm default 1e-5 (modeling_chineseclip.py:170); EZCLIP_OPT_BLOCK_LN_EPS
 
   // conv1 (stride == kernel, no bias) = im2col + GEMM              :237-239
   EZ_TRY(im2col_patches(pixels, ws.patches, B, m->cfg.image_resolution, m->cfg.vision_patch_size, m->Kpad, dt, stream));
@@ -777,9 +777,10 @@ int encode_text_clip(ezclip_model* m, const int64_t* ids, int B, int L, float* o
   const size_t need = layout_text_clip(m, B, L, save, wsp, &ws);
   EZ_REQUIRE(ws_bytes >= need, "encode_text: workspace too small (%zu < %zu)", ws_bytes, need);
   const int W = m->cfg.text_hidden_size, E = m->cfg.embed_dim, M = B * L, dt = m->dtype;
-  const float eps = 1e-5f;
+  const float eps = m->block_ln_eps;
   // x = token_embedding(text) + positional_embedding                :355-357
-  EZ_TRY(clip_text_embed(ids, m->P(m->tok_p), m->P(m->tpos2_p), ws.layers[0].x_in, ws.eot, B, L, W, m->cfg.vocab_size, dt, stream));
+  EZ_TRY(clip_text_embed(ids, m->P(m->tok_p), m->P(m->tpos2_p), ws.layers[0].x_in, ws.eot, B, L, W, m->cfg.vocab_size,
+                         m->text_eot_id, dt, stream));
   bool stats_ready = false;
   const BlockDims bd{M, W, B, L, m->theads, 1};                     // causal: build_attention_mask :343-349
   const int nl = m->cfg.text_num_hidden_layers;

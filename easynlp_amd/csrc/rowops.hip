@@ -357,14 +357,18 @@ __global__ __launch_bounds__(256) void clip_text_embed_kernel(const int64_t* ids
   }
 }
 
-// idx[b] = argmax_t ids[b, t] (first maximum, as torch.argmax): the EOT position (modeling_openclip.py:364-366)
-__global__ void argmax_rows_kernel(const int64_t* ids, int* idx, int B, int L) {
+// idx[b] = argmax_t ids[b, t] (first maximum, as torch.argmax): the EOT position (modeling_openclip.py:364-366);
+// eot_id >= 0: first t with ids[b, t] == eot_id instead (wukong TextTransformer: x[(text == 102).nonzero()],
+// modeling_wukong.py:349,359 -- one such token per row is the caller's contract; 0 when the row has none)
+__global__ void argmax_rows_kernel(const int64_t* ids, int* idx, int B, int L, int64_t eot_id) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   int64_t best = ids[(int64_t)b * L];
+  if (eot_id >= 0) best = best == eot_id;
   int bi = 0;
   for (int t = 1; t < L; ++t) {
-    const int64_t v = ids[(int64_t)b * L + t];
+    int64_t v = ids[(int64_t)b * L + t];
+    if (eot_id >= 0) v = v == eot_id;
     if (v > best) { best = v; bi = t; }
   }
   idx[b] = bi;
@@ -699,13 +703,13 @@ int vit_assemble_ln(const void* patch, const float* cls, const float* pos, const
 }
 
 int clip_text_embed(const int64_t* ids, const float* tok, const float* pos, void* x, int* eot_idx, int B, int L, int W, int vocab,
-                    int dtype, hipStream_t stream) {
+                    int64_t eot_id, int dtype, hipStream_t stream) {
   EZ_REQUIRE(W % 4 == 0 && W <= 256 * kMaxChunks, "clip_text_embed: width %d unsupported", W);
   const int64_t rows = (int64_t)B * L;
   const int blocks = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
   EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((clip_text_embed_kernel<T>), dim3(blocks), dim3(256), 0, stream, ids, tok, pos, (T*)x, B, L,
                                           W, vocab));
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, ids, eot_idx, B, L);
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, ids, eot_idx, B, L, eot_id);
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libezclip_hip.so")
 DTYPE_F32 = 0
 DTYPE_BF16 = 1
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF, ACT_TANH = 0, 1, 2, 3
-OPT_TEXT_POOLER, OPT_VISION_FROZEN, OPT_TEXT_LN_EPS, OPT_TEXT_PAD_ID = 1, 2, 3, 4
+OPT_TEXT_POOLER, OPT_VISION_FROZEN, OPT_TEXT_LN_EPS, OPT_TEXT_PAD_ID, OPT_BLOCK_LN_EPS, OPT_TEXT_EOT_ID = 1, 2, 3, 4, 5, 6
 
 
 class EzclipError(RuntimeError):

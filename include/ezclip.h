@@ -114,11 +114,19 @@ int ezclip_refresh_weights(ezclip_handle h, void* stream);
  *   EZCLIP_OPT_TEXT_LN_EPS      layer_norm_eps of the text tower (default 1e-12)
  *   EZCLIP_OPT_TEXT_PAD_ID      padding_idx of the word / position embeddings (no gradient for that row; default 0)
  * and two optional parameters "visual.proj_bias" / "text_projection_bias" [embed_dim] (vision_projection /
- * text_projection are nn.Linear with bias there); unbound = no bias. */
+ * text_projection are nn.Linear with bias there); unbound = no bias.
+ * ---- wukong_clip (easynlp/appzoo/wukong_clip/model.py:44-73; modelzoo/models/wukong/modeling_wukong.py:238-361) -------
+ * the EZCLIP_TEXT_CLIP towers with
+ *   EZCLIP_OPT_BLOCK_LN_EPS     eps of every LayerNorm of the residual-attention-block towers: ViT incl. ln_pre / ln_post,
+ *                               EZCLIP_TEXT_CLIP text tower incl. ln_final (default 1e-5; wukong builds them with 1e-7)
+ *   EZCLIP_OPT_TEXT_EOT_ID      EZCLIP_TEXT_CLIP only: the text feature is taken at the first position holding this token
+ *                               id (wukong: 102, `x[(text == 102).nonzero()]`) instead of argmax(ids); -1 = argmax (default) */
 #define EZCLIP_OPT_TEXT_POOLER 1
 #define EZCLIP_OPT_VISION_FROZEN 2
 #define EZCLIP_OPT_TEXT_LN_EPS 3
 #define EZCLIP_OPT_TEXT_PAD_ID 4
+#define EZCLIP_OPT_BLOCK_LN_EPS 5
+#define EZCLIP_OPT_TEXT_EOT_ID 6
 int ezclip_set_option(ezclip_handle h, int key, double value);
 /* ezclip_encode_text / ezclip_backward_text with the per-token inputs RobertaModel takes (model.py:131-133): device
  * int64 [batch, seq_len] each, any may be NULL: position_ids (default 0..L-1; RobertaEmbeddings' pad-aware ids

@@ -290,25 +290,26 @@ def vit_forward(sd, cfg, pixels, taps: Optional[dict] = None):
     dt = sd["visual.proj"].dtype
     P, W = cfg["vision_patch_size"], cfg["vision_width"]
     heads = W // 64                                           # :289
+    eps = cfg.get("block_ln_eps", VIT_LN_EPS)           # wukong builds its LayerNorms with 1e-7 (wukong_oracle.py)
     x = patchify(pixels.to(dt), P) @ sd["visual.conv1.weight"].reshape(W, -1).t()   # :237-239
     B = x.shape[0]
     cls = sd["visual.class_embedding"].expand(B, 1, W)         # :240
     x = torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"]   # :241
-    x = layer_norm(x, sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], VIT_LN_EPS)  # :242
+    x = layer_norm(x, sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], eps)  # :242
     if taps is not None:
         taps["vit.ln_pre"] = x
     for i in range(cfg["vision_layers"]):
         p = f"visual.transformer.resblocks.{i}."
-        h = layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], VIT_LN_EPS)
+        h = layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], eps)
         x = x + mha_self_attention(h, sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"],
                                    sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"],
                                    heads, taps=taps, tap_prefix=f"vit.{i}.")       # :203
-        h = layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], VIT_LN_EPS)
+        h = layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], eps)
         h = quick_gelu(linear(h, sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"]))
         x = x + linear(h, sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"])   # :204
         if taps is not None:
             taps[f"vit.{i}.out"] = x
-    x = layer_norm(x[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], VIT_LN_EPS)  # :248
+    x = layer_norm(x[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], eps)  # :248
     return x @ sd["visual.proj"]                                # :250-251
 
 

@@ -29,8 +29,11 @@ OPENCLIP_CONFIGS: Dict[str, dict] = {
 
 def chinese_style_config(cfg: dict) -> dict:
     """vision-tower view for clip_oracle.vit_forward"""
-    return dict(vision_patch_size=cfg["vision_patch_size"], vision_width=cfg["vision_width"], vision_layers=cfg["vision_layers"],
-                image_resolution=cfg["image_resolution"], embed_dim=cfg["embed_dim"])
+    out = dict(vision_patch_size=cfg["vision_patch_size"], vision_width=cfg["vision_width"], vision_layers=cfg["vision_layers"],
+               image_resolution=cfg["image_resolution"], embed_dim=cfg["embed_dim"])
+    if "block_ln_eps" in cfg:
+        out["block_ln_eps"] = cfg["block_ln_eps"]
+    return out
 
 
 def param_shapes(cfg: dict) -> Dict[str, tuple]:
@@ -97,20 +100,23 @@ def make_inputs(cfg: dict, batch: int, seed: int = 0):
 
 
 def text_forward(sd, cfg, text):
-    """OPEN_CLIP.encode_text, modeling_openclip.py:354-368"""
+    """OPEN_CLIP.encode_text, modeling_openclip.py:354-368 (cfg keys block_ln_eps / eot_id: the wukong variant, wukong_oracle.py)"""
     T, heads = cfg["transformer_width"], cfg["transformer_heads"]
+    eps = cfg.get("block_ln_eps", O.VIT_LN_EPS)
     B, L = text.shape
     x = sd["token_embedding.weight"][text] + sd["positional_embedding"][:L]                 # :355-357
     mask = torch.full((L, L), float("-inf"), dtype=x.dtype).triu_(1)                        # :343-349
     for i in range(cfg["transformer_layers"]):
         p = f"transformer.resblocks.{i}."
-        h = O.layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], O.VIT_LN_EPS)
+        h = O.layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], eps)
         x = x + O.mha_self_attention(h, sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"], sd[p + "attn.out_proj.weight"],
                                      sd[p + "attn.out_proj.bias"], heads, attn_mask=mask)
-        h = O.layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], O.VIT_LN_EPS)
+        h = O.layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], eps)
         h = O.quick_gelu(O.linear(h, sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"]))
         x = x + O.linear(h, sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"])
-    x = O.layer_norm(x, sd["ln_final.weight"], sd["ln_final.bias"], O.VIT_LN_EPS)          # :361
+    x = O.layer_norm(x, sd["ln_final.weight"], sd["ln_final.bias"], eps)          # :361
+    if cfg.get("eot_id") is not None:
+        return x[(text == cfg["eot_id"]).nonzero(as_tuple=True)] @ sd["text_projection"]   # modeling_wukong.py:349,359-360
     return x[torch.arange(B), text.argmax(dim=-1)] @ sd["text_projection"]                  # :366
 
 

@@ -222,6 +222,49 @@ OPENCLIP_CASES = [("openclip_tiny_b6", "oc_tiny", 6, 1234, 3, True), ("openclip_
 HF_CASES = [("hf_tiny_b6_l24", "hf_tiny", 6, 24, 1234, 3, True), ("hf_small_b5_l40", "hf_small", 5, 40, 99, 7, False)]
 
 
+def run_wukong_case(name, cfg_name, B, wseed, iseed, full):
+    """The REAL reference WukongCLIP (appzoo/wukong_clip/model.py:8-73; WukongModel, LayerNorm eps 1e-7, feature of the
+    token 102), loaded from a synthetic checkpoint directory."""
+    import json
+    import tempfile
+    from oracle import wukong_oracle as WK
+    R.install_shims()
+    from easynlp.appzoo.wukong_clip.model import WukongCLIP
+    torch.manual_seed(0)
+    cfg = WK.WUKONG_CONFIGS[cfg_name]
+    sd = WK.make_state_dict(cfg, wseed)
+    d = tempfile.mkdtemp()
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    torch.save(sd, os.path.join(d, "pytorch_model.bin"))
+    app = WukongCLIP(d)
+    app.eval()
+    px, ids = WK.make_inputs(cfg, B, iseed)
+    fo, _ = app({"pixel_values": px, "input_ids": ids})
+    loss = app.compute_loss(fo, [])["loss"]
+    loss.backward()
+    out = {"meta": np.array([cfg_name, str(B), str(wseed), str(iseed), torch.__version__, np.__version__]),
+           "image_features": fo["image_features"].detach().numpy(), "text_features": fo["text_features"].detach().numpy(),
+           "logit_scale": fo["logit_scale"].detach().numpy(), "loss": np.float32(loss.item())}
+    names = [n for n, _ in app.named_parameters()]
+    assert sorted(names) == sorted(sd), (set(names) ^ set(sd))
+    for n, p in app.named_parameters():
+        if p.grad is None:
+            out["nograd/" + n] = np.zeros(0, np.float32)
+        elif full:
+            out["grad/" + n] = p.grad.numpy()
+        else:
+            norm, samp, idx = grad_digest(p.grad)
+            out["gnorm/" + n] = np.float64(norm)
+            out["gsamp/" + n] = samp
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "loss", loss.item(), "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+WUKONG_CASES = [("wukong_tiny_b6", "wk_tiny", 6, 1234, 3, True), ("wukong_small_b5", "wk_small", 5, 99, 7, False)]
+
+
 def run_dataset_case(name="dataset_tsv_b7"):
     """The reference's own CLIPDataset (appzoo/clip/data.py:152-295) over a small TSV: text \\t urlsafe-base64(PNG).
     Fixture: the TSV, vocab.txt, the token tensors of batch_fn, and per-image SHA-256 of the float32 pixel_values (the
@@ -282,3 +325,6 @@ if __name__ == "__main__":
             run_openclip_case(*case)
     if not only or "dataset_tsv_b7" in only:
         run_dataset_case()
+    for case in WUKONG_CASES:
+        if not only or case[0] in only:
+            run_wukong_case(*case)

@@ -1,0 +1,37 @@
+"""Drop-in for ``easynlp.appzoo.text2video_retrieval.evaluator.Text2VideoRetrievalEvaluator`` (evaluator.py:28-73):
+text->video R@1/5/10 and their mean over the validation set; the per-query sort loop is ``ezclip_recall_ranks``."""
+from __future__ import annotations
+
+import time
+
+import torch
+
+from ..clip.evaluator import Evaluator, recall_at_k
+
+
+class Text2VideoRetrievalEvaluator(Evaluator):
+
+    def __init__(self, valid_dataset, **kwargs):
+        super().__init__(valid_dataset, **kwargs)
+        self.metrics = ["accuracy", "f1"]
+        self.before = 0.0
+
+    def evaluate(self, model):
+        model.eval()
+        total_spent_time = 0.0
+        video_all, text_all = [], []
+        for _step, batch in enumerate(self.valid_loader):
+            t0 = time.time()
+            with torch.no_grad():
+                outputs = model(batch, feat=True) if getattr(model, "_engine", None) is not None else model(batch)
+            total_spent_time += time.time() - t0
+            video_all.append(outputs["video_embeds"])
+            text_all.append(outputs["text_embeds"])
+        video_embeds, text_embeds = torch.cat(video_all, dim=0), torch.cat(text_all, dim=0)
+        query_len = text_embeds.shape[0]
+        (mean_recall, r1, r5, r10), (r1_stat, r5_stat, r10_stat) = recall_at_k(text_embeds, video_embeds)
+        result = [item * 100 for item in (mean_recall, r1, r5, r10)]
+        print("r1_num:" + str(r1_stat), "r5_num:" + str(r5_stat), "r10_num:" + str(r10_stat), "query_num:" + str(query_len))
+        print("r1(%):" + str(result[1]), "r5(%):" + str(result[2]), "r10(%):" + str(result[3]), "mean_recall(%):" + str(result[0]))
+        print("Inference time = {:.2f}s, [{:.4f} ms / sample] ".format(total_spent_time, total_spent_time * 1000 / query_len))
+        return [("mean_recall", mean_recall)]

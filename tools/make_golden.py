@@ -265,6 +265,49 @@ def run_wukong_case(name, cfg_name, B, wseed, iseed, full):
 WUKONG_CASES = [("wukong_tiny_b6", "wk_tiny", 6, 1234, 3, True), ("wukong_small_b5", "wk_small", 5, 99, 7, False)]
 
 
+def run_t2v_case(name, cfg_name, B, T, wseed, iseed, full):
+    """The REAL reference Text2VideoRetrieval (appzoo/text2video_retrieval/model.py:39-121): OPEN_CLIP per frame + masked
+    mean pooling, loaded from a synthetic open_clip checkpoint directory."""
+    import json
+    import tempfile
+    from oracle import open_clip_oracle as OC
+    from oracle import text2video_oracle as TV
+    R.install_shims()
+    from easynlp.appzoo.text2video_retrieval.model import Text2VideoRetrieval
+    torch.manual_seed(0)
+    cfg = OC.OPENCLIP_CONFIGS[cfg_name]
+    sd = OC.make_state_dict(cfg, wseed)
+    d = tempfile.mkdtemp()
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    torch.save({"open_clip." + k: v for k, v in sd.items()}, os.path.join(d, "pytorch_model.bin"))
+    app = Text2VideoRetrieval(d)
+    app.eval()
+    px, masks, ids = TV.make_inputs(cfg, B, T, iseed)
+    fo = app({"pixel_values": px.clone(), "video_masks": masks.clone(), "input_ids": ids.clone()})
+    loss = app.compute_loss(fo, [])["loss"]
+    loss.backward()
+    out = {"meta": np.array([cfg_name, str(B), str(T), str(wseed), str(iseed), torch.__version__, np.__version__]),
+           "video_embeds": fo["video_embeds"].detach().numpy(), "text_embeds": fo["text_embeds"].detach().numpy(),
+           "logits_per_text": fo["logits_per_text"].detach().numpy(), "loss": np.float32(loss.item())}
+    for n, p in app.named_parameters():
+        n = n.replace("open_clip.", "", 1)
+        if p.grad is None:
+            out["nograd/" + n] = np.zeros(0, np.float32)
+        elif full:
+            out["grad/" + n] = p.grad.numpy()
+        else:
+            norm, samp, idx = grad_digest(p.grad)
+            out["gnorm/" + n] = np.float64(norm)
+            out["gsamp/" + n] = samp
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "loss", loss.item(), "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+T2V_CASES = [("t2v_tiny_b4_t3", "oc_tiny", 4, 3, 1234, 3, False), ("t2v_small_b3_t5", "oc_small", 3, 5, 99, 7, False)]
+
+
 def run_dataset_case(name="dataset_tsv_b7"):
     """The reference's own CLIPDataset (appzoo/clip/data.py:152-295) over a small TSV: text \\t urlsafe-base64(PNG).
     Fixture: the TSV, vocab.txt, the token tensors of batch_fn, and per-image SHA-256 of the float32 pixel_values (the
@@ -328,3 +371,6 @@ if __name__ == "__main__":
     for case in WUKONG_CASES:
         if not only or case[0] in only:
             run_wukong_case(*case)
+    for case in T2V_CASES:
+        if not only or case[0] in only:
+            run_t2v_case(*case)

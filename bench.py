@@ -28,7 +28,11 @@ import os
 import sys
 import time
 
-import torch
+# multi-process GPU work on this platform needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); the launcher
+# normally exports it already
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -292,7 +296,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": wl["dtype"], "data": "synthetic",
-            "config": {"workload": args.workload, "model": model_name,
+            "config": {"workload": args.workload, "towers": model_name,
                        "pairs_per_gpu": B, "global_batch": world * B, "image": "224x224", "seq_len": S,
                        "stages": "encode_image+encode_text" + ("+allgather" if world > 1 else "")
                                  + "+similarity(2 dirs)+InfoNCE" + ("+backward" if wl["backward"] else ""),

@@ -186,3 +186,67 @@ def test_all_three_checkpoint_flavours_keep_the_reference_state_dict(tmp_path):
     assert set(got2) == {"open_clip." + k for k in OC.param_shapes(ocfg)}
     for k, v in osd.items():
         assert torch.equal(got2["open_clip." + k], v), k
+
+
+def test_wukong_and_text2video_applications_construct_from_reference_checkpoints(tmp_path):
+    """WukongCLIP (appzoo/wukong_clip/model.py:14-42) and Text2VideoRetrieval (appzoo/text2video_retrieval/model.py:46-62)
+    load the reference's checkpoint directories and expose the reference's state-dict keys; the two Wukong options reach
+    the library (construction, option setting and loading are host-side: no GPU needed)."""
+    import json
+    import torch
+    from easynlp_amd import lib as L
+    from easynlp_amd.appzoo.text2video_retrieval import Text2VideoRetrieval
+    from easynlp_amd.appzoo.wukong_clip import WukongCLIP
+    from oracle import clip_oracle as O
+    from oracle import open_clip_oracle as OC
+    from oracle import ref_harness as R
+    from oracle import wukong_oracle as WK
+    d1 = tmp_path / "wk"
+    os.makedirs(str(d1))
+    cfg = WK.WUKONG_CONFIGS["wk_small"]
+    sd = WK.make_state_dict(cfg, 2)
+    with open(os.path.join(str(d1), "config.json"), "w") as f:
+        json.dump(cfg, f)
+    torch.save(sd, os.path.join(str(d1), "pytorch_model.bin"))
+    app = WukongCLIP.from_pretrained(str(d1), user_defined_parameters={})
+    got = app.state_dict()
+    assert set(got) == set(sd) and {n for n, _ in app.named_parameters()} == set(sd)
+    for k, v in sd.items():
+        assert torch.equal(got[k], v), k
+    assert json.loads(app.config.to_json_string()) == cfg
+    # the library sees its own names bound to the same storage
+    assert app._params["token_embedding.weight"].data_ptr() == dict(app.named_parameters())["model.text_encoder.embedding_table"].data_ptr()
+    # options: accepted on this handle, rejected where they do not apply / out of range
+    app._engine.set_option(L.OPT_BLOCK_LN_EPS, 1e-7)
+    app._engine.set_option(L.OPT_TEXT_EOT_ID, 102)
+    with pytest.raises(L.EzclipError):
+        app._engine.set_option(L.OPT_TEXT_EOT_ID, 10 ** 7)
+    with pytest.raises(L.EzclipError):
+        app._engine.set_option(L.OPT_BLOCK_LN_EPS, 0.0)
+    # a checkpoint with a missing tower key does not load silently (WukongModel loads each tower strictly)
+    d1b = tmp_path / "wk_bad"
+    os.makedirs(str(d1b))
+    with open(os.path.join(str(d1b), "config.json"), "w") as f:
+        json.dump(cfg, f)
+    torch.save({k: v for k, v in sd.items() if not k.endswith("ln_final.bias")}, os.path.join(str(d1b), "pytorch_model.bin"))
+    with pytest.raises(RuntimeError):
+        WukongCLIP(str(d1b))
+    # the token-id option is only defined for the CLIP text tower
+    d0 = tmp_path / "cc"
+    ccfg = O.CONFIGS["tiny"]
+    R.write_checkpoint_dir(str(d0), ccfg, O.make_state_dict(ccfg, 1))
+    from easynlp_amd.appzoo.clip import CLIPApp
+    capp = CLIPApp(str(d0))
+    with pytest.raises(L.EzclipError):
+        capp._engine.set_option(L.OPT_TEXT_EOT_ID, 102)
+    with pytest.raises(L.EzclipError):
+        Text2VideoRetrieval(str(d0))                      # only open_clip checkpoints (model.py:54-62)
+    d2 = tmp_path / "oc"
+    os.makedirs(str(d2))
+    ocfg = OC.OPENCLIP_CONFIGS["oc_tiny"]
+    osd = OC.make_state_dict(ocfg, 4)
+    with open(os.path.join(str(d2), "config.json"), "w") as f:
+        json.dump(ocfg, f)
+    torch.save({"open_clip." + k: v for k, v in osd.items()}, os.path.join(str(d2), "pytorch_model.bin"))
+    t2v = Text2VideoRetrieval.from_pretrained(str(d2))
+    assert set(t2v.state_dict()) == {"open_clip." + k for k in OC.param_shapes(ocfg)}

@@ -128,6 +128,10 @@ class WukongCLIP(CLIPApp):
 
     def forward(self, inputs):
         dev = self.logit_scale.device
+        if inputs.get("pixel_values") is None and inputs.get("images") is not None:
+            # batches of the drop-in WukongCLIPDataset: decoded uint8 images -> the reference's float32 pixel_values on the GPU
+            R = int(inputs.get("image_size") or self._engine.cfg["image_resolution"])
+            inputs["pixel_values"] = L.preprocess_images(inputs["images"], size=R, crop=R, device=dev)
         px = inputs["pixel_values"].to(dev) if inputs.get("pixel_values") is not None else None     # model.py:45-46
         ids = None
         if inputs.get("input_ids") is not None:                                                      # model.py:51-52

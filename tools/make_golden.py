@@ -351,6 +351,53 @@ def run_dataset_case(name="dataset_tsv_b7"):
     print("wrote", out, os.path.getsize(out))
 
 
+WUKONG_CORPUS = ["a photo of a cat", "the red dogs.", "中文猫图", "zzz unknownword " * 12, "", "photo, of THE Dog", "狗 a 图",
+                 "Café naïve ÀB", "a\tb\nc  d", "[CLS] a [SEP]", "don't stop-me", "ａｂｃ full-width", "a\u200bb\ufffdc", "x" * 150,
+                 "y" * 201, "dogs,cats.the;a", "abc中def文", "  leading and trailing  ", "«quoted» „text“ …", "1+1=2 & 50% off!",
+                 "\U00020000 extension-B ideograph", "a\u0301 combining", "MiXeD CaSe ÉCOLE", "tab\tsep", "a\x00b\x07c", "　ideographic　space"]
+
+
+def run_wukong_dataset_case(name="wukong_dataset_b5"):
+    """The reference's own WukongCLIPDataset / FullTokenizer (appzoo/wukong_clip/data.py:136-241, bert_tokenizer.py) over
+    the images of dataset_tsv_b7 with a BERT-layout vocabulary ([CLS] = 101, [SEP] = 102): token tensors of batch_fn,
+    per-image SHA-256 of pixel_values, and the wordpiece ids of a corpus of edge-case strings."""
+    import hashlib
+    import tempfile
+    R.install_shims()
+    from easynlp.appzoo.wukong_clip.bert_tokenizer import FullTokenizer
+    from easynlp.appzoo.wukong_clip.data import WukongCLIPDataset
+    base = np.load(os.path.join(ROOT, "tests", "golden", "dataset_tsv_b7.npz"))
+    # the reference's Wukong pipeline has no convert('RGB') (data.py:82-83): greyscale rows raise there -- keep the RGB rows
+    import base64, io
+    from PIL import Image
+    rows = [r for r in base["tsv"].tobytes().decode("utf-8").split("\n") if r]
+    rows = [r for r in rows if Image.open(io.BytesIO(base64.urlsafe_b64decode(r.split("\t")[1]))).mode == "RGB"]
+    tsv = "\n".join(rows) + "\n"
+    words = [w for w in base["vocab"].tobytes().decode("utf-8").split("\n") if not w.startswith("[")]
+    vocab = ["[PAD]"] + ["[unused%d]" % i for i in range(1, 100)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words + \
+            ["é", "cafe", "naive", "ab", "+", "=", "&", "%", "!", "1", "2", "50", "off", "mixed", "case", "ecole", "«", "»", "…", "-", "'"]
+    assert vocab.index("[SEP]") == 102 and vocab.index("[CLS]") == 101
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "vocab.txt"), "w") as f:
+            f.write("\n".join(vocab) + "\n")
+        with open(os.path.join(d, "data.tsv"), "w") as f:
+            f.write(tsv)
+        ds = WukongCLIPDataset(d, os.path.join(d, "data.tsv"), 32, input_schema="text:str:1,image:str:1",
+                               first_sequence="text", second_sequence="image")
+        batch = ds.batch_fn([ds[i] for i in range(len(ds))])
+        tok = FullTokenizer(vocab_file=os.path.join(d, "vocab.txt"))
+        corpus_ids = [tok.convert_tokens_to_ids(tok.tokenize(t)) for t in WUKONG_CORPUS]
+    px = batch["pixel_values"].numpy()
+    assert px.dtype == np.float32 and px.shape[1:] == (3, 224, 224) and sorted(batch) == ["input_ids", "pixel_values"]
+    out = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(out, vocab=np.frombuffer("\n".join(vocab).encode("utf-8"), dtype=np.uint8),
+                        tsv=np.frombuffer(tsv.encode("utf-8"), dtype=np.uint8), input_ids=batch["input_ids"].numpy(),
+                        pixel_sha256=np.array([hashlib.sha256(np.ascontiguousarray(px[i]).tobytes()).hexdigest() for i in range(len(px))]),
+                        corpus=np.frombuffer("\x1e".join(WUKONG_CORPUS).encode("utf-8"), dtype=np.uint8),
+                        corpus_ids=np.array([",".join(map(str, ids)) for ids in corpus_ids]))
+    print("wrote", out, os.path.getsize(out))
+
+
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     only = sys.argv[1:]
@@ -371,6 +418,8 @@ if __name__ == "__main__":
     for case in WUKONG_CASES:
         if not only or case[0] in only:
             run_wukong_case(*case)
+    if not only or "wukong_dataset_b5" in only:
+        run_wukong_dataset_case()
     for case in T2V_CASES:
         if not only or case[0] in only:
             run_t2v_case(*case)

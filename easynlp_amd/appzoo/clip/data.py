@@ -4,8 +4,9 @@ for the local TSV format ``text \\t urlsafe-base64(encoded image)`` the tutorial
 schema and calls ``convert_single_row_to_example``; the DataLoader collates with ``batch_fn``).
 
 What stays where the reference has it (CPU, DataLoader workers): reading the file, WordPiece tokenisation with the
-checkpoint's ``vocab.txt`` (padding='max_length', truncation, max_length=max_seq_length, data.py:250-253), base64 + image
-decode (data.py:240-244).
+checkpoint's ``vocab.txt`` (padding='max_length', truncation, max_length=max_seq_length, data.py:250-253) -- or, for
+open_clip checkpoints, the byte-level BPE of bpe_tokenizer.py over the gzip merges file (77 ids, data.py:246-249) --
+base64 + image decode (data.py:240-244).
 
 What moves to the GPU: the per-image ``_resize`` / ``_center_crop`` / ``_normalize`` (data.py:256-262).  ``batch_fn`` emits
 the decoded images under ``'images'`` (plus ``'image_size'``) instead of ``'pixel_values'`` and the drop-in
@@ -75,9 +76,6 @@ class CLIPDataset(torch.utils.data.Dataset):
             self.raw_config = json.load(f)
         mt = self.raw_config.get("model_type")
         self.model_type = mt if mt in ("open_clip", "chinese_clip") else "huggingface_clip"          # data.py:196-201
-        if self.model_type == "open_clip":
-            raise L.EzclipError("open_clip checkpoints tokenise with the BPE SimpleTokenizer (data.py:226-227): feed "
-                                "pre-tokenised input_ids; CLIPDataset covers the WordPiece flavours")
         if str(data_file).endswith("tar"):
             raise L.EzclipError("webdataset tar input (data.py:203-217) is not covered; use the TSV format")
         if not input_schema:
@@ -90,7 +88,11 @@ class CLIPDataset(torch.utils.data.Dataset):
             self.data_rows = f.readlines()
         self.text_col = first_sequence
         self.image_col = second_sequence
-        self.tokenizer = load_wordpiece_tokenizer(os.path.join(path, "vocab.txt"))                 # data.py:229
+        if self.model_type == "open_clip":                                                         # data.py:225-229
+            from .bpe_tokenizer import SimpleTokenizer
+            self.openclip_tokenizer = SimpleTokenizer(bpe_path=os.path.join(path, "vocab.txt"))   # (a gzip merges file)
+        else:
+            self.tokenizer = load_wordpiece_tokenizer(os.path.join(path, "vocab.txt"))
         self.max_text_length = max_seq_length
         self.size = self.crop_size = int(image_size)             # data.py:231-236 fixes 224; other resolutions by keyword
 
@@ -110,8 +112,12 @@ class CLIPDataset(torch.utils.data.Dataset):
         from PIL import Image
         text = row[self.text_col]
         image = Image.open(io.BytesIO(base64.urlsafe_b64decode(row[self.image_col])))             # data.py:242
-        tk = self.tokenizer([text], padding="max_length", truncation=True, max_length=self.max_text_length,
-                            return_tensors="pt")                                                    # data.py:250-253
+        if self.model_type == "open_clip":                                                         # data.py:246-249: always 77
+            from .bpe_tokenizer import openclip_tokenize
+            tk = {"input_ids": openclip_tokenize([text], context_length=77, _tokenizer=self.openclip_tokenizer)}
+        else:
+            tk = self.tokenizer([text], padding="max_length", truncation=True, max_length=self.max_text_length,
+                                return_tensors="pt")                                                # data.py:250-253
         if image.mode not in ("RGB", "L"):
             raise L.EzclipError("image mode %r is not on the GPU pre-processing path (the reference resizes palette / alpha "
                                 "images in their own mode); convert('RGB') upstream" % image.mode)

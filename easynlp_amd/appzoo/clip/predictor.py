@@ -55,6 +55,13 @@ class CLIPPredictor(Predictor):
         self.size = self.crop_size = int(cfg.get("image_resolution", 224))      # reference: 224 (predictor.py:66-70)
 
     @property
+    def openclip_tokenizer(self):
+        if getattr(self, "_bpe", None) is None:
+            from .bpe_tokenizer import SimpleTokenizer
+            self._bpe = SimpleTokenizer(bpe_path=os.path.join(self.model_dir, "vocab.txt"))       # predictor.py:55
+        return self._bpe
+
+    @property
     def tokenizer(self):
         if self._tokenizer is None:
             from .data import load_wordpiece_tokenizer
@@ -76,8 +83,8 @@ class CLIPPredictor(Predictor):
         for record in in_data:
             text = record.get(self.first_sequence, None)
             if text is not None and "input_ids" not in record and getattr(self.multi_modal, "model_type", "") == "open_clip":
-                raise L.EzclipError("open_clip checkpoints use the BPE SimpleTokenizer (predictor.py:91-93): pass records with "
-                                    "tokenised 'input_ids' [1, context_length]")
+                from .bpe_tokenizer import openclip_tokenize               # predictor.py:91-94: BPE, always 77 ids
+                record["input_ids"] = openclip_tokenize([text], context_length=77, _tokenizer=self.openclip_tokenizer)
             if text is not None and "input_ids" not in record:            # predictor.py:95-101
                 tked = self.tokenizer(text, padding="max_length", truncation=True, max_length=max_seq_length,
                                       return_tensors="pt")

@@ -90,12 +90,6 @@ def test_huggingface_flavour_and_what_is_not_covered(tmp_path):
     assert ds.model_type == "huggingface_clip"
     b = ds.batch_fn([ds[0], ds[1]])
     assert np.array_equal(b["input_ids"].numpy(), g["input_ids"][:2]) and "token_type_ids" in b and "attention_mask" in b
-    with open(os.path.join(d, "config.json"), "w") as f:
-        json.dump({"model_type": "open_clip"}, f)
-    with pytest.raises(L.EzclipError):
-        _dataset(d)
-    with open(os.path.join(d, "config.json"), "w") as f:
-        json.dump({"model_type": "chinese_clip"}, f)
     with pytest.raises(L.EzclipError):
         CLIPDataset(d, os.path.join(d, "shard-000.tar"), 20, input_schema=SCHEMA, first_sequence="text", second_sequence="image")
     # a palette image is refused (the reference resizes it in 'P' mode; not on the device path) -- loudly, not silently converted
@@ -112,6 +106,28 @@ def test_huggingface_flavour_and_what_is_not_covered(tmp_path):
     db = CLIPDataset(d, os.path.join(d, "bad.tsv"), 20, input_schema=SCHEMA, first_sequence="text", second_sequence="image")
     with pytest.raises(RuntimeError):
         db[0]
+
+
+def test_open_clip_flavour_tokenises_with_the_bpe_merges_file(tmp_path):
+    """model_type open_clip (data.py:225-227,246-249): vocab.txt is the gzip merges file, captions become 77 BPE ids; the
+    ids of the fixture captions are the reference tokenizer's (tests/golden/openclip_bpe_corpus.npz)."""
+    import gzip
+    g, d = _materialise(tmp_path, model_type="open_clip")
+    b = np.load(os.path.join(os.path.dirname(GOLD), "openclip_bpe_corpus.npz"))
+    with gzip.open(os.path.join(d, "vocab.txt"), "wb") as f:
+        f.write(b["merges"].tobytes())
+    corpus = b["corpus"].tobytes().decode("utf-8").split("\x1e")
+    rows = g["tsv"].tobytes().decode("utf-8").split("\n")[:-1]
+    keep = [i for i, t in enumerate(corpus) if "\t" not in t and "\n" not in t][:len(rows)]
+    with open(os.path.join(d, "oc.tsv"), "w") as f:
+        for i, r in zip(keep, rows):
+            f.write(corpus[i] + "\t" + r.split("\t")[1] + "\n")
+    ds = CLIPDataset(d, os.path.join(d, "oc.tsv"), 32, input_schema=SCHEMA, first_sequence="text", second_sequence="image")
+    assert ds.model_type == "open_clip"
+    batch = ds.batch_fn([ds[i] for i in range(len(ds))])
+    assert tuple(batch["input_ids"].shape) == (len(rows), 77) and "attention_mask" not in batch and "token_type_ids" not in batch
+    # a TSV row is stripped of its newline only, the tokenizer cleans the rest: same ids as the reference's tokens77 rows
+    assert np.array_equal(batch["input_ids"].numpy(), b["tokens77"][keep])
 
 
 @pytest.mark.gpu

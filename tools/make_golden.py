@@ -398,6 +398,80 @@ def run_wukong_dataset_case(name="wukong_dataset_b5"):
     print("wrote", out, os.path.getsize(out))
 
 
+BPE_TRAIN_TEXT = ("a photo of a cat . a photo of a dog . the red dogs and the red cats are running in the garden . "
+                  "two people riding bikes near the river , it's a sunny day ! she'll say they've done it ; i'm here , we're there . "
+                  "photograph photography photographer telephoto 2023 1999 100% caf\u00e9 na\u00efve fa\u00e7ade "
+                  "\u4e2d\u6587 \u732b \u56fe \u4e2d\u6587\u732b\u56fe running runner runs ran the then there these those ") * 3
+
+BPE_CORPUS = ["a photo of a cat", "The RED dogs.", "two people riding bikes near the river", "it's a sunny day! she'll say they've done it",
+              "photographers' telephoto lens, 2023", "", "   spaced    out \t text \n", "caf\u00e9 na\u00efve fa\u00e7ade", "\u4e2d\u6587\u732b\u56fe",
+              "&amp;lt;b&amp;gt; html &quot;entities&quot; &amp;amp;", "<start_of_text> inside <end_of_text> text", "emoji \U0001F600 and symbols #$%^&*()",
+              "word " * 60, "x", "'s 't 're don't I'M", "100% of 1,234.56", "under_score-and-dash", "\u00bd \u2460 \u0663"]
+
+
+def _train_bpe(text, n_merges):
+    """a minimal BPE trainer (most frequent adjacent pair, ties by first occurrence) -- only to obtain a realistic merges
+    file for the tokenizer fixtures; the tokenizers under test only READ merges"""
+    import collections
+    import regex
+    R.install_shims()
+    from easynlp.modelzoo.models.clip.openclip_tokenizer import bytes_to_unicode
+    enc = bytes_to_unicode()
+    pat = regex.compile(r"""'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+""", regex.IGNORECASE)
+    words = collections.Counter()
+    for tok in pat.findall(text.lower()):
+        sym = [enc[b] for b in tok.encode("utf-8")]
+        sym[-1] += "</w>"
+        words[tuple(sym)] += 1
+    merges = []
+    for _ in range(n_merges):
+        pairs = collections.Counter()
+        for w, c in words.items():
+            for a, b in zip(w[:-1], w[1:]):
+                pairs[(a, b)] += c
+        if not pairs:
+            break
+        best = max(pairs.items(), key=lambda kv: kv[1])[0]
+        merges.append(best)
+        new = collections.Counter()
+        for w, c in words.items():
+            out, i = [], 0
+            while i < len(w):
+                if i + 1 < len(w) and (w[i], w[i + 1]) == best:
+                    out.append(w[i] + w[i + 1]); i += 2
+                else:
+                    out.append(w[i]); i += 1
+            new[tuple(out)] += c
+        words = new
+    return merges
+
+
+def run_bpe_case(name="openclip_bpe_corpus"):
+    """The reference's SimpleTokenizer / openclip_tokenize (modelzoo/models/clip/openclip_tokenizer.py, appzoo/clip/data.py:
+    137-161) over a gzip merges file trained here: ids of an edge-case corpus and the [n, 77] / [n, 16] token tensors."""
+    import gzip
+    import tempfile
+    R.install_shims()
+    from easynlp.appzoo.clip.data import openclip_tokenize
+    from easynlp.modelzoo.models.clip.openclip_tokenizer import SimpleTokenizer
+    merges = _train_bpe(BPE_TRAIN_TEXT, 400)
+    blob = "#version: synthetic fixture\n" + "\n".join(a + " " + b for a, b in merges) + "\n"
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "vocab.txt")
+        with gzip.open(path, "wb") as f:
+            f.write(blob.encode("utf-8"))
+        tok = SimpleTokenizer(bpe_path=path)
+        ids = [tok.encode(t) for t in BPE_CORPUS]
+        t77 = openclip_tokenize(BPE_CORPUS, context_length=77, _tokenizer=tok).numpy()
+        t16 = openclip_tokenize(BPE_CORPUS, context_length=16, _tokenizer=tok).numpy()
+        meta = np.array([str(tok.vocab_size), str(tok.encoder["<start_of_text>"]), str(tok.encoder["<end_of_text>"]), str(len(merges))])
+    out = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(out, merges=np.frombuffer(blob.encode("utf-8"), dtype=np.uint8),
+                        corpus=np.frombuffer("\x1e".join(BPE_CORPUS).encode("utf-8"), dtype=np.uint8),
+                        corpus_ids=np.array([",".join(map(str, x)) for x in ids]), tokens77=t77, tokens16=t16, meta=meta)
+    print("wrote", out, os.path.getsize(out), "merges", len(merges))
+
+
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     only = sys.argv[1:]
@@ -420,6 +494,8 @@ if __name__ == "__main__":
             run_wukong_case(*case)
     if not only or "wukong_dataset_b5" in only:
         run_wukong_dataset_case()
+    if not only or "openclip_bpe_corpus" in only:
+        run_bpe_case()
     for case in T2V_CASES:
         if not only or case[0] in only:
             run_t2v_case(*case)

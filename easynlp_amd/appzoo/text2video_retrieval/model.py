@@ -38,6 +38,15 @@ class Text2VideoRetrieval(CLIPApp):
     def forward(self, inputs, feat=None):
         dev = self._params["text_projection"].device
         B = T = None
+        if inputs.get("pixel_values") is None and inputs.get("images") is not None:
+            # batches of the drop-in Text2VideoRetrievalDataset: per clip a list of decoded uint8 frames -> the reference's
+            # float32 pixel_values [B, T, 3, R, R] on the GPU (bit-identical to its PIL sequence)
+            clips = inputs["images"]
+            R = int(inputs.get("image_size") or self._engine.cfg["image_resolution"])
+            if len({len(c) for c in clips}) != 1:
+                raise L.EzclipError("Text2VideoRetrieval: every clip of a batch must hold the same number of frames")
+            flat = L.preprocess_images([f for c in clips for f in c], size=R, crop=R, device=dev)
+            inputs["pixel_values"] = flat.view(len(clips), len(clips[0]), *flat.shape[1:])
         if inputs.get("pixel_values") is not None:                                     # model.py:69-73
             px = inputs["pixel_values"].to(dev)
             if px.dim() != 5:

@@ -67,6 +67,9 @@ def install_shims() -> None:
                 if name == "ftfy":
                     m.fix_text = lambda s: s
                 sys.modules[name] = m
+    import numpy as _np
+    if not hasattr(_np, "long"):        # removed in numpy 2; text2video_retrieval/data.py:253 still spells the mask dtype so
+        _np.long = _np.int64
     _installed = True
 
 

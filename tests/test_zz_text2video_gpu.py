@@ -104,3 +104,51 @@ def test_text2video_eval_path_and_evaluator(tmp_path):
     res = Text2VideoRetrievalEvaluator(DS(), eval_batch_size=6).evaluate(app)
     want = O.recall_at_k(out["text_embeds"].cpu().float(), out["video_embeds"].cpu().float())
     assert res[0][0] == "mean_recall" and abs(res[0][1] - want[0]) < 1e-9
+
+
+def test_text2video_dataset_batches_and_predictor(tmp_path):
+    """DataLoader(Text2VideoRetrievalDataset) -> forward (frames resized on the GPU) and the predictor's two record kinds,
+    against the oracle fed with the same pre-processed frames."""
+    import gzip
+    from easynlp_amd import lib as L
+    from easynlp_amd.appzoo.text2video_retrieval import Text2VideoRetrievalDataset, Text2VideoRetrievalPredictor
+    g = np.load(os.path.join(GOLD, "t2v_dataset_b3.npz"))
+    bpe = np.load(os.path.join(GOLD, "openclip_bpe_corpus.npz"))
+    d = str(tmp_path)
+    cfg = dict(OC.OPENCLIP_CONFIGS["oc_small"], image_resolution=224, vision_patch_size=32,
+               vocab_size=int(bpe["meta"][0]), context_length=77)
+    sd = OC.make_state_dict(cfg, 9)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    torch.save({"open_clip." + k: v for k, v in sd.items()}, os.path.join(d, "pytorch_model.bin"))
+    with gzip.open(os.path.join(d, "vocab.txt"), "wb") as f:
+        f.write(bpe["merges"].tobytes())
+    for k in g.files:
+        if k.startswith("png/"):
+            path = os.path.join(d, k[len("png/"):])
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "wb") as f:
+                f.write(g[k].tobytes())
+    with open(os.path.join(d, "data.tsv"), "w") as f:
+        for i, cap in enumerate(g["captions"]):
+            f.write(str(cap) + "\t" + os.path.join(d, "clip%d" % i) + "\n")
+    ds = Text2VideoRetrievalDataset(d, os.path.join(d, "data.tsv"), 77, input_schema="text:str:1,image:str:1",
+                                    first_sequence="text", second_sequence="image")
+    app = Text2VideoRetrieval(d, user_defined_parameters={"clip_compute_dtype": "fp32"}).cuda().eval()
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False, collate_fn=ds.batch_fn)))
+    clips = [list(c) for c in batch["images"]]
+    with torch.no_grad():
+        out = app(batch)
+        px = L.preprocess_images([f for c in clips for f in c], size=224, crop=224).cpu().view(3, 12, 3, 224, 224)
+        ref = TV.forward(sd, cfg, px, torch.from_numpy(g["video_masks"]), torch.from_numpy(g["input_ids"]))
+    assert tuple(batch["pixel_values"].shape) == (36, 3, 224, 224)          # forward flattens the clips in place, as the reference
+    assert float((out["video_embeds"].cpu() - ref["video_embeds"]).abs().max()) < 1e-5
+    assert float((out["text_embeds"].cpu() - ref["text_embeds"]).abs().max()) < 1e-5
+    vp = Text2VideoRetrievalPredictor(d, first_sequence="image", user_defined_parameters={"clip_compute_dtype": "fp32"})
+    vout = vp.run([{"image": os.path.join(d, "clip%d" % i)} for i in range(3)])
+    vf = np.array([[float(x) for x in o["video_feat"].split("\t")] for o in vout], np.float32)
+    assert np.abs(vf - ref["video_embeds"].numpy()).max() < 1e-5
+    tp = Text2VideoRetrievalPredictor(d, first_sequence="text", user_defined_parameters={"clip_compute_dtype": "fp32"})
+    tout = tp.run([{"text": str(c)} for c in g["captions"]])
+    tf = np.array([[float(x) for x in o["text_feat"].split("\t")] for o in tout], np.float32)
+    assert np.abs(tf - ref["text_embeds"].numpy()).max() < 1e-5

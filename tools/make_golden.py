@@ -472,6 +472,64 @@ def run_bpe_case(name="openclip_bpe_corpus"):
     print("wrote", out, os.path.getsize(out), "merges", len(merges))
 
 
+def run_t2v_dataset_case(name="t2v_dataset_b3"):
+    """The reference's own Text2VideoRetrievalDataset (appzoo/text2video_retrieval/data.py:163-279) over three clips stored as
+    frame directories (12 / 5 / 1 frames, several sizes, one greyscale frame) with the BPE merges of openclip_bpe_corpus:
+    token tensor, video masks, and the SHA-256 of every frame's float32 pixel_values keyed by frame file name (the frame
+    ORDER is os.listdir's and belongs to the directory, not to the fixture)."""
+    import gzip
+    import hashlib
+    import io
+    import tempfile
+    from PIL import Image
+    R.install_shims()
+    from easynlp.appzoo.text2video_retrieval.data import Text2VideoRetrievalDataset
+    bpe = np.load(os.path.join(ROOT, "tests", "golden", "openclip_bpe_corpus.npz"))
+    rng = np.random.RandomState(5)
+    captions = ["two people riding bikes near the river", "a photo of a cat", "The RED dogs."]
+    specs = [[(64, 48, "RGB")] * 12, [(224, 224, "RGB"), (300, 200, "RGB"), (100, 160, "L"), (224, 250, "RGB"), (17, 33, "RGB")], [(90, 90, "RGB")]]
+    frames = {}
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "config.json"), "w") as f:
+            json.dump({"model_type": "open_clip"}, f)
+        with gzip.open(os.path.join(d, "vocab.txt"), "wb") as f:
+            f.write(bpe["merges"].tobytes())
+        rows = []
+        for ci, (cap, spec) in enumerate(zip(captions, specs)):
+            cdir = os.path.join(d, "clip%d" % ci)
+            os.makedirs(cdir)
+            for fi, (w, h, mode) in enumerate(spec):
+                arr = rng.randint(0, 256, size=(h, w, 3) if mode == "RGB" else (h, w)).astype(np.uint8)
+                buf = io.BytesIO()
+                Image.fromarray(arr, mode).save(buf, format="PNG")
+                fname = "f%02d.png" % fi
+                with open(os.path.join(cdir, fname), "wb") as f:
+                    f.write(buf.getvalue())
+                frames["clip%d/%s" % (ci, fname)] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
+            rows.append(cap + "\t" + cdir)
+        with open(os.path.join(d, "data.tsv"), "w") as f:
+            f.write("\n".join(rows) + "\n")
+        ds = Text2VideoRetrievalDataset(d, os.path.join(d, "data.tsv"), 77, input_schema="text:str:1,image:str:1",
+                                        first_sequence="text", second_sequence="image")
+        batch = ds.batch_fn([ds[i] for i in range(len(ds))])
+        order = [os.listdir(os.path.join(d, "clip%d" % ci)) for ci in range(3)]
+    px = batch["pixel_values"].numpy()
+    assert px.shape == (3, 12, 3, 224, 224) and px.dtype == np.float32
+    sha = {}
+    for ci in range(3):
+        for fi, fname in enumerate(order[ci]):
+            sha["clip%d/%s" % (ci, fname)] = hashlib.sha256(np.ascontiguousarray(px[ci, fi]).tobytes()).hexdigest()
+    pad_sha = hashlib.sha256(np.ascontiguousarray(px[2, 11]).tobytes()).hexdigest()
+    assert all(hashlib.sha256(np.ascontiguousarray(px[2, k]).tobytes()).hexdigest() == pad_sha for k in range(1, 12))
+    out = {"captions": np.array(captions), "input_ids": batch["input_ids"].numpy(), "video_masks": batch["video_masks"].numpy(),
+           "frame_names": np.array(sorted(frames)), "frame_sha256": np.array([sha[k] for k in sorted(frames)]), "pad_sha256": np.array(pad_sha)}
+    for k in sorted(frames):
+        out["png/" + k] = frames[k]
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path))
+
+
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     only = sys.argv[1:]
@@ -496,6 +554,8 @@ if __name__ == "__main__":
         run_wukong_dataset_case()
     if not only or "openclip_bpe_corpus" in only:
         run_bpe_case()
+    if not only or "t2v_dataset_b3" in only:
+        run_t2v_dataset_case()
     for case in T2V_CASES:
         if not only or case[0] in only:
             run_t2v_case(*case)

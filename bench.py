@@ -216,9 +216,9 @@ def main():
                 if p.grad is not None:
                     p.grad.zero_()
             loss = app.contrastive_step(px, ids, process_group=pg, backward=True)
-            if world > 1:       # DDP-style gradient averaging belongs to a training step (trainer.py:101-108)
-                from easynlp_amd import parallel as P
-                P.average_gradients(list(app.parameters()))
+            if world > 1:       # the gradient all-reduce belongs to a training step (DDP in trainer.py:101-108); the embedding
+                from easynlp_amd import parallel as P    # gradients are those of the global mean loss, so ranks hold partial sums
+                P.sum_gradients(list(app.parameters()))
             return loss
         with torch.no_grad():
             return app.contrastive_step(px, ids, process_group=pg, backward=False)

@@ -331,6 +331,55 @@ class _InfoNCEFn(torch.autograd.Function):
         return d
 
 
+def fused_infonce_shard(eng, txt_all, img_all, n, off, logit_scale, grad_scale, want_grads):
+    """``ezclip_infonce_fused`` on this rank's ``n`` rows (starting at ``off``) of both directions against all ``N`` columns:
+    (loss = mean over the local rows, d_text [N, E], d_image [N, E], d_logit_scale) -- the gradients only when asked."""
+    lib = eng.lib
+    N, e = img_all.shape
+    key = ("nce", n, N, e)
+    ws = eng._ws.get(key)
+    if ws is None:
+        ws = L.alloc_bytes(lib.ezclip_infonce_workspace_bytes(n, N, e), img_all.device)
+        eng._ws[key] = ws
+    loss = torch.empty((), dtype=torch.float32, device=img_all.device)
+    if not want_grads:
+        L.check(lib.ezclip_infonce_fused(L.ptr(txt_all), L.ptr(img_all), n, N, off, e, L.ptr(logit_scale), 1.0, L.ptr(loss),
+                                         None, None, None, L.ptr(ws), ws.numel(), L.stream_ptr()), "infonce_fused")
+        return loss, None, None, None
+    d_txt = torch.empty((N, e), dtype=torch.float32, device=img_all.device)
+    d_img = torch.empty((N, e), dtype=torch.float32, device=img_all.device)
+    d_ls = torch.empty((), dtype=torch.float32, device=img_all.device)
+    L.check(lib.ezclip_infonce_fused(L.ptr(txt_all), L.ptr(img_all), n, N, off, e, L.ptr(logit_scale), float(grad_scale),
+                                     L.ptr(loss), L.ptr(d_txt), L.ptr(d_img), L.ptr(d_ls), L.ptr(ws), ws.numel(),
+                                     L.stream_ptr()), "infonce_fused")
+    return loss, d_txt, d_img, d_ls
+
+
+class _GlobalInfoNCEFn(torch.autograd.Function):
+    """contrastive_scope='global' on the autograd path (what Trainer + DDP drive): all-gather the embeddings, this rank's
+    rows of both directions against every column (row-local log-sum-exps: no second collective), reduce-scatter the
+    embedding gradients back to their owners.  The loss is the mean over the LOCAL rows and the gradients are those of the
+    SUM of the ranks' losses w.r.t. the local embeddings, so that DDP's gradient averaging yields the gradient of the global
+    mean loss.  ``shard_fn`` computes the rank-local part (the HIP kernel; the CPU oracle in the gloo tests)."""
+
+    @staticmethod
+    def forward(ctx, shard_fn, group, txt, img, logit_scale):
+        n = txt.shape[0]
+        img_all, txt_all, off = P.gather_embeddings(img.detach().contiguous(), txt.detach().contiguous(), group)
+        need = any(ctx.needs_input_grad[2:5])
+        loss, d_txt, d_img, d_ls = shard_fn(txt_all, img_all, n, off, logit_scale.detach(), 1.0, need)
+        ctx.need = need
+        if need:
+            d_img_l, d_txt_l = P.scatter_embedding_grads(d_img, d_txt, n, group)
+            ctx.save_for_backward(d_txt_l, d_img_l, d_ls.reshape(logit_scale.shape))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d_txt, d_img, d_ls = ctx.saved_tensors
+        return None, None, g * d_txt, g * d_img, g * d_ls
+
+
 class CLIPApp(Application):
 
     @classmethod
@@ -343,6 +392,11 @@ class CLIPApp(Application):
         if isinstance(udp, dict) and "app_parameters" in udp:
             udp = dict(udp, **udp["app_parameters"])
         self.compute_dtype = L.dtype_code(kwargs.get("compute_dtype", udp.get("clip_compute_dtype", "bf16")))
+        # 'local' = the reference's behaviour under DDP (each rank's own pairs, model.py:154-164);
+        # 'global' = every rank's rows against the pairs of ALL ranks (RCCL all-gather of the embeddings)
+        self.contrastive_scope = str(kwargs.get("contrastive_scope", udp.get("contrastive_scope", "local")))
+        if self.contrastive_scope not in ("local", "global"):
+            raise L.EzclipError("contrastive_scope must be 'local' or 'global', got %r" % self.contrastive_scope)
         self._engine = None
         self._params: Dict[str, nn.Parameter] = {}
         if pretrained_model_name_or_path is None:
@@ -698,6 +752,12 @@ class CLIPApp(Application):
             image_embeds, text_embeds = self.encode(inputs["pixel_values"], inputs["input_ids"])
         if feat is True:
             return {"image_embeds": image_embeds, "text_embeds": text_embeds}
+        if self.contrastive_scope == "global" and self.training:
+            # the [n, N] logits stay inside the fused kernel's workspace: the dict carries the loss instead
+            eng = self._engine
+            loss = _GlobalInfoNCEFn.apply(lambda *a: fused_infonce_shard(eng, *a), None, text_embeds, image_embeds, self.logit_scale)
+            return {"loss": loss, "logits_per_text": None, "logits_per_image": None,
+                    "image_embeds": image_embeds, "text_embeds": text_embeds}
         logits_per_text = _SimilarityFn.apply(text_embeds, image_embeds, self.logit_scale)
         logits_per_image = logits_per_text.T
         return {"logits_per_text": logits_per_text, "logits_per_image": logits_per_image,
@@ -710,5 +770,7 @@ class CLIPApp(Application):
         return _InfoNCEFn.apply(similarity)
 
     def compute_loss(self, forward_outputs, label_ids, **kwargs):
+        if forward_outputs.get("loss") is not None:          # contrastive_scope='global': computed with the exchange in forward
+            return {"loss": forward_outputs["loss"]}
         loss = self.clip_loss(forward_outputs["logits_per_text"])
         return {"loss": loss}

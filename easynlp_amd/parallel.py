@@ -51,9 +51,16 @@ def scatter_embedding_grads(d_img_all: torch.Tensor, d_txt_all: torch.Tensor, n_
     return mine[:, :e].contiguous(), mine[:, e:].contiguous()
 
 
-def average_gradients(params, group=None, bucket_bytes: int = 256 << 20) -> None:
-    """DDP-style gradient averaging with large flat buckets: xGMI rings are per-link bound, so few
-    big all-reduces (256 MiB) beat many 25 MiB ones."""
+def sum_gradients(params, group=None, bucket_bytes: int = 256 << 20) -> None:
+    """Sum parameter gradients over ranks.  This is what follows ``CLIPApp.contrastive_step(backward=True)`` with a
+    process group: its embedding gradients are already those of the GLOBAL mean loss (grad_scale 1 / world inside), so
+    the per-rank parameter gradients are partial sums of the true gradient."""
+    average_gradients(params, group, bucket_bytes, average=False)
+
+
+def average_gradients(params, group=None, bucket_bytes: int = 256 << 20, average: bool = True) -> None:
+    """DDP-style gradient averaging (``average=False``: plain sum) with large flat buckets: xGMI rings are per-link bound,
+    so few big all-reduces (256 MiB) beat many 25 MiB ones."""
     world, _ = world_info(group)
     if world == 1:
         return
@@ -65,7 +72,8 @@ def average_gradients(params, group=None, bucket_bytes: int = 256 << 20) -> None
             return
         flat = torch.cat([g.reshape(-1) for g in bucket])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat.div_(world)
+        if average:
+            flat.div_(world)
         off = 0
         for g in bucket:
             g.copy_(flat[off:off + g.numel()].view_as(g))

@@ -56,11 +56,82 @@ def _worker(rank, world, port, n, e, q):
         p.grad = torch.full((5,), float(rank + 1))
         P.average_gradients([p])
         assert torch.allclose(p.grad, torch.full((5,), (1 + world) / 2.0))
+        p.grad = torch.full((5,), float(rank + 1))
+        P.sum_gradients([p])
+        assert torch.allclose(p.grad, torch.full((5,), world * (1 + world) / 2.0))
         q.put((rank, "ok"))
     except Exception as ex:  # pragma: no cover
         q.put((rank, repr(ex)))
     finally:
         dist.destroy_process_group()
+
+
+def _oracle_shard(txt_all, img_all, n, off, ls, grad_scale, need):
+    """stand-in for the HIP kernel behind fused_infonce_shard: this rank's rows of the global InfoNCE + gradients"""
+    with torch.enable_grad():            # (autograd.Function.forward runs with grad mode off)
+        ta, ia = txt_all.clone().requires_grad_(True), img_all.clone().requires_grad_(True)
+        lsv = ls.clone().requires_grad_(True)
+        loss = O.global_clip_loss_rank(ta, ia, lsv, off // n, n)
+        if not need:
+            return loss.detach(), None, None, None
+        (loss * grad_scale).backward()
+    return loss.detach(), ta.grad, ia.grad, lsv.grad
+
+
+def _scope_worker(rank, world, port, n, e, q):
+    """contrastive_scope='global' on the autograd path under DDP semantics: per-rank backward through _GlobalInfoNCEFn,
+    parameter gradients AVERAGED over ranks == gradient of the single-process full-batch loss."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from easynlp_amd import parallel as P
+        from easynlp_amd.appzoo.clip.model import _GlobalInfoNCEFn
+        g = torch.Generator().manual_seed(7)
+        X = torch.randn(world * n, e, generator=g, dtype=torch.float64)          # raw "image" / "text" features of all pairs
+        Y = X + 0.5 * torch.randn(world * n, e, generator=g, dtype=torch.float64)
+        W0 = torch.randn(e, e, generator=g, dtype=torch.float64) / e ** 0.5      # the replicated "encoder" parameters
+        V0 = torch.randn(e, e, generator=g, dtype=torch.float64) / e ** 0.5
+        ls0 = torch.tensor(1.5, dtype=torch.float64)
+        enc = lambda x, w: torch.nn.functional.normalize(x @ w, dim=-1)       # noqa: E731
+        sl = slice(rank * n, (rank + 1) * n)
+        W, V, ls = (torch.nn.Parameter(t.clone()) for t in (W0, V0, ls0))
+        loss = _GlobalInfoNCEFn.apply(_oracle_shard, None, enc(Y[sl], V), enc(X[sl], W), ls)
+        loss.backward()
+        P.average_gradients([W, V, ls])                                          # what DDP does
+        Wf, Vf, lsf = (t.clone().requires_grad_(True) for t in (W0, V0, ls0))
+        full = O.clip_loss((enc(Y, Vf) @ enc(X, Wf).t()) * lsf.exp())
+        full.backward()
+        lt = torch.tensor([loss.item()], dtype=torch.float64)
+        dist.all_reduce(lt)
+        assert abs(lt.item() / world - full.item()) < 1e-12                      # mean of the rank losses = the global loss
+        for a, b in ((W, Wf), (V, Vf), (ls, lsf)):
+            assert float((a.grad - b.grad).abs().max()) < 1e-11
+        # no gradient requested: forward only, nothing saved, no second collective
+        with torch.no_grad():
+            l2 = _GlobalInfoNCEFn.apply(_oracle_shard, None, enc(Y[sl], V0), enc(X[sl], W0), ls0)
+        assert abs(l2.item() - loss.item()) < 1e-12
+        q.put((rank, "ok"))
+    except Exception as ex:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(ex) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,e", [(4, 8), (9, 16)])
+def test_global_scope_autograd_path_under_ddp_averaging_world2_gloo(n, e):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scope_worker, args=(r, world, port, n, e, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
 
 
 @pytest.mark.parametrize("n,e", [(3, 8), (16, 32)])

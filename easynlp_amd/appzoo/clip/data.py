@@ -99,6 +99,11 @@ class CLIPDataset(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.data_rows)
 
+    @property
+    def label_enumerate_values(self):
+        """read by Trainer.save_checkpoint (core/trainer.py:429-438); BaseDataset's default (appzoo/dataset.py:261-263)"""
+        return ["0", "1"]
+
     def __getitem__(self, item):
         row = parse_row_by_schema(self.data_rows[item].strip("\n"), self.input_schema)          # dataset.py:160-196
         try:

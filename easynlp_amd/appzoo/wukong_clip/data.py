@@ -43,6 +43,11 @@ class WukongCLIPDataset(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.data_rows)
 
+    @property
+    def label_enumerate_values(self):
+        """read by Trainer.save_checkpoint (core/trainer.py:429-438); BaseDataset's default (appzoo/dataset.py:261-263)"""
+        return ["0", "1"]
+
     def tokenize(self, texts, context_length: int = 32) -> torch.Tensor:
         return self.tokenizer.tokenize_batch(texts, context_length)
 

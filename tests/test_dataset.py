@@ -59,6 +59,7 @@ def test_tokens_equal_the_reference_batch(tmp_path):
         assert batch[k].dtype == torch.int64
         assert np.array_equal(batch[k].numpy(), g[k]), k
     assert batch["label_ids"] == [] and "pixel_values" not in batch
+    assert ds.label_enumerate_values == ["0", "1"]              # Trainer.save_checkpoint reads it (trainer.py:429)
     # rows: truncated to max_seq_length (row 3), empty text = [CLS][SEP] (row 4)
     assert int(batch["attention_mask"][3].sum()) == 20 and int(batch["attention_mask"][4].sum()) == 2
 

@@ -134,6 +134,74 @@ def test_global_scope_autograd_path_under_ddp_averaging_world2_gloo(n, e):
     assert all(r[1] == "ok" for r in res), res
 
 
+def _ddp_worker(rank, world, port, ckpt, q):
+    """The drop-in CLIPApp (contrastive_scope=global) under REAL DistributedDataParallel, as the reference Trainer wraps it
+    (trainer.py:101-108: find_unused_parameters=True) -- tower encodes and the rank-local InfoNCE shard stood in for by the
+    oracle.  Every rank's averaged gradients must equal the single-process gradients of the reference loss on the
+    concatenated batch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from easynlp_amd.appzoo.clip import model as CM
+
+        def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+            sd = {n: p for n, p in self.chinese_clip.named_parameters()}
+            return (O.encode_image(sd, self.raw_config, pixel_values) if pixel_values is not None else None,
+                    O.encode_text(sd, self.raw_config, input_ids) if input_ids is not None else None)
+        CM.CLIPApp.encode = oracle_encode
+        CM.fused_infonce_shard = lambda eng, *a: _oracle_shard(*a)
+        cfg = O.CONFIGS["tiny"]
+        n = 3
+        px, ids = O.make_inputs(cfg, world * n, 16, 21)
+        app = CM.CLIPApp(ckpt, user_defined_parameters={"contrastive_scope": "global"})
+        app.train()
+        ddp = torch.nn.parallel.DistributedDataParallel(app, broadcast_buffers=False, find_unused_parameters=True)
+        sl = slice(rank * n, (rank + 1) * n)
+        out = ddp({"pixel_values": px[sl].clone(), "input_ids": ids[sl].clone()})
+        loss = app.compute_loss(out, [])["loss"]
+        loss.backward()
+        # single process, whole batch, reference math
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in app.chinese_clip.named_parameters()}
+        full = O.clip_loss(O.clip_forward(sd, cfg, px, ids)["logits_per_text"])
+        full.backward()
+        lt = torch.tensor([loss.item()], dtype=torch.float64)
+        dist.all_reduce(lt)
+        assert abs(lt.item() / world - full.item()) < 1e-5
+        checked = 0
+        for name, p in app.chinese_clip.named_parameters():
+            ref = sd[name].grad
+            if ref is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, name      # the unused pooler
+                continue
+            assert float((p.grad - ref).norm()) <= 2e-4 * float(ref.norm()) + 1e-7, name
+            checked += 1
+        assert checked >= 30
+        q.put((rank, "ok"))
+    except Exception as ex:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(ex) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dropin_app_global_scope_under_real_ddp_world2_gloo(tmp_path):
+    from oracle import ref_harness as R
+    cfg = O.CONFIGS["tiny"]
+    R.write_checkpoint_dir(str(tmp_path), cfg, O.make_state_dict(cfg, 9))
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
 @pytest.mark.parametrize("n,e", [(3, 8), (16, 32)])
 def test_global_contrastive_exchange_world2_gloo(n, e):
     world = 2

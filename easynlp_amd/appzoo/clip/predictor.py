@@ -39,7 +39,7 @@ class Predictor(object):
 
 class CLIPPredictor(Predictor):
 
-    def __init__(self, model_dir, model_cls=None, first_sequence=None, second_sequence=None, sequence_length=64,
+    def __init__(self, model_dir, model_cls=None, first_sequence=None, second_sequence=None, sequence_length=128,
                  user_defined_parameters=None, *args, **kwargs):
         super().__init__()
         if model_cls is None:

@@ -1,0 +1,145 @@
+"""Drop-in boundary, evaluate and predict: the reference CLIPEvaluator / CLIPPredictor on the reference CLIPApp
+against the drop-in CLIPEvaluator / CLIPPredictor on the drop-in CLIPApp, same checkpoint directory, same TSV / records, on
+the CPU.  Device compute of the drop-in is stood in for by the oracle (encodes, image pre-processing, recall ranks), so the
+test covers the surrounding contract: record formats in, feature strings out, which modality a record exports, default
+arguments, the evaluator's metric tuple."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_oracle as O
+from oracle import preprocess_oracle as P
+from oracle import ref_harness as R
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "dataset_tsv_b7.npz")
+SCHEMA = dict(input_schema="text:str:1,image:str:1", first_sequence="text", second_sequence="image")
+
+
+@pytest.mark.skipif(not R.reference_available(), reason="reference checkout not present")
+def test_reference_and_dropin_predictor_and_evaluator_agree(tmp_path, monkeypatch):
+    R.install_shims()
+    from easynlp.appzoo.clip.data import CLIPDataset as RefDataset
+    from easynlp.appzoo.clip.evaluator import CLIPEvaluator as RefEvaluator
+    from easynlp.appzoo.clip.model import CLIPApp as RefApp
+    from easynlp.appzoo.clip.predictor import CLIPPredictor as RefPredictor
+    from easynlp_amd import lib as L
+    from easynlp_amd.appzoo.clip import CLIPEvaluator, CLIPPredictor
+    from easynlp_amd.appzoo.clip import evaluator as EV
+    from easynlp_amd.appzoo.clip import model as CM
+    from easynlp_amd.appzoo.clip.data import CLIPDataset
+
+    g = np.load(GOLD)
+    d = str(tmp_path)
+    vocab = g["vocab"].tobytes().decode().split("\n")
+    cfg = dict(O.CONFIGS["tiny"], vocab_size=len(vocab), image_resolution=224, vision_patch_size=32, vision_width=64, vision_layers=1)
+    R.write_checkpoint_dir(d, cfg, O.make_state_dict(cfg, 8))
+    with open(os.path.join(d, "vocab.txt"), "wb") as f:
+        f.write(g["vocab"].tobytes() + b"\n")
+    tsv = os.path.join(d, "valid.tsv")
+    with open(tsv, "wb") as f:
+        f.write(g["tsv"].tobytes())
+    rows = [r.split("\t") for r in g["tsv"].tobytes().decode("utf-8").split("\n")[:-1]]
+
+    # no GPU here: .cuda() is the identity for both implementations, the drop-in's device work is the oracle's
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+
+    def oracle_preprocess(images, size=224, crop=224, mean=L.CLIP_MEAN, std=L.CLIP_STD, device="cpu"):
+        outs = []
+        for im in images:
+            a = np.asarray(im)
+            outs.append(P.preprocess(np.repeat(a[:, :, None], 3, axis=2) if a.ndim == 2 else a, size=size, crop=crop))
+        return torch.from_numpy(np.stack(outs))
+
+    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+        sd = {n: p for n, p in self.chinese_clip.named_parameters()}
+        return (O.encode_image(sd, self.raw_config, pixel_values) if pixel_values is not None else None,
+                O.encode_text(sd, self.raw_config, input_ids) if input_ids is not None else None)
+
+    def oracle_recall(t, v, ks=(1, 5, 10)):
+        r = O.recall_at_k(t.float(), v.float())
+        return r, tuple(int(round(x * t.shape[0])) for x in r[1:])
+
+    class OracleSimilarity:
+        apply = staticmethod(lambda t, i, ls: (t @ i.t()) * ls.exp())
+
+    monkeypatch.setattr(L, "preprocess_images", oracle_preprocess)
+    monkeypatch.setattr(CM.CLIPApp, "encode", oracle_encode)
+    monkeypatch.setattr(CM, "_SimilarityFn", OracleSimilarity)
+    monkeypatch.setattr(EV, "recall_at_k", oracle_recall)
+
+    def feats(out, key):
+        assert all(set(o) == {key} for o in out)
+        return np.array([[float(x) for x in o[key].split("\t")] for o in out], np.float32)
+
+    # ---- predictor: image records, text records, records carrying both (the text wins, predictor.py:118-138)
+    ref_p = RefPredictor(d, first_sequence="text", second_sequence="image", sequence_length=20)
+    my_p = CLIPPredictor(d, first_sequence="text", second_sequence="image", sequence_length=20)
+    for make, key in ((lambda r: {"image": r[1]}, "image_feat"), (lambda r: {"text": r[0]}, "text_feat"),
+                      (lambda r: {"text": r[0], "image": r[1]}, "text_feat")):
+        ref_out = ref_p.run([make(r) for r in rows])
+        my_out = my_p.run([make(r) for r in rows])
+        a, b = feats(ref_out, key), feats(my_out, key)
+        assert a.shape == b.shape == (7, cfg["embed_dim"]) and np.abs(a - b).max() < 2e-6, key
+    # per-record sequence_length overrides the constructor's (predictor.py:83-87)
+    a = ref_p.preprocess([{"text": rows[0][0], "sequence_length": 12}])[0]["input_ids"]
+    b = my_p.preprocess([{"text": rows[0][0], "sequence_length": 12}])[0]["input_ids"]
+    assert tuple(a.shape) == tuple(b.shape) == (1, 12) and torch.equal(a, b)
+    # defaults of the constructor (predictor.py:66-68)
+    assert CLIPPredictor(d).sequence_length == RefPredictor(d).sequence_length == 128
+
+    # ---- evaluator
+    ref_ev = RefEvaluator(valid_dataset=RefDataset(d, tsv, 20, **SCHEMA), eval_batch_size=4)
+    my_ev = CLIPEvaluator(valid_dataset=CLIPDataset(d, tsv, 20, **SCHEMA), eval_batch_size=4)
+    ref_res = ref_ev.evaluate(RefApp(d))
+    my_res = my_ev.evaluate(CM.CLIPApp(d))
+    assert ref_res[0][0] == my_res[0][0] == "mean_recall" and abs(ref_res[0][1] - my_res[0][1]) < 1e-9
+
+
+@pytest.mark.skipif(not R.reference_available(), reason="reference checkout not present")
+def test_reference_and_dropin_wukong_predictor_agree(tmp_path, monkeypatch):
+    """WukongCLIPPredictor (wukong_clip/predictor.py:30-139) on WukongCLIP: reference vs drop-in, same records (RGB rows of
+    the TSV fixture, BERT-layout vocabulary with [SEP] = 102), drop-in device compute stood in for by the oracle."""
+    import json
+    R.install_shims()
+    from easynlp.appzoo.wukong_clip.predictor import WukongCLIPPredictor as RefPredictor
+    from easynlp_amd import lib as L
+    from easynlp_amd.appzoo.clip import model as CM
+    from easynlp_amd.appzoo.wukong_clip import WukongCLIPPredictor
+    from oracle import wukong_oracle as WK
+    g = np.load(os.path.join(os.path.dirname(GOLD), "wukong_dataset_b5.npz"))
+    d = str(tmp_path)
+    vocab = g["vocab"].tobytes().decode("utf-8").split("\n")
+    cfg = {"model": {"visual": dict(input_resolution=224, patch_size=32, width=64, layers=1, heads=1, output_dim=64),
+                     "text": dict(context_length=32, vocab_size=len(vocab), output_dim=64, width=64, layers=2, heads=1)}}
+    sd = WK.make_state_dict(cfg, 4, small_embeddings=False)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    torch.save(sd, os.path.join(d, "pytorch_model.bin"))
+    with open(os.path.join(d, "vocab.txt"), "wb") as f:
+        f.write(g["vocab"].tobytes() + b"\n")
+    rows = [r.split("\t") for r in g["tsv"].tobytes().decode("utf-8").split("\n")[:-1]]
+
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+
+    def oracle_preprocess(images, size=224, crop=224, mean=L.CLIP_MEAN, std=L.CLIP_STD, device="cpu"):
+        return torch.from_numpy(np.stack([P.preprocess(np.asarray(im), size=size, crop=crop) for im in images]))
+
+    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+        fo = WK.wukong_forward({"model." + n: p for n, p in self.model.named_parameters()}, self.raw_config, pixel_values, input_ids)
+        return fo["image_features"], fo["text_features"]
+
+    monkeypatch.setattr(L, "preprocess_images", oracle_preprocess)
+    monkeypatch.setattr(CM.CLIPApp, "encode", oracle_encode)
+    ref_p = RefPredictor(d, first_sequence="text", second_sequence="image")
+    my_p = WukongCLIPPredictor(d, first_sequence="text", second_sequence="image")
+    for make, key in ((lambda r: {"image": r[1]}, "image_feat"), (lambda r: {"text": r[0]}, "text_feat")):
+        with torch.no_grad():
+            ref_out = ref_p.run([make(r) for r in rows])
+        my_out = my_p.run([make(r) for r in rows])
+        assert all(set(o) == {key} for o in my_out) and len(ref_out) == len(my_out) == 5
+        a = np.array([[float(x) for x in o[key].split("\t")] for o in ref_out], np.float32)
+        b = np.array([[float(x) for x in o[key].split("\t")] for o in my_out], np.float32)
+        assert np.abs(a - b).max() < 2e-6, key
+    assert torch.equal(ref_p.tokenize(["a photo of a cat", ""]), my_p.tokenize(["a photo of a cat", ""]))

@@ -418,10 +418,14 @@ class CLIPApp(Application):
         if self.raw_config.get("model_type") != "chinese_clip":
             # reference model.py:73: anything else is the huggingface_clip flavour (text_config / vision_config)
             self.model_type = "huggingface_clip"
-            self._build_hf(self.raw_config)
             ckpt = os.path.join(path, "pytorch_model.bin")
-            if os.path.exists(ckpt):
-                state = torch.load(ckpt, map_location="cpu")                              # model.py:78
+            state = torch.load(ckpt, map_location="cpu") if os.path.exists(ckpt) else None        # model.py:78
+            if state is not None and "text_projection.weight" in state:
+                # the reference sizes the projections from the checkpoint tensors (model.py:93-96), not from config.json --
+                # and a config.json written by its Trainer carries CLIPConfig's default projection_dim (512) whatever the model
+                self.raw_config = dict(self.raw_config, projection_dim=int(state["text_projection.weight"].shape[0]))
+            self._build_hf(self.raw_config)
+            if state is not None:
                 own = self.state_dict()
                 missing = [k for k in self._hf_params if k not in state]
                 if missing:

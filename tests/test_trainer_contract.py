@@ -20,19 +20,39 @@ from oracle import ref_harness as R
 
 _SCRIPT = r'''
 import sys, os, json
-ROOT, WORK = sys.argv[1], sys.argv[2]
+ROOT, WORK, FLAVOUR = sys.argv[1], sys.argv[2], sys.argv[3]
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from oracle import ref_harness as R, clip_oracle as O, preprocess_oracle as P
 R.install_shims()
+from oracle import hf_clip_oracle as H, open_clip_oracle as OC
 g = np.load(os.path.join(ROOT, "tests", "golden", "dataset_tsv_b7.npz"))
 vocab = g["vocab"].tobytes().decode().split("\n")
-# the datasets emit 224 x 224 images: a 224-resolution model with tiny widths
-cfg = dict(O.CONFIGS["tiny"], vocab_size=len(vocab), image_resolution=224, vision_patch_size=32, vision_width=64, vision_layers=1)
-init = O.make_state_dict(cfg, 5)
 ck = os.path.join(WORK, "ckpt")
-R.write_checkpoint_dir(ck, cfg, init)
-open(os.path.join(ck, "vocab.txt"), "wb").write(g["vocab"].tobytes() + b"\n")
+# the datasets emit 224 x 224 images: 224-resolution models with tiny widths
+if FLAVOUR == "chinese_clip":
+    cfg = dict(O.CONFIGS["tiny"], vocab_size=len(vocab), image_resolution=224, vision_patch_size=32, vision_width=64, vision_layers=1)
+    init = {"chinese_clip." + k: v for k, v in O.make_state_dict(cfg, 5).items()}
+    R.write_checkpoint_dir(ck, cfg, O.make_state_dict(cfg, 5))
+    open(os.path.join(ck, "vocab.txt"), "wb").write(g["vocab"].tobytes() + b"\n")
+elif FLAVOUR == "huggingface_clip":
+    cfg = dict(text_config=dict(H.HF_CONFIGS["hf_tiny"]["text_config"], vocab_size=len(vocab)),
+               vision_config=dict(H.HF_CONFIGS["hf_tiny"]["vision_config"], hidden_size=64, intermediate_size=256, num_hidden_layers=1,
+                                  num_attention_heads=1, image_size=224, patch_size=32), projection_dim=64)
+    init = H.make_state_dict(cfg, 5)
+    R.write_hf_checkpoint_dir(ck, cfg, init)
+    open(os.path.join(ck, "vocab.txt"), "wb").write(g["vocab"].tobytes() + b"\n")
+else:
+    import gzip
+    bpe = np.load(os.path.join(ROOT, "tests", "golden", "openclip_bpe_corpus.npz"))
+    cfg = dict(OC.OPENCLIP_CONFIGS["oc_tiny"], image_resolution=224, vision_patch_size=32, vision_width=64, vision_layers=1,
+               context_length=77, vocab_size=int(bpe["meta"][0]))
+    init = {"open_clip." + k: v for k, v in OC.make_state_dict(cfg, 5).items()}
+    os.makedirs(ck)
+    json.dump(cfg, open(os.path.join(ck, "config.json"), "w"))
+    torch.save(init, os.path.join(ck, "pytorch_model.bin"))
+    with gzip.open(os.path.join(ck, "vocab.txt"), "wb") as f:
+        f.write(bpe["merges"].tobytes())
 tsv = os.path.join(WORK, "train.tsv")
 open(tsv, "wb").write(g["tsv"].tobytes())
 sys.argv = ["x", "--mode", "train", "--tables", tsv + "," + tsv, "--input_schema", "text:str:1,image:str:1",
@@ -67,6 +87,12 @@ def oracle_preprocess(images, size=224, crop=224, mean=L.CLIP_MEAN, std=L.CLIP_S
         outs.append(P.preprocess(np.repeat(a[:, :, None], 3, axis=2) if a.ndim == 2 else a, size=size, crop=crop))
     return torch.from_numpy(np.stack(outs))
 def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+    if FLAVOUR == "huggingface_clip":
+        out = H.hf_clip_forward(dict(self._hf_params), cfg, pixel_values, input_ids, token_type_ids, attention_mask)
+        return out["image_embeds"], out["text_embeds"]
+    if FLAVOUR == "open_clip":
+        out = OC.open_clip_forward({n: p for n, p in self.open_clip.named_parameters()}, cfg, pixel_values, input_ids)
+        return out["image_embeds"], out["text_embeds"]
     sd = {n: p for n, p in self.chinese_clip.named_parameters()}
     return (O.encode_image(sd, self.raw_config, pixel_values) if pixel_values is not None else None,
             O.encode_text(sd, self.raw_config, input_ids) if input_ids is not None else None)
@@ -83,15 +109,21 @@ fa, fb = (sorted(os.listdir(os.path.join(WORK, d))) for d in ("out_reference", "
 a = torch.load(os.path.join(WORK, "out_reference", "pytorch_model.bin"), map_location="cpu")
 b = torch.load(os.path.join(WORK, "out_dropin", "pytorch_model.bin"), map_location="cpu")
 diff = max(float((a[k].float() - b[k].float()).abs().max()) for k in a) if set(a) == set(b) else -1.0
-moved = max(float((a[k].float() - init[k.replace("chinese_clip.", "")].float()).abs().max()) for k in a if "position_ids" not in k)
+moved = max(float((a[k].float() - init[k].float().reshape(a[k].shape)).abs().max()) for k in a if "position_ids" not in k)
 ca, cb = (json.load(open(os.path.join(WORK, d, "config.json"))) for d in ("out_reference", "out_dropin"))
+# each implementation loads the directory the other one's training run wrote
+ref_on_dropin = RefApp(os.path.join(WORK, "out_dropin")).state_dict()
+dropin_on_ref = CM.CLIPApp(os.path.join(WORK, "out_reference")).state_dict()
+cross = max(max(float((ref_on_dropin[k].float() - b[k].float().reshape(ref_on_dropin[k].shape)).abs().max()) for k in b if "position_ids" not in k),
+            max(float((dropin_on_ref[k].float() - a[k].float().reshape(dropin_on_ref[k].shape)).abs().max()) for k in a if "position_ids" not in k))
 print("RESULT " + json.dumps({"files_equal": fa == fb, "files": fa, "keys_equal": set(a) == set(b), "n_keys": len(a),
-                              "max_diff": diff, "moved": moved, "config_equal": ca == cb}))
+                              "max_diff": diff, "moved": moved, "config_equal": ca == cb, "cross_load_diff": cross}))
 '''
 
 
 @pytest.mark.skipif(not R.reference_available(), reason="reference checkout not present")
-def test_reference_trainer_trains_the_dropin_like_the_reference(tmp_path):
+@pytest.mark.parametrize("flavour", ["chinese_clip", "huggingface_clip", "open_clip"])
+def test_reference_trainer_trains_the_dropin_like_the_reference(tmp_path, flavour):
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "run.py"
@@ -102,12 +134,17 @@ def test_reference_trainer_trains_the_dropin_like_the_reference(tmp_path):
     port = sock.getsockname()[1]
     sock.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    r = subprocess.run([sys.executable, str(script), root, str(tmp_path)], capture_output=True, text=True, cwd=str(tmp_path),
+    r = subprocess.run([sys.executable, str(script), root, str(tmp_path), flavour], capture_output=True, text=True, cwd=str(tmp_path),
                        timeout=600, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
     assert r.returncode == 0 and lines, (r.stdout[-1500:], r.stderr[-3000:])
     res = json.loads(lines[-1][len("RESULT "):])
     assert res["files_equal"] and "pytorch_model.bin" in res["files"] and "config.json" in res["files"], res
-    assert res["keys_equal"] and res["config_equal"], res
+    assert res["keys_equal"], res
+    # config.json: the raw dict for chinese_clip / open_clip (Config_Wrapper, model.py:32-38).  In the huggingface_clip flavour the
+    # reference writes its expanded CLIPConfig (every PretrainedConfig default), the drop-in the text_config / vision_config it
+    # was given; both re-load in both implementations, which is what cross_load_diff checks
+    assert res["config_equal"] or flavour == "huggingface_clip", res
+    assert res["cross_load_diff"] == 0.0, res
     assert res["moved"] > 5e-5, res                       # the two AdamW steps did change the weights ...
     assert 0 <= res["max_diff"] < 2e-6, res                # ... and both runs ended in the same place

@@ -1,7 +1,7 @@
 """Drop-in boundary, end to end on the CPU: the REAL reference ``Trainer`` (easynlp/core/trainer.py) trains
 
-  (a) the reference CLIPApp fed by the reference CLIPDataset, and
-  (b) the drop-in CLIPApp fed by the drop-in CLIPDataset,
+  (a) the reference CLIPApp (or WukongCLIP) fed by the reference CLIPDataset (WukongCLIPDataset), and
+  (b) the drop-in application fed by the drop-in dataset,
 
 from the same checkpoint directory, TSV, arguments and sampler seed, and saves both with ``Trainer.save_checkpoint``.
 Device compute of (b) is stood in for by the CPU oracle (tower encodes, similarity, loss, image pre-processing) -- so what is
@@ -42,6 +42,35 @@ elif FLAVOUR == "huggingface_clip":
     init = H.make_state_dict(cfg, 5)
     R.write_hf_checkpoint_dir(ck, cfg, init)
     open(os.path.join(ck, "vocab.txt"), "wb").write(g["vocab"].tobytes() + b"\n")
+elif FLAVOUR == "wukong":
+    from oracle import wukong_oracle as WK
+    g = np.load(os.path.join(ROOT, "tests", "golden", "wukong_dataset_b5.npz"))       # RGB rows, BERT-layout vocab ([SEP] = 102)
+    vocab = g["vocab"].tobytes().decode().split("\n")
+    cfg = {"model": {"visual": dict(input_resolution=224, patch_size=32, width=64, layers=1, heads=1, output_dim=64),
+                     "text": dict(context_length=32, vocab_size=len(vocab), output_dim=64, width=64, layers=2, heads=1)}}
+    init = WK.make_state_dict(cfg, 5, small_embeddings=False)
+    os.makedirs(ck)
+    json.dump(cfg, open(os.path.join(ck, "config.json"), "w"))
+    torch.save(init, os.path.join(ck, "pytorch_model.bin"))
+    open(os.path.join(ck, "vocab.txt"), "wb").write(g["vocab"].tobytes() + b"\n")
+elif FLAVOUR == "text2video":
+    import gzip
+    from oracle import text2video_oracle as TV
+    bpe = np.load(os.path.join(ROOT, "tests", "golden", "openclip_bpe_corpus.npz"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "t2v_dataset_b3.npz"))
+    cfg = dict(OC.OPENCLIP_CONFIGS["oc_tiny"], image_resolution=224, vision_patch_size=32, vision_width=64, vision_layers=1,
+               context_length=77, vocab_size=int(bpe["meta"][0]))
+    init = {"open_clip." + k: v for k, v in OC.make_state_dict(cfg, 5).items()}
+    os.makedirs(ck)
+    json.dump(cfg, open(os.path.join(ck, "config.json"), "w"))
+    torch.save(init, os.path.join(ck, "pytorch_model.bin"))
+    with gzip.open(os.path.join(ck, "vocab.txt"), "wb") as f:
+        f.write(bpe["merges"].tobytes())
+    for k in g.files:                                   # the clips: one directory of frame images each
+        if k.startswith("png/"):
+            os.makedirs(os.path.dirname(os.path.join(WORK, k[4:])), exist_ok=True)
+            open(os.path.join(WORK, k[4:]), "wb").write(g[k].tobytes())
+    g = {"tsv": np.frombuffer("".join("%s\t%s\n" % (c, os.path.join(WORK, "clip%d" % i)) for i, c in enumerate(g["captions"])).encode(), dtype=np.uint8)}
 else:
     import gzip
     bpe = np.load(os.path.join(ROOT, "tests", "golden", "openclip_bpe_corpus.npz"))
@@ -58,7 +87,8 @@ open(tsv, "wb").write(g["tsv"].tobytes())
 sys.argv = ["x", "--mode", "train", "--tables", tsv + "," + tsv, "--input_schema", "text:str:1,image:str:1",
             "--first_sequence", "text", "--second_sequence", "image", "--checkpoint_dir", os.path.join(WORK, "out"),
             "--learning_rate", "1e-4", "--epoch_num", "1", "--random_seed", "42", "--save_checkpoint_steps", "2",
-            "--sequence_length", "20", "--micro_batch_size", "4", "--app_name", "clip", "--worker_gpu", "0",
+            "--sequence_length", "20", "--micro_batch_size", "3" if FLAVOUR in ("wukong", "text2video") else "4",
+            "--app_name", {"wukong": "wukong_clip", "text2video": "clip4clip"}.get(FLAVOUR, "clip"), "--worker_gpu", "0",
             "--user_defined_parameters", "pretrain_model_name_or_path=" + ck]
 from easynlp.utils import initialize_easynlp
 args = initialize_easynlp()
@@ -73,8 +103,15 @@ def train(app, ds, out):
     tr.train()
     tr.save_checkpoint(save_best=True)
 
-from easynlp.appzoo.clip.model import CLIPApp as RefApp
-from easynlp.appzoo.clip.data import CLIPDataset as RefDataset
+if FLAVOUR == "wukong":
+    from easynlp.appzoo.wukong_clip.model import WukongCLIP as RefApp
+    from easynlp.appzoo.wukong_clip.data import WukongCLIPDataset as RefDataset
+elif FLAVOUR == "text2video":
+    from easynlp.appzoo.text2video_retrieval.model import Text2VideoRetrieval as RefApp
+    from easynlp.appzoo.text2video_retrieval.data import Text2VideoRetrievalDataset as RefDataset
+else:
+    from easynlp.appzoo.clip.model import CLIPApp as RefApp
+    from easynlp.appzoo.clip.data import CLIPDataset as RefDataset
 train(RefApp(ck), RefDataset(ck, tsv, 20, **SCHEMA), os.path.join(WORK, "out_reference"))
 
 from easynlp_amd import lib as L
@@ -87,9 +124,17 @@ def oracle_preprocess(images, size=224, crop=224, mean=L.CLIP_MEAN, std=L.CLIP_S
         outs.append(P.preprocess(np.repeat(a[:, :, None], 3, axis=2) if a.ndim == 2 else a, size=size, crop=crop))
     return torch.from_numpy(np.stack(outs))
 def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+    if FLAVOUR == "wukong":
+        fo = WK.wukong_forward({"model." + n: p for n, p in self.model.named_parameters()}, cfg, pixel_values, input_ids)
+        return fo["image_features"], fo["text_features"]
     if FLAVOUR == "huggingface_clip":
         out = H.hf_clip_forward(dict(self._hf_params), cfg, pixel_values, input_ids, token_type_ids, attention_mask)
         return out["image_embeds"], out["text_embeds"]
+    if FLAVOUR == "text2video":          # (the application pools the frames itself: encode returns per-frame features)
+        sd = {n: p for n, p in self.open_clip.named_parameters()}
+        img = O.l2_normalize(O.vit_forward(sd, OC.chinese_style_config(cfg), pixel_values)) if pixel_values is not None else None
+        txt = O.l2_normalize(OC.text_forward(sd, cfg, input_ids)) if input_ids is not None else None
+        return img, txt
     if FLAVOUR == "open_clip":
         out = OC.open_clip_forward({n: p for n, p in self.open_clip.named_parameters()}, cfg, pixel_values, input_ids)
         return out["image_embeds"], out["text_embeds"]
@@ -103,7 +148,18 @@ class OracleInfoNCE:
 L.preprocess_images = oracle_preprocess
 CM.CLIPApp.encode = oracle_encode
 CM._SimilarityFn, CM._InfoNCEFn = OracleSimilarity, OracleInfoNCE
-train(CM.CLIPApp(ck), CLIPDataset(ck, tsv, 20, **SCHEMA), os.path.join(WORK, "out_dropin"))
+DropApp = CM.CLIPApp
+if FLAVOUR == "wukong":
+    import easynlp_amd.appzoo.wukong_clip.model as WM
+    from easynlp_amd.appzoo.wukong_clip import WukongCLIPDataset as CLIPDataset
+    WM._SimilarityFn, WM._InfoNCEFn = OracleSimilarity, OracleInfoNCE
+    DropApp = WM.WukongCLIP
+if FLAVOUR == "text2video":
+    import easynlp_amd.appzoo.text2video_retrieval.model as TM
+    from easynlp_amd.appzoo.text2video_retrieval import Text2VideoRetrievalDataset as CLIPDataset
+    TM._SimilarityFn = OracleSimilarity
+    DropApp = TM.Text2VideoRetrieval
+train(DropApp(ck), CLIPDataset(ck, tsv, 20, **SCHEMA), os.path.join(WORK, "out_dropin"))
 
 fa, fb = (sorted(os.listdir(os.path.join(WORK, d))) for d in ("out_reference", "out_dropin"))
 a = torch.load(os.path.join(WORK, "out_reference", "pytorch_model.bin"), map_location="cpu")
@@ -113,7 +169,7 @@ moved = max(float((a[k].float() - init[k].float().reshape(a[k].shape)).abs().max
 ca, cb = (json.load(open(os.path.join(WORK, d, "config.json"))) for d in ("out_reference", "out_dropin"))
 # each implementation loads the directory the other one's training run wrote
 ref_on_dropin = RefApp(os.path.join(WORK, "out_dropin")).state_dict()
-dropin_on_ref = CM.CLIPApp(os.path.join(WORK, "out_reference")).state_dict()
+dropin_on_ref = DropApp(os.path.join(WORK, "out_reference")).state_dict()
 cross = max(max(float((ref_on_dropin[k].float() - b[k].float().reshape(ref_on_dropin[k].shape)).abs().max()) for k in b if "position_ids" not in k),
             max(float((dropin_on_ref[k].float() - a[k].float().reshape(dropin_on_ref[k].shape)).abs().max()) for k in a if "position_ids" not in k))
 print("RESULT " + json.dumps({"files_equal": fa == fb, "files": fa, "keys_equal": set(a) == set(b), "n_keys": len(a),
@@ -122,7 +178,7 @@ print("RESULT " + json.dumps({"files_equal": fa == fb, "files": fa, "keys_equal"
 
 
 @pytest.mark.skipif(not R.reference_available(), reason="reference checkout not present")
-@pytest.mark.parametrize("flavour", ["chinese_clip", "huggingface_clip", "open_clip"])
+@pytest.mark.parametrize("flavour", ["chinese_clip", "huggingface_clip", "open_clip", "wukong", "text2video"])
 def test_reference_trainer_trains_the_dropin_like_the_reference(tmp_path, flavour):
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -143,6 +143,24 @@ def test_reference_and_dropin_wukong_predictor_agree(tmp_path, monkeypatch):
         b = np.array([[float(x) for x in o[key].split("\t")] for o in my_out], np.float32)
         assert np.abs(a - b).max() < 2e-6, key
     assert torch.equal(ref_p.tokenize(["a photo of a cat", ""]), my_p.tokenize(["a photo of a cat", ""]))
+    # evaluator (wukong_clip/evaluator.py:26-80), each on its own dataset class
+    from easynlp.appzoo.wukong_clip.data import WukongCLIPDataset as RefDataset
+    from easynlp.appzoo.wukong_clip.evaluator import WukongCLIPEvaluator as RefEvaluator
+    from easynlp.appzoo.wukong_clip.model import WukongCLIP as RefApp
+    from easynlp_amd.appzoo.wukong_clip import WukongCLIP, WukongCLIPDataset, WukongCLIPEvaluator
+    from easynlp_amd.appzoo.wukong_clip import evaluator as WE
+
+    def oracle_recall(t, v, ks=(1, 5, 10)):
+        r = O.recall_at_k(t.float(), v.float())
+        return r, tuple(int(round(x * t.shape[0])) for x in r[1:])
+    monkeypatch.setattr(WE, "recall_at_k", oracle_recall)
+    tsv = os.path.join(d, "valid.tsv")
+    with open(tsv, "wb") as f:
+        f.write(g["tsv"].tobytes())
+    ref_res = RefEvaluator(valid_dataset=RefDataset(d, tsv, 32, **SCHEMA), user_defined_parameters={}, eval_batch_size=2).evaluate(RefApp(d))
+    my_res = WukongCLIPEvaluator(valid_dataset=WukongCLIPDataset(d, tsv, 32, **SCHEMA), user_defined_parameters={},
+                                 eval_batch_size=2).evaluate(WukongCLIP(d))
+    assert ref_res[0][0] == my_res[0][0] == "mean_recall" and abs(ref_res[0][1] - my_res[0][1]) < 1e-9
 
 
 @pytest.mark.skipif(not R.reference_available(), reason="reference checkout not present")

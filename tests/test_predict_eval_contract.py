@@ -89,6 +89,20 @@ def test_reference_and_dropin_predictor_and_evaluator_agree(tmp_path, monkeypatc
     # defaults of the constructor (predictor.py:66-68)
     assert CLIPPredictor(d).sequence_length == RefPredictor(d).sequence_length == 128
 
+    # ---- the --mode predict pipeline: the reference PredictorManager drives either predictor over a TSV (core/predictor.py:181-229)
+    from easynlp.core.predictor import PredictorManager
+    outs = {}
+    for name, pred in (("reference", ref_p), ("dropin", my_p)):
+        outs[name] = os.path.join(d, "pred_%s.tsv" % name)
+        PredictorManager(predictor=pred, input_file=tsv, input_schema="text:str:1,image:str:1", output_file=outs[name],
+                         output_schema="text_feat", append_cols="text", batch_size=3).run()
+    la, lb = (open(outs[k]).read().split("\n") for k in ("reference", "dropin"))
+    assert len(la) == len(lb) == 8 and la[-1] == lb[-1] == ""
+    for ra, rb, row in zip(la[:-1], lb[:-1], rows):
+        fa, fb = ra.split("\t"), rb.split("\t")
+        assert len(fa) == len(fb) == cfg["embed_dim"] + 1 and fa[-1] == fb[-1] == row[0]          # features ..., appended text column
+        assert np.abs(np.array(fa[:-1], np.float32) - np.array(fb[:-1], np.float32)).max() < 2e-6
+
     # ---- evaluator
     ref_ev = RefEvaluator(valid_dataset=RefDataset(d, tsv, 20, **SCHEMA), eval_batch_size=4)
     my_ev = CLIPEvaluator(valid_dataset=CLIPDataset(d, tsv, 20, **SCHEMA), eval_batch_size=4)

@@ -95,13 +95,14 @@ args = initialize_easynlp()
 from easynlp.core.trainer import Trainer
 SCHEMA = dict(input_schema="text:str:1,image:str:1", first_sequence="text", second_sequence="image")
 
-def train(app, ds, out):
+SCORES = {}
+def train(app, ds, out, evaluator):
     args.checkpoint_dir = out
     os.makedirs(out, exist_ok=True)
-    tr = Trainer(model=app, train_dataset=ds, evaluator=None)
+    tr = Trainer(model=app, train_dataset=ds, evaluator=evaluator)
     torch.manual_seed(123)                       # the RandomSampler draws its permutation from the global generator
-    tr.train()
-    tr.save_checkpoint(save_best=True)
+    tr.train()                                   # evaluates at step 2 and saves the best checkpoint itself (trainer.py:367-384)
+    SCORES[out] = (evaluator.best_valid_score, os.path.exists(os.path.join(out, "pytorch_model.bin")))
 
 if FLAVOUR == "wukong":
     from easynlp.appzoo.wukong_clip.model import WukongCLIP as RefApp
@@ -112,7 +113,16 @@ elif FLAVOUR == "text2video":
 else:
     from easynlp.appzoo.clip.model import CLIPApp as RefApp
     from easynlp.appzoo.clip.data import CLIPDataset as RefDataset
-train(RefApp(ck), RefDataset(ck, tsv, 20, **SCHEMA), os.path.join(WORK, "out_reference"))
+if FLAVOUR == "wukong":
+    from easynlp.appzoo.wukong_clip.evaluator import WukongCLIPEvaluator as RefEval
+    ref_eval = RefEval(valid_dataset=RefDataset(ck, tsv, 20, **SCHEMA), user_defined_parameters={}, eval_batch_size=4)
+elif FLAVOUR == "text2video":
+    from easynlp.appzoo.text2video_retrieval.evaluator import Text2VideoRetrievalEvaluator as RefEval
+    ref_eval = RefEval(valid_dataset=RefDataset(ck, tsv, 20, **SCHEMA), eval_batch_size=4)
+else:
+    from easynlp.appzoo.clip.evaluator import CLIPEvaluator as RefEval
+    ref_eval = RefEval(valid_dataset=RefDataset(ck, tsv, 20, **SCHEMA), eval_batch_size=4)
+train(RefApp(ck), RefDataset(ck, tsv, 20, **SCHEMA), os.path.join(WORK, "out_reference"), ref_eval)
 
 from easynlp_amd import lib as L
 from easynlp_amd.appzoo.clip import model as CM
@@ -159,7 +169,22 @@ if FLAVOUR == "text2video":
     from easynlp_amd.appzoo.text2video_retrieval import Text2VideoRetrievalDataset as CLIPDataset
     TM._SimilarityFn = OracleSimilarity
     DropApp = TM.Text2VideoRetrieval
-train(DropApp(ck), CLIPDataset(ck, tsv, 20, **SCHEMA), os.path.join(WORK, "out_dropin"))
+def oracle_recall(t, v, ks=(1, 5, 10)):
+    r = O.recall_at_k(t.float(), v.float())
+    return r, tuple(int(round(x * t.shape[0])) for x in r[1:])
+from easynlp_amd.appzoo.clip import evaluator as EV
+EV.recall_at_k = oracle_recall
+if FLAVOUR == "wukong":
+    import easynlp_amd.appzoo.wukong_clip.evaluator as WE
+    WE.recall_at_k = oracle_recall
+    my_eval = WE.WukongCLIPEvaluator(valid_dataset=CLIPDataset(ck, tsv, 20, **SCHEMA), user_defined_parameters={}, eval_batch_size=4)
+elif FLAVOUR == "text2video":
+    import easynlp_amd.appzoo.text2video_retrieval.evaluator as TE
+    TE.recall_at_k = oracle_recall
+    my_eval = TE.Text2VideoRetrievalEvaluator(valid_dataset=CLIPDataset(ck, tsv, 20, **SCHEMA), eval_batch_size=4)
+else:
+    my_eval = EV.CLIPEvaluator(valid_dataset=CLIPDataset(ck, tsv, 20, **SCHEMA), eval_batch_size=4)
+train(DropApp(ck), CLIPDataset(ck, tsv, 20, **SCHEMA), os.path.join(WORK, "out_dropin"), my_eval)
 
 fa, fb = (sorted(os.listdir(os.path.join(WORK, d))) for d in ("out_reference", "out_dropin"))
 a = torch.load(os.path.join(WORK, "out_reference", "pytorch_model.bin"), map_location="cpu")
@@ -173,7 +198,8 @@ dropin_on_ref = DropApp(os.path.join(WORK, "out_reference")).state_dict()
 cross = max(max(float((ref_on_dropin[k].float() - b[k].float().reshape(ref_on_dropin[k].shape)).abs().max()) for k in b if "position_ids" not in k),
             max(float((dropin_on_ref[k].float() - a[k].float().reshape(dropin_on_ref[k].shape)).abs().max()) for k in a if "position_ids" not in k))
 print("RESULT " + json.dumps({"files_equal": fa == fb, "files": fa, "keys_equal": set(a) == set(b), "n_keys": len(a),
-                              "max_diff": diff, "moved": moved, "config_equal": ca == cb, "cross_load_diff": cross}))
+                              "max_diff": diff, "moved": moved, "config_equal": ca == cb, "cross_load_diff": cross,
+                              "scores": [SCORES[os.path.join(WORK, d)] for d in ("out_reference", "out_dropin")]}))
 '''
 
 
@@ -202,5 +228,8 @@ def test_reference_trainer_trains_the_dropin_like_the_reference(tmp_path, flavou
     # was given; both re-load in both implementations, which is what cross_load_diff checks
     assert res["config_equal"] or flavour == "huggingface_clip", res
     assert res["cross_load_diff"] == 0.0, res
+    # the Trainer evaluated both with their own evaluator class, got the same mean recall and saved the best checkpoint itself
+    (ref_score, ref_saved), (my_score, my_saved) = res["scores"]
+    assert ref_saved and my_saved and 0.0 < ref_score <= 1.0 and abs(ref_score - my_score) < 1e-9, res
     assert res["moved"] > 5e-5, res                       # the two AdamW steps did change the weights ...
     assert 0 <= res["max_diff"] < 2e-6, res                # ... and both runs ended in the same place

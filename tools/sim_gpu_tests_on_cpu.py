@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""Development aid (test infrastructure, like tools/make_golden.py): run GPU-marked tests on a box WITHOUT a GPU, with the
+library's device work replaced by the CPU oracle (tower encodes, similarity, InfoNCE, fused shard, recall ranks, image
+pre-processing) and ``.cuda()`` made the identity.  It proves nothing about the kernels -- it catches mistakes in the tests
+and in the host code they drive (shapes, keys, contracts) before a GPU minute is spent on them.
+
+    python tools/sim_gpu_tests_on_cpu.py [pytest paths ...]      (default: the tests/test_zz_* files and their relatives)
+"""
+import sys, types, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch, pytest
+from easynlp_amd import lib as L
+from easynlp_amd.appzoo.clip import model as CM
+from easynlp_amd.appzoo.clip import evaluator as EV
+from oracle import clip_oracle as O, open_clip_oracle as OC, wukong_oracle as WK, preprocess_oracle as P
+
+torch.nn.Module.cuda = lambda self, *a, **k: self
+torch.Tensor.cuda = lambda self, *a, **k: self
+
+def fake_pre(images, size=224, crop=224, mean=L.CLIP_MEAN, std=L.CLIP_STD, device="cpu"):
+    outs = []
+    for im in images:
+        a = np.asarray(im)
+        if a.ndim == 2: a = np.repeat(a[:, :, None], 3, axis=2)
+        outs.append(P.preprocess(a, size=size, crop=crop))
+    return torch.from_numpy(np.stack(outs))
+L.preprocess_images = fake_pre
+
+def fake_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+    mt = getattr(self, "model_type", None)
+    if mt == "wukong":
+        sd = {"model." + n: p for n, p in self.model.named_parameters()}
+        fo = WK.wukong_forward(sd, self.raw_config, pixel_values, input_ids)
+        return fo["image_features"], fo["text_features"]
+    assert mt == "open_clip", mt
+    sd = {n: p for n, p in self.open_clip.named_parameters()}
+    cfg = self.raw_config
+    img = O.l2_normalize(O.vit_forward(sd, OC.chinese_style_config(cfg), pixel_values.float())) if pixel_values is not None else None
+    txt = O.l2_normalize(OC.text_forward(sd, cfg, input_ids)) if input_ids is not None else None
+    return img, txt
+CM.CLIPApp.encode = fake_encode
+
+class FakeSim:
+    @staticmethod
+    def apply(t, i, ls): return (t @ i.t()) * ls.exp()
+class FakeNCE:
+    @staticmethod
+    def apply(logits): return O.clip_loss(logits)
+CM._SimilarityFn = FakeSim; CM._InfoNCEFn = FakeNCE
+import easynlp_amd.appzoo.wukong_clip.model as WM
+import easynlp_amd.appzoo.text2video_retrieval.model as TM
+WM._SimilarityFn = FakeSim; WM._InfoNCEFn = FakeNCE; TM._SimilarityFn = FakeSim
+
+def fake_recall(t, v, ks=(1, 5, 10)):
+    r = O.recall_at_k(t.float(), v.float())
+    n = t.shape[0]
+    return r, tuple(int(round(x * n)) for x in r[1:])
+EV.recall_at_k = fake_recall
+import easynlp_amd.appzoo.wukong_clip.evaluator as WE, easynlp_amd.appzoo.text2video_retrieval.evaluator as TE
+WE.recall_at_k = fake_recall; TE.recall_at_k = fake_recall
+
+def fake_cstep(self, px, ids, process_group=None, backward=False, **kw):
+    img, txt = self.encode(px, ids)
+    loss = O.clip_loss((txt @ img.t()) * self.logit_scale.exp())
+    if backward: loss.backward()
+    return loss.detach()
+CM.CLIPApp.contrastive_step = fake_cstep
+WM.WukongCLIP.contrastive_step = lambda self, px, ids, process_group=None, backward=False, **kw: (self._check_tail_tokens(ids), fake_cstep(self, px, ids, backward=backward))[1]
+
+def fake_shard(eng, txt_all, img_all, n, off, ls, grad_scale, need):
+    with torch.enable_grad():
+        ta, ia = txt_all.clone().requires_grad_(True), img_all.clone().requires_grad_(True)
+        lsv = ls.clone().requires_grad_(True)
+        loss = O.global_clip_loss_rank(ta, ia, lsv.reshape(()), off // n, n)
+        if not need:
+            return loss.detach(), None, None, None
+        (loss * grad_scale).backward()
+    return loss.detach(), ta.grad, ia.grad, lsv.grad
+CM.fused_infonce_shard = fake_shard
+_orig_encode = fake_encode
+def enc2(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+    if getattr(self, "model_type", None) == "chinese_clip":
+        sd = {n: p for n, p in self.chinese_clip.named_parameters()}
+        img = O.encode_image(sd, self.raw_config, pixel_values) if pixel_values is not None else None
+        txt = O.encode_text(sd, self.raw_config, input_ids) if input_ids is not None else None
+        return img, txt
+    return _orig_encode(self, pixel_values, input_ids, token_type_ids, attention_mask)
+CM.CLIPApp.encode = enc2
+torch.cuda.is_available = lambda: True        # conftest then leaves the gpu-marked tests alone
+DEFAULT = ["test_zz_global_scope_gpu.py", "test_zz_text2video_gpu.py", "test_zz_wukong_io_gpu.py", "test_wukong_gpu.py",
+           "test_text2video_data.py", "test_wukong_data.py"]
+paths = sys.argv[1:] or [os.path.join(ROOT, "tests", f) for f in DEFAULT]
+sys.exit(pytest.main(["-q", "-p", "no:cacheprovider", "-m", "gpu"] + paths))

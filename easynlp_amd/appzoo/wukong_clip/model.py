@@ -95,30 +95,6 @@ class WukongCLIP(CLIPApp):
         named = dict(tree.named_parameters())
         self._params: Dict[str, nn.Parameter] = {n: named[reference_name(n)] for n in eng.names}
 
-    @classmethod
-    def from_config(cls, config: dict, seed: int = 0, device="cuda", compute_dtype="bf16"):
-        """Random-init model (VisualTransformer / TextTransformer init scales, modeling_wukong.py:279-290,325-336)."""
-        app = cls(None, compute_dtype=compute_dtype)
-        app._build_wukong(dict(config))
-        app.to(device)
-        g = torch.Generator(device=device).manual_seed(seed)
-        with torch.no_grad():
-            for n, p in app._params.items():
-                if n == "logit_scale":
-                    continue
-                if ".ln_" in n or n.startswith("ln_"):
-                    p.fill_(1.0) if n.endswith("weight") else p.zero_()
-                elif n.endswith("bias"):
-                    p.zero_()
-                elif n == "token_embedding.weight":
-                    p.copy_(torch.randn(p.shape, generator=g, device=device) * 0.02)
-                elif n == "positional_embedding":
-                    p.copy_(torch.randn(p.shape, generator=g, device=device) * 0.01)
-                else:
-                    fan = p.shape[0] if n in ("visual.proj", "text_projection") or p.dim() == 1 else p[0].numel()
-                    p.copy_(torch.randn(p.shape, generator=g, device=device) * fan ** -0.5)
-        return app
-
     def _check_tail_tokens(self, input_ids: torch.Tensor) -> None:
         # x[(text == 102).nonzero()] yields one row per sample only if every row holds exactly one such token; the reference
         # would silently return a different number of rows otherwise -- here it is an error

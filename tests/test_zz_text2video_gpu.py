@@ -152,3 +152,23 @@ def test_text2video_dataset_batches_and_predictor(tmp_path):
     tout = tp.run([{"text": str(c)} for c in g["captions"]])
     tf = np.array([[float(x) for x in o["text_feat"].split("\t")] for o in tout], np.float32)
     assert np.abs(tf - ref["text_embeds"].numpy()).max() < 1e-5
+
+
+def test_gpu_frame_pixel_values_equal_the_reference(tmp_path):
+    """every frame's float32 pixel_values == the reference's, bit for bit (incl. the greyscale frame, up- and down-scaling,
+    and the black padding frames)"""
+    import hashlib
+    from easynlp_amd import lib as L
+    from tests.test_text2video_data import _dataset, _materialise
+    g, d = _materialise(tmp_path)
+    ds = _dataset(d)
+    batch = ds.batch_fn([ds[i] for i in range(len(ds))])
+    flat = [f for c in batch["images"] for f in c]
+    px = L.preprocess_images(flat, size=224, crop=224).cpu().numpy().reshape(3, 12, 3, 224, 224)
+    want = dict(zip([str(x) for x in g["frame_names"]], [str(x) for x in g["frame_sha256"]]))
+    for ci in range(3):
+        names = os.listdir(os.path.join(d, "clip%d" % ci))
+        for fi, name in enumerate(names):
+            assert hashlib.sha256(np.ascontiguousarray(px[ci, fi]).tobytes()).hexdigest() == want["clip%d/%s" % (ci, name)], (ci, name)
+        for fi in range(len(names), 12):
+            assert hashlib.sha256(np.ascontiguousarray(px[ci, fi]).tobytes()).hexdigest() == str(g["pad_sha256"])

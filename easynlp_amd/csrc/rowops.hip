@@ -206,6 +206,46 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* x, int64_t xs, con
       }
     }
   };
+#ifdef EZ_LNBWD_PACKED
+  // Experiment hook (tools/build_variants.py): bf16 rows stay PACKED while in flight (2 VGPRs per 4
+  // elements instead of 4), so four rows per wave fit where two unpacked ones did -- twice the bytes in flight at the
+  // same occupancy.  Same per-row arithmetic in the same order: results are bit-identical to the default path.
+  if constexpr (sizeof(T) == 2) {
+    constexpr int R = 4;
+    auto load_raw = [&](int row, uint2 (&xr)[NC], uint2 (&dr)[NC], uint2 (&rr)[NC], float& mean, float& rstd) {
+      const bool ok = row < rows;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = (lane + c * 64) * 4;
+        xr[c] = dr[c] = rr[c] = make_uint2(0u, 0u);
+        if (ok && col < D) {
+          xr[c] = *reinterpret_cast<const uint2*>(x + (int64_t)row * xs + col);
+          dr[c] = *reinterpret_cast<const uint2*>(dy + (int64_t)row * dys + col);
+          if (dres != nullptr) rr[c] = *reinterpret_cast<const uint2*>(dres + (int64_t)row * drs + col);
+        }
+      }
+      mean = ok ? mean_i[row] : 0.f;
+      rstd = ok ? rstd_i[row] : 0.f;
+    };
+    auto unpack4 = [](const uint2& t, float (&v)[4]) {
+      v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+      v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    };
+    for (int row = gw; row < rows; row += R * nwaves) {
+      uint2 xr[R][NC], dr[R][NC], rr[R][NC];
+      float mr[R], sr[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) load_raw(row + k * nwaves, xr[k], dr[k], rr[k], mr[k], sr[k]);
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        float xv[NC][4], dv[NC][4], rv[NC][4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { unpack4(xr[k][c], xv[c]); unpack4(dr[k][c], dv[c]); unpack4(rr[k][c], rv[c]); }
+        process(row + k * nwaves, xv, dv, rv, mr[k], sr[k]);
+      }
+    }
+  } else
+#endif
   for (int row = gw; row < rows; row += 2 * nwaves) {
     float xa[NC][4], da[NC][4], ra[NC][4], xb[NC][4], dbb[NC][4], rb[NC][4];
     float ma, sa, mb, sb;

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""Build experiment variants of libezclip_hip.so under tools/bin/var_<name>/ (same objects, gemm8p.hip recompiled
-with extra -D flags).  Run a tool against one with LD_LIBRARY_PATH=tools/bin/var_<name>.
+"""Build experiment variants of libezclip_hip.so under tools/bin/var_<name>/ (same objects, ONE source recompiled with
+extra -D flags: gemm8p.hip unless the name says otherwise).  Run a tool against one with LD_LIBRARY_PATH=tools/bin/var_<name>.
 
-    python tools/build_variants.py name1:-DFOO=1 name2:"-DBAR -DBAZ=2" ...
+    python tools/build_variants.py name1:-DFOO=1 name2:"-DBAR -DBAZ=2" lnpacked@rowops.hip:-DEZ_LNBWD_PACKED ...
 """
 import os
 import shlex
@@ -20,13 +20,16 @@ def main():
     csrc = B.HERE
     for spec in sys.argv[1:]:
         name, _, defs = spec.partition(":")
+        name, _, which = name.partition("@")
+        which = which or "gemm8p.hip"
+        assert which in B.SOURCES, which
         d = os.path.join(HERE, "bin", "var_" + name)
         os.makedirs(d, exist_ok=True)
         objs = []
         for src in B.SOURCES:
             o = os.path.join(csrc, "build", src.replace(".hip", ".o"))
-            if src == "gemm8p.hip":
-                o = os.path.join(d, "gemm8p.o")
+            if src == which:
+                o = os.path.join(d, which.replace(".hip", ".o"))
                 subprocess.check_call([B.hipcc()] + B.FLAGS + shlex.split(defs) + ["-c", os.path.join(csrc, src), "-o", o])
             objs.append(o)
         subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(d, "libezclip_hip.so")] + objs)

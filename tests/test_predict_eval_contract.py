@@ -259,3 +259,79 @@ def test_reference_and_dropin_text2video_predictor_and_evaluator_agree(tmp_path,
     my_res = Text2VideoRetrievalEvaluator(valid_dataset=Text2VideoRetrievalDataset(d, tsv, 77, **schema),
                                           eval_batch_size=2).evaluate(Text2VideoRetrieval(d))
     assert ref_res[0][0] == my_res[0][0] == "mean_recall" and abs(ref_res[0][1] - my_res[0][1]) < 1e-9
+
+
+@pytest.mark.skipif(not R.reference_available(), reason="reference checkout not present")
+def test_forward_contract_matches_the_reference_app(tmp_path, monkeypatch):
+    """CLIPApp.forward / compute_loss (appzoo/clip/model.py:106-164), reference vs drop-in (oracle compute): returned keys,
+    which entries are None, shapes and values for both / one modality and feat=True, and the in-place mutation of the
+    ``inputs`` dict (model.py:116-123) that callers such as the evaluator rely on."""
+    R.install_shims()
+    from easynlp.appzoo.clip.model import CLIPApp as RefApp
+    from easynlp_amd.appzoo.clip import model as CM
+    cfg = O.CONFIGS["tiny"]
+    R.write_checkpoint_dir(str(tmp_path), cfg, O.make_state_dict(cfg, 2))
+
+    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+        sd = {n: p for n, p in self.chinese_clip.named_parameters()}
+        return (O.encode_image(sd, self.raw_config, pixel_values) if pixel_values is not None else None,
+                O.encode_text(sd, self.raw_config, input_ids) if input_ids is not None else None)
+
+    class OracleSimilarity:
+        apply = staticmethod(lambda t, i, ls: (t @ i.t()) * ls.exp())
+
+    class OracleInfoNCE:
+        apply = staticmethod(lambda logits: O.clip_loss(logits))
+
+    monkeypatch.setattr(CM.CLIPApp, "encode", oracle_encode)
+    monkeypatch.setattr(CM, "_SimilarityFn", OracleSimilarity)
+    monkeypatch.setattr(CM, "_InfoNCEFn", OracleInfoNCE)
+    ref, mine = RefApp(str(tmp_path)).eval(), CM.CLIPApp(str(tmp_path)).eval()
+    px, ids = O.make_inputs(cfg, 5, 12, 1)
+    tt, am = torch.zeros_like(ids), (ids != 0).long()
+
+    def same(a, b, path):
+        assert (a is None) == (b is None), path
+        if a is None:
+            return
+        if isinstance(a, torch.Tensor):
+            assert isinstance(b, torch.Tensor) and a.shape == b.shape and a.dtype == b.dtype, path
+            assert float((a.float() - b.float()).abs().max()) < 2e-5, path
+        else:
+            assert a == b, path
+
+    cases = [dict(pixel_values=px, input_ids=ids, token_type_ids=tt, attention_mask=am, label_ids=[]),
+             dict(pixel_values=px, input_ids=ids), dict(input_ids=ids), dict(pixel_values=px)]
+    # (an explicit ``None`` value fails in the reference, which tests key presence only, model.py:116-123; the drop-in accepts it)
+    for case in cases:
+        for feat in (None, True):
+            if feat is None and not (case.get("pixel_values") is not None and case.get("input_ids") is not None):
+                continue                              # logits need both modalities (the reference fails in torch.matmul)
+            ia = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in case.items()}
+            ib = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in case.items()}
+            with torch.no_grad():
+                oa, ob = ref(ia, feat=feat), mine(ib, feat=feat)
+            assert set(oa) == set(ob), (sorted(case), feat)
+            for k in oa:
+                same(oa[k], ob[k], (sorted(case), feat, k))
+            assert set(ia) == set(ib), (sorted(case), feat)             # the same keys were added to / kept in `inputs`
+            for k in ia:
+                same(ia[k], ib[k], (sorted(case), feat, "inputs." + k))
+    # the loss dict, through autograd
+    oa = ref({"pixel_values": px.clone(), "input_ids": ids.clone()})
+    ob = mine({"pixel_values": px.clone(), "input_ids": ids.clone()})
+    la, lb = ref.compute_loss(oa, [])["loss"], mine.compute_loss(ob, [])["loss"]
+    assert la.shape == lb.shape == () and abs(la.item() - lb.item()) < 1e-5
+    la.backward()
+    lb.backward()
+    ga = dict(ref.named_parameters())
+    for n, p in mine.named_parameters():
+        if ga[n].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+        else:
+            assert float((p.grad - ga[n].grad).norm()) <= 1e-4 * float(ga[n].grad.norm()) + 1e-7, n
+    # neither modality: both refuse
+    with pytest.raises(Exception):
+        ref({}, feat=True)
+    with pytest.raises(Exception):
+        mine({}, feat=True)

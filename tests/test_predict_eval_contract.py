@@ -335,3 +335,63 @@ def test_forward_contract_matches_the_reference_app(tmp_path, monkeypatch):
         ref({}, feat=True)
     with pytest.raises(Exception):
         mine({}, feat=True)
+
+
+@pytest.mark.skipif(not R.reference_available(), reason="reference checkout not present")
+def test_open_clip_flavour_predictor_and_dataset_agree_with_the_reference(tmp_path, monkeypatch):
+    """model_type open_clip: raw captions go through the BPE tokenizer in both CLIPPredictor and CLIPDataset
+    (predictor.py:91-94, data.py:246-249); reference vs drop-in on the same records / TSV."""
+    import gzip
+    import json
+    R.install_shims()
+    from easynlp.appzoo.clip.data import CLIPDataset as RefDataset
+    from easynlp.appzoo.clip.predictor import CLIPPredictor as RefPredictor
+    from easynlp_amd import lib as L
+    from easynlp_amd.appzoo.clip import CLIPPredictor
+    from easynlp_amd.appzoo.clip import model as CM
+    from easynlp_amd.appzoo.clip.data import CLIPDataset
+    from oracle import open_clip_oracle as OC
+    gold = os.path.dirname(GOLD)
+    bpe, g = np.load(os.path.join(gold, "openclip_bpe_corpus.npz")), np.load(GOLD)
+    d = str(tmp_path)
+    cfg = dict(OC.OPENCLIP_CONFIGS["oc_tiny"], image_resolution=224, vision_patch_size=32, vision_width=64, vision_layers=1,
+               context_length=77, vocab_size=int(bpe["meta"][0]))
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    torch.save({"open_clip." + k: v for k, v in OC.make_state_dict(cfg, 6).items()}, os.path.join(d, "pytorch_model.bin"))
+    with gzip.open(os.path.join(d, "vocab.txt"), "wb") as f:
+        f.write(bpe["merges"].tobytes())
+    tsv = os.path.join(d, "valid.tsv")
+    with open(tsv, "wb") as f:
+        f.write(g["tsv"].tobytes())
+    rows = [r.split("\t") for r in g["tsv"].tobytes().decode("utf-8").split("\n")[:-1]]
+
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+
+    def oracle_preprocess(images, size=224, crop=224, mean=L.CLIP_MEAN, std=L.CLIP_STD, device="cpu"):
+        outs = []
+        for im in images:
+            a = np.asarray(im)
+            outs.append(P.preprocess(np.repeat(a[:, :, None], 3, axis=2) if a.ndim == 2 else a, size=size, crop=crop))
+        return torch.from_numpy(np.stack(outs))
+
+    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+        sd = {n: p for n, p in self.open_clip.named_parameters()}
+        img = O.l2_normalize(O.vit_forward(sd, OC.chinese_style_config(cfg), pixel_values)) if pixel_values is not None else None
+        txt = O.l2_normalize(OC.text_forward(sd, cfg, input_ids)) if input_ids is not None else None
+        return img, txt
+
+    monkeypatch.setattr(L, "preprocess_images", oracle_preprocess)
+    monkeypatch.setattr(CM.CLIPApp, "encode", oracle_encode)
+    ref_p = RefPredictor(d, first_sequence="text", second_sequence="image")
+    my_p = CLIPPredictor(d, first_sequence="text", second_sequence="image")
+    for make, key in ((lambda r: {"text": r[0]}, "text_feat"), (lambda r: {"image": r[1]}, "image_feat")):
+        ref_out, my_out = ref_p.run([make(r) for r in rows]), my_p.run([make(r) for r in rows])
+        a = np.array([[float(x) for x in o[key].split("\t")] for o in ref_out], np.float32)
+        b = np.array([[float(x) for x in o[key].split("\t")] for o in my_out], np.float32)
+        assert a.shape == b.shape == (7, cfg["embed_dim"]) and np.abs(a - b).max() < 2e-6, key
+    schema = dict(input_schema="text:str:1,image:str:1", first_sequence="text", second_sequence="image")
+    rds, mds = RefDataset(d, tsv, 32, **schema), CLIPDataset(d, tsv, 32, **schema)
+    rb, mb = rds.batch_fn([rds[i] for i in range(7)]), mds.batch_fn([mds[i] for i in range(7)])
+    assert torch.equal(rb["input_ids"], mb["input_ids"]) and tuple(mb["input_ids"].shape) == (7, 77)
+    assert torch.equal(rb["pixel_values"], oracle_preprocess(mb["images"]))          # the oracle IS the reference's PIL pipeline

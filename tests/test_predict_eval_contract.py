@@ -395,3 +395,55 @@ def test_open_clip_flavour_predictor_and_dataset_agree_with_the_reference(tmp_pa
     rb, mb = rds.batch_fn([rds[i] for i in range(7)]), mds.batch_fn([mds[i] for i in range(7)])
     assert torch.equal(rb["input_ids"], mb["input_ids"]) and tuple(mb["input_ids"].shape) == (7, 77)
     assert torch.equal(rb["pixel_values"], oracle_preprocess(mb["images"]))          # the oracle IS the reference's PIL pipeline
+
+
+@pytest.mark.skipif(not R.reference_available(), reason="reference checkout not present")
+def test_huggingface_flavour_predictor_agrees_with_the_reference(tmp_path, monkeypatch):
+    """huggingface_clip: text records carry token_type_ids / attention_mask into RobertaModel (predictor.py:95-101,124-134)"""
+    R.install_shims()
+    from easynlp.appzoo.clip.predictor import CLIPPredictor as RefPredictor
+    from easynlp_amd import lib as L
+    from easynlp_amd.appzoo.clip import CLIPPredictor
+    from easynlp_amd.appzoo.clip import model as CM
+    from oracle import hf_clip_oracle as H
+    g = np.load(GOLD)
+    d = str(tmp_path)
+    vocab = g["vocab"].tobytes().decode().split("\n")
+    cfg = dict(text_config=dict(H.HF_CONFIGS["hf_tiny"]["text_config"], vocab_size=len(vocab)),
+               vision_config=dict(H.HF_CONFIGS["hf_tiny"]["vision_config"], hidden_size=64, intermediate_size=256, num_hidden_layers=1,
+                                  num_attention_heads=1, image_size=224, patch_size=32), projection_dim=64)
+    R.write_hf_checkpoint_dir(d, cfg, H.make_state_dict(cfg, 3))
+    with open(os.path.join(d, "vocab.txt"), "wb") as f:
+        f.write(g["vocab"].tobytes() + b"\n")
+    rows = [r.split("\t") for r in g["tsv"].tobytes().decode("utf-8").split("\n")[:-1]]
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+
+    def oracle_preprocess(images, size=224, crop=224, mean=L.CLIP_MEAN, std=L.CLIP_STD, device="cpu"):
+        outs = []
+        for im in images:
+            a = np.asarray(im)
+            outs.append(P.preprocess(np.repeat(a[:, :, None], 3, axis=2) if a.ndim == 2 else a, size=size, crop=crop))
+        return torch.from_numpy(np.stack(outs))
+
+    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+        sd = dict(self._hf_params)
+        img = txt = None
+        if input_ids is not None:       # (hf_clip_forward wants both modalities: feed a dummy image / text for the other side)
+            px = torch.zeros(input_ids.shape[0], 3, 224, 224)
+            txt = H.hf_clip_forward(sd, cfg, px, input_ids, token_type_ids, attention_mask)["text_embeds"]
+        if pixel_values is not None:
+            ids = torch.ones(pixel_values.shape[0], 4, dtype=torch.long)
+            img = H.hf_clip_forward(sd, cfg, pixel_values, ids, torch.zeros_like(ids), torch.ones_like(ids))["image_embeds"]
+        return img, txt
+
+    monkeypatch.setattr(L, "preprocess_images", oracle_preprocess)
+    monkeypatch.setattr(CM.CLIPApp, "encode", oracle_encode)
+    ref_p = RefPredictor(d, first_sequence="text", second_sequence="image", sequence_length=20)
+    my_p = CLIPPredictor(d, first_sequence="text", second_sequence="image", sequence_length=20)
+    for make, key in ((lambda r: {"text": r[0]}, "text_feat"), (lambda r: {"image": r[1]}, "image_feat")):
+        with torch.no_grad():
+            ref_out = ref_p.run([make(r) for r in rows])
+        my_out = my_p.run([make(r) for r in rows])
+        a = np.array([[float(x) for x in o[key].split("\t")] for o in ref_out], np.float32)
+        b = np.array([[float(x) for x in o[key].split("\t")] for o in my_out], np.float32)
+        assert a.shape == b.shape == (7, 64) and np.abs(a - b).max() < 2e-6, key

@@ -53,6 +53,17 @@ def recall_at_k(text_embeds, image_embeds, ks=(1, 5, 10)):
     return (sum(rs) / len(rs),) + tuple(rs), stats
 
 
+def recall_report(text_embeds, gallery_embeds, spent_seconds: float):
+    """text -> gallery R@1/5/10 + mean, printed the way the reference evaluators do (clip/evaluator.py:62-72), returned as the
+    metric list the Trainer compares (``[("mean_recall", fraction)]``)"""
+    n = text_embeds.shape[0]
+    (mean_recall, r1, r5, r10), hits = recall_at_k(text_embeds, gallery_embeds)
+    print(" ".join("r%d_num:%d" % (k, h) for k, h in zip((1, 5, 10), hits)), "query_num:" + str(n))
+    print(" ".join("%s(%%):%s" % (name, v * 100) for name, v in (("r1", r1), ("r5", r5), ("r10", r10), ("mean_recall", mean_recall))))
+    print("Inference time = {:.2f}s, [{:.4f} ms / sample] ".format(spent_seconds, spent_seconds * 1000 / max(n, 1)))
+    return [("mean_recall", mean_recall)]
+
+
 class CLIPEvaluator(Evaluator):
 
     def __init__(self, valid_dataset, **kwargs):
@@ -73,13 +84,4 @@ class CLIPEvaluator(Evaluator):
             text_embeds_all.append(outputs["text_embeds"])
         image_embeds_tensor = torch.cat(image_embeds_all, dim=0)
         text_embeds_tensor = torch.cat(text_embeds_all, dim=0)
-        query_len = text_embeds_tensor.size()[0]
-        (mean_recall, r1, r5, r10), (r1_stat, r5_stat, r10_stat) = recall_at_k(text_embeds_tensor, image_embeds_tensor)
-        result = [item * 100 for item in (mean_recall, r1, r5, r10)]
-        print("r1_num:" + str(r1_stat), "r5_num:" + str(r5_stat), "r10_num:" + str(r10_stat),
-              "query_num:" + str(query_len))
-        print("r1(%):" + str(result[1]), "r5(%):" + str(result[2]), "r10(%):" + str(result[3]),
-              "mean_recall(%):" + str(result[0]))
-        print("Inference time = {:.2f}s, [{:.4f} ms / sample] ".format(total_spent_time,
-                                                                      total_spent_time * 1000 / query_len))
-        return [("mean_recall", mean_recall)]
+        return recall_report(text_embeds_tensor, image_embeds_tensor, total_spent_time)

@@ -6,7 +6,8 @@ import time
 
 import torch
 
-from ..clip.evaluator import Evaluator, recall_at_k
+from ..clip import evaluator as _clip_evaluator
+from ..clip.evaluator import Evaluator
 
 
 class Text2VideoRetrievalEvaluator(Evaluator):
@@ -28,10 +29,4 @@ class Text2VideoRetrievalEvaluator(Evaluator):
             video_all.append(outputs["video_embeds"])
             text_all.append(outputs["text_embeds"])
         video_embeds, text_embeds = torch.cat(video_all, dim=0), torch.cat(text_all, dim=0)
-        query_len = text_embeds.shape[0]
-        (mean_recall, r1, r5, r10), (r1_stat, r5_stat, r10_stat) = recall_at_k(text_embeds, video_embeds)
-        result = [item * 100 for item in (mean_recall, r1, r5, r10)]
-        print("r1_num:" + str(r1_stat), "r5_num:" + str(r5_stat), "r10_num:" + str(r10_stat), "query_num:" + str(query_len))
-        print("r1(%):" + str(result[1]), "r5(%):" + str(result[2]), "r10(%):" + str(result[3]), "mean_recall(%):" + str(result[0]))
-        print("Inference time = {:.2f}s, [{:.4f} ms / sample] ".format(total_spent_time, total_spent_time * 1000 / query_len))
-        return [("mean_recall", mean_recall)]
+        return _clip_evaluator.recall_report(text_embeds, video_embeds, total_spent_time)

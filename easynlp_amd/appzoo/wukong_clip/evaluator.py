@@ -8,7 +8,8 @@ import time
 
 import torch
 
-from ..clip.evaluator import Evaluator, recall_at_k
+from ..clip import evaluator as _clip_evaluator
+from ..clip.evaluator import Evaluator
 
 
 class WukongCLIPEvaluator(Evaluator):
@@ -32,15 +33,10 @@ class WukongCLIPEvaluator(Evaluator):
             image_all.append(outputs["image_features"])
             text_all.append(outputs["text_features"])
         image_embeds, text_embeds = torch.cat(image_all, dim=0), torch.cat(text_all, dim=0)
-        query_len = text_embeds.shape[0]
         if self.cal_sim:
             similarity = (text_embeds * image_embeds).sum(dim=1)
             print("pair number: ", similarity.shape)
             print(similarity)
             print("averaged consine similarity ", similarity.mean())
             return None
-        (mean_recall, r1, r5, r10), (r1_stat, r5_stat, r10_stat) = recall_at_k(text_embeds, image_embeds)
-        result = [item * 100 for item in (mean_recall, r1, r5, r10)]
-        print("r1_num:" + str(r1_stat), "r5_num:" + str(r5_stat), "r10_num:" + str(r10_stat), "query_num:" + str(query_len))
-        print("r1(%):" + str(result[1]), "r5(%):" + str(result[2]), "r10(%):" + str(result[3]), "mean_recall(%):" + str(result[0]))
-        return [("mean_recall", mean_recall)]
+        return _clip_evaluator.recall_report(text_embeds, image_embeds, total_spent_time)

@@ -162,12 +162,12 @@ def test_reference_and_dropin_wukong_predictor_agree(tmp_path, monkeypatch):
     from easynlp.appzoo.wukong_clip.evaluator import WukongCLIPEvaluator as RefEvaluator
     from easynlp.appzoo.wukong_clip.model import WukongCLIP as RefApp
     from easynlp_amd.appzoo.wukong_clip import WukongCLIP, WukongCLIPDataset, WukongCLIPEvaluator
-    from easynlp_amd.appzoo.wukong_clip import evaluator as WE
+    from easynlp_amd.appzoo.clip import evaluator as EV
 
     def oracle_recall(t, v, ks=(1, 5, 10)):
         r = O.recall_at_k(t.float(), v.float())
         return r, tuple(int(round(x * t.shape[0])) for x in r[1:])
-    monkeypatch.setattr(WE, "recall_at_k", oracle_recall)
+    monkeypatch.setattr(EV, "recall_at_k", oracle_recall)
     tsv = os.path.join(d, "valid.tsv")
     with open(tsv, "wb") as f:
         f.write(g["tsv"].tobytes())
@@ -192,7 +192,7 @@ def test_reference_and_dropin_text2video_predictor_and_evaluator_agree(tmp_path,
     from easynlp_amd.appzoo.clip import model as CM
     from easynlp_amd.appzoo.text2video_retrieval import (Text2VideoRetrieval, Text2VideoRetrievalDataset,
                                                           Text2VideoRetrievalEvaluator, Text2VideoRetrievalPredictor)
-    from easynlp_amd.appzoo.text2video_retrieval import evaluator as TE
+    from easynlp_amd.appzoo.clip import evaluator as EV
     from easynlp_amd.appzoo.text2video_retrieval import model as TM
     from oracle import open_clip_oracle as OC
     gold = os.path.dirname(GOLD)
@@ -241,7 +241,7 @@ def test_reference_and_dropin_text2video_predictor_and_evaluator_agree(tmp_path,
     monkeypatch.setattr(L, "preprocess_images", oracle_preprocess)
     monkeypatch.setattr(CM.CLIPApp, "encode", oracle_encode)
     monkeypatch.setattr(TM, "_SimilarityFn", OracleSimilarity)
-    monkeypatch.setattr(TE, "recall_at_k", oracle_recall)
+    monkeypatch.setattr(EV, "recall_at_k", oracle_recall)
 
     def feats(out, key):
         assert all(set(o) == {key} for o in out)

@@ -176,3 +176,28 @@ def test_clipapp_forward_takes_dataset_batches(tmp_path):
         a = app({"images": images, "image_size": res, "input_ids": torch.from_numpy(g["input_ids"])})
         b = app({"pixel_values": px, "input_ids": torch.from_numpy(g["input_ids"])})
     assert torch.equal(a["logits_per_text"], b["logits_per_text"]) and torch.equal(a["image_embeds"], b["image_embeds"])
+
+
+def test_parse_row_by_schema_fuzz_against_the_reference():
+    from oracle import ref_harness as R
+    if not R.reference_available():
+        pytest.skip("reference checkout not present")
+    R.install_shims()
+    import random
+    from easynlp.utils import parse_row_by_schema as ref_parse
+    rnd = random.Random(4)
+    for _ in range(500):
+        ncol = rnd.randint(1, 4)
+        schema, fields = [], []
+        for c in range(ncol):
+            typ, length = rnd.choice(["str", "int", "float"]), rnd.choice([1, 1, 3])
+            schema.append("c%d:%s:%d" % (c, typ, length))
+            if typ == "str":
+                fields.append("".join(rnd.choice("ab ,:中x") for _ in range(rnd.randint(0, 6))))
+            else:
+                vals = [str(rnd.randint(-9, 9)) if typ == "int" else "%.3f" % rnd.uniform(-2, 2) for _ in range(length)]
+                fields.append(",".join(vals))
+        extra = rnd.choice([0, 0, 1, -1])                       # a surplus column, or one column short
+        row_fields = fields + ["zz"] if extra == 1 else (fields[:-1] if extra == -1 and ncol > 1 else fields)
+        row = "\t".join(row_fields) + rnd.choice(["", "\n"])
+        assert parse_row_by_schema(row, ",".join(schema)) == ref_parse(row, ",".join(schema)), (row, schema)

@@ -201,3 +201,34 @@ def test_parse_row_by_schema_fuzz_against_the_reference():
         row_fields = fields + ["zz"] if extra == 1 else (fields[:-1] if extra == -1 and ncol > 1 else fields)
         row = "\t".join(row_fields) + rnd.choice(["", "\n"])
         assert parse_row_by_schema(row, ",".join(schema)) == ref_parse(row, ",".join(schema)), (row, schema)
+
+
+def test_wordpiece_loader_fuzz_against_the_reference_tokenizer(tmp_path):
+    """load_wordpiece_tokenizer (the installed transformers' BertTokenizer, 4.x or 5.x) vs the reference's vendored
+    BertTokenizer.from_pretrained(vocab.txt) (data.py:229) with the dataset's call (padding / truncation / max_length):
+    control characters, CJK, accents, full-width forms, 100-character words, special tokens inside the text."""
+    from oracle import ref_harness as R
+    if not R.reference_available():
+        pytest.skip("reference checkout not present")
+    R.install_shims()
+    import random
+    from easynlp.modelzoo import BertTokenizer as RefTok
+    from easynlp_amd.appzoo.clip.data import load_wordpiece_tokenizer
+    g = np.load(os.path.join(os.path.dirname(GOLD), "wukong_dataset_b5.npz"))          # BERT-layout vocabulary
+    vp = os.path.join(str(tmp_path), "vocab.txt")
+    with open(vp, "wb") as f:
+        f.write(g["vocab"].tobytes() + b"\n")
+    ref, mine = RefTok.from_pretrained(vp), load_wordpiece_tokenizer(vp)
+    rnd = random.Random(11)
+    alphabet = list("abcdefghijklmnopqrstuvwxyzABCXYZ  \t,.;:!?'\"-_()[]{}<>@#$%^&*+=~`|\\/0123456789") + \
+        list("中文猫狗图的了，。！？「」·—…éÀüñçøßÆ") + ["​", "�", "\x07", " ", "　", "́", "\U0001F600", "\U00020000", "ａ", "①", "ｶ", "ﾞ", "ก", "ั"]
+    for it in range(1500):
+        t = "".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 40)))
+        if it % 40 == 0:
+            t += "x" * rnd.choice([99, 100, 101, 150])
+        if it % 55 == 0:
+            t += " [SEP] [CLS] [MASK] [UNK] [PAD]"
+        a = ref([t], padding="max_length", truncation=True, max_length=24, return_tensors="pt")
+        b = mine([t], padding="max_length", truncation=True, max_length=24, return_tensors="pt")
+        for k in ("input_ids", "token_type_ids", "attention_mask"):
+            assert a[k].tolist() == b[k].tolist(), (k, t)

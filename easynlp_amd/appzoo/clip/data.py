@@ -70,7 +70,7 @@ class CLIPDataset(torch.utils.data.Dataset):
 
     def __init__(self, pretrained_model_name_or_path, data_file, max_seq_length, input_schema=None, first_sequence=None,
                  label_name=None, second_sequence=None, label_enumerate_values=None, user_defined_parameters=None,
-                 skip_first_line: bool = False, image_size: int = 224, *args, **kwargs):
+                 skip_first_line: bool = False, image_size: int = 224, pack_batches: bool = False, *args, **kwargs):
         path = pretrained_model_name_or_path
         with open(os.path.join(path, "config.json"), "r") as f:
             self.raw_config = json.load(f)
@@ -94,6 +94,7 @@ class CLIPDataset(torch.utils.data.Dataset):
         else:
             self.tokenizer = load_wordpiece_tokenizer(os.path.join(path, "vocab.txt"))
         self.max_text_length = max_seq_length
+        self.pack_batches = bool(pack_batches)      # batch_fn packs the images into one uint8 tensor (in the DataLoader worker)
         self.size = self.crop_size = int(image_size)             # data.py:231-236 fixes 224; other resolutions by keyword
 
     def __len__(self):
@@ -135,5 +136,7 @@ class CLIPDataset(torch.utils.data.Dataset):
             if all(k in f["text"] for f in features):
                 out[k] = torch.cat([f["text"][k] for f in features], dim=0)
         out["images"] = [f["image"] for f in features]
+        if self.pack_batches:
+            out["images"] = L.pack_images(out["images"])
         out["image_size"] = self.size
         return out

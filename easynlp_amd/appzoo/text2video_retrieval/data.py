@@ -55,7 +55,7 @@ class Text2VideoRetrievalDataset(torch.utils.data.Dataset):
 
     def __init__(self, pretrained_model_name_or_path, data_file, max_seq_length, input_schema=None, first_sequence=None,
                  label_name=None, second_sequence=None, label_enumerate_values=None, user_defined_parameters=None,
-                 skip_first_line: bool = False, *args, **kwargs):
+                 skip_first_line: bool = False, pack_batches: bool = False, *args, **kwargs):
         path = pretrained_model_name_or_path
         with open(os.path.join(path, "config.json"), "r") as f:
             self.raw_config = json.load(f)
@@ -76,6 +76,7 @@ class Text2VideoRetrievalDataset(torch.utils.data.Dataset):
         self.max_text_length = max_seq_length
         self.size = self.crop_size = 224
         self.max_frames = MAX_FRAMES
+        self.pack_batches = bool(pack_batches)      # batch_fn packs all frames into one uint8 tensor (in the DataLoader worker)
 
     def __len__(self):
         return len(self.data_rows)
@@ -101,6 +102,9 @@ class Text2VideoRetrievalDataset(torch.utils.data.Dataset):
 
     def batch_fn(self, features):
         """data.py:257-279; 'images' (per clip: 12 decoded uint8 frames) + 'image_size' stand in for 'pixel_values'"""
+        clips = [f["frames"] for f in features]
+        if self.pack_batches:
+            clips = dict(L.pack_images([fr for c in clips for fr in c]), clips=len(clips))
         return {"input_ids": torch.cat([f["text"]["input_ids"] for f in features], dim=0),
                 "video_masks": torch.cat([f["video_masks"] for f in features], dim=0),
-                "images": [f["frames"] for f in features], "image_size": self.size, "label_ids": []}
+                "images": clips, "image_size": self.size, "label_ids": []}

@@ -43,10 +43,17 @@ class Text2VideoRetrieval(CLIPApp):
             # float32 pixel_values [B, T, 3, R, R] on the GPU (bit-identical to its PIL sequence)
             clips = inputs["images"]
             R = int(inputs.get("image_size") or self._engine.cfg["image_resolution"])
-            if len({len(c) for c in clips}) != 1:
-                raise L.EzclipError("Text2VideoRetrieval: every clip of a batch must hold the same number of frames")
-            flat = L.preprocess_images([f for c in clips for f in c], size=R, crop=R, device=dev)
-            inputs["pixel_values"] = flat.view(len(clips), len(clips[0]), *flat.shape[1:])
+            if L.is_packed_images(clips):              # packed by the dataset's batch_fn: all frames in one buffer
+                n_clips = int(clips["clips"])
+                flat = L.preprocess_images(clips, size=R, crop=R, device=dev)
+                if n_clips <= 0 or flat.shape[0] % n_clips:
+                    raise L.EzclipError("Text2VideoRetrieval: %d packed frames do not split into %d clips" % (flat.shape[0], n_clips))
+                inputs["pixel_values"] = flat.view(n_clips, flat.shape[0] // n_clips, *flat.shape[1:])
+            else:
+                if len({len(c) for c in clips}) != 1:
+                    raise L.EzclipError("Text2VideoRetrieval: every clip of a batch must hold the same number of frames")
+                flat = L.preprocess_images([f for c in clips for f in c], size=R, crop=R, device=dev)
+                inputs["pixel_values"] = flat.view(len(clips), len(clips[0]), *flat.shape[1:])
         if inputs.get("pixel_values") is not None:                                     # model.py:69-73
             px = inputs["pixel_values"].to(dev)
             if px.dim() != 5:

@@ -25,7 +25,7 @@ class WukongCLIPDataset(torch.utils.data.Dataset):
 
     def __init__(self, pretrained_model_name_or_path, data_file, max_seq_length=32, input_schema=None, first_sequence=None,
                  label_name=None, second_sequence=None, label_enumerate_values=None, user_defined_parameters=None,
-                 skip_first_line: bool = False, image_size: int = 224, *args, **kwargs):
+                 skip_first_line: bool = False, image_size: int = 224, pack_batches: bool = False, *args, **kwargs):
         if not input_schema:
             raise L.EzclipError("WukongCLIPDataset needs input_schema, e.g. 'text:str:1,image:str:1'")
         self.input_schema = input_schema
@@ -38,6 +38,7 @@ class WukongCLIPDataset(torch.utils.data.Dataset):
         self.image_col = second_sequence
         self.tokenizer = FullTokenizer(vocab_file=os.path.join(pretrained_model_name_or_path, "vocab.txt"))    # :171
         self.max_text_length = max_seq_length
+        self.pack_batches = bool(pack_batches)      # batch_fn packs the images into one uint8 tensor (in the DataLoader worker)
         self.size = self.crop_size = int(image_size)                                                          # :174-178: 224
 
     def __len__(self):
@@ -72,5 +73,6 @@ class WukongCLIPDataset(torch.utils.data.Dataset):
 
     def batch_fn(self, features):
         """:231-241 -- 'images' (decoded uint8 arrays) + 'image_size' stand in for 'pixel_values'"""
+        images = [f["image"] for f in features]
         return {"input_ids": torch.cat([f["text"]["input_ids"] for f in features], dim=0),
-                "images": [f["image"] for f in features], "image_size": self.size}
+                "images": L.pack_images(images) if self.pack_batches else images, "image_size": self.size}

@@ -247,12 +247,15 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)      # easynlp/appzoo/clip/data.
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
-def preprocess_images(images, size: int = 224, crop: int = 224, mean=CLIP_MEAN, std=CLIP_STD, device="cuda") -> torch.Tensor:
-    """Decoded images -> float32 ``pixel_values`` [n, 3, crop, crop] on the GPU (ezclip_preprocess_images: Pillow-exact
-    bicubic resize of the shorter side to ``size``, centre crop, /255, normalise).  ``images``: uint8 HWC RGB numpy
-    arrays ([H, W] / [H, W, 1] greyscale is replicated, as ``convert('RGB')`` does after the reference's resize)."""
+def pack_images(images, pin: bool = False) -> dict:
+    """Decoded images -> ONE contiguous uint8 buffer + descriptors, the layout ``ezclip_preprocess_images`` reads:
+    ``{"data": uint8 [total] (each image HWC RGB, starts 16-byte aligned), "desc": int64 [n, 3] (offset, width, height)}``.
+    Pure host work with no GPU call: ``batch_fn`` of the drop-in datasets can run it inside the DataLoader workers
+    (``pack_batches=True``), so that the per-image copies are spread over the workers and the training process only moves
+    one tensor to the device.  ``images``: uint8 HWC RGB numpy arrays ([H, W] / [H, W, 1] greyscale is replicated, as
+    ``convert('RGB')`` does after the reference's resize).  ``pin``: allocate the buffer in pinned memory (only in the
+    process that owns the GPU context -- never in a DataLoader worker)."""
     import numpy as np
-    lib = load()
     arrs = []
     for im in images:
         a = np.asarray(im)
@@ -269,16 +272,41 @@ def preprocess_images(images, size: int = 224, crop: int = 224, mean=CLIP_MEAN, 
     n = len(arrs)
     if n == 0:
         raise EzclipError("preprocess_images: empty batch")
-    desc = (EzclipImageDesc * n)()
+    desc = torch.empty((n, 3), dtype=torch.int64)
     off = 0
     for i, a in enumerate(arrs):
-        desc[i].offset, desc[i].width, desc[i].height = off, a.shape[1], a.shape[0]
+        desc[i, 0], desc[i, 1], desc[i, 2] = off, a.shape[1], a.shape[0]
         off += (a.size + 15) // 16 * 16
-    host = torch.empty(off + 16, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else torch.empty(off + 16, dtype=torch.uint8)
-    hv = host.numpy()
+    data = torch.empty(off + 16, dtype=torch.uint8)
+    if pin:
+        data = data.pin_memory()
+    hv = data.numpy()
     for i, a in enumerate(arrs):
-        hv[desc[i].offset:desc[i].offset + a.size] = a.reshape(-1)
-    packed = host.to(device, non_blocking=True)
+        o = int(desc[i, 0])
+        hv[o:o + a.size] = a.reshape(-1)
+    return {"data": data, "desc": desc}
+
+
+def is_packed_images(x) -> bool:
+    return isinstance(x, dict) and "data" in x and "desc" in x
+
+
+def preprocess_images(images, size: int = 224, crop: int = 224, mean=CLIP_MEAN, std=CLIP_STD, device="cuda") -> torch.Tensor:
+    """Decoded images -> float32 ``pixel_values`` [n, 3, crop, crop] on the GPU (ezclip_preprocess_images: Pillow-exact
+    bicubic resize of the shorter side to ``size``, centre crop, /255, normalise).  ``images``: a list of uint8 HWC RGB
+    numpy arrays (see ``pack_images``) or the dict ``pack_images`` returns (possibly pinned / already on the device)."""
+    lib = load()
+    packed_in = images if is_packed_images(images) else pack_images(images, pin=torch.cuda.is_available())
+    data, dtab = packed_in["data"], packed_in["desc"]
+    n = int(dtab.shape[0])
+    rows = dtab.cpu().tolist()
+    desc = (EzclipImageDesc * n)()
+    for i, (o, w, h) in enumerate(rows):
+        desc[i].offset, desc[i].width, desc[i].height = int(o), int(w), int(h)
+    # one host -> device copy: asynchronous from pinned memory (the list path packs into a pinned buffer; a DataLoader with
+    # pin_memory=True pins the workers' packed batches in its own thread), a single staged copy from pageable memory
+    host = None if data.is_cuda else data
+    packed = data if data.is_cuda else data.to(device, non_blocking=True)
     nbytes = lib.ezclip_preprocess_workspace_bytes(desc, n, size, crop)
     if nbytes == 0:
         raise EzclipError("preprocess_images: %s" % last_error())

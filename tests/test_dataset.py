@@ -85,6 +85,21 @@ def test_dataloader_with_workers_collates_through_batch_fn(tmp_path):
     assert np.array_equal(torch.cat([b["input_ids"] for b in batches]).numpy(), g["input_ids"])
 
 
+def test_pack_batches_moves_the_image_copies_into_the_workers(tmp_path):
+    """pack_batches=True: batch_fn (run by the DataLoader workers) returns ONE uint8 tensor + descriptors instead of a list
+    of arrays -- the same bytes L.pack_images makes of the list, through worker IPC as well"""
+    g, d = _materialise(tmp_path)
+    plain, packed = _dataset(d), _dataset(d, pack_batches=True)
+    want = L.pack_images(plain.batch_fn([plain[i] for i in range(7)])["images"])
+    dl = torch.utils.data.DataLoader(packed, batch_size=7, shuffle=False, collate_fn=packed.batch_fn, num_workers=2)
+    batch = next(iter(dl))
+    assert L.is_packed_images(batch["images"]) and batch["image_size"] == 224
+    assert torch.equal(batch["images"]["desc"], want["desc"])
+    for o, w, h in want["desc"].tolist():
+        assert torch.equal(batch["images"]["data"][o:o + w * h * 3], want["data"][o:o + w * h * 3])
+    assert np.array_equal(batch["input_ids"].numpy(), g["input_ids"])
+
+
 def test_huggingface_flavour_and_what_is_not_covered(tmp_path):
     g, d = _materialise(tmp_path, model_type=None)
     ds = _dataset(d)

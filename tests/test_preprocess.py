@@ -84,6 +84,30 @@ def test_rejects_what_the_path_does_not_cover():
 
 # ------------------------------------------------------------------------------------------------ GPU
 
+def test_pack_images_layout():
+    """host side of ezclip_preprocess_images' input: HWC RGB bytes, 16-byte aligned starts, (offset, width, height) rows;
+    greyscale replicated, non-contiguous views made contiguous -- checked against a direct restatement"""
+    rs = np.random.RandomState(0)
+    imgs = [rs.randint(0, 256, (37, 50, 3), dtype=np.uint8), rs.randint(0, 256, (20, 31), dtype=np.uint8),
+            rs.randint(0, 256, (5, 7, 1), dtype=np.uint8), rs.randint(0, 256, (64, 64, 3), dtype=np.uint8)[:, ::2]]
+    p = L.pack_images(imgs)
+    assert L.is_packed_images(p) and not L.is_packed_images(imgs) and p["data"].dtype == torch.uint8 and p["desc"].dtype == torch.int64
+    off = 0
+    for (o, w, h), im in zip(p["desc"].tolist(), imgs):
+        a = im if im.ndim == 3 else im[:, :, None]
+        a = np.repeat(a, 3, axis=2) if a.shape[2] == 1 else a
+        assert (o, w, h) == (off, a.shape[1], a.shape[0]) and o % 16 == 0
+        assert np.array_equal(p["data"].numpy()[o:o + a.size].reshape(a.shape), a)
+        off += (a.size + 15) // 16 * 16
+    assert p["data"].numel() == off + 16
+    with pytest.raises(L.EzclipError):
+        L.pack_images([])
+    with pytest.raises(L.EzclipError):
+        L.pack_images([np.zeros((4, 4, 4), np.uint8)])
+    with pytest.raises(L.EzclipError):
+        L.pack_images([np.zeros((4, 4, 3), np.float32)])
+
+
 @pytest.mark.gpu
 def test_device_preprocess_is_bit_identical_to_the_reference_pipeline():
     imgs = [_img(w, h, i) for i, (w, h) in enumerate(SIZES)]

@@ -17,8 +17,16 @@ from oracle import clip_oracle as O, open_clip_oracle as OC, wukong_oracle as WK
 
 torch.nn.Module.cuda = lambda self, *a, **k: self
 torch.Tensor.cuda = lambda self, *a, **k: self
+_dl_init = torch.utils.data.DataLoader.__init__
+def _dl_init_no_pin(self, *a, **k):
+    k["pin_memory"] = False                   # pinning needs a device context
+    _dl_init(self, *a, **k)
+torch.utils.data.DataLoader.__init__ = _dl_init_no_pin
 
 def fake_pre(images, size=224, crop=224, mean=L.CLIP_MEAN, std=L.CLIP_STD, device="cpu"):
+    if L.is_packed_images(images):
+        buf = images["data"].numpy()
+        images = [buf[o:o + w * h * 3].reshape(h, w, 3) for o, w, h in images["desc"].tolist()]
     outs = []
     for im in images:
         a = np.asarray(im)

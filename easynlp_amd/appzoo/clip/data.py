@@ -1,5 +1,6 @@
 """Data side of the path -- mirror of ``easynlp.appzoo.clip.data.CLIPDataset`` (easynlp/appzoo/clip/data.py:152-295)
-for the local TSV format ``text \\t urlsafe-base64(encoded image)`` the tutorials use (``input_schema`` such as
+for the local TSV format ``text \\t urlsafe-base64(encoded image)`` the tutorials use, and for webdataset tar shards
+(``read_webdataset_tar``) (``input_schema`` such as
 ``"text:str:1,image:str:1"``; base class contract easynlp/appzoo/dataset.py:39-215: ``__getitem__`` parses the row by the
 schema and calls ``convert_single_row_to_example``; the DataLoader collates with ``batch_fn``).
 
@@ -45,6 +46,61 @@ def parse_row_by_schema(row: str, input_schema: str) -> Dict[str, object]:
     return out
 
 
+def expand_braces(pattern: str) -> List[str]:
+    """``"shard-{000..012}.tar"`` / ``"{a,b}.tar"`` -> file names (the shell-style brace notation webdataset accepts for
+    its ``urls``; numeric ranges keep their zero padding)"""
+    i = pattern.find("{")
+    if i < 0:
+        return [pattern]
+    j = pattern.find("}", i)
+    if j < 0:
+        return [pattern]
+    head, body, tail = pattern[:i], pattern[i + 1:j], pattern[j + 1:]
+    if ".." in body:
+        lo, hi = body.split("..", 1)
+        width = len(lo) if lo.startswith("0") or hi.startswith("0") else 0
+        alts = [str(v).zfill(width) for v in range(int(lo), int(hi) + 1)]
+    else:
+        alts = body.split(",")
+    return [name for a in alts for name in expand_braces(head + a + tail)]
+
+
+def read_webdataset_tar(urls: str, rank: int = 0, world: int = 1) -> List[Dict[str, object]]:
+    """The tar branch of the reference dataset (data.py:203-217: ``wds.WebDataset(data_file, nodesplitter=...)
+    .decode("pil").to_tuple("jpg;png", "json")``, every sample kept in memory as ``{'text': json['caption'], 'image': PIL}``)
+    restated with ``tarfile`` (webdataset is not part of this image, so this branch cannot be compared with the reference
+    here: PARITY UNPINNED for it).  webdataset's conventions: consecutive members sharing the path up to the first dot of
+    the base name form one sample, the rest of the name is the field; ``jpg;png`` takes the first of the two present;
+    ``decode("pil")`` yields an RGB image; shards are dealt to ranks as ``urls[rank::world]`` (the reference's nodesplitter)."""
+    import tarfile
+    from PIL import Image
+    rows: List[Dict[str, object]] = []
+    for path in expand_braces(urls)[rank::world]:
+        with tarfile.open(path, "r:*") as tf:
+            key, fields = None, {}
+
+            def flush():
+                if key is None:
+                    return
+                img = next((fields[e] for e in ("jpg", "png") if e in fields), None)
+                if img is None or "json" not in fields:       # to_tuple("jpg;png", "json") fails on an incomplete sample too
+                    raise L.EzclipError("%s: sample %r lacks %s" % (path, key, "an image (jpg / png)" if img is None else "its json"))
+                meta = json.loads(fields["json"].decode("utf-8"))
+                rows.append({"text": meta["caption"], "image": Image.open(io.BytesIO(img)).convert("RGB")})
+            for m in tf:
+                if not m.isfile():
+                    continue
+                dirname, base = os.path.split(m.name)
+                stem, _, ext = base.partition(".")
+                k = os.path.join(dirname, stem)
+                if k != key:
+                    flush()
+                    key, fields = k, {}
+                fields[ext.lower()] = tf.extractfile(m).read()
+            flush()
+    return rows
+
+
 def load_wordpiece_tokenizer(vocab_path: str):
     """``BertTokenizer.from_pretrained(dir + '/vocab.txt')`` of the reference (data.py:229, predictor.py:52) with the installed
     ``transformers``: 4.x takes ``vocab_file=``, 5.x takes the token -> id table and silently ignores ``vocab_file`` (every
@@ -76,16 +132,21 @@ class CLIPDataset(torch.utils.data.Dataset):
             self.raw_config = json.load(f)
         mt = self.raw_config.get("model_type")
         self.model_type = mt if mt in ("open_clip", "chinese_clip") else "huggingface_clip"          # data.py:196-201
-        if str(data_file).endswith("tar"):
-            raise L.EzclipError("webdataset tar input (data.py:203-217) is not covered; use the TSV format")
-        if not input_schema:
-            raise L.EzclipError("CLIPDataset needs input_schema, e.g. 'text:str:1,image:str:1'")
-        self.input_schema = input_schema
-        self.column_names = [t.split(":")[0] for t in input_schema.split(",")]
-        with io.open(data_file) as f:
-            if skip_first_line:
-                f.readline()
-            self.data_rows = f.readlines()
+        self.data_source = "tar" if str(data_file)[-3:] == "tar" else "local"
+        if self.data_source == "tar":                                                         # data.py:203-217
+            import torch.distributed as dist
+            on = dist.is_available() and dist.is_initialized()
+            self.input_schema, self.column_names = "tar", []
+            self.data_rows = read_webdataset_tar(str(data_file), dist.get_rank() if on else 0, dist.get_world_size() if on else 1)
+        else:
+            if not input_schema:
+                raise L.EzclipError("CLIPDataset needs input_schema, e.g. 'text:str:1,image:str:1'")
+            self.input_schema = input_schema
+            self.column_names = [t.split(":")[0] for t in input_schema.split(",")]
+            with io.open(data_file) as f:
+                if skip_first_line:
+                    f.readline()
+                self.data_rows = f.readlines()
         self.text_col = first_sequence
         self.image_col = second_sequence
         if self.model_type == "open_clip":                                                         # data.py:225-229
@@ -106,7 +167,10 @@ class CLIPDataset(torch.utils.data.Dataset):
         return ["0", "1"]
 
     def __getitem__(self, item):
-        row = parse_row_by_schema(self.data_rows[item].strip("\n"), self.input_schema)          # dataset.py:160-196
+        if self.data_source == "tar":
+            row = self.data_rows[item]                                                           # dataset.py:191-192
+        else:
+            row = parse_row_by_schema(self.data_rows[item].strip("\n"), self.input_schema)      # dataset.py:160-196
         try:
             return self.convert_single_row_to_example(row)
         except L.EzclipError:
@@ -116,8 +180,11 @@ class CLIPDataset(torch.utils.data.Dataset):
 
     def convert_single_row_to_example(self, row: Dict[str, str]):
         from PIL import Image
-        text = row[self.text_col]
-        image = Image.open(io.BytesIO(base64.urlsafe_b64decode(row[self.image_col])))             # data.py:242
+        if self.data_source == "tar":                                                            # data.py:236-238
+            text, image = row["text"], row["image"]
+        else:
+            text = row[self.text_col]
+            image = Image.open(io.BytesIO(base64.urlsafe_b64decode(row[self.image_col])))         # data.py:242
         if self.model_type == "open_clip":                                                         # data.py:246-249: always 77
             from .bpe_tokenizer import openclip_tokenize
             tk = {"input_ids": openclip_tokenize([text], context_length=77, _tokenizer=self.openclip_tokenizer)}

@@ -427,7 +427,8 @@ class CLIPApp(Application):
             self._build_hf(self.raw_config)
             if state is not None:
                 own = self.state_dict()
-                missing = [k for k in self._hf_params if k not in state]
+                # (a checkpoint without 'logit_scale' keeps the ln(1 / 0.07) initialisation, model.py:101-104)
+                missing = [k for k in self._hf_params if k not in state and k != "logit_scale"]
                 if missing:
                     raise L.EzclipError("checkpoint lacks %d parameters, e.g. %s" % (len(missing), missing[:3]))
                 self.load_state_dict({k: v for k, v in state.items() if k in own}, strict=False)

@@ -250,3 +250,23 @@ def test_wukong_and_text2video_applications_construct_from_reference_checkpoints
     torch.save({"open_clip." + k: v for k, v in osd.items()}, os.path.join(str(d2), "pytorch_model.bin"))
     t2v = Text2VideoRetrieval.from_pretrained(str(d2))
     assert set(t2v.state_dict()) == {"open_clip." + k for k in OC.param_shapes(ocfg)}
+
+
+def test_huggingface_checkpoint_without_logit_scale_keeps_the_default(tmp_path):
+    """appzoo/clip/model.py:101-104: 'logit_scale' is optional in a huggingface_clip checkpoint (ln(1 / 0.07) otherwise);
+    any other missing tensor is an error"""
+    import math
+    import torch
+    from easynlp_amd import lib as L
+    from easynlp_amd.appzoo.clip import CLIPApp
+    from oracle import hf_clip_oracle as H
+    from oracle import ref_harness as R
+    cfg = H.HF_CONFIGS["hf_tiny"]
+    sd = H.make_state_dict(cfg, 2)
+    R.write_hf_checkpoint_dir(str(tmp_path), cfg, {k: v for k, v in sd.items() if k != "logit_scale"})
+    app = CLIPApp(str(tmp_path))
+    assert abs(float(app.state_dict()["logit_scale"].reshape(-1)[0]) - math.log(1 / 0.07)) < 1e-6
+    assert torch.equal(app.state_dict()["text_projection.weight"], sd["text_projection.weight"])
+    R.write_hf_checkpoint_dir(str(tmp_path), cfg, {k: v for k, v in sd.items() if k != "text_projection.bias"})
+    with pytest.raises(L.EzclipError):
+        CLIPApp(str(tmp_path))

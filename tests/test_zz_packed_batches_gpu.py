@@ -34,8 +34,10 @@ def test_packed_and_list_batches_are_bit_identical(tmp_path):
     plain = CLIPDataset(d, tsv, 20, image_size=res, **SCHEMA)
     packed = CLIPDataset(d, tsv, 20, image_size=res, pack_batches=True, **SCHEMA)
     b_list = plain.batch_fn([plain[i] for i in range(7)])
+    # workers are spawned (the parent already holds a HIP context: no fork after that), and a stuck loader fails instead of hanging
     b_pack = next(iter(torch.utils.data.DataLoader(packed, batch_size=7, shuffle=False, collate_fn=packed.batch_fn,
-                                                   num_workers=2, pin_memory=True)))
+                                                   num_workers=2, pin_memory=True, multiprocessing_context="spawn",
+                                                   timeout=180)))
     assert L.is_packed_images(b_pack["images"])
     px_list = L.preprocess_images(b_list["images"], size=224, crop=224)
     px_pack = L.preprocess_images(b_pack["images"], size=224, crop=224)

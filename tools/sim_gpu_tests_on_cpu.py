@@ -98,5 +98,6 @@ CM.CLIPApp.encode = enc2
 torch.cuda.is_available = lambda: True        # conftest then leaves the gpu-marked tests alone
 DEFAULT = ["test_zz_global_scope_gpu.py", "test_zz_packed_batches_gpu.py", "test_zz_text2video_gpu.py", "test_zz_wukong_io_gpu.py", "test_wukong_gpu.py",
            "test_text2video_data.py", "test_wukong_data.py"]
-paths = sys.argv[1:] or [os.path.join(ROOT, "tests", f) for f in DEFAULT]
-sys.exit(pytest.main(["-q", "-p", "no:cacheprovider", "-m", "gpu"] + paths))
+if __name__ == "__main__":           # (spawned DataLoader workers re-import this module: they must not start pytest again)
+    paths = sys.argv[1:] or [os.path.join(ROOT, "tests", f) for f in DEFAULT]
+    sys.exit(pytest.main(["-q", "-p", "no:cacheprovider", "-m", "gpu"] + paths))

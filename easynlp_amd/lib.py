@@ -14,7 +14,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libezclip_hip.so")
+# EZCLIP_LIB: load another build of the same library (experiment variants of tools/build_variants.py); unset = the in-tree one
+LIB_PATH = os.environ.get("EZCLIP_LIB") or os.path.join(_HERE, "csrc", "libezclip_hip.so")
 
 DTYPE_F32 = 0
 DTYPE_BF16 = 1

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Build experiment variants of libezclip_hip.so under tools/bin/var_<name>/ (same objects, ONE source recompiled with
-extra -D flags: gemm8p.hip unless the name says otherwise).  Run a tool against one with LD_LIBRARY_PATH=tools/bin/var_<name>.
+extra -D flags: gemm8p.hip unless the name says otherwise).  Run a C tool against one with LD_LIBRARY_PATH=tools/bin/var_<name>, a Python
+tool / test with EZCLIP_LIB=tools/bin/var_<name>/libezclip_hip.so.
 
     python tools/build_variants.py name1:-DFOO=1 name2:"-DBAR -DBAZ=2" lnpacked@rowops.hip:-DEZ_LNBWD_PACKED ...
 """

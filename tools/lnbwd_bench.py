@@ -3,8 +3,8 @@
 
 A/B against the packed-staging experiment (rowops.hip, -DEZ_LNBWD_PACKED: four bf16 rows in flight per wave):
     python tools/build_variants.py lnpacked@rowops.hip:-DEZ_LNBWD_PACKED
-    python tools/lnbwd_bench.py;  LD_LIBRARY_PATH=tools/bin/var_lnpacked python tools/lnbwd_bench.py
-(the results must be bit-identical: run tests/test_ops_gpu.py -k layernorm_bwd with the same LD_LIBRARY_PATH)."""
+    python tools/lnbwd_bench.py;  EZCLIP_LIB=tools/bin/var_lnpacked/libezclip_hip.so python tools/lnbwd_bench.py
+(the results must be bit-identical: run tests/test_ops_gpu.py -k layernorm_bwd with the same EZCLIP_LIB)."""
 import os
 import sys
 import time

@@ -2,22 +2,29 @@
 """Headline benchmark: image-text pairs/sec of the CLIP retrieval hot path
 (ViT-B/16 + BERT-base dual-encoder forward + InfoNCE loss) on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-also] [--no-cpu-baseline]
 
-A "step" = one pass of the hot path over one synthetic batch that is already
-resident in HBM: encode_image + encode_text (+ RCCL all-gather of both embedding
-sets when N > 1) + similarity (both directions) + InfoNCE.  Rank 0 prints ONE
-JSON line.  Workloads (BASELINE.json configs):
+`--gpus N` with N > 1 launches itself: one process per GPU under `python -m torch.distributed.run` on 127.0.0.1 (RCCL);
+started under an external launcher (WORLD_SIZE set) it uses that one.
 
-  bf16_b1024_fwd_loss   (default) ViT-B/16 + BERT-base, bf16 MFMA, 1024 pairs/GPU, 64 tokens
-  bf16_b1024_train      same + full backward (only when the backward kernels are built)
-  fp32_b256_fwd_sim     config 2: exact-f32 MFMA, 256 pairs, forward + similarity
+A "step" = one pass of the hot path over one synthetic batch that is already resident in HBM: encode_image +
+encode_text (+ RCCL all-gather of both embedding sets when N > 1) + similarity (both directions) + InfoNCE.  Rank 0
+prints ONE JSON line.  The headline (`value`) is the default workload; the same line carries every other BASELINE.json
+configuration this box can run under `also` (a few steps each):
 
-`roofline` describes the dominant kernel (the MFMA GEMM): algorithmic FLOPs of its
-launches / their HIP-event durations, measured live on the launch stream in extra
-(untimed) steps.  `cpu_baseline` times the CPU oracle (a torch-CPU port of the
-reference algorithm) on the host cores on a bounded sample of the same workload.
+  bf16_b1024_fwd_loss        (default, headline) ViT-B/16 + BERT-base, bf16 MFMA, 1024 pairs/GPU, 64 tokens
+  bf16_b1024_train           config 3: + full backward into a flat gradient arena (+ overlapped gradient all-reduce, N > 1)
+  bf16_b1024_train_opt       the same + torch.optim.AdamW(fused) step + the library's weight re-pack: a whole training step
+  fp32_b256_fwd_sim          config 2: exact-f32 MFMA, 256 pairs, forward + similarity
+  bf16_vitl14_b512_*         config 5: ViT-L/14 + BERT-base-architecture text tower, 512 pairs
+  bf16_hf_vitl14_b512_train  config 5 as the reference trains it (huggingface_clip flavour: frozen vision tower)
+  *_autograd                 the same work through the drop-in boundary the reference Trainer drives:
+                             CLIPApp.forward() + compute_loss() + loss.backward() (core/trainer.py:628,646,661)
+
+`roofline` describes the dominant kernel (the MFMA GEMM): algorithmic FLOPs of its launches / their HIP-event
+durations, measured live on the launch stream in extra (untimed, single-stream) steps.  `cpu_baseline` times the
+imported reference (`kind: reference`, only where /root/reference exists) or the CPU oracle (`kind: port`, a torch-CPU
+restatement of the reference algorithm) on the host cores on a bounded sample of the same workload.
 """
 from __future__ import annotations
 
@@ -57,14 +64,23 @@ HF_VITL14_ROBERTA = dict(
                        patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5),
     projection_dim=768)
 
+# path: "fused" = CLIPApp.contrastive_step (one C call per stage, no autograd bookkeeping);
+#       "autograd" = forward() + compute_loss() + backward() through the autograd glue (the reference Trainer's calls)
 WORKLOADS = {
     "bf16_b1024_fwd_loss": dict(dtype="bf16", batch=1024, seq=64, backward=False),
     "bf16_b1024_train": dict(dtype="bf16", batch=1024, seq=64, backward=True),
+    "bf16_b1024_train_opt": dict(dtype="bf16", batch=1024, seq=64, backward=True, optimizer=True),
+    "bf16_b1024_fwd_loss_autograd": dict(dtype="bf16", batch=1024, seq=64, backward=False, path="autograd"),
+    "bf16_b1024_train_autograd": dict(dtype="bf16", batch=1024, seq=64, backward=True, path="autograd"),
     "fp32_b256_fwd_sim": dict(dtype="fp32", batch=256, seq=64, backward=False),
     "bf16_vitl14_b512_fwd_loss": dict(dtype="bf16", batch=512, seq=64, backward=False, model="vitl14"),
     "bf16_vitl14_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="vitl14"),
     "bf16_hf_vitl14_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="hf_vitl14"),
 }
+# what the default run adds to the headline line (BASELINE.json configs 3, 2, 5 + the boundary overhead)
+ALSO_N1 = ["bf16_b1024_train", "bf16_b1024_train_opt", "bf16_b1024_fwd_loss_autograd", "bf16_b1024_train_autograd",
+           "fp32_b256_fwd_sim", "bf16_vitl14_b512_fwd_loss", "bf16_vitl14_b512_train", "bf16_hf_vitl14_b512_train"]
+ALSO_MULTI = ["bf16_b1024_train"]          # config 4 "(+bwd)": gradient all-reduce overlapped with the backward pass
 
 # algorithmic GFLOP per pair (multiply-add = 2; padded tiles and softmax/LN excluded)
 GFLOP_FWD_PER_PAIR = 46.152
@@ -116,10 +132,24 @@ def synth_batch(batch, seq, vocab, device, seed):
     return px, ids
 
 
-def cpu_baseline(seconds_target=12.0):
-    """The CPU oracle (torch-CPU restatement of the reference path, oracle/clip_oracle.py)
-    on the host cores: fp32 forward + similarity + InfoNCE on 8-pair batches."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seconds_target=10.0):
+    """The reference path on the host cores, fp32, 8-pair batches: forward + similarity + InfoNCE (`value`)
+    and forward + loss + backward (`train_value`).  Where the reference checkout exists (the build container) it IS the
+    imported reference `CLIPApp` (`kind: reference`); on the GPU box (no /root/reference) it is the CPU oracle, a
+    torch-CPU restatement of the same algorithm (`kind: port`; profiles/README.md records that the two run at the same
+    speed on the build container)."""
     from oracle import clip_oracle as O
+    from oracle import ref_harness as R
     # a small-batch CPU forward stops scaling (and collapses from oversubscription) beyond a few
     # dozen threads: use at most 32 and report the number actually used
     cores = min(os.cpu_count() or 1, 32)
@@ -127,28 +157,238 @@ def cpu_baseline(seconds_target=12.0):
     cfg = O.CONFIGS["vitb16_bertbase"]
     sd = O.make_state_dict(cfg, 1234)
     px, ids = O.make_inputs(cfg, 8, 64, 0)
-    with torch.no_grad():
-        out = O.clip_forward(sd, cfg, px, ids)       # warm-up
-        O.clip_loss(out["logits_per_text"])
+    kind = "port"
+    if R.reference_available():
+        import tempfile
+        try:
+            with tempfile.TemporaryDirectory() as d:
+                R.write_checkpoint_dir(d, cfg, sd)
+                ref = R.reference_clip_app(d)
+            ref.eval()
+            kind = "reference"
+
+            def fwd():
+                out = ref({"pixel_values": px.clone(), "input_ids": ids.clone()})
+                return ref.compute_loss(out, [])["loss"]
+
+            def train():
+                ref.zero_grad(set_to_none=True)
+                fwd().backward()
+        except Exception as e:      # a broken checkout must not take the bench line with it
+            print("cpu_baseline: reference import failed (%s); timing the port" % e, file=sys.stderr)
+            kind = "port"
+    if kind == "port":
+        def fwd():
+            out = O.clip_forward(sd, cfg, px, ids)
+            return O.clip_loss(out["logits_per_text"])
+
+        def train():
+            O.forward_loss_backward(sd, cfg, px, ids)
+
+    def timed(fn, budget, cap):
+        fn()                                    # warm-up
         n, t0 = 0, time.perf_counter()
         while True:
-            out = O.clip_forward(sd, cfg, px, ids)
-            O.clip_loss(out["logits_per_text"])
+            fn()
             n += 1
             el = time.perf_counter() - t0
-            if el >= seconds_target or n >= 40:
-                break
-    model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {"value": round(8 * n / el, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d x (8 pairs, 224x224 + 64 tokens) fp32 fwd+similarity+InfoNCE, torch CPU %s, %s"
-                      % (n, torch.__version__, model)}
+            if el >= budget or n >= cap:
+                return n, el
+
+    with torch.no_grad():
+        n, el = timed(fwd, seconds_target, 40)
+    nt, elt = timed(train, seconds_target * 0.8, 12)
+    return {"value": round(8 * n / el, 3), "unit": "pairs/s", "cores": cores, "kind": kind,
+            "train_value": round(8 * nt / elt, 3),
+            "sample": "%d x (8 pairs, 224x224 + 64 tokens) fp32 fwd+similarity+InfoNCE and %d x fwd+loss+backward, torch CPU %s, %s"
+                      % (n, nt, torch.__version__, _cpu_model())}
+
+
+def relaunch(args):
+    """`python bench.py --gpus N` without an external launcher: one process per GPU under torch.distributed.run."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+          [a for a in sys.argv[1:] if a != "--launcher"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EZCLIP_BENCH_LAUNCHED="1")
+    sys.exit(subprocess.run(cmd, env=env, cwd=ROOT).returncode)
+
+
+class Ctx:
+    pass
+
+
+def build_app(wl, device, text_dropout=0.0):
+    from easynlp_amd.appzoo.clip import CLIPApp
+    model_cfg = VITL14_ROBERTA if wl.get("model") == "vitl14" else VITB16_BERTBASE
+    name = ("ViT-L/14 + chinese-roberta-wwm-ext (BERT-base arch)" if wl.get("model") == "vitl14"
+            else "ViT-B/16 + BERT-base") + " (chinese_clip), random init"
+    if text_dropout > 0:
+        model_cfg = dict(model_cfg, text_hidden_dropout_prob=text_dropout, text_attention_probs_dropout_prob=text_dropout)
+    if wl.get("model") == "hf_vitl14":
+        app = CLIPApp.from_hf_config(HF_VITL14_ROBERTA, seed=1234, device=device, compute_dtype=wl["dtype"])
+        name = "huggingface_clip: frozen ViT-L/14 + chinese-roberta-wwm-ext (BERT-base arch) + pooler, random init"
+    else:
+        app = CLIPApp.from_config(model_cfg, seed=1234, device=device, compute_dtype=wl["dtype"])
+    app.eval()
+    if text_dropout > 0 or (wl["backward"] and wl.get("path") == "autograd"):
+        app.train()             # what Trainer does (core/trainer.py:281); dropout probabilities are 0 unless --text-dropout
+    return app, name
+
+
+def gflop_per_pair(wl):
+    if wl.get("model") == "hf_vitl14":
+        return GFLOP_TRAIN_PER_PAIR_HF_VITL14, None
+    if wl.get("model") == "vitl14":
+        return (GFLOP_TRAIN_PER_PAIR_VITL14 if wl["backward"] else GFLOP_FWD_PER_PAIR_VITL14), None
+    cls_last = os.environ.get("EZCLIP_CLS_LAST", "1") != "0"
+    cls_train = os.environ.get("EZCLIP_CLS_TRAIN", "1") != "0"
+    if wl["backward"]:
+        return (GFLOP_TRAIN_EXECUTED_PER_PAIR if cls_train else GFLOP_TRAIN_PER_PAIR), GFLOP_TRAIN_PER_PAIR
+    return (GFLOP_FWD_EXECUTED_PER_PAIR if cls_last else GFLOP_FWD_PER_PAIR), GFLOP_FWD_PER_PAIR
+
+
+def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, profile=True):
+    """Build the model of workload `name`, run `warmup` untimed and exactly `steps` timed steps (barrier + synchronize on
+    both sides, MAX over ranks), then the roofline leg.  Returns the fields of the JSON line for this workload."""
+    import torch.distributed as dist
+    from easynlp_amd import lib as L
+    from easynlp_amd import parallel as P
+    wl = dict(WORKLOADS[name])
+    if batch_override:
+        wl["batch"] = batch_override
+    B, S = wl["batch"], wl["seq"]
+    world, rank, device = c.world, c.rank, c.device
+    app, model_name = build_app(wl, device, text_dropout)
+    px, ids = synth_batch(B, S, VITB16_BERTBASE["vocab_size"], device, seed=1000 + rank)
+    pg = True if world > 1 else False
+    autograd = wl.get("path") == "autograd"
+    if autograd and world > 1:
+        app.contrastive_scope = "global"
+    opt = None
+    if wl.get("optimizer"):
+        # a real in-place weight update per step: the next forward re-packs the library's bf16 / transposed copies
+        opt = torch.optim.AdamW([p for p in app.parameters() if p.requires_grad], lr=1e-6, eps=1e-6, weight_decay=0.01, fused=True)
+    hf_inputs = {}
+    if wl.get("model") == "hf_vitl14":
+        hf_inputs = {"token_type_ids": torch.zeros_like(ids), "attention_mask": ids.ne(0).long()}
+
+    def step():
+        if autograd:
+            if wl["backward"]:
+                for p in app.parameters():          # optimizer.zero_grad() of the Trainer loop (set_to_none, core/trainer.py:337)
+                    p.grad = None
+                out = app(dict({"pixel_values": px, "input_ids": ids}, **hf_inputs))
+                loss = app.compute_loss(out, [])["loss"]
+                loss.backward()
+                if world > 1:                       # what DDP's hooks do for the reference (not overlapped on this path)
+                    P.average_gradients(list(app.parameters()))
+                return loss.detach()
+            with torch.no_grad():
+                out = app(dict({"pixel_values": px, "input_ids": ids}, **hf_inputs))
+                return app.compute_loss(out, [])["loss"]
+        if wl["backward"]:
+            # the gradient all-reduce belongs to a training step (DDP in trainer.py:101-108): buckets of the flat gradient
+            # arena go out while the backward pass is still running; the embedding gradients are those of the global mean
+            # loss, so ranks hold partial sums and the reduction is a SUM
+            loss = app.contrastive_step(px, ids, process_group=pg, backward=True, zero_grad=True, reduce_gradients=world > 1)
+            if opt is not None:
+                opt.step()
+                app._engine.mark_weights_dirty()
+            return loss
+        with torch.no_grad():
+            return app.contrastive_step(px, ids, process_group=pg, backward=False)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+    step_ms = elapsed / steps * 1e3
+
+    # ---- roofline leg: per-launch HIP events around the dominant kernel (untimed extra steps, towers back to back on
+    # one stream so that no two timed kernels share the CUs) ----
+    lib = L.load()
+    roof, extra = None, {}
+    if profile:
+        nprof = 2
+        two = app.two_streams
+        app.two_streams = False
+        step()
+        fence()
+        if rank == 0:
+            L.check(lib.ezclip_profile_begin())
+        for _ in range(nprof):      # every rank steps (the collectives need all of them); only rank 0 records events
+            step()
+        fence()
+        app.two_streams = two
+        if rank == 0:
+            res = {}
+            for cls, kname in ((0, "gemm"), (1, "attention"), (2, "layernorm")):
+                ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+                L.check(lib.ezclip_profile_end(cls, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n)))
+                res[kname] = (ms.value, work.value, n.value)
+            ms, flops, n = res["gemm"]
+            peak = PEAK_TFLOPS[wl["dtype"]]
+            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            traffic = pmc_traffic(name)
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": (traffic or {}).get("bytes_per_launch"),
+                    "traffic_detail": traffic,
+                    "kernel": ("ezclip::gemm_nt_8p_kernel / gemm_tn_8p_kernel (bf16, 256x256x64 8-phase)"
+                               if wl["dtype"] == "bf16" else "ezclip::gemm_nt_kernel<fp32> (128x128, exact-f32 MFMA)"),
+                    "launches_per_step": n // nprof, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
+                    "algorithmic_gflop_per_launch": round(flops / max(n, 1) / 1e9, 3)}
+            # shares of the single-stream step (the timed steps overlap the towers on two streams)
+            extra["time_share"] = {k: round(v[0] / nprof / step_ms, 4) for k, v in res.items()}
+            a_ms, a_fl, a_n = res["attention"]
+            extra["attention_tflops"] = round(a_fl / (a_ms * 1e-3) / 1e12, 2) if a_ms > 0 else None
+            l_ms, l_by, l_n = res["layernorm"]
+            extra["layernorm_gbps"] = round(l_by / (l_ms * 1e-3) / 1e9, 1) if l_ms > 0 else None
+    buckets = getattr(app, "last_grad_buckets", None)
+    two_streams = bool(app.two_streams)
+    del app, opt
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    gflop, gflop_all = gflop_per_pair(wl)
+    value = world * B * steps / elapsed
+    out = {
+        "workload": name, "value": round(value, 2), "ms_per_step": round(step_ms, 3), "dtype": wl["dtype"],
+        "towers": model_name, "pairs_per_gpu": B, "seq_len": S, "path": wl.get("path", "fused"),
+        "stages": "encode_image+encode_text" + ("+allgather" if world > 1 else "") + "+similarity(2 dirs)+InfoNCE"
+                  + ("+backward" if wl["backward"] else "") + ("+grad_allreduce(overlapped)" if wl["backward"] and world > 1 and not autograd else "")
+                  + ("+AdamW+repack" if wl.get("optimizer") else ""),
+        "two_streams": two_streams, "loss": round(loss_val, 5),
+        "gflop_per_pair": {"algorithmic_all_tokens": gflop_all, "executed": round(gflop, 3)},
+        "model_tflops_per_gpu": round(value / world * gflop / 1e3, 2),
+        "model_mfma_frac": round(value / world * gflop / 1e3 / PEAK_TFLOPS[wl["dtype"]], 4),
+        "roofline": roof,
+    }
+    if buckets:
+        out["grad_allreduce_buckets_mib"] = [round((e - s) * 4 / 2 ** 20, 1) for s, e in buckets]
+    out.update(extra)
+    return out
 
 
 def main():
@@ -159,28 +399,30 @@ def main():
     ap.add_argument("--workload", default="bf16_b1024_fwd_loss", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="only the headline workload (no `also` object)")
+    ap.add_argument("--also", default="", help="comma-separated workloads for the `also` object (default: every BASELINE config)")
+    ap.add_argument("--also-steps", type=int, default=5)
+    ap.add_argument("--launcher", action="store_true", help="self-launch under torch.distributed.run even for --gpus 1")
     ap.add_argument("--text-dropout", type=float, default=0.0,
                     help="BERT hidden / attention dropout probability and train() mode (reference default 0.1; BASELINE runs 0)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.launcher):
+        relaunch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                 "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     assert world == max(1, args.gpus), "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)   # "nccl" is RCCL on ROCm
 
     from easynlp_amd import lib as L
-    from easynlp_amd.appzoo.clip import CLIPApp
-
     if os.environ.get("EZCLIP_NO_LNFOLD"):      # A/B switch: separate LayerNorm kernels in the inference path too
         L.check(L.load().ezclip_debug_set(2, 0))
     if os.environ.get("EZCLIP_CLS_LAST"):       # A/B switch: 0 = evaluate the last block of each tower for every token
@@ -189,131 +431,62 @@ def main():
         L.check(L.load().ezclip_debug_set(4, int(os.environ["EZCLIP_CLS_TRAIN"])))
     if os.environ.get("EZCLIP_LNFOLD_MODE"):    # A/B switch: 2 = folded LayerNorm with a separate statistics pass
         L.check(L.load().ezclip_debug_set(2, int(os.environ["EZCLIP_LNFOLD_MODE"])))
-    wl = dict(WORKLOADS[args.workload])
-    if args.batch:
-        wl["batch"] = args.batch
-    B, S = wl["batch"], wl["seq"]
-    model_cfg = VITL14_ROBERTA if wl.get("model") == "vitl14" else VITB16_BERTBASE
-    model_name = ("ViT-L/14 + chinese-roberta-wwm-ext (BERT-base arch)" if wl.get("model") == "vitl14"
-                  else "ViT-B/16 + BERT-base") + " (chinese_clip), random init"
-    if args.text_dropout > 0:
-        model_cfg = dict(model_cfg, text_hidden_dropout_prob=args.text_dropout,
-                         text_attention_probs_dropout_prob=args.text_dropout)
-    if wl.get("model") == "hf_vitl14":
-        app = CLIPApp.from_hf_config(HF_VITL14_ROBERTA, seed=1234, device=device, compute_dtype=wl["dtype"])
-        model_name = "huggingface_clip: frozen ViT-L/14 + chinese-roberta-wwm-ext (BERT-base arch) + pooler, random init"
-    else:
-        app = CLIPApp.from_config(model_cfg, seed=1234, device=device, compute_dtype=wl["dtype"])
-    app.eval()
-    if args.text_dropout > 0:
-        app.train()
-    px, ids = synth_batch(B, S, VITB16_BERTBASE["vocab_size"], device, seed=1000 + rank)
-    pg = True if world > 1 else False
 
-    def step():
-        if wl["backward"]:
-            for p in app.parameters():
-                if p.grad is not None:
-                    p.grad.zero_()
-            loss = app.contrastive_step(px, ids, process_group=pg, backward=True)
-            if world > 1:       # the gradient all-reduce belongs to a training step (DDP in trainer.py:101-108); the embedding
-                from easynlp_amd import parallel as P    # gradients are those of the global mean loss, so ranks hold partial sums
-                P.sum_gradients(list(app.parameters()))
-            return loss
-        with torch.no_grad():
-            return app.contrastive_step(px, ids, process_group=pg, backward=False)
+    if os.environ.get("EZCLIP_RASTER_GM"):      # A/B switch: tile order of the persistent GEMM (0 column-fastest, g super-rows of g)
+        L.check(L.load().ezclip_debug_set(6, int(os.environ["EZCLIP_RASTER_GM"])))
+    if os.environ.get("EZCLIP_FUSE_QKV"):       # A/B switch: 0 = BERT q / k / v as three products
+        L.check(L.load().ezclip_debug_set(7, int(os.environ["EZCLIP_FUSE_QKV"])))
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        loss = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss_val = float(loss.item())
-
-    # ---- roofline leg: per-launch HIP events around the dominant kernel (untimed extra steps) ----
-    lib = L.load()
-    roof = None
-    extra = {}
-    nprof = 2
-    if rank == 0:
-        L.check(lib.ezclip_profile_begin())
-    for _ in range(nprof):      # every rank steps (the collectives need all of them); only rank 0 records events
-        step()
-    fence()
-    if rank == 0:
-        res = {}
-        for cls, name in ((0, "gemm"), (1, "attention"), (2, "layernorm")):
-            ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-            L.check(lib.ezclip_profile_end(cls, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n)))
-            res[name] = (ms.value, work.value, n.value)
-        ms, flops, n = res["gemm"]
-        peak = PEAK_TFLOPS[wl["dtype"]]
-        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": (pmc_traffic(args.workload) or {}).get("bytes_per_launch"),
-                "traffic_detail": pmc_traffic(args.workload),
-                "kernel": ("ezclip::gemm_nt_8p_kernel / gemm_tn_8p_kernel (bf16, 256x256x64 8-phase)"
-                           if wl["dtype"] == "bf16" else "ezclip::gemm_nt_kernel<fp32> (128x128, exact-f32 MFMA)"),
-                "launches_per_step": n // nprof, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
-                "algorithmic_gflop_per_launch": round(flops / max(n, 1) / 1e9, 3)}
-        step_ms = elapsed / args.steps * 1e3
-        extra["time_share"] = {k: round(v[0] / nprof / step_ms, 4) for k, v in res.items()}
-        a_ms, a_fl, a_n = res["attention"]
-        extra["attention_tflops"] = round(a_fl / (a_ms * 1e-3) / 1e12, 2) if a_ms > 0 else None
-        l_ms, l_by, l_n = res["layernorm"]
-        extra["layernorm_gbps"] = round(l_by / (l_ms * 1e-3) / 1e9, 1) if l_ms > 0 else None
+    c = Ctx()
+    c.world, c.rank, c.device = world, rank, device
+    head = run_workload(args.workload, c, args.steps, args.warmup, args.batch, args.text_dropout)
+    also = {}
+    if not args.no_also:
+        names = [n for n in args.also.split(",") if n] or (ALSO_N1 if world == 1 else ALSO_MULTI)
+        for n in names:
+            if n == args.workload:
+                continue
+            try:
+                r = run_workload(n, c, args.also_steps, 2, args.batch, args.text_dropout)
+            except Exception as e:          # one configuration failing (e.g. out of memory) must not lose the headline
+                torch.cuda.empty_cache()
+                r = {"workload": n, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                if world > 1:
+                    raise
+            if rank == 0:
+                keep = ("value", "ms_per_step", "dtype", "path", "stages", "pairs_per_gpu", "loss", "model_tflops_per_gpu",
+                        "model_mfma_frac", "time_share", "grad_allreduce_buckets_mib", "error")
+                also[n] = {k: r[k] for k in keep if k in r}
+                if r.get("roofline"):
+                    also[n]["roofline_frac"] = r["roofline"]["frac"]
+                    also[n]["roofline_achieved_tflops"] = r["roofline"]["achieved"]
 
     if rank == 0:
-        pairs = world * B * args.steps
-        value = pairs / elapsed
-        if wl.get("model") == "hf_vitl14":
-            gflop = GFLOP_TRAIN_PER_PAIR_HF_VITL14
-        elif wl.get("model") == "vitl14":
-            gflop = GFLOP_TRAIN_PER_PAIR_VITL14 if wl["backward"] else GFLOP_FWD_PER_PAIR_VITL14
-        else:
-            cls_last = os.environ.get("EZCLIP_CLS_LAST", "1") != "0"
-            cls_train = os.environ.get("EZCLIP_CLS_TRAIN", "1") != "0"
-            if wl["backward"]:
-                gflop = GFLOP_TRAIN_EXECUTED_PER_PAIR if cls_train else GFLOP_TRAIN_PER_PAIR
-            else:
-                gflop = GFLOP_FWD_EXECUTED_PER_PAIR if cls_last else GFLOP_FWD_PER_PAIR
+        wl = WORKLOADS[args.workload]
         out = {
             "metric": "image-text pairs/sec (fwd+loss) " + ("ViT-L/14+roberta-wwm-ext" if wl.get("model") in ("vitl14", "hf_vitl14")
                                                             else "ViT-B/16+BERT-base"),
-            "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "value": head["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": wl["dtype"], "data": "synthetic",
-            "config": {"workload": args.workload, "towers": model_name,
-                       "pairs_per_gpu": B, "global_batch": world * B, "image": "224x224", "seq_len": S,
-                       "stages": "encode_image+encode_text" + ("+allgather" if world > 1 else "")
-                                 + "+similarity(2 dirs)+InfoNCE" + ("+backward" if wl["backward"] else ""),
+            "dtype": head["dtype"], "data": "synthetic",
+            "config": {"workload": args.workload, "towers": head["towers"],
+                       "pairs_per_gpu": head["pairs_per_gpu"], "global_batch": world * head["pairs_per_gpu"], "image": "224x224",
+                       "seq_len": head["seq_len"], "stages": head["stages"], "path": head["path"],
                        "contrastive_scope": "global" if world > 1 else "local", "parallelism": "dp%d" % world,
-                       "text_dropout": args.text_dropout},
-            "loss": round(loss_val, 5),
-            "gflop_per_pair": {"algorithmic_all_tokens": (GFLOP_TRAIN_PER_PAIR if wl["backward"] else GFLOP_FWD_PER_PAIR)
-                               if wl.get("model") is None else None, "executed": round(gflop, 3)},
-            "model_tflops_per_gpu": round(value / world * gflop / 1e3, 2),
-            "model_mfma_frac": round(value / world * gflop / 1e3 / PEAK_TFLOPS[wl["dtype"]], 4),
-            "roofline": roof,
+                       "two_streams": head["two_streams"], "text_dropout": args.text_dropout},
+            "rccl_ranks": world if use_dist else 0,
         }
-        out.update(extra)
+        for k in ("loss", "gflop_per_pair", "model_tflops_per_gpu", "model_mfma_frac", "roofline", "time_share", "attention_tflops",
+                  "layernorm_gbps", "grad_allreduce_buckets_mib"):
+            if k in head:
+                out[k] = head[k]
+        if also:
+            out["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

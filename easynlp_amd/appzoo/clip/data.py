@@ -122,6 +122,39 @@ def load_wordpiece_tokenizer(vocab_path: str):
     return tok
 
 
+_warned_modes = set()
+
+
+def decoded_pixels(image, size: int, crop: int) -> "np.ndarray":
+    """Decoded PIL image -> the uint8 array that travels to ``ezclip_preprocess_images``.
+
+    RGB and greyscale images go to the GPU as they are (its resampler is Pillow's 8-bit path, bit for bit).  Every other
+    mode -- palette and alpha PNGs, CMYK JPEGs, 16-bit / float images, GIF frames, all common in scraped image-text data --
+    takes the reference's own CPU path for the steps that depend on the mode: ``_resize`` (PIL BICUBIC on the shorter
+    side, IN THE IMAGE'S OWN MODE: nearest for 'P', premultiplied for alpha, 4 channels for CMYK), ``_center_crop``, and
+    the ``convert('RGB')`` that ``_normalize`` starts with (appzoo/clip/data.py:29-72,113-115).  What remains for the
+    GPU is /255 and the normalisation: the resampler sees an image that already has the target size and passes it through
+    unchanged (unit windows), so ``pixel_values`` equal the reference's for these images too."""
+    if image.mode in ("RGB", "L"):
+        return np.asarray(image)
+    if image.mode not in _warned_modes:
+        _warned_modes.add(image.mode)
+        import warnings
+        warnings.warn("image mode %r: resize / crop run on the CPU in that mode (as the reference does) before the GPU "
+                      "pre-processing; RGB / L images are resized on the GPU" % image.mode)
+    from PIL import Image
+    width, height = image.size
+    short, long = (width, height) if width <= height else (height, width)
+    if short != size:                                                              # _resize, data.py:52-72
+        new_short, new_long = size, int(size * long / short)
+        new_w, new_h = (new_short, new_long) if width <= height else (new_long, new_short)
+        image = image.resize((new_w, new_h), Image.BICUBIC)
+    width, height = image.size                                                     # _center_crop, data.py:29-50
+    top, left = int((height - crop + 1) * 0.5), int((width - crop + 1) * 0.5)
+    image = image.crop((left, top, left + crop, top + crop))
+    return np.asarray(image.convert("RGB"))                                        # _normalize's first step, data.py:113-115
+
+
 class CLIPDataset(torch.utils.data.Dataset):
 
     def __init__(self, pretrained_model_name_or_path, data_file, max_seq_length, input_schema=None, first_sequence=None,
@@ -191,10 +224,7 @@ class CLIPDataset(torch.utils.data.Dataset):
         else:
             tk = self.tokenizer([text], padding="max_length", truncation=True, max_length=self.max_text_length,
                                 return_tensors="pt")                                                # data.py:250-253
-        if image.mode not in ("RGB", "L"):
-            raise L.EzclipError("image mode %r is not on the GPU pre-processing path (the reference resizes palette / alpha "
-                                "images in their own mode); convert('RGB') upstream" % image.mode)
-        return {"text": tk, "image": np.asarray(image)}
+        return {"text": tk, "image": decoded_pixels(image, self.size, self.crop_size)}
 
     def batch_fn(self, features):
         """data.py:275-295; the decoded images travel as ``'images'`` (list of uint8 HWC / HW arrays)."""

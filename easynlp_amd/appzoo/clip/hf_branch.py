@@ -143,7 +143,9 @@ class HFState:
         rp = self.params()
         srcs = [n for lst in self.map.packed.values() for n in lst] + list(self.map.transposed.values())
         sig = tuple((rp[n].data_ptr(), rp[n]._version) for n in srcs)
-        if sig != self._sig:
+        # (a backward pass since the last pack: the reference's optimizers step through p.data, which bumps no version
+        # counter -- core/optimizers.py:367,451,462 -- so the derived copies are rebuilt whenever the engine is dirty)
+        if sig != self._sig or self.app._engine._weights_dirty:
             with torch.no_grad():
                 fresh = {lib: torch.cat([rp[n].detach() for n in lst], dim=0) for lib, lst in self.map.packed.items()}
                 fresh.update({lib: rp[ref].detach().t() for lib, ref in self.map.transposed.items()})
@@ -198,9 +200,11 @@ class HFEncodeFn(torch.autograd.Function):
         eng.sync_params(tensors, with_backward=need_grad)
         img = txt = None
         ctx.ws_img = ctx.ws_txt = None
+        from .model import _WsToken
+        ctx.token = _WsToken() if need_grad else None
         if pixels is not None:
             pixels = pixels.contiguous().float()
-            img, ctx.ws_img = eng.encode_image(pixels, need_grad)
+            img, ctx.ws_img = eng.encode_image(pixels, need_grad, owner=ctx.token)
         if ids is not None:
             ids = ids.contiguous().long()
             tt, am = tt.contiguous().long(), am.contiguous().long()
@@ -208,7 +212,7 @@ class HFEncodeFn(torch.autograd.Function):
             ctx.drop = app._next_dropout()
             eng.set_text_dropout(*ctx.drop)
             ctx.extras = (pos, tt, am)
-            txt, ctx.ws_txt = eng.encode_text(ids, need_grad, extras=ctx.extras)
+            txt, ctx.ws_txt = eng.encode_text(ids, need_grad, extras=ctx.extras, owner=ctx.token)
         ctx.app, ctx.pixels, ctx.ids = app, pixels, ids
         ctx.has = (img is not None, txt is not None)
         dev = params[0].device
@@ -233,12 +237,14 @@ class HFEncodeFn(torch.autograd.Function):
             k = tensors[n].numel()
             grads[n] = flat[off:off + k].view(tensors[n].shape)
             off += k + (-k) % 4
-        eng.sync_params(tensors, with_backward=True, grads=grads)
+        eng.sync_params(tensors, with_backward=True, grads=grads, refresh_if_dirty=False)
         if ctx.has[0]:
-            eng.backward_image(ctx.pixels, d_img, ctx.ws_img)      # frozen tower: projection gradients only
+            eng.backward_image(ctx.pixels, d_img.contiguous(), ctx.ws_img)      # frozen tower: projection gradients only
         if ctx.has[1]:
             eng.set_text_dropout(*ctx.drop)
-            eng.backward_text(ctx.ids, d_txt, ctx.ws_txt, extras=ctx.extras)
+            eng.backward_text(ctx.ids, d_txt.contiguous(), ctx.ws_txt, extras=ctx.extras)
+        if ctx.token is not None:
+            ctx.token.released = True
         by_ref = st.map_grads(grads)
         out = []
         for name in app._hf_param_order:

@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import json
 import os
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -106,7 +107,15 @@ class HipClipEngine:
         self._bind_sig = None
         self._content_sig = None
         self._ws: Dict[tuple, torch.Tensor] = {}
-        self._grad_flat: Optional[torch.Tensor] = None
+        self._ws_owner: Dict[tuple, "weakref.ref"] = {}      # save=True workspaces: the autograd ctx token that still needs them
+        # Set by every backward pass: an optimizer step normally follows, and the reference's optimizers update through
+        # ``p.data`` (easynlp/core/optimizers.py:367,451,462), which does NOT bump ``p._version`` -- the packed copies are
+        # refreshed at the next forward whether or not the version counters moved.
+        self._weights_dirty = False
+        self._side: Dict[str, "torch.cuda.Stream"] = {}
+        self._arenas: Dict[str, "P.GradArena"] = {}
+        self._progress_cb = None
+        self.uses_pooler = bool(hf_branch)
         self.embed_dim = int(cfg["embed_dim"])
 
     def __del__(self):
@@ -119,16 +128,20 @@ class HipClipEngine:
 
     # -- parameter binding ---------------------------------------------------------------
     def sync_params(self, params: Dict[str, torch.Tensor], with_backward: bool,
-                    grads: Optional[Dict[str, torch.Tensor]] = None) -> None:
+                    grads: Optional[Dict[str, torch.Tensor]] = None, refresh_if_dirty: bool = True) -> None:
         """(Re)bind device pointers when tensors moved, and refresh the packed
-        weights when the parameter *contents* changed (optimizer step /
-        load_state_dict bump ``_version``)."""
+        weights when the parameter *contents* may have changed: a version counter
+        moved (``load_state_dict``, torch.optim steps), a backward pass ran since
+        the last pack (``p.data`` updates of the reference's optimizers leave
+        ``_version`` alone), or ``mark_weights_dirty()`` was called."""
         plist = [params[n] for n in self.names]
-        bind_sig = (tuple(p.data_ptr() for p in plist),
-                    None if grads is None else tuple((grads[n].data_ptr() if grads.get(n) is not None else 0) for n in self.names))
+        ptrs = tuple(p.data_ptr() for p in plist)
+        gsig = None if grads is None else tuple((grads[n].data_ptr() if grads.get(n) is not None else 0) for n in self.names)
         dev = plist[0].device
         rebound = False
-        if bind_sig != self._bind_sig:
+        # (a call without `grads` -- a forward -- leaves the gradient buffers of the last backward bound: with the persistent
+        # gradient arena the ~400 bind calls happen once, not twice per step)
+        if self._bind_sig is None or ptrs != self._bind_sig[0] or (gsig is not None and gsig != self._bind_sig[1]):
             for n, p in zip(self.names, plist):
                 if not p.is_cuda:
                     raise L.EzclipError("parameter %s is on %s: move the model to a GPU (no CPU path)" % (n, p.device))
@@ -138,8 +151,8 @@ class HipClipEngine:
                 g = grads.get(n) if grads is not None else None
                 L.check(self.lib.ezclip_bind_param(self.handle, n.encode(), L.ptr(p), L.ptr(g), shp, p.dim()),
                         "bind_param(%s)" % n)
-            rebound = self._bind_sig is None or bind_sig[0] != self._bind_sig[0]
-            self._bind_sig = bind_sig
+            rebound = self._bind_sig is None or ptrs != self._bind_sig[0]
+            self._bind_sig = (ptrs, gsig)
         grow = self._shadow is None or (with_backward and not self._shadow_backward) or self._shadow.device != dev
         if grow:
             wb = with_backward or self._shadow_backward
@@ -149,27 +162,85 @@ class HipClipEngine:
             L.check(self.lib.ezclip_set_shadow(self.handle, L.ptr(self._shadow), self._shadow.numel(), 1 if wb else 0),
                     "set_shadow")
         content_sig = tuple(p._version for p in plist)
-        if grow or rebound or content_sig != self._content_sig:
+        if grow or rebound or content_sig != self._content_sig or (self._weights_dirty and refresh_if_dirty):
             L.check(self.lib.ezclip_refresh_weights(self.handle, L.stream_ptr()), "refresh_weights")
             self._content_sig = content_sig
+            self._weights_dirty = False
 
-    def workspace(self, kind: str, batch: int, seq_len: int, save: bool, device) -> torch.Tensor:
+    def mark_weights_dirty(self) -> None:
+        """The parameter values changed in a way torch cannot see (writes through ``p.data`` / raw pointers): re-pack the
+        library's copies at the next forward."""
+        self._weights_dirty = True
+
+    def workspace(self, kind: str, batch: int, seq_len: int, save: bool, device, owner=None) -> torch.Tensor:
+        """The activation workspace of one tower pass.  One buffer per (kind, save) is cached and reused -- except that a
+        ``save=True`` buffer belongs to the forward that filled it until the matching backward has run (``owner``: the
+        token the autograd ctx holds): a second grad-enabled forward in between (two micro-batches whose losses are
+        summed, an extra feature call between forward and backward) gets a buffer of its own instead of overwriting
+        the saved activations."""
         key = (kind, batch, seq_len, save, str(device))
+        if kind == "image":
+            nbytes = self.lib.ezclip_image_workspace_bytes(self.handle, batch, 1 if save else 0)
+        else:
+            nbytes = self.lib.ezclip_text_workspace_bytes(self.handle, batch, seq_len, 1 if save else 0)
         ws = self._ws.get(key)
+        if save and ws is not None:
+            prev = self._ws_owner.get(key)
+            prev = prev() if prev is not None else None
+            if prev is not None and prev is not owner and not prev.released:
+                return L.alloc_bytes(nbytes, device)          # lives as long as the caller's ctx holds it
         if ws is None:
-            if kind == "image":
-                n = self.lib.ezclip_image_workspace_bytes(self.handle, batch, 1 if save else 0)
-            else:
-                n = self.lib.ezclip_text_workspace_bytes(self.handle, batch, seq_len, 1 if save else 0)
-            # keep at most one workspace per (kind, save): batch shape changes are rare
+            # keep at most one cached workspace per (kind, save): batch shape changes are rare
             for k in [k for k in self._ws if k[0] == kind and k[3] == save]:
                 del self._ws[k]
-            ws = L.alloc_bytes(n, device)
+                self._ws_owner.pop(k, None)
+            ws = L.alloc_bytes(nbytes, device)
             self._ws[key] = ws
+        if save:
+            if owner is not None:
+                self._ws_owner[key] = weakref.ref(owner)
+            else:
+                self._ws_owner.pop(key, None)
         return ws
 
+    # -- streams: the two towers are independent until the similarity ----------------------------------
+    def side_stream(self, device) -> "torch.cuda.Stream":
+        """A second HIP stream for the text tower: the image tower's persistent GEMMs leave CUs idle in their last
+        partial round of tiles (2364 tiles on 256 CUs = 9.23 rounds for the N = 768 products), which the other tower's
+        kernels fill when both are in flight."""
+        st = self._side.get(str(device))
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            self._side[str(device)] = st
+        return st
+
+    # -- gradient arena / progress hook -------------------------------------------------------------------
+    def grad_names(self) -> List[str]:
+        """Parameters the backward pass writes: everything but the BertPooler of a chinese_clip model (computed by the
+        reference's BertModel but unused, so its ``.grad`` stays None there too -- modeling_chineseclip.py:349-350)."""
+        return [n for n in self.names if not (n.startswith("bert.pooler.") and not self.uses_pooler)]
+
+    def grad_arena(self, which: str, device) -> "P.GradArena":
+        """'step': contrastive_step's (its views ARE the parameters' ``.grad``); 'autograd': _EncodeFn.backward's (views
+        are handed to autograd and reused once nothing references them any more)."""
+        a = self._arenas.get(which)
+        if a is None or a.flat.device != torch.device(device):
+            a = P.GradArena(self.grad_names(), self.shapes, device, keep_views=(which == "step"))
+            self._arenas[which] = a
+        return a
+
+    def set_progress_hook(self, fn) -> None:
+        """fn(tower, stage) from inside ezclip_backward_* (include/ezclip.h: ezclip_set_backward_progress); None removes it."""
+        if fn is None:
+            self._progress_cb = None
+            L.check(self.lib.ezclip_set_backward_progress(self.handle, None, None), "set_backward_progress")
+            return
+        self._progress_cb = L.PROGRESS_FN(lambda user, tower, stage: fn(int(tower), int(stage)))
+        L.check(self.lib.ezclip_set_backward_progress(self.handle, L.C.cast(self._progress_cb, L.C.c_void_p), None),
+                "set_backward_progress")
+
     # -- forward -----------------------------------------------------------------------------
-    def encode_image(self, pixels: torch.Tensor, save: bool) -> (torch.Tensor, torch.Tensor):
+    def encode_image(self, pixels: torch.Tensor, save: bool, owner=None, stream=None) -> (torch.Tensor, torch.Tensor):
         pixels = pixels.contiguous()
         if pixels.dtype != torch.float32:
             pixels = pixels.float()
@@ -178,26 +249,26 @@ class HipClipEngine:
         if tuple(pixels.shape[1:]) != (3, R, R):
             raise L.EzclipError("pixel_values must be [B,3,%d,%d], got %s" % (R, R, tuple(pixels.shape)))
         out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=pixels.device)
-        ws = self.workspace("image", B, 0, save, pixels.device)
+        ws = self.workspace("image", B, 0, save, pixels.device, owner)
         L.check(self.lib.ezclip_encode_image(self.handle, L.ptr(pixels), B, L.ptr(out), L.ptr(ws), ws.numel(),
-                                             1 if save else 0, L.stream_ptr()), "encode_image")
+                                             1 if save else 0, L.stream_ptr(stream)), "encode_image")
         return out, ws
 
-    def encode_text(self, ids: torch.Tensor, save: bool, extras=None) -> (torch.Tensor, torch.Tensor):
+    def encode_text(self, ids: torch.Tensor, save: bool, extras=None, owner=None, stream=None) -> (torch.Tensor, torch.Tensor):
         """extras: (position_ids, token_type_ids, attention_mask) int64 [B, S] device tensors (huggingface_clip branch)"""
         ids = ids.contiguous()
         if ids.dtype != torch.int64:
             ids = ids.long()
         B, S = ids.shape
         out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=ids.device)
-        ws = self.workspace("text", B, S, save, ids.device)
+        ws = self.workspace("text", B, S, save, ids.device, owner)
         if extras is None:
             L.check(self.lib.ezclip_encode_text(self.handle, L.ptr(ids), B, S, L.ptr(out), L.ptr(ws), ws.numel(),
-                                                1 if save else 0, L.stream_ptr()), "encode_text")
+                                                1 if save else 0, L.stream_ptr(stream)), "encode_text")
         else:
             pos, tt, am = extras
             L.check(self.lib.ezclip_encode_text_ex(self.handle, L.ptr(ids), L.ptr(pos), L.ptr(tt), L.ptr(am), B, S, L.ptr(out),
-                                                   L.ptr(ws), ws.numel(), 1 if save else 0, L.stream_ptr()), "encode_text_ex")
+                                                   L.ptr(ws), ws.numel(), 1 if save else 0, L.stream_ptr(stream)), "encode_text_ex")
         return out, ws
 
     def set_text_dropout(self, hidden_p: float, attn_p: float, seed: int) -> None:
@@ -205,44 +276,76 @@ class HipClipEngine:
         L.check(self.lib.ezclip_set_text_dropout(self.handle, float(hidden_p), float(attn_p), int(seed)),
                 "set_text_dropout")
 
-    def backward_image(self, pixels, d_emb, ws):
-        L.check(self.lib.ezclip_backward_image(self.handle, L.ptr(pixels), pixels.shape[0], L.ptr(d_emb.contiguous()),
-                                               L.ptr(ws), ws.numel(), L.stream_ptr()), "backward_image")
+    def backward_image(self, pixels, d_emb, ws, stream=None):
+        self._weights_dirty = True
+        L.check(self.lib.ezclip_backward_image(self.handle, L.ptr(pixels), pixels.shape[0], L.ptr(d_emb),
+                                               L.ptr(ws), ws.numel(), L.stream_ptr(stream)), "backward_image")
 
-    def backward_text(self, ids, d_emb, ws, extras=None):
+    def backward_text(self, ids, d_emb, ws, extras=None, stream=None):
+        self._weights_dirty = True
         if extras is None:
             L.check(self.lib.ezclip_backward_text(self.handle, L.ptr(ids), ids.shape[0], ids.shape[1],
-                                                  L.ptr(d_emb.contiguous()), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                                                  L.ptr(d_emb), L.ptr(ws), ws.numel(), L.stream_ptr(stream)),
                     "backward_text")
         else:
             pos, tt, am = extras
             L.check(self.lib.ezclip_backward_text_ex(self.handle, L.ptr(ids), L.ptr(pos), L.ptr(tt), L.ptr(am), ids.shape[0],
-                                                     ids.shape[1], L.ptr(d_emb.contiguous()), L.ptr(ws), ws.numel(),
-                                                     L.stream_ptr()), "backward_text_ex")
+                                                     ids.shape[1], L.ptr(d_emb), L.ptr(ws), ws.numel(),
+                                                     L.stream_ptr(stream)), "backward_text_ex")
 
     def set_option(self, key: int, value: float) -> None:
         L.check(self.lib.ezclip_set_option(self.handle, int(key), float(value)), "set_option")
 
 
+class _WsToken:
+    """Ownership of the save-for-backward workspaces of one forward (HipClipEngine.workspace)."""
+    __slots__ = ("released", "__weakref__")
+
+    def __init__(self):
+        self.released = False
+
+
+def _run_towers(eng, two_streams, run_image, run_text):
+    """Enqueue the image tower on the current stream and the text tower on the engine's side stream (``two_streams``) or
+    both on the current stream.  Everything enqueued before is visible to both; on return the current stream has joined
+    the side stream.  Tensors are allocated under the current stream in either case (the callables only pass an explicit
+    stream handle to the library)."""
+    if not two_streams or run_image is None or run_text is None:
+        a = run_image(None) if run_image is not None else None
+        b = run_text(None) if run_text is not None else None
+        return a, b
+    main = torch.cuda.current_stream()
+    side = eng.side_stream(main.device)
+    side.wait_stream(main)
+    b = run_text(side)
+    a = run_image(None)
+    main.wait_stream(side)
+    return a, b
+
+
 class _EncodeFn(torch.autograd.Function):
-    """(pixels, ids, *params) -> (image_embeds, text_embeds); backward runs the HIP
-    backward kernels into a zeroed flat gradient buffer and hands autograd views of it."""
+    """(pixels, ids, *params) -> (image_embeds, text_embeds); backward runs the HIP backward kernels into a flat gradient
+    arena (one memset, completion-ordered: parallel.GradArena) and hands autograd views of it."""
 
     @staticmethod
     def forward(ctx, app, need_grad, pixels, ids, *params):
         eng = app._engine   # (grad mode is always off inside Function.forward: the caller decides need_grad)
         named = dict(zip(eng.names, params))
         eng.sync_params(named, with_backward=need_grad)
-        img = txt = None
         ctx.ws_img = ctx.ws_txt = None
+        ctx.token = _WsToken() if need_grad else None
+        run_i = run_t = None
         if pixels is not None:
             pixels = pixels.contiguous().float()
-            img, ctx.ws_img = eng.encode_image(pixels, need_grad)
+            run_i = lambda st: eng.encode_image(pixels, need_grad, owner=ctx.token, stream=st)
         if ids is not None:
             ids = ids.contiguous().long()
             ctx.drop = app._next_dropout()          # (hidden_p, attn_p, seed); zeros in eval mode
             eng.set_text_dropout(*ctx.drop)
-            txt, ctx.ws_txt = eng.encode_text(ids, need_grad)
+            run_t = lambda st: eng.encode_text(ids, need_grad, owner=ctx.token, stream=st)
+        ri, rt = _run_towers(eng, app.two_streams, run_i, run_t)
+        img, ctx.ws_img = ri if ri is not None else (None, None)
+        txt, ctx.ws_txt = rt if rt is not None else (None, None)
         ctx.app, ctx.pixels, ctx.ids = app, pixels, ids
         ctx.n_params = len(params)
         ctx.has = (img is not None, txt is not None)
@@ -259,19 +362,34 @@ class _EncodeFn(torch.autograd.Function):
         eng = app._engine
         params = dict(zip(eng.names, [app._params[n] for n in eng.names]))
         dev = next(iter(params.values())).device
-        total = sum(p.numel() + (-p.numel()) % 4 for p in params.values())
-        flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        grads, off = {}, 0
-        for n, p in params.items():
-            grads[n] = flat[off:off + p.numel()].view(p.shape)
-            off += p.numel() + (-p.numel()) % 4
-        eng.sync_params(params, with_backward=True, grads=grads)
+        arena = eng.grad_arena("autograd", dev)
+        # The persistent arena is reused when nobody references the views handed out last time any more (the Trainer's
+        # optimizer.zero_grad() dropped them: core/trainer.py:337).  Otherwise -- gradient accumulation, two forwards
+        # feeding one backward -- this pass writes into a buffer of its own and autograd adds it to the live gradients.
+        if not arena.lent():
+            arena.zero()
+            views = arena.make_views(arena.flat)
+        else:
+            _, views = arena.fresh()
+        eng.sync_params(params, with_backward=True, grads=views, refresh_if_dirty=False)
+        run_i = run_t = None
         if ctx.has[0]:
-            eng.backward_image(ctx.pixels, d_img, ctx.ws_img)
+            d_img = d_img.contiguous()
+            run_i = lambda st: eng.backward_image(ctx.pixels, d_img, ctx.ws_img, stream=st)
         if ctx.has[1]:
+            d_txt = d_txt.contiguous()
             eng.set_text_dropout(*ctx.drop)         # the masks of the matching forward
-            eng.backward_text(ctx.ids, d_txt, ctx.ws_txt)
-        out = [grads[n] if params[n].requires_grad else None for n in eng.names]
+            run_t = lambda st: eng.backward_text(ctx.ids, d_txt, ctx.ws_txt, stream=st)
+        _run_towers(eng, app.two_streams, run_i, run_t)
+        if ctx.token is not None:
+            ctx.token.released = True
+        out = []
+        for n in eng.names:
+            # None where the reference's autograd leaves None: frozen parameters, the unused BertPooler, logit_scale (its
+            # gradient comes from the similarity), the tower that did not run
+            tower = P.grad_group(n)[0]
+            ran = tower < 2 and ctx.has[tower]
+            out.append(views[n] if (n in views and ran and params[n].requires_grad) else None)
         return (None, None, None, None) + tuple(out)
 
 
@@ -399,6 +517,10 @@ class CLIPApp(Application):
             raise L.EzclipError("contrastive_scope must be 'local' or 'global', got %r" % self.contrastive_scope)
         self._engine = None
         self._params: Dict[str, nn.Parameter] = {}
+        # image tower on the current stream, text tower on a second one (they meet at the similarity): on by default,
+        # --user_defined_parameters 'clip_two_streams=0' or EZCLIP_TWO_STREAMS=0 runs them back to back
+        self.two_streams = str(kwargs.get("two_streams", udp.get("clip_two_streams", os.environ.get("EZCLIP_TWO_STREAMS", "1")))) \
+            not in ("0", "False", "false")
         if pretrained_model_name_or_path is None:
             return
         path = pretrained_model_name_or_path
@@ -597,7 +719,7 @@ class CLIPApp(Application):
 
     # ------------------------------------------------------------------------------------
     def contrastive_step(self, pixel_values, input_ids, process_group=None, backward=False, token_type_ids=None,
-                         attention_mask=None):
+                         attention_mask=None, zero_grad=False, reduce_gradients=False, bucket_bytes=64 << 20):
         """Fast path without autograd bookkeeping: dual-encoder forward + InfoNCE
         (+ full backward into ``.grad`` when ``backward=True``), one C call per stage.
 
@@ -606,6 +728,12 @@ class CLIPApp(Application):
         evaluates its own rows of both directions (row-local LSE, no second
         collective in the forward), and the embedding gradients are summed back
         with a reduce-scatter.  Returns the (rank-local mean) loss tensor.
+
+        ``zero_grad``: clear the gradients first (one memset of the flat gradient arena the ``.grad`` tensors are views
+        of) instead of accumulating.  ``reduce_gradients``: sum the parameter gradients over the ranks, bucket by bucket
+        WHILE the backward pass runs (parallel.OverlappedGradReducer driven by ezclip_set_backward_progress) -- what
+        DistributedDataParallel does for the reference (core/trainer.py:101-108).  The embedding gradients are those of
+        the global MEAN loss, so the sum is the gradient of that loss.
         """
         import torch.distributed as dist
         eng = self._engine
@@ -614,6 +742,14 @@ class CLIPApp(Application):
         extras, transposed = None, []
         pixel_values = pixel_values.contiguous()
         input_ids = input_ids.contiguous()
+        if pixel_values.dtype != torch.float32:
+            pixel_values = pixel_values.float()
+        if input_ids.dtype != torch.int64:
+            input_ids = input_ids.long()
+        world, rank, pg = 1, 0, None
+        if process_group is not False and dist.is_available() and dist.is_initialized():
+            pg = None if process_group in (None, True) else process_group
+            world, rank = dist.get_world_size(pg), dist.get_rank(pg)
         if hf:
             # huggingface_clip: the library's parameters are views / derived copies of the reference-named ones
             # (hf_branch.py); gradients land in the reference parameters' .grad (projections through a transposed scratch)
@@ -626,6 +762,7 @@ class CLIPApp(Application):
             extras = (HB.position_ids_from_input_ids(input_ids, pad), tt.contiguous(), am.contiguous())
         else:
             params = self._params
+        reducer = None
         if backward:
             grads = {}
             if hf:
@@ -641,25 +778,45 @@ class CLIPApp(Application):
                         p = self._hf_params[st.map.reference_name(n)]
                         if p.grad is None:
                             p.grad = torch.zeros_like(p)
+                        elif zero_grad:
+                            p.grad.zero_()
                         grads[n] = p.grad
+                if zero_grad:
+                    self.logit_scale.grad.zero_()
             else:
-                for n, p in params.items():
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                    grads[n] = p.grad
+                # .grad tensors are views of ONE flat arena in completion order (parallel.GradArena): zeroing is one
+                # memset, an all-reduce bucket is one slice
+                arena = eng.grad_arena("step", pixel_values.device)
+                mine = all(p.grad is None or arena.owns(n, p.grad) for n, p in params.items() if n in arena.views)
+                fresh = [n for n in arena.views if params[n].grad is None]
+                if mine and (zero_grad or len(fresh) == len(arena.views)):
+                    arena.zero()
+                else:
+                    for n in arena.views:
+                        g = params[n].grad
+                        if g is None:
+                            arena.views[n].zero_()
+                        elif zero_grad:
+                            g.zero_()
+                for n in fresh:
+                    params[n].grad = arena.views[n]
+                grads = {n: params[n].grad for n in arena.views}
+                if reduce_gradients and (world > 1 or reduce_gradients == "force"):      # ("force": single-rank hardware tests)
+                    if not all(arena.owns(n, g) for n, g in grads.items()):
+                        raise L.EzclipError("reduce_gradients needs the gradients in the engine's arena: drop foreign "
+                                            ".grad tensors first (optimizer.zero_grad(set_to_none=True))")
+                    reducer = P.OverlappedGradReducer(arena, pg, bucket_bytes)
             eng.sync_params(params, with_backward=True, grads=grads)
         else:
             eng.sync_params(params, with_backward=False)
-        img, ws_i = eng.encode_image(pixel_values, backward)
         drop = self._next_dropout()
         eng.set_text_dropout(*drop)
-        txt, ws_t = eng.encode_text(input_ids, backward, extras=extras)
+        (img, ws_i), (txt, ws_t) = _run_towers(
+            eng, self.two_streams,
+            lambda s_: eng.encode_image(pixel_values, backward, stream=s_),
+            lambda s_: eng.encode_text(input_ids, backward, extras=extras, stream=s_))
         n = img.shape[0]
         e = img.shape[1]
-        world, rank, pg = 1, 0, None
-        if process_group is not False and dist.is_available() and dist.is_initialized():
-            pg = None if process_group in (None, True) else process_group
-            world, rank = dist.get_world_size(pg), dist.get_rank(pg)
         if world > 1:
             img_all, txt_all, _ = P.gather_embeddings(img, txt, pg)     # one RCCL all-gather for both towers
         else:
@@ -686,13 +843,33 @@ class CLIPApp(Application):
             d_img_l, d_txt_l = P.scatter_embedding_grads(d_img, d_txt, n, pg)   # one RCCL reduce-scatter
         else:
             d_img_l, d_txt_l = d_img, d_txt
-        self.logit_scale.grad.add_(d_ls)
-        eng.backward_image(pixel_values, d_img_l, ws_i)
-        eng.set_text_dropout(*drop)
-        eng.backward_text(input_ids, d_txt_l, ws_t, extras=extras)
+        self.logit_scale.grad.add_(d_ls.reshape(self.logit_scale.grad.shape))
+        two = self.two_streams
+        main = torch.cuda.current_stream()
+        side = eng.side_stream(main.device) if two else None
+        if reducer is not None:
+            streams = {0: main, 1: side if two else main}
+
+            def on_progress(tower, stage):        # runs inside ezclip_backward_*: order the bucket behind THAT tower's stream
+                with torch.cuda.stream(streams[tower]):
+                    reducer.notify(tower, stage)
+            reducer.notify(2, P.STAGE_HEAD)       # logit_scale
+            eng.set_progress_hook(on_progress)
+        try:
+            _run_towers(eng, two,
+                        lambda s_: eng.backward_image(pixel_values, d_img_l, ws_i, stream=s_),
+                        lambda s_: eng.backward_text(input_ids, d_txt_l, ws_t, extras=extras, stream=s_))
+        finally:
+            if reducer is not None:
+                eng.set_progress_hook(None)
+        if reducer is not None:
+            reducer.finish()
+            self.last_grad_buckets = list(reducer.buckets)
         for p, scratch in transposed:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
+            elif zero_grad:
+                p.grad.zero_()
             p.grad.add_(scratch.t())
         return loss
 

@@ -21,6 +21,7 @@ from io import BytesIO
 import torch
 
 from ... import lib as L
+from .data import decoded_pixels
 
 
 class Predictor(object):
@@ -95,11 +96,8 @@ class CLIPPredictor(Predictor):
             if blob is not None and "pixel_values" not in record:         # predictor.py:102-103
                 from PIL import Image
                 img = Image.open(BytesIO(base64.urlsafe_b64decode(blob)))
-                if img.mode not in ("RGB", "L"):
-                    # palette / alpha / CMYK images: the reference resizes them in their own mode (nearest for 'P',
-                    # premultiplied for alpha) before convert('RGB'); off this path
-                    raise L.EzclipError("image mode %r is not on the GPU pre-processing path; convert('RGB') upstream" % img.mode)
-                images.append(img)
+                # (palette / alpha / CMYK images: resized and cropped on the CPU in their own mode, as the reference does)
+                images.append(decoded_pixels(img, self.size, self.crop_size))
                 owners.append(record)
         if images:                                                        # predictor.py:104-113, batched on the GPU
             px = L.preprocess_images(images, size=self.size, crop=self.crop_size)

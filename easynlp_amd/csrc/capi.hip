@@ -228,6 +228,13 @@ int ezclip_backward_text(ezclip_handle h, const int64_t* ids, int batch, int seq
   return backward_text(h, ids, batch, seq_len, d_emb, ws, ws_bytes, S(stream));
 }
 
+int ezclip_set_backward_progress(ezclip_handle h, ezclip_progress_fn fn, void* user) {
+  EZ_REQUIRE(h, "ezclip_set_backward_progress: null handle");
+  h->progress_fn = fn;
+  h->progress_user = user;
+  return EZ_OK;
+}
+
 int ezclip_set_option(ezclip_handle h, int key, double value) {
   EZ_REQUIRE(h, "ezclip_set_option: null handle");
   switch (key) {
@@ -310,6 +317,8 @@ int ezclip_debug_set(int key, int value) {
   if (key == 3) { set_cls_last(value); return EZ_OK; }
   if (key == 4) { set_cls_last_train(value); return EZ_OK; }
   if (key == 5) { set_device_resample_tables(value); return EZ_OK; }
+  if (key == 6) { set_gemm_raster(value); return EZ_OK; }
+  if (key == 7) { set_fuse_bert_qkv(value); return EZ_OK; }
   set_error("ezclip_debug_set: unknown key %d", key);
   return EZ_ERR_INVALID;
 }
@@ -327,6 +336,26 @@ int ezclip_op_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, vo
   g.bias = bias; g.R = residual; g.ldr = ldr;
   g.M = m; g.N = n; g.K = k; g.act = act; g.out_f32 = out_f32;
   return gemm_nt(g, dtype, S(stream));
+}
+
+int ezclip_op_gemm_nt_ex(const ezclip_gemm_desc* d, void* stream) {
+  EZ_REQUIRE(d && d->a_dev && d->b_dev && d->c_dev, "ezclip_op_gemm_nt_ex: null argument");
+  GemmArgs g;
+  g.A = d->a_dev; g.lda = d->lda; g.B = d->b_dev; g.ldb = d->ldb; g.C = d->c_dev; g.ldc = d->ldc; g.C2 = d->c2_dev;
+  g.bias = d->bias_dev; g.R = d->residual_dev; g.ldr = d->ldr; g.U = d->u_dev; g.ldu = d->ldu;
+  g.ln_stats = d->ln_stats_dev; g.ln_c1 = d->ln_c1_dev; g.ln_c2 = d->ln_c2_dev;
+  g.rowstat_part = d->rowstat_part_dev; g.colsum = d->colsum_dev;
+  g.alpha = d->alpha; g.M = d->m; g.N = d->n; g.K = d->k; g.act = d->act; g.out_f32 = d->out_f32;
+  const int fk = d->force_kernel;
+  EZ_REQUIRE(fk == -1 || fk == 0 || fk == 2 || fk == 24, "ezclip_op_gemm_nt_ex: force_kernel %d", fk);
+  if (fk >= 2) EZ_REQUIRE(gemm_nt_8p_eligible(g, d->dtype), "ezclip_op_gemm_nt_ex: the 8-phase kernel does not take this problem");
+  set_gemm_variant(fk);
+  const int rc = gemm_nt(g, d->dtype, S(stream));
+  set_gemm_variant(-1);
+  return rc;
+}
+int ezclip_op_layernorm_stats(const void* x, int64_t xs, float eps, int rows, int d, int dtype, float* stats, void* stream) {
+  return layernorm_row_stats(x, xs, eps, rows, d, dtype, stats, S(stream));
 }
 
 int ezclip_op_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc, int m, int n, int k,

@@ -187,11 +187,27 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
       c.rdB[s] = (uint32_t)(wn * 32 + l31) * 128 + ch;
     }
   }
+  // Tile order.  An XCD works on 32 consecutive logical tiles at a time (xcd_remap), and what its L2 has to fetch per
+  // round is one A row panel per distinct tile row + one B panel per distinct tile column.  n-fastest order makes that
+  // 32 / tiles_n rows + tiles_n columns (N = 3072: 2.7 + 12); with raster_gm = g the tiles of g consecutive tile rows are
+  // walked column by column, so a round covers g rows x 32 / g columns (g = 4: 4 + 8) -- fewer panels through the fabric.
+  const int tiles_m = (p.M + 255) >> 8;
   auto tile_origin = [&](int v, int& m0, int& n0) {
     const int t = xcd_remap(v, ntiles);
-    const int tm = t / tiles_n;
+    int tm, tn;
+    if (p.raster_gm > 0) {
+      const int per = p.raster_gm * tiles_n;
+      const int grp = t / per, u = t - grp * per;
+      const int first = grp * p.raster_gm;
+      const int gsz = min(p.raster_gm, tiles_m - first);
+      tn = u / gsz;
+      tm = first + (u - tn * gsz);
+    } else {
+      tm = t / tiles_n;
+      tn = t - tm * tiles_n;
+    }
     m0 = tm << 8;
-    n0 = (t - tm * tiles_n) << 8;
+    n0 = tn << 8;
   };
   // per-lane DMA source offsets of a tile; recomputed from the lane id every time (a handful of integer ops):
   // kept live across the main loop they get spilled, and the reload's compiler-counted vmcnt drains the queue
@@ -591,6 +607,11 @@ bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype) {
 
 int g_gemm8p_ablate = 0;
 void set_gemm8p_ablate(int v) { g_gemm8p_ablate = v; }
+#ifndef EZ_RASTER_GM_DEFAULT
+#define EZ_RASTER_GM_DEFAULT 0
+#endif
+int g_gemm8p_raster = EZ_RASTER_GM_DEFAULT;
+void set_gemm_raster(int gm) { g_gemm8p_raster = gm < 0 ? EZ_RASTER_GM_DEFAULT : gm; }
 
 namespace {
 int g_num_cus = 0;
@@ -611,6 +632,7 @@ int launch_8p(const GemmArgs& p, int tiles, int grid, hipStream_t stream) {
 int gemm_nt_8p(const GemmArgs& p_in, hipStream_t stream) {
   GemmArgs p = p_in;
   p.vec_ok = g_gemm8p_ablate;
+  p.raster_gm = (p.N >> 8) > 1 ? g_gemm8p_raster : 0;
   if (g_num_cus == 0) {
     int dev = 0;
     EZ_HIP(hipGetDevice(&dev));

@@ -42,6 +42,7 @@ struct GemmArgs {
   int act = 0;                                // ezclip::Act
   int out_f32 = 0;                            // bf16 inputs, f32 output
   int vec_ok = 0;                             // (set by the launcher)
+  int raster_gm = 0;                          // (set by the 8-phase launcher) tile order: 0 n-fastest; g > 0: super-rows of g row tiles, m-fastest inside
 };
 // C = act(alpha * exp(scale) * A.B^T + bias) + R
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream);
@@ -53,6 +54,7 @@ int gemm_nt_8p(const GemmArgs& p, hipStream_t stream);
 bool gemm_nt_4w_eligible(const GemmArgs& p, int dtype);
 int gemm_nt_4w(const GemmArgs& p, hipStream_t stream);
 void set_gemm_variant(int v);   // debugging / sweeps: -1 heuristic, 0 = 128x128 tile, 1 = 256x256 tile
+void set_gemm_raster(int gm);   // tile order of the persistent 8-phase kernel (GemmArgs::raster_gm); -1: built-in default
 
 // C[N,K] (+)= A[M,N]^T . B[M,K]   (weight gradients; contraction over rows)
 struct GemmTNArgs {

@@ -39,6 +39,7 @@ struct ezclip_model {
     int fold_g = -1, fold_b = -1, fold_bias = -1;   // param indices of the LN gain / shift and the Linear bias
     void* sf = nullptr;
     float *c1 = nullptr, *c2 = nullptr;
+    bool s_external = false;  // `s` is a slice of a block laid out elsewhere (BertLayer::qkv_s)
   };
   struct VitLayer {
     Weight in_w, out_w, fc_w, proj_w;
@@ -47,6 +48,10 @@ struct ezclip_model {
   struct BertLayer {
     Weight q_w, k_w, v_w, o_w, i_w, d_w;
     int q_b, k_b, v_b, o_b, i_b, d_b, ln1_w, ln1_b, ln2_w, ln2_b;
+    // bf16: the packed query / key / value weights sit back to back ([3H, ldk]: q | k | v rows) next to a packed copy of
+    // the three biases, so the projections run as ONE N = 3H product (or N = 2H for key | value) instead of three N = H ones
+    void* qkv_s = nullptr;
+    float* qkv_bias = nullptr;
   };
   Weight conv_w, vproj_w, tproj_w, pool_w;
   int vproj_b = -1, tproj_b = -1, pool_b = -1;    // optional parameters (huggingface_clip branch): projection biases, pooler
@@ -73,6 +78,11 @@ struct ezclip_model {
   float drop_hidden = 0.f, drop_attn = 0.f;
   uint64_t drop_seed = 0;
 
+  // ezclip_set_backward_progress: host callback after each parameter group's gradient kernels are enqueued
+  ezclip_progress_fn progress_fn = nullptr;
+  void* progress_user = nullptr;
+  void progress(int tower, int stage) const { if (progress_fn) progress_fn(progress_user, tower, stage); }
+
   void* shadow = nullptr;
   size_t shadow_bytes = 0;
   bool shadow_backward = false;
@@ -89,6 +99,7 @@ size_t model_shadow_layout(ezclip_model* m, char* base, bool with_backward);  //
 int model_refresh_weights(ezclip_model* m, hipStream_t stream);
 void set_cls_last_train(int on);     // 1 (default): the same on the training path (forward with save + backward)
 void set_cls_last(int on);           // 1 (default): on the inference path the last block of a tower runs on the CLS rows only
+void set_fuse_bert_qkv(int on);      // 1 (default): BERT q / k / v projections as one product on the bf16 path
 void set_fold_layernorm(int mode);   // 0: separate LayerNorm kernels; 1: folded + row statistics from the producing GEMM; 2: folded + separate statistics pass
 
 size_t image_workspace_bytes(const ezclip_model* m, int B, bool save);

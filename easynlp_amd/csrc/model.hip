@@ -192,6 +192,7 @@ int model_create(const ezclip_config* c, ezclip_model** out, int text_arch) {
       L.d_b = add_param(m, p + "output.dense.bias", {H});
       L.ln2_w = add_param(m, p + "output.LayerNorm.weight", {H});
       L.ln2_b = add_param(m, p + "output.LayerNorm.bias", {H});
+      if (m->dtype == EZCLIP_BF16) L.q_w.s_external = L.k_w.s_external = L.v_w.s_external = true;
       m->bert.push_back(L);
     }
     // chinese_clip: computed by the reference but unused (kept for the checkpoint contract).  huggingface_clip: the text
@@ -224,8 +225,15 @@ static bool needs_pack(const ezclip_model* m, const ezclip_model::Weight& w) {
 size_t model_shadow_layout(ezclip_model* m, char* base, bool with_backward) {
   Arena a(base);
   const size_t esz = dtype_size(m->dtype);
+  for (auto& L : m->bert) {
+    if (!L.q_w.s_external) continue;
+    const size_t one = (size_t)L.q_w.N * L.q_w.ldk * esz;         // (a multiple of 256 bytes: N and ldk are multiples of 64)
+    char* blk = static_cast<char*>(a.take(3 * one));
+    float* fb = a.takef(3 * (size_t)L.q_w.N);
+    if (base) { L.qkv_s = blk; L.qkv_bias = fb; L.q_w.s = blk; L.k_w.s = blk + one; L.v_w.s = blk + 2 * one; }
+  }
   for_each_weight(m, [&](ezclip_model::Weight& w) {
-    void* s = needs_pack(m, w) ? a.take((size_t)w.N * w.ldk * esz) : nullptr;
+    void* s = w.s_external ? w.s : (needs_pack(m, w) ? a.take((size_t)w.N * w.ldk * esz) : nullptr);
     void* st = nullptr;
     // conv1 needs no input gradient (pixels are data)
     if (with_backward && &w != &m->conv_w) st = a.take((size_t)w.K * w.ldn * esz);
@@ -272,6 +280,14 @@ int model_refresh_weights(ezclip_model* m, hipStream_t stream) {
                             : transpose_cast(src, w.K, w.N, w.K, w.st, w.ldn, m->dtype, stream);
     }
   });
+  for (auto& L : m->bert) {
+    if (rc != EZ_OK || L.qkv_bias == nullptr) continue;
+    const int H = L.q_w.N;
+    const int bp[3] = {L.q_b, L.k_b, L.v_b};
+    for (int i = 0; i < 3 && rc == EZ_OK; ++i)
+      rc = check_hip(hipMemcpyAsync(L.qkv_bias + (size_t)i * H, m->P(bp[i]), (size_t)H * 4, hipMemcpyDeviceToDevice, stream),
+                     "hipMemcpyAsync(qkv bias)");
+  }
   if (rc == EZ_OK) m->weights_fresh = true;
   return rc;
 }
@@ -299,6 +315,40 @@ static int linear(const ezclip_model* m, const void* A, int64_t lda, const ezcli
   GemmArgs g = linear_args(m, A, lda, w, bias_p, C, ldc, M, act, R, ldr, C2, out_f32);
   g.rowstat_part = rowstat_part;
   return gemm_nt(g, m->dtype, stream);
+}
+
+#define EZ_TRY(expr)                 \
+  do {                               \
+    int _rc = (expr);                \
+    if (_rc != EZ_OK) return _rc;    \
+  } while (0)
+
+// the same against a raw packed [N, ldb] weight block and bias pointer (fused BERT q | k | v projections)
+static int linear_ptr(const ezclip_model* m, const void* A, int64_t lda, const void* Bw, int64_t ldb, int N, const float* bias,
+                      void* C, int64_t ldc, int M, hipStream_t stream) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.B = Bw; g.ldb = ldb; g.C = C; g.ldc = ldc; g.bias = bias;
+  g.M = M; g.N = N; g.K = (int)ldb;
+  return gemm_nt(g, m->dtype, stream);
+}
+
+static bool g_fuse_bert_qkv = true;
+void set_fuse_bert_qkv(int on) { g_fuse_bert_qkv = on != 0; }
+
+// BertSelfAttention's query / key / value Linear (modeling_bert.py:172-200) into the packed [M, 3H] buffer: one product
+// against the stacked weights where the library holds them back to back (bf16), three otherwise.  first = 1: key and value only.
+static int bert_qkv_proj(const ezclip_model* m, const ezclip_model::BertLayer& Lw, const void* x, int64_t ldx, char* qkv, int M,
+                         int first, hipStream_t stream) {
+  const int H = m->cfg.text_hidden_size;
+  const size_t esz = dtype_size(m->dtype);
+  if (g_fuse_bert_qkv && Lw.qkv_s != nullptr) {
+    const char* w = static_cast<const char*>(Lw.qkv_s) + (size_t)first * H * Lw.q_w.ldk * esz;
+    return linear_ptr(m, x, ldx, w, Lw.q_w.ldk, (3 - first) * H, Lw.qkv_bias + (size_t)first * H, qkv + (size_t)first * H * esz,
+                      3 * H, M, stream);
+  }
+  if (first == 0) EZ_TRY(linear(m, x, ldx, Lw.q_w, Lw.q_b, qkv, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  EZ_TRY(linear(m, x, ldx, Lw.k_w, Lw.k_b, qkv + H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  return linear(m, x, ldx, Lw.v_w, Lw.v_b, qkv + 2 * H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream);
 }
 
 // C = act(LayerNorm(X) . W^T + bias) with the LayerNorm folded into the product (bf16 inference): X is read raw.
@@ -341,12 +391,6 @@ static bool can_emit_rowstats(const ezclip_model* m, const void* A, int64_t lda,
   g.rowstat_part = part;
   return gemm_nt_uses_8p(g, m->dtype);
 }
-
-#define EZ_TRY(expr)                 \
-  do {                               \
-    int _rc = (expr);                \
-    if (_rc != EZ_OK) return _rc;    \
-  } while (0)
 
 // ------------------------------------------------------- image workspace ---
 namespace {
@@ -817,8 +861,7 @@ static int bert_last_layer_cls(ezclip_model* m, const ezclip_model::BertLayer& L
   char* z = a + blk;
   char* x_out = z + blk;
   EZ_TRY(linear(m, b.x_in, (int64_t)L * H, Lw.q_w, Lw.q_b, q_cls, H, B, ACT_NONE, nullptr, 0, nullptr, false, stream));
-  EZ_TRY(linear(m, b.x_in, H, Lw.k_w, Lw.k_b, qkv + H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
-  EZ_TRY(linear(m, b.x_in, H, Lw.v_w, Lw.v_b, qkv + 2 * H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  EZ_TRY(bert_qkv_proj(m, Lw, b.x_in, H, qkv, M, 1, stream));
   AttnArgs at;
   at.k = qkv + H * esz; at.v = qkv + 2 * H * esz;
   at.row_stride = 3 * H;
@@ -842,8 +885,7 @@ static int bert_last_layer_cls_save(ezclip_model* m, const ezclip_model::BertLay
   char* ctx_cls = (char*)b.ctx;
   char* q_cls = ctx_cls + blk;
   EZ_TRY(linear(m, b.x_in, (int64_t)L * H, Lw.q_w, Lw.q_b, q_cls, H, B, ACT_NONE, nullptr, 0, nullptr, false, stream));
-  EZ_TRY(linear(m, b.x_in, H, Lw.k_w, Lw.k_b, qkv + H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
-  EZ_TRY(linear(m, b.x_in, H, Lw.v_w, Lw.v_b, qkv + 2 * H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  EZ_TRY(bert_qkv_proj(m, Lw, b.x_in, H, qkv, M, 1, stream));
   AttnArgs at;
   at.k = qkv + H * esz; at.v = qkv + 2 * H * esz;
   at.row_stride = 3 * H;
@@ -896,9 +938,7 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
     const BertBufs& b = ws.layers[i];
     // BertSelfAttention: separate q/k/v Linear                        :172-200
     char* qkv = (char*)b.qkv;
-    EZ_TRY(linear(m, b.x_in, H, Lw.q_w, Lw.q_b, qkv, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
-    EZ_TRY(linear(m, b.x_in, H, Lw.k_w, Lw.k_b, qkv + H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
-    EZ_TRY(linear(m, b.x_in, H, Lw.v_w, Lw.v_b, qkv + 2 * H * esz, 3 * H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
+    EZ_TRY(bert_qkv_proj(m, Lw, b.x_in, H, qkv, M, 0, stream));
     AttnArgs at;
     at.q = qkv; at.k = qkv + H * esz; at.v = qkv + 2 * H * esz;
     at.row_stride = 3 * H;
@@ -1091,7 +1131,10 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
   // feat = ln_post(x[:,0]) @ proj                                         :248-251
   EZ_TRY(wgrad(m, gfeatT, E, ws.cls_ln, W, m->vproj_w, B, stream));
   if (m->Gp(m->vproj_b)) EZ_TRY(colsum_add(ws.gfeat, E, B, E, m->Gp(m->vproj_b), EZCLIP_F32, stream));
-  if (m->opt_vision_frozen) return EZ_OK;      // image_embeds = vision_outputs[1].detach()   appzoo/clip/model.py:140
+  if (m->opt_vision_frozen) {                  // image_embeds = vision_outputs[1].detach()   appzoo/clip/model.py:140
+    m->progress(0, EZCLIP_STAGE_HEAD);
+    return EZ_OK;
+  }
   EZ_TRY(dgrad(m, gfeatT, E, m->vproj_w, ws.gcls, W, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
   const int nl = m->cfg.vision_layers;
   const void* xl = ws.layers[nl - 1].x_out;
@@ -1102,15 +1145,21 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
     // x_out of the last block is [B, W]; d x_out lands compact in gx (+ the block's c_proj bias gradient)
     EZ_TRY(ln_bwd(m, xl, W, ws.gcls, W, m->lnpost_w, m->lnpost_b, ws.mpost, ws.rpost, ws.gx, W, nullptr, 0, B, W, stream,
                   m->vit[nl - 1].proj_b));
+    m->progress(0, EZCLIP_STAGE_HEAD);         // visual.proj, ln_post
     EZ_TRY(resblock_backward_cls(m, m->vit[nl - 1], ws.layers[nl - 1], bd, bg, nl > 1 ? m->vit[nl - 2].proj_b : -1, stream));
+    m->progress(0, nl - 1);
   } else {
     EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * W * esz, stream));
     // (gx is zero outside the CLS rows: its column sums are the last block's c_proj bias gradient)
     EZ_TRY(ln_bwd(m, xl, (int64_t)Lv * W, ws.gcls, W, m->lnpost_w, m->lnpost_b, ws.mpost, ws.rpost, ws.gx, (int64_t)Lv * W,
                   nullptr, 0, B, W, stream, m->vit[nl - 1].proj_b));
+    m->progress(0, EZCLIP_STAGE_HEAD);
   }
-  for (int i = nl - (cls_train ? 2 : 1); i >= 0; --i)
+  for (int i = nl - (cls_train ? 2 : 1); i >= 0; --i) {
+    // (block i's c_proj bias gradient was written by block i + 1's last LayerNorm backward: everything of block i is final)
     EZ_TRY(resblock_backward(m, m->vit[i], ws.layers[i], bd, bg, i > 0 ? m->vit[i - 1].proj_b : -1, stream));
+    m->progress(0, i);
+  }
   // x = ln_pre(cat(cls, conv(patches)) + pos)                                          :237-242
   EZ_TRY(ln_bwd(m, ws.x0, W, ws.gx, W, m->lnpre_w, m->lnpre_b, ws.m0, ws.r0, ws.gx2, W, nullptr, 0, M, W, stream));
   if (m->Gp(m->pos_p)) EZ_TRY(batch_sum_add(ws.gx2, B, Lv, Lv, W, m->Gp(m->pos_p), dt, stream));
@@ -1129,6 +1178,7 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
       EZ_TRY(add_cols_f32(m->Gp(m->conv_w.p), m->Kpatch, ws.gconv, m->Kpad, W, m->Kpatch, stream));
     }
   }
+  m->progress(0, EZCLIP_STAGE_EMBED);          // class / positional embedding, conv1, ln_pre
   return EZ_OK;
 }
 
@@ -1191,15 +1241,19 @@ static int backward_text_clip(ezclip_model* m, const int64_t* ids, int B, int L,
   // d x_eot (+ the last block's c_proj bias gradient = its column sums: every other row of d x is zero)
   EZ_TRY(ln_bwd(m, ws.eot_rows, W, ws.gcls, W, m->lnf_w, m->lnf_b, ws.mpost, ws.rpost, ws.geot, W, nullptr, 0, B, W, stream,
                 m->ttx[nl - 1].proj_b));
+  m->progress(1, EZCLIP_STAGE_HEAD);           // text_projection, ln_final
   EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * W * esz, stream));
   EZ_TRY(gather_rows(ws.geot, ws.eot, ws.gx, B, L, W, 1, dt, stream));
   const BlockDims bd{M, W, B, L, m->theads, 1};
   const BlockGrads bg{ws.gx, ws.gx2, ws.gtmp, ws.gqkv, ws.gbig, ws.gbpart};
-  for (int i = nl - 1; i >= 0; --i)
+  for (int i = nl - 1; i >= 0; --i) {
     EZ_TRY(resblock_backward(m, m->ttx[i], ws.layers[i], bd, bg, i > 0 ? m->ttx[i - 1].proj_b : -1, stream));
+    m->progress(1, i);
+  }
   // x = token_embedding[ids] + positional_embedding: index-add and batch sum of d x
   if (m->Gp(m->tok_p)) EZ_TRY(bert_word_grad(ids, ws.gx, m->Gp(m->tok_p), M, W, m->cfg.vocab_size, dt, stream, -1));
   if (m->Gp(m->tpos2_p)) EZ_TRY(batch_sum_add(ws.gx, B, L, L, W, m->Gp(m->tpos2_p), dt, stream));
+  m->progress(1, EZCLIP_STAGE_EMBED);
   return EZ_OK;
 }
 
@@ -1242,7 +1296,11 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     EZ_TRY(dgrad(m, gfeatT, E, m->tproj_w, ws.gx, xl_ld, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
     EZ_TRY(wgrad(m, gfeatT, E, xl, xl_ld, m->tproj_w, B, stream));
   }
-  if (cls_train) EZ_TRY(bert_last_layer_cls_backward(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws, B, L, stream));
+  m->progress(1, EZCLIP_STAGE_HEAD);           // text_projection (+ bias), pooler
+  if (cls_train) {
+    EZ_TRY(bert_last_layer_cls_backward(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws, B, L, stream));
+    m->progress(1, nlayers - 1);
+  }
   for (int i = nlayers - (cls_train ? 2 : 1); i >= 0; --i) {
     const auto& Lw = m->bert[i];
     const BertBufs& b = ws.layers[i];
@@ -1297,6 +1355,7 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
       EZ_TRY(bgrad(m, gq + H * esz, 3 * H, M, H, Lw.k_b, stream));
       EZ_TRY(bgrad(m, gq + 2 * H * esz, 3 * H, M, H, Lw.v_b, stream));
     }
+    m->progress(1, i);
   }
   // embeddings: dropout(LN(word[ids] + type[0] + pos[t]))                       modeling_bert.py:117-128
   if (hp > 0.f) EZ_TRY(dropout_rows(ws.gx, H, nullptr, 0, ws.gx, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream));
@@ -1314,6 +1373,7 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     else
       EZ_TRY(batch_sum_add(ws.gx2, B, L, L, H, m->Gp(m->tpos_p), dt, stream));
   }
+  m->progress(1, EZCLIP_STAGE_EMBED);
   return EZ_OK;
 }
 

@@ -40,6 +40,19 @@ class EzclipImageDesc(C.Structure):
 
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 
+# ezclip_progress_fn (include/ezclip.h): void (*)(void* user, int tower, int stage)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)
+STAGE_HEAD, STAGE_EMBED = 1000000, -1
+
+
+class EzclipGemmDesc(C.Structure):
+    """ezclip_gemm_desc (include/ezclip.h)"""
+    _fields_ = [("a", _vp), ("lda", _i64), ("b", _vp), ("ldb", _i64), ("c", _vp), ("ldc", _i64), ("c2", _vp),
+                ("bias", _vp), ("residual", _vp), ("ldr", _i64), ("u", _vp), ("ldu", _i64),
+                ("ln_stats", _vp), ("ln_c1", _vp), ("ln_c2", _vp), ("rowstat_part", _vp), ("colsum", _vp),
+                ("alpha", _f), ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("act", C.c_int32),
+                ("dtype", C.c_int32), ("out_f32", C.c_int32), ("force_kernel", C.c_int32)]
+
 # name -> (restype, argtypes): every symbol include/ezclip.h declares
 SIGNATURES = {
     "ezclip_last_error": (C.c_char_p, []),
@@ -69,6 +82,9 @@ SIGNATURES = {
     "ezclip_profile_begin": (_i, []),
     "ezclip_profile_end": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "ezclip_op_gemm_nt": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
+    "ezclip_op_gemm_nt_ex": (_i, [C.POINTER(EzclipGemmDesc), _vp]),
+    "ezclip_op_layernorm_stats": (_i, [_vp, _i64, _f, _i, _i, _i, _vp, _vp]),
+    "ezclip_set_backward_progress": (_i, [_vp, _vp, _vp]),
     "ezclip_op_gemm_tn": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "ezclip_op_layernorm": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     "ezclip_op_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -123,8 +139,9 @@ def check(rc: int, what: str = "") -> None:
         raise EzclipError("%s failed (rc=%d): %s" % (what or "ezclip call", rc, last_error()))
 
 
-def stream_ptr() -> int:
-    return int(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(stream=None) -> int:
+    """hipStream_t of a torch stream (default: the current one)."""
+    return int((stream if stream is not None else torch.cuda.current_stream()).cuda_stream)
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -175,6 +192,39 @@ def op_gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, residual=None, act=A
                                 ptr(residual), residual.stride(0) if residual is not None else 0, M, N, K, act, dt,
                                 1 if (out_f32 and dt == DTYPE_BF16) else 0, stream_ptr()), "op_gemm_nt")
     return c
+
+
+def op_gemm_nt_ex(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor] = None, bias=None, residual=None, u=None,
+                  c2=None, ln_stats=None, ln_c1=None, ln_c2=None, rowstat_part=None, colsum=None, act=ACT_NONE,
+                  alpha: float = 1.0, force_kernel: int = -1) -> torch.Tensor:
+    """Every epilogue of the NT GEMM (ezclip_op_gemm_nt_ex); force_kernel: -1 heuristic, 0 128x128, 2 persistent 8-phase,
+    24 8-phase with one workgroup per tile."""
+    lib = load()
+    dt = DTYPE_BF16 if a.dtype == torch.bfloat16 else DTYPE_F32
+    M, K = a.shape
+    N = b.shape[0]
+    if c is None:
+        c = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    d = EzclipGemmDesc()
+    d.a, d.lda, d.b, d.ldb, d.c, d.ldc = ptr(a) if a.is_contiguous() else a.data_ptr(), a.stride(0), ptr(b), b.stride(0), ptr(c), c.stride(0)
+    d.c2, d.bias = ptr(c2), ptr(bias)
+    d.residual, d.ldr = ptr(residual), (residual.stride(0) if residual is not None else 0)
+    d.u, d.ldu = ptr(u), (u.stride(0) if u is not None else 0)
+    d.ln_stats, d.ln_c1, d.ln_c2 = ptr(ln_stats), ptr(ln_c1), ptr(ln_c2)
+    d.rowstat_part, d.colsum = ptr(rowstat_part), ptr(colsum)
+    d.alpha, d.m, d.n, d.k, d.act, d.dtype, d.out_f32, d.force_kernel = float(alpha), M, N, K, int(act), dt, 0, int(force_kernel)
+    check(lib.ezclip_op_gemm_nt_ex(C.byref(d), stream_ptr()), "op_gemm_nt_ex")
+    return c
+
+
+def op_layernorm_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
+    """[rows, 2] float32: (rstd, -mean * rstd) of LayerNorm over the last dim."""
+    lib = load()
+    dt = DTYPE_BF16 if x.dtype == torch.bfloat16 else DTYPE_F32
+    out = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
+    check(lib.ezclip_op_layernorm_stats(ptr(x), x.stride(0), float(eps), x.shape[0], x.shape[1], dt, ptr(out), stream_ptr()),
+          "op_layernorm_stats")
+    return out
 
 
 def op_layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float, want_stats=False):

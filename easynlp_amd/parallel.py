@@ -9,7 +9,8 @@ contributions to *all* rows; ONE reduce-scatter (sum) returns the rows it owns.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+import re
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -86,3 +87,151 @@ def average_gradients(params, group=None, bucket_bytes: int = 256 << 20, average
             flush()
             bucket, size = [], 0
     flush()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Gradient arena + overlapped all-reduce (the data-parallel half of a training step; reference: the bucketed
+# all-reduce hooks of DistributedDataParallel that easynlp/core/trainer.py:101-108 wraps the model in).
+#
+# The library finishes the gradients group by group -- head, block L-1 ... block 0, embeddings, image tower first, then
+# the text tower -- and says so through ``ezclip_set_backward_progress``.  ``GradArena`` lays every gradient out in ONE
+# flat float32 buffer in exactly that order, so "the groups finished so far" is always one contiguous byte range:
+# zeroing the gradients is one memset, and a bucket of the all-reduce is one slice (no ``torch.cat`` staging copies).
+# ``OverlappedGradReducer`` turns progress notifications into asynchronous all-reduces of such slices while the
+# backward kernels of the remaining groups are still running.  Buckets are float32 (the gradients' own dtype: the sum is
+# what DDP would produce); over xGMI a ring all-reduce is per-link bound, so buckets are few and large (64 MiB default).
+
+STAGE_HEAD, STAGE_EMBED = 1000000, -1          # include/ezclip.h: EZCLIP_STAGE_HEAD / EZCLIP_STAGE_EMBED
+_LAYER_RE = re.compile(r"(?:^|\.)(?:resblocks|layer|layers)\.(\d+)\.")
+_HEAD_NAMES = ("visual.proj", "visual.proj_bias", "visual.ln_post.weight", "visual.ln_post.bias", "text_projection",
+               "text_projection_bias", "ln_final.weight", "ln_final.bias", "bert.pooler.dense.weight",
+               "bert.pooler.dense.bias")
+
+
+def grad_group(name: str) -> Tuple[int, int]:
+    """(tower, stage) of a library parameter name: the progress notification after which its gradient is final.
+    tower 0 image / 1 text / 2 neither (logit_scale: written by the contrastive step itself, before either tower)."""
+    if name == "logit_scale":
+        return (2, STAGE_HEAD)
+    tower = 0 if name.startswith("visual.") else 1
+    if name in _HEAD_NAMES:
+        return (tower, STAGE_HEAD)
+    m = _LAYER_RE.search(name)
+    if m:
+        return (tower, int(m.group(1)))
+    return (tower, STAGE_EMBED)
+
+
+def _completion_key(group: Tuple[int, int]):
+    tower, stage = group
+    t = {2: 0, 0: 1, 1: 2}[tower]                 # logit_scale, image tower, text tower
+    s = 0 if stage == STAGE_HEAD else (10 ** 9 if stage == STAGE_EMBED else 10 ** 6 - stage)
+    return (t, s)
+
+
+class GradArena:
+    """One flat float32 buffer for the gradients of ``names`` (shapes ``shapes``), grouped in completion order."""
+
+    def __init__(self, names: Sequence[str], shapes: Dict[str, tuple], device, align: int = 64, keep_views: bool = True):
+        groups: Dict[Tuple[int, int], List[str]] = {}
+        for n in names:
+            groups.setdefault(grad_group(n), []).append(n)
+        self.group_order = sorted(groups, key=_completion_key)
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        self.group_range: Dict[Tuple[int, int], Tuple[int, int]] = {}
+        off = 0
+        for g in self.group_order:
+            start = off
+            for n in groups[g]:
+                k = 1
+                for d in shapes[n]:
+                    k *= int(d)
+                self.offsets[n] = (off, k)
+                off += k + (-k) % 4                      # every view 16-byte aligned (ezclip_bind_param)
+            off += (-off) % align                        # every group 256-byte aligned
+            self.group_range[g] = (start, off)
+        self.total = off
+        self.shapes = {n: tuple(int(d) for d in shapes[n]) for n in names}
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.views = self.make_views(self.flat) if keep_views else {}
+        self._base_refs = self._storage_refs()
+
+    def _storage_refs(self) -> int:
+        fn = getattr(torch._C, "_storage_Use_Count", None)
+        return int(fn(self.flat.untyped_storage()._cdata)) if fn is not None else -1
+
+    def lent(self) -> bool:
+        """Does anything besides the arena itself still reference its memory (views handed to autograd that live on as
+        ``.grad``, or sit in the engine waiting to be accumulated)?  Unknown (no storage use count in this torch) = yes."""
+        n = self._storage_refs()
+        return n < 0 or n > self._base_refs
+
+    def make_views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return {n: flat[o:o + k].view(self.shapes[n]) for n, (o, k) in self.offsets.items()}
+
+    def fresh(self) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """A second, zeroed buffer with the same layout (a backward pass whose results autograd must ADD to live gradients)."""
+        flat = torch.zeros(self.total, dtype=torch.float32, device=self.flat.device)
+        return flat, self.make_views(flat)
+
+    def zero(self) -> None:
+        self.flat.zero_()
+
+    def owns(self, name: str, t: Optional[torch.Tensor]) -> bool:
+        v = self.views.get(name)
+        return t is not None and v is not None and t.data_ptr() == v.data_ptr() and t.shape == v.shape
+
+
+class OverlappedGradReducer:
+    """All-reduce (sum) the arena's gradients over ``group`` while the backward pass is still running.
+
+    ``notify(tower, stage)`` is called (from the library's progress hook) when a group's kernels have been enqueued; once
+    the finished-but-unsent range reaches ``bucket_bytes`` it is all-reduced asynchronously -- on RCCL that runs on the
+    process group's own stream, ordered behind everything enqueued so far on the current stream.  ``finish()`` sends the
+    rest, waits for every bucket (the current stream then waits for the collectives) and applies ``scale``."""
+
+    def __init__(self, arena: GradArena, group=None, bucket_bytes: int = 64 << 20, scale: float = 1.0,
+                 all_reduce: Optional[Callable] = None):
+        self.arena, self.group, self.bucket_bytes, self.scale = arena, group, int(bucket_bytes), float(scale)
+        self._all_reduce = all_reduce or (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        self.reset()
+
+    def reset(self) -> None:
+        self._done = set()
+        self._sent = 0                 # element offset up to which buckets have been launched
+        self._works: List = []
+        self.buckets: List[Tuple[int, int]] = []
+
+    def _frontier(self) -> int:
+        end = self._sent
+        for g in self.arena.group_order:
+            s, e = self.arena.group_range[g]
+            if e <= end:
+                continue
+            if g not in self._done:
+                break
+            end = e
+        return end
+
+    def _launch(self, upto: int) -> None:
+        if upto <= self._sent:
+            return
+        self.buckets.append((self._sent, upto))
+        self._works.append(self._all_reduce(self.arena.flat[self._sent:upto]))
+        self._sent = upto
+
+    def notify(self, tower: int, stage: int) -> None:
+        self._done.add((tower, stage))
+        end = self._frontier()
+        if (end - self._sent) * 4 >= self.bucket_bytes:
+            self._launch(end)
+
+    def finish(self) -> None:
+        """Every group is final (the backward calls have returned): send what is left, wait, scale."""
+        self._launch(self.arena.total)
+        for w in self._works:
+            if w is not None:
+                w.wait()
+        if self.scale != 1.0:
+            self.arena.flat.mul_(self.scale)
+        self._works = []

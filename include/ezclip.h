@@ -199,6 +199,19 @@ int ezclip_backward_text(ezclip_handle h, const int64_t* input_ids_dev, int batc
                          const float* d_embeds_dev, void* workspace_dev, size_t workspace_bytes,
                          void* stream);
 
+/* Progress of a running ezclip_backward_image / ezclip_backward_text: `fn(user, tower, stage)` is called ON THE HOST,
+ * from inside the backward call, each time every kernel that writes the gradients of one parameter group has been
+ * ENQUEUED on the stream (nothing is synchronised: the caller records an event / starts a collective ordered behind the
+ * stream).  tower: 0 image, 1 text.  stage: EZCLIP_STAGE_HEAD (projection, ln_post / ln_final, pooler), then the layer
+ * index L-1 ... 0 (all parameters of that block), then EZCLIP_STAGE_EMBED (embedding tables, ln_pre / embedding
+ * LayerNorm, conv1) -- the order in which the groups' gradients become final.  This is the hook a data-parallel caller
+ * uses to overlap the gradient all-reduce with the rest of the backward pass, as DistributedDataParallel's bucket
+ * hooks do for the reference (easynlp/core/trainer.py:101-108).  fn = NULL removes the hook. */
+#define EZCLIP_STAGE_HEAD 1000000
+#define EZCLIP_STAGE_EMBED (-1)
+typedef void (*ezclip_progress_fn)(void* user, int tower, int stage);
+int ezclip_set_backward_progress(ezclip_handle h, ezclip_progress_fn fn, void* user);
+
 /* ---- input pipeline (image half) ---------------------------------------------------- */
 /* CLIPDataset.convert_single_row_to_example's image branch on the GPU (easynlp/appzoo/clip/data.py:256-262):
  * _resize (:52-72, PIL BICUBIC, shorter side -> size) -> _center_crop (:29-50) -> _normalize (:101-135: /255,
@@ -245,7 +258,9 @@ int ezclip_recall_ranks(const float* text_dev, const float* image_dev, int n, in
  * 2 8-phase, 3 4-wave 256x128);  key 1: attention kernels (-1 heuristic, 0 general two-pass kernels only);
  * key 2: LayerNorm folding on the bf16 inference path (0 off, 1 folded + statistics from the producing GEMM, 2 folded +
  * separate statistics pass);  key 3: last-block CLS-only evaluation on the inference path (1 on, 0 off);  key 4: the same on the training path;  key 5: resampling window
- * tables of ezclip_preprocess_images built on the device (1, default) or on the host (0). */
+ * tables of ezclip_preprocess_images built on the device (1, default) or on the host (0);  key 6: tile order of the persistent
+ * GEMM (0 column-fastest, g > 0 super-rows of g row tiles walked column by column, -1 the built-in default);  key 7: BERT
+ * query / key / value projections as one N = 3 * hidden product on the bf16 path (1, default) or three products (0). */
 int ezclip_debug_set(int key, int value);
 int ezclip_profile_begin(void);
 int ezclip_profile_end(int kernel_class, double* total_ms, double* total_work, int* launches);
@@ -254,6 +269,31 @@ int ezclip_profile_end(int kernel_class, double* total_ms, double* total_work, i
 int ezclip_op_gemm_nt(const void* a_dev, int64_t lda, const void* b_dev, int64_t ldb, void* c_dev, int64_t ldc,
                       const float* bias_dev, const void* residual_dev, int64_t ldr, int m, int n, int k,
                       int act, int dtype, int out_f32, void* stream);
+/* Every epilogue of the NT GEMM (what the towers use internally), for parity tests at full size:
+ *   C = act(alpha * A.B^T + bias) + R                         (c2_dev: also the value before act / residual)
+ *   C = (alpha * A.B^T) * act'(U)                              (u_dev; colsum_dev[n] += sum_m C[m][n], f32 [n])
+ *   C = act(rstd_m * (A.B^T) - rstd_m mean_m c1[n] + c2[n])   (ln_stats_dev [m][2] = (rstd, -mean rstd), ln_c1 / ln_c2 [n])
+ *   rowstat_part_dev [m][n / 64][2]: per row and 64-column slab (sum, sum of squares) of the rounded outputs (with R only)
+ * force_kernel: -1 heuristic, 0 the 128x128 kernel, 2 the persistent 8-phase kernel, 24 the 8-phase kernel launched with
+ * one workgroup per tile (no persistent loop).  Unsupported combinations return an error (no silent fallback). */
+typedef struct ezclip_gemm_desc {
+  const void* a_dev; int64_t lda;       /* [m, k] */
+  const void* b_dev; int64_t ldb;       /* [n, k] */
+  void* c_dev; int64_t ldc;             /* [m, n] */
+  void* c2_dev;                         /* optional [m, n] (ldc) */
+  const float* bias_dev;                /* optional [n] */
+  const void* residual_dev; int64_t ldr;
+  const void* u_dev; int64_t ldu;
+  const float* ln_stats_dev; const float* ln_c1_dev; const float* ln_c2_dev;
+  float* rowstat_part_dev;
+  float* colsum_dev;
+  float alpha;
+  int32_t m, n, k, act, dtype, out_f32, force_kernel;
+} ezclip_gemm_desc;
+int ezclip_op_gemm_nt_ex(const ezclip_gemm_desc* d, void* stream);
+/* stats[row] = (rstd, -mean * rstd) of LayerNorm(x[row]) -- the operand of the folded-LayerNorm epilogue */
+int ezclip_op_layernorm_stats(const void* x_dev, int64_t x_stride, float eps, int rows, int d, int dtype, float* stats_dev,
+                              void* stream);
 int ezclip_op_gemm_tn(const void* a_dev, int64_t lda, const void* b_dev, int64_t ldb, float* c_dev, int64_t ldc,
                       int m, int n, int k, int accumulate, int dtype, void* stream);
 int ezclip_op_layernorm(const void* x_dev, int64_t x_stride, void* y_dev, int64_t y_stride, const float* g_dev,

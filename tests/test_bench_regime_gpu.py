@@ -1,0 +1,273 @@
+"""Parity in the regime bench.py runs in (GPU).
+
+The headline workloads launch the persistent 8-phase GEMM with thousands of 256 x 256 tiles on 256 CUs: the
+multi-tile loop (next tile's LDS-DMA issued under the epilogue, the relaxed first-K-tile wait, the XCD-aware raster
+over rounds -- gemm8p.hip) is the only path they execute, and it only exists when a launch has more tiles than CUs.
+These tests assert numerics THERE:
+
+* op level -- every epilogue the towers use (bias / activation / residual, row-stat partials, second pre-activation
+  output, act'(U) with fused column sums, folded LayerNorm) at M ~ 70 000 ragged rows (274 row tiles x 3..12 column
+  tiles = 822..3288 tiles): bit-equal to the 128 x 128 kernel where that kernel has the epilogue, bit-equal to the same
+  kernel launched one workgroup per tile (no persistent loop) everywhere, and within bf16 rounding of an fp64
+  evaluation on sampled rows;  the weight-gradient kernel at full contraction length;
+* model level -- ViT-B/16 + BERT-base at 64 and 256 pairs: the bf16 pipeline against the fp32 pipeline (which the
+  small-batch tests pin to the real reference at 1e-5) and the CPU oracle on a 16-pair sample; loss and the gradient of
+  every parameter.
+
+Reference semantics: modeling_chineseclip.py:184-253 (ViT blocks), modeling_bert.py:349-526 (BERT layers).
+"""
+import math
+
+import pytest
+import torch
+
+from easynlp_amd import lib as L
+from oracle import clip_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+M_BIG = 70011            # 274 row tiles, the last one ragged (123 rows)
+
+
+def _inputs(M, N, K, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    a = (torch.randn(M, K, generator=g, device=DEV) * 0.5).bfloat16()
+    b = (torch.randn(N, K, generator=g, device=DEV) * 0.2).bfloat16()
+    bias = torch.randn(N, generator=g, device=DEV)
+    res = torch.randn(M, N, generator=g, device=DEV).bfloat16()
+    u = torch.randn(M, N, generator=g, device=DEV).bfloat16()
+    return a, b, bias, res, u
+
+
+def _rows(M, n=48, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randint(0, M, (n,), generator=g)
+    idx[0], idx[1], idx[2] = 0, M - 1, (M // 256) * 256          # first row, last (ragged tile), first row of the ragged tile
+    return idx.to(DEV)
+
+
+def _act64(z, act):
+    if act == L.ACT_QUICKGELU:
+        return O.quick_gelu(z)
+    if act == L.ACT_GELU_ERF:
+        return O.gelu_erf(z)
+    return z
+
+
+def _act_grad64(u, act):
+    u = u.clone().requires_grad_(True)
+    _act64(u, act).sum().backward()
+    return u.grad
+
+
+def _tiles(M, N):
+    return ((M + 255) // 256) * (N // 256)
+
+
+@pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (768, 3072)])
+@pytest.mark.parametrize("epi", ["bias", "bias_res_ps", "bias_qgelu", "bias_gelu_c2", "u_qgelu_colsum", "u_gelu_colsum"])
+def test_gemm_nt_persistent_regime(N, K, epi):
+    M = M_BIG
+    assert _tiles(M, N) > 3 * 256          # at least three rounds of tiles on a 256-CU part
+    a, b, bias, res, u = _inputs(M, N, K, seed=N + K)
+    act = L.ACT_QUICKGELU if "qgelu" in epi else (L.ACT_GELU_ERF if "gelu" in epi else L.ACT_NONE)
+    kw = dict(act=act)
+    if epi.startswith("u_"):
+        kw["u"] = u                       # dX = (dY . W) * act'(U); colsum = the bias gradient
+    else:
+        kw["bias"] = bias
+    if "res" in epi:
+        kw["residual"] = res
+    outs = {}
+    for fk in (0, 2, 24):
+        extra = {}
+        if "ps" in epi and fk != 0:
+            extra["rowstat_part"] = torch.full((M, N // 64, 2), float("nan"), device=DEV)
+        if "c2" in epi:
+            extra["c2"] = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        if "colsum" in epi:
+            extra["colsum"] = torch.zeros(N, device=DEV)
+        c = L.op_gemm_nt_ex(a, b, force_kernel=fk, **kw, **extra)
+        torch.cuda.synchronize()
+        outs[fk] = (c, extra)
+    c0, c2, c24 = outs[0][0], outs[2][0], outs[24][0]
+    assert torch.equal(c2, c24), "persistent multi-tile loop differs from one-workgroup-per-tile launches"
+    assert torch.equal(c2, c0), "8-phase kernel differs from the 128x128 kernel"
+    if "c2" in epi:
+        assert torch.equal(outs[2][1]["c2"], outs[0][1]["c2"]) and torch.equal(outs[2][1]["c2"], outs[24][1]["c2"])
+    # fp64 on sampled rows
+    idx = _rows(M)
+    z = a[idx].double() @ b.double().t()
+    if epi.startswith("u_"):
+        ref = z * _act_grad64(u[idx].double(), act)
+    else:
+        ref = _act64(z + bias.double(), act)
+        if "c2" in epi:
+            pre = z + bias.double()
+            assert float((outs[2][1]["c2"][idx].double() - pre).abs().max()) < 0.06 * max(1.0, math.sqrt(K) / 8)
+    if "res" in epi:
+        ref = ref + res[idx].double()
+    tol = 0.06 * max(1.0, math.sqrt(K) / 8)
+    assert float((c2[idx].double() - ref).abs().max()) < tol
+    if "colsum" in epi:
+        # fused (atomics per wave tile) vs the separate column-sum pass of the other kernel vs fp64 of the rounded output
+        exact = c2.double().sum(0)
+        for fk in (0, 2, 24):
+            got = outs[fk][1]["colsum"].double()
+            assert float((got - exact).abs().max()) < 2e-3 * float(exact.abs().max() + c2.double().abs().sum(0).max() * 1e-3)
+    if "ps" in epi:
+        part = outs[2][1]["rowstat_part"]
+        assert torch.equal(part, outs[24][1]["rowstat_part"])
+        cs = c2.float().reshape(M, N // 64, 64)
+        s1, s2 = cs.double().sum(-1), (cs.double() ** 2).sum(-1)
+        assert float((part[..., 0].double() - s1).abs().max()) < 1e-3 * max(1.0, float(s1.abs().max()))
+        assert float((part[..., 1].double() - s2).abs().max()) < 1e-4 * float(s2.abs().max())
+
+
+@pytest.mark.parametrize("N,act", [(2304, L.ACT_NONE), (3072, L.ACT_QUICKGELU)])
+def test_gemm_nt_folded_layernorm_persistent_regime(N, act):
+    """in_proj / c_fc of the bf16 inference path: LayerNorm folded into the product (GemmArgs::ln_stats)."""
+    M, K, eps = M_BIG, 768, 1e-5
+    g = torch.Generator(device=DEV).manual_seed(N)
+    x = (torch.randn(M, K, generator=g, device=DEV) * 1.5 + 0.3).bfloat16()
+    w = torch.randn(N, K, generator=g, device=DEV) * 0.05
+    gain = 1 + 0.2 * torch.randn(K, generator=g, device=DEV)
+    shift = 0.1 * torch.randn(K, generator=g, device=DEV)
+    bias = torch.randn(N, generator=g, device=DEV)
+    wf = (w * gain).bfloat16()                                      # W o g, rounded as the library packs it
+    c1 = wf.float().sum(1).contiguous()
+    c2v = (w.double() @ shift.double() + bias.double()).float().contiguous()
+    stats = L.op_layernorm_stats(x, eps)
+    outs = {}
+    for fk in (2, 24):
+        outs[fk] = L.op_gemm_nt_ex(x, wf, ln_stats=stats, ln_c1=c1, ln_c2=c2v, act=act, force_kernel=fk)
+        torch.cuda.synchronize()
+    assert torch.equal(outs[2], outs[24]), "persistent multi-tile loop differs from one-workgroup-per-tile launches"
+    idx = _rows(M)
+    xr = x[idx].double()
+    # the row statistics themselves
+    mu, var = xr.mean(-1), xr.var(-1, unbiased=False)
+    rstd = torch.rsqrt(var + eps)
+    assert float((stats[idx, 0].double() - rstd).abs().max() / rstd.abs().max()) < 1e-5
+    assert float((stats[idx, 1].double() + mu * rstd).abs().max()) < 1e-4
+    # LN(x) W^T + b evaluated directly in fp64 (gain folded as the library rounds it)
+    ln = (xr - mu[:, None]) * rstd[:, None]
+    ref = _act64(ln @ wf.double().t() + c2v.double(), act)
+    assert float((outs[2][idx].double() - ref).abs().max()) < 0.06
+
+
+@pytest.mark.parametrize("N,K", [(3072, 768), (768, 3072), (768, 768)])
+def test_gemm_tn_full_contraction(N, K):
+    """Weight gradients dW = dY^T X over ~70 000 rows: split partials + fixed-order reduction (bit-reproducible), ragged M."""
+    M = M_BIG
+    g = torch.Generator(device=DEV).manual_seed(N * 3 + K)
+    dy = torch.randn(M, N, generator=g, device=DEV).bfloat16()
+    x = torch.randn(M, K, generator=g, device=DEV).bfloat16()
+    lib = L.load()
+    outs = []
+    for rep in range(2):
+        c = torch.full((N, K), 1.0, device=DEV)
+        L.check(lib.ezclip_op_gemm_tn(dy.data_ptr(), N, x.data_ptr(), K, c.data_ptr(), K, M, N, K, 1, L.DTYPE_BF16, L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(c)
+    assert torch.equal(outs[0], outs[1]), "weight gradient is not bit-reproducible"
+    # the 128x128 atomics kernel (another accumulation order) and fp64 on sampled output rows
+    L.check(lib.ezclip_debug_set(0, 0))
+    try:
+        c0 = torch.full((N, K), 1.0, device=DEV)
+        L.check(lib.ezclip_op_gemm_tn(dy.data_ptr(), N, x.data_ptr(), K, c0.data_ptr(), K, M, N, K, 1, L.DTYPE_BF16, L.stream_ptr()))
+        torch.cuda.synchronize()
+    finally:
+        L.check(lib.ezclip_debug_set(0, -1))
+    rows = torch.randint(0, N, (24,), generator=torch.Generator().manual_seed(1)).to(DEV)
+    ref = 1.0 + dy[:, rows].double().t() @ x.double()
+    scale = math.sqrt(M)
+    assert float((outs[0][rows].double() - ref).abs().max()) < 2e-5 * scale
+    assert float((c0[rows].double() - ref).abs().max()) < 2e-4 * scale
+    assert float((outs[0] - c0).abs().max()) < 2e-4 * scale
+
+
+# ------------------------------------------------------------------------------------------------------ model level
+
+VITB16 = dict(
+    model_type="chinese_clip", embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768,
+    vision_patch_size=16, vocab_size=21128, text_attention_probs_dropout_prob=0.0, text_hidden_act="gelu",
+    text_hidden_dropout_prob=0.0, text_hidden_size=768, text_initializer_range=0.02, text_intermediate_size=3072,
+    text_max_position_embeddings=512, text_num_attention_heads=12, text_num_hidden_layers=12, text_type_vocab_size=2)
+
+
+def _synth(batch, seq, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    px = torch.randn((batch, 3, 224, 224), generator=g, device=DEV)
+    ids = torch.randint(1, VITB16["vocab_size"], (batch, seq), generator=g, device=DEV)
+    lens = torch.randint(8, seq + 1, (batch,), generator=g, device=DEV)
+    return px, ids * (torch.arange(seq, device=DEV)[None, :] < lens[:, None])
+
+
+def _train_step(app, px, ids):
+    for p in app.parameters():
+        p.grad = None
+    loss = app.contrastive_step(px, ids, process_group=False, backward=True, zero_grad=True)
+    torch.cuda.synchronize()
+    return float(loss.item()), {n: p.grad.detach().clone() for n, p in app._params.items() if p.grad is not None}
+
+
+@pytest.mark.parametrize("B", [64, 256])
+def test_vitb16_bertbase_bf16_against_fp32_and_oracle(B):
+    """B = 64: 49 x {3, 9, 12} = 147..588 tiles per ViT GEMM (one to three rounds); B = 256: 197 x ... = 591..2364 tiles
+    (up to ten rounds) -- the persistent regime of the headline run."""
+    from easynlp_amd.appzoo.clip import CLIPApp
+    S = 64
+    px, ids = _synth(B, S, seed=1000)
+    res = {}
+    for dtype in ("fp32", "bf16"):
+        app = CLIPApp.from_config(VITB16, seed=1234, device=DEV, compute_dtype=dtype)
+        app.eval()
+        with torch.no_grad():
+            out = app({"pixel_values": px, "input_ids": ids})
+            loss_ag = float(app.compute_loss(out, [])["loss"].item())
+            loss_fused = float(app.contrastive_step(px, ids, process_group=False).item())
+        loss_bwd, grads = _train_step(app, px, ids)
+        res[dtype] = dict(img=out["image_embeds"].float().cpu(), txt=out["text_embeds"].float().cpu(), loss_ag=loss_ag,
+                          loss_fused=loss_fused, loss_bwd=loss_bwd, grads={n: g.cpu() for n, g in grads.items()})
+        if dtype == "fp32":
+            sd = {k: v.detach().cpu() for k, v in app._params.items()}
+        del app, out, grads
+        torch.cuda.empty_cache()
+    f, h = res["fp32"], res["bf16"]
+    # (1) the fp32 pipeline against the CPU oracle on a 16-pair sample (the towers are per-sample: rows are independent)
+    sample = torch.arange(0, B, B // 16)[:16]
+    cfg = O.CONFIGS["vitb16_bertbase"]
+    with torch.no_grad():
+        ref = O.clip_forward(sd, cfg, px[sample].cpu(), ids[sample].cpu())
+    assert float((f["img"][sample] - ref["image_embeds"]).abs().max()) < 2e-5
+    assert float((f["txt"][sample] - ref["text_embeds"]).abs().max()) < 2e-5
+    # ... and its loss against the oracle's formula on the full embedding sets (fp64)
+    scale = math.exp(float(sd["logit_scale"]))
+    logits = scale * f["txt"].double() @ f["img"].double().t()
+    ref_loss = float(O.clip_loss(logits))
+    assert abs(f["loss_ag"] - ref_loss) < 1e-4 and abs(f["loss_fused"] - ref_loss) < 1e-4 and abs(f["loss_bwd"] - ref_loss) < 1e-4
+    # (2) bf16 against fp32: embeddings, loss
+    assert float((h["img"] - f["img"]).abs().max()) < 1e-2 and float((h["txt"] - f["txt"]).abs().max()) < 1e-2
+    assert float(torch.nn.functional.cosine_similarity(h["img"], f["img"]).min()) > 0.9995
+    assert float(torch.nn.functional.cosine_similarity(h["txt"], f["txt"]).min()) > 0.9995
+    for k in ("loss_ag", "loss_fused", "loss_bwd"):
+        assert abs(h[k] - ref_loss) < 5e-3, (k, h[k], ref_loss)
+    # (3) every parameter gradient: same set, and bf16 within the bf16 bound of the small-batch golden tests
+    #     (6 % of its own norm + 1 % of the largest gradient norm among same-shape parameters of the tower)
+    assert set(h["grads"]) == set(f["grads"])
+    assert not any(n.startswith("bert.pooler") for n in f["grads"])
+    by_shape = {}
+    for n, g in f["grads"].items():
+        key = (n.split(".")[0], tuple(g.shape))
+        by_shape[key] = max(by_shape.get(key, 0.0), float(g.double().norm()))
+    worst = []
+    for n, g in f["grads"].items():
+        gn = float(g.double().norm())
+        assert math.isfinite(gn) and gn > 0, n
+        err = float((h["grads"][n].double() - g.double()).norm())
+        bound = 6e-2 * gn + 1e-2 * by_shape[(n.split(".")[0], tuple(g.shape))]
+        worst.append((err / bound, n, err, gn))
+    worst.sort(reverse=True)
+    print("worst bf16 gradient deviations (fraction of bound, name, |diff|, |ref|):", worst[:6])
+    assert worst[0][0] < 1.0, worst[:6]

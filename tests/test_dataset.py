@@ -17,6 +17,7 @@ import torch
 
 from easynlp_amd import lib as L
 from easynlp_amd.appzoo.clip.data import CLIPDataset, parse_row_by_schema
+from oracle import ref_harness as R
 
 PIL = pytest.importorskip("PIL.Image")
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "dataset_tsv_b7.npz")
@@ -108,14 +109,34 @@ def test_huggingface_flavour_and_what_is_not_covered(tmp_path):
     assert np.array_equal(b["input_ids"].numpy(), g["input_ids"][:2]) and "token_type_ids" in b and "attention_mask" in b
     with pytest.raises(FileNotFoundError):              # a tar shard that does not exist
         CLIPDataset(d, os.path.join(d, "shard-000.tar"), 20, input_schema=SCHEMA, first_sequence="text", second_sequence="image")
-    # a palette image is refused (the reference resizes it in 'P' mode; not on the device path) -- loudly, not silently converted
-    buf = io.BytesIO()
-    PIL.fromarray(np.arange(64, dtype=np.uint8).reshape(8, 8), "P").save(buf, format="PNG")
+    # palette / alpha / CMYK images take the reference's own CPU steps for what depends on the mode (resize IN that mode,
+    # crop, convert('RGB')) and reach the GPU as 224 x 224 RGB: /255 and the normalisation of exactly those bytes are the
+    # reference's pixel_values (checked against the reference pipeline itself when the checkout is present)
+    rng = np.random.RandomState(5)
+    rows = []
+    for mode, shape in (("P", (300, 417)), ("RGBA", (260, 231, 4)), ("CMYK", (224, 500, 4)), ("LA", (231, 260, 2))):
+        im = PIL.fromarray(rng.randint(0, 255, shape, dtype=np.uint8), mode)
+        if mode == "P":
+            im.putpalette([int(v) for v in rng.randint(0, 255, 768)])
+        buf = io.BytesIO()
+        im.save(buf, format="TIFF" if mode == "CMYK" else "PNG")
+        rows.append((im, base64.urlsafe_b64encode(buf.getvalue()).decode()))
     with open(os.path.join(d, "p.tsv"), "w") as f:
-        f.write("a\t" + base64.urlsafe_b64encode(buf.getvalue()).decode() + "\n")
+        for i, (_, b64) in enumerate(rows):
+            f.write("caption %d\t%s\n" % (i, b64))
     dp = CLIPDataset(d, os.path.join(d, "p.tsv"), 20, input_schema=SCHEMA, first_sequence="text", second_sequence="image")
-    with pytest.raises(L.EzclipError):
-        dp[0]
+    with pytest.warns(UserWarning, match="resize / crop run on the CPU"):
+        got = [dp[i]["image"] for i in range(len(rows))]
+    assert all(a.shape == (224, 224, 3) and a.dtype == np.uint8 for a in got)
+    if R.reference_available():
+        R.install_shims()
+        from easynlp.appzoo.clip import data as RD
+        mean, std = np.array(L.CLIP_MEAN, dtype=np.float32), np.array(L.CLIP_STD, dtype=np.float32)
+        for (im, b64), a in zip(rows, got):
+            src = PIL.open(io.BytesIO(base64.urlsafe_b64decode(b64)))
+            ref = RD._normalize(RD._center_crop(RD._resize(src, 224), 224))              # data.py:256-262
+            mine = ((a.astype(np.float32) / 255.0).transpose(2, 0, 1) - mean[:, None, None]) / std[:, None, None]
+            assert np.array_equal(mine.astype(np.float32), ref.astype(np.float32)), src.mode
     # a corrupt row surfaces as the reference's RuntimeError (dataset.py:196-201)
     with open(os.path.join(d, "bad.tsv"), "w") as f:
         f.write("a\tnot-an-image\n")

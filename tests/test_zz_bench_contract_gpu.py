@@ -1,26 +1,48 @@
-"""bench.py's one JSON line (the driver's contract) on a small batch: required keys, types, the roofline and cpu_baseline
-objects.  Ordered last: written after the round's GPU minutes were spent (bench.py itself ran on hardware all round; the
-`config` key rename is what this guards)."""
+"""bench.py's one JSON line (the driver's contract) on a small batch: required keys, types, the roofline object, the
+`also` object that carries the other BASELINE configurations -- and the LOSS the line reports against the CPU oracle run
+on the same synthetic batch and the same random-init weights (a bench that computed garbage fast would pass the key
+checks; ln(batch) alone would survive large errors, the oracle's value does not)."""
 import json
+import math
 import os
 import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_prints_one_contract_line():
+def _run(*extra):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64",
-                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+                        "--no-cpu-baseline"] + list(extra), capture_output=True, text=True, cwd=ROOT, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def _oracle_loss(batch):
+    """The oracle on bench.py's synthetic batch and weights (same seeds, same device generator)."""
+    sys.path.insert(0, ROOT)
+    import bench as B
+    from easynlp_amd.appzoo.clip import CLIPApp
+    from oracle import clip_oracle as O
+    app = CLIPApp.from_config(B.VITB16_BERTBASE, seed=1234, device="cuda", compute_dtype="fp32")
+    sd = {k: v.detach().cpu() for k, v in app._params.items()}
+    px, ids = B.synth_batch(batch, 64, B.VITB16_BERTBASE["vocab_size"], torch.device("cuda"), seed=1000)
+    with torch.no_grad():
+        out = O.clip_forward(sd, O.CONFIGS["vitb16_bertbase"], px.cpu(), ids.cpu())
+        return float(O.clip_loss(out["logits_per_text"]))
+
+
+def test_bench_prints_one_contract_line():
+    out = _run("--also", "bf16_b1024_train,bf16_b1024_fwd_loss_autograd,bf16_b1024_train_autograd,bf16_b1024_train_opt",
+               "--also-steps", "1")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline"):
+              "dtype", "data", "config", "roofline", "also", "loss"):
         assert k in out, k
     assert out["unit"] == "pairs/s" and out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1
     assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None
@@ -31,3 +53,22 @@ def test_bench_prints_one_contract_line():
         assert k in roof, k
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
     assert 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    # the loss of every workload on this batch: the oracle's value (bf16 bound of the model tests: 5e-3 at full size;
+    # a training step with the optimizer reports the loss BEFORE its single update, so it is the same number)
+    ref = _oracle_loss(64)
+    assert abs(ref - math.log(64)) < 0.2                      # random init: near ln N, but not equal to it
+    assert abs(out["loss"] - ref) < 5e-3, (out["loss"], ref)
+    for name, a in out["also"].items():
+        assert "error" not in a, (name, a)
+        assert a["value"] > 0 and a["ms_per_step"] > 0
+        # (the AdamW workload has already moved the weights by the time its timed step reports a loss)
+        assert abs(a["loss"] - ref) < (5e-2 if name.endswith("_opt") else 5e-3), (name, a["loss"], ref)
+    assert out["also"]["bf16_b1024_train_autograd"]["path"] == "autograd"
+
+
+def test_bench_self_launches_under_torch_distributed_run():
+    """`python bench.py --gpus N` must work unattended (no external launcher): with --launcher the same code path runs for
+    N = 1 -- re-exec under torch.distributed.run on 127.0.0.1, RCCL process group, one JSON line from rank 0."""
+    out = _run("--launcher", "--no-also")
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["value"] > 0
+    assert out["config"]["parallelism"] == "dp1"

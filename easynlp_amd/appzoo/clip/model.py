@@ -305,7 +305,7 @@ class _WsToken:
         self.released = False
 
 
-def _run_towers(eng, two_streams, run_image, run_text):
+def _run_towers(eng, two_streams, run_image, run_text, image_first=False):
     """Enqueue the image tower on the current stream and the text tower on the engine's side stream (``two_streams``) or
     both on the current stream.  Everything enqueued before is visible to both; on return the current stream has joined
     the side stream.  Tensors are allocated under the current stream in either case (the callables only pass an explicit
@@ -317,8 +317,12 @@ def _run_towers(eng, two_streams, run_image, run_text):
     main = torch.cuda.current_stream()
     side = eng.side_stream(main.device)
     side.wait_stream(main)
-    b = run_text(side)
-    a = run_image(None)
+    if image_first:                # (host-side enqueue order only: the backward pass reports the image tower's groups first)
+        a = run_image(None)
+        b = run_text(side)
+    else:
+        b = run_text(side)
+        a = run_image(None)
     main.wait_stream(side)
     return a, b
 
@@ -380,7 +384,7 @@ class _EncodeFn(torch.autograd.Function):
             d_txt = d_txt.contiguous()
             eng.set_text_dropout(*ctx.drop)         # the masks of the matching forward
             run_t = lambda st: eng.backward_text(ctx.ids, d_txt, ctx.ws_txt, stream=st)
-        _run_towers(eng, app.two_streams, run_i, run_t)
+        _run_towers(eng, app.two_streams, run_i, run_t, image_first=True)
         if ctx.token is not None:
             ctx.token.released = True
         out = []
@@ -858,7 +862,7 @@ class CLIPApp(Application):
         try:
             _run_towers(eng, two,
                         lambda s_: eng.backward_image(pixel_values, d_img_l, ws_i, stream=s_),
-                        lambda s_: eng.backward_text(input_ids, d_txt_l, ws_t, extras=extras, stream=s_))
+                        lambda s_: eng.backward_text(input_ids, d_txt_l, ws_t, extras=extras, stream=s_), image_first=True)
         finally:
             if reducer is not None:
                 eng.set_progress_hook(None)

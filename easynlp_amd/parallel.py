@@ -197,7 +197,7 @@ class OverlappedGradReducer:
         self.reset()
 
     def reset(self) -> None:
-        self._done = set()
+        self._done = {}                # group -> event recorded on the stream that produced it (None on the CPU)
         self._sent = 0                 # element offset up to which buckets have been launched
         self._works: List = []
         self.buckets: List[Tuple[int, int]] = []
@@ -216,12 +216,22 @@ class OverlappedGradReducer:
     def _launch(self, upto: int) -> None:
         if upto <= self._sent:
             return
+        # a bucket may hold groups produced on another stream than the current one (the towers run on two streams, and a
+        # group that finished early is sent together with the later one that completes the contiguous range)
+        for g, ev in self._done.items():
+            s, e = self.arena.group_range[g]
+            if ev is not None and s < upto and e > self._sent:
+                torch.cuda.current_stream().wait_event(ev)
         self.buckets.append((self._sent, upto))
         self._works.append(self._all_reduce(self.arena.flat[self._sent:upto]))
         self._sent = upto
 
     def notify(self, tower: int, stage: int) -> None:
-        self._done.add((tower, stage))
+        ev = None
+        if self.arena.flat.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()                # on the current stream: the caller enters the producing tower's stream first
+        self._done[(tower, stage)] = ev
         end = self._frontier()
         if (end - self._sent) * 4 >= self.bucket_bytes:
             self._launch(end)

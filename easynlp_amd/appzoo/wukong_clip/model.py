@@ -128,4 +128,4 @@ class WukongCLIP(CLIPApp):
 
     def contrastive_step(self, pixel_values, input_ids, process_group=None, backward=False, **kw):
         self._check_tail_tokens(input_ids)
-        return super().contrastive_step(pixel_values, input_ids, process_group=process_group, backward=backward)
+        return super().contrastive_step(pixel_values, input_ids, process_group=process_group, backward=backward, **kw)

@@ -205,7 +205,8 @@ def test_clipapp_forward_takes_dataset_batches(tmp_path):
     assert tuple(out["logits_per_text"].shape) == (7, 7) and tuple(batch["pixel_values"].shape) == (7, 3, res, res)
     loss = app.compute_loss(out, batch["label_ids"])["loss"]
     loss.backward()
-    assert torch.isfinite(loss) and all(p.grad is not None for p in app.parameters() if p.requires_grad)
+    # (every parameter but the BertPooler, which chinese_clip computes and never uses: .grad stays None as in the reference)
+    assert torch.isfinite(loss) and all(p.grad is not None for n, p in app.named_parameters() if p.requires_grad and "pooler" not in n)
     px = L.preprocess_images(images, size=res, crop=res)
     app.eval()
     with torch.no_grad():

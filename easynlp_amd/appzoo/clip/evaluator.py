@@ -32,16 +32,34 @@ class Evaluator(object):
         raise NotImplementedError
 
 
-def recall_ranks(text_embeds: torch.Tensor, image_embeds: torch.Tensor) -> torch.Tensor:
-    """rank[i] = #{j : <t_i, v_j> > <t_i, v_i>} (+ ties with j < i) on the GPU."""
+def recall_ranks(text_embeds: torch.Tensor, image_embeds: torch.Tensor, block_rows: int = 4096, group=None,
+                 shard: bool = False) -> torch.Tensor:
+    """rank[i] = #{j : <t_i, v_j> > <t_i, v_i>} (+ ties with j < i) on the GPU, ``block_rows`` queries at a time: the only
+    scratch is one [block_rows, n] similarity block (never n x n).  ``shard=True`` under an initialised process group:
+    every rank holds the same embeddings (the reference evaluator runs the whole validation set on each rank,
+    core/evaluator.py:20-27), ranks split the query blocks and exchange the integer ranks with one all-gather."""
+    import torch.distributed as dist
     lib = L.load()
     t = text_embeds.detach().float().contiguous()
     v = image_embeds.detach().float().contiguous()
     n, e = t.shape
-    rank = torch.empty(n, dtype=torch.int32, device=t.device)
-    scratch = torch.empty(n * n, dtype=torch.float32, device=t.device)
-    L.check(lib.ezclip_recall_ranks(L.ptr(t), L.ptr(v), n, e, L.ptr(rank), L.ptr(scratch), L.stream_ptr()),
-            "recall_ranks")
+    world, me = 1, 0
+    if shard and dist.is_available() and dist.is_initialized():
+        world, me = dist.get_world_size(group), dist.get_rank(group)
+    per = (n + world - 1) // world                         # this rank's queries: [lo, hi)
+    lo, hi = min(n, me * per), min(n, (me + 1) * per)
+    rank = torch.zeros(per * world if world > 1 else n, dtype=torch.int32, device=t.device)
+    rows_max = max(1, min(int(block_rows), hi - lo)) if hi > lo else 1
+    scratch = torch.empty(rows_max * n, dtype=torch.float32, device=t.device)
+    for r0 in range(lo, hi, rows_max):
+        rows = min(rows_max, hi - r0)
+        out = rank[(me * per if world > 1 else 0) + (r0 - lo):]
+        L.check(lib.ezclip_recall_ranks_rows(L.ptr(t[r0:r0 + rows]), L.ptr(v), rows, r0, n, e, out.data_ptr(), L.ptr(scratch),
+                                             L.stream_ptr()), "recall_ranks_rows")
+    if world > 1:
+        mine = rank[me * per:(me + 1) * per].contiguous()
+        dist.all_gather_into_tensor(rank, mine, group=group)
+        rank = rank[:n]
     return rank
 
 

@@ -20,7 +20,6 @@
 // other's math.
 #include "ezclip_common.h"
 #include "kernels.h"
-#include "gemm_pipe.h"      // hand-issued LDS-DMA / buffer loads with counted waits
 
 namespace ezclip {
 namespace {
@@ -48,7 +47,30 @@ __device__ __forceinline__ void dma_rows(char* dst, const char* gbase, int64_t r
   }
 }
 
-// (up to 9 waves = 288 tokens: ViT-L/14 has 257; 104 VGPRs leave room for three waves on a SIMD)
+// max / sum of a value with the one held by lane ^ 32 (the other half of the same query's scores): one
+// v_permlane32_swap instead of an LDS round trip (ds_bpermute)
+__device__ __forceinline__ void swap_halves(float v, float& x0, float& x1) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  x0 = __uint_as_float(r[0]);      // lanes < 32: own value / lanes >= 32: the partner's
+  x1 = __uint_as_float(r[1]);      // lanes < 32: the partner's / lanes >= 32: own value
+}
+
+// max(a, b, c) without the canonicalising v_max x, x hipcc puts in front of every fmaxf whose operand comes out of an MFMA
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// (up to 9 waves = 288 tokens: ViT-L/14 has 257; 104 VGPRs leave room for four waves on a SIMD)
+//
+// The kernel is VALU-bound, not HBM-bound: streaming the K / V tiles under the math (round 2 experiment) did not move
+// it, the per-score instruction count does.  So the softmax runs in the base-2 domain with the scale folded into one
+// fma per score (p = 2^(s c - m c), c = scale log2 e: fma + v_exp_f32 instead of fma, sub, mul, v_exp_f32), the row sums
+// use four independent partial sums, the running output is only rescaled when some lane's maximum moved
+// (multiplying by exactly 1 otherwise), the cross-half exchanges are v_permlane32_swap, and every wave has queries
+// (64 * nt threads).  HAS_KB: additive key bias (BERT); without it the scores never touch LDS.
+template <bool HAS_KB, bool CAUSAL>
 __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int head = blockIdx.x, b = blockIdx.y;
@@ -62,12 +84,15 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
   float* kb = reinterpret_cast<float*>(smem + 2 * LKP * 128);
   const int64_t rs = a.row_stride * 2;
   const int64_t base = ((int64_t)b * L * a.row_stride + head * 64) * 2;
+  constexpr float kLog2e = 1.4426950408889634f;
 
   const int nwaves = (int)(blockDim.x >> 6);
   dma_rows<0>(kimg, reinterpret_cast<const char*>(a.k) + base, rs, LKP, L, wave, nwaves, lane);
   dma_rows<1>(vimg, reinterpret_cast<const char*>(a.v) + base, rs, LKP, L, wave, nwaves, lane);
-  for (int key = tid; key < LKP; key += (int)blockDim.x)
-    kb[key] = key < L ? (a.key_bias ? a.key_bias[(int64_t)b * L + key] : 0.f) : -INFINITY;
+  if constexpr (HAS_KB) {      // key bias in base-2 units; keys >= L: -inf
+    for (int key = tid; key < LKP; key += (int)blockDim.x)
+      kb[key] = key < L ? a.key_bias[(int64_t)b * L + key] * kLog2e : -INFINITY;
+  }
 
   // this wave's 32 queries
   const int qb = wave;
@@ -99,8 +124,9 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  // m: running maximum -- HAS_KB: of the base-2 scores s c + kb log2 e; else of the raw dot products (c > 0: same arg max)
   float m = -INFINITY, l = 0.f;
-  const float scale = a.scale;
+  const float c = a.scale * kLog2e;
 #pragma unroll 1
   for (int t = 0; t < nt; ++t) {
     f32x16_t acc;
@@ -113,37 +139,60 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
       mma32(acc, kf, qf[s], bf16_t());                       // D[key][q]
     }
     float x[16];
-    float tmax = -INFINITY;
+    if constexpr (HAS_KB) {
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const float4 kb4 = *reinterpret_cast<const float4*>(kb + 32 * t + 8 * qd + 4 * h);
-      x[4 * qd + 0] = fmaf(acc[4 * qd + 0], scale, kb4.x);
-      x[4 * qd + 1] = fmaf(acc[4 * qd + 1], scale, kb4.y);
-      x[4 * qd + 2] = fmaf(acc[4 * qd + 2], scale, kb4.z);
-      x[4 * qd + 3] = fmaf(acc[4 * qd + 3], scale, kb4.w);
+      for (int qd = 0; qd < 4; ++qd) {
+        const float4 kb4 = *reinterpret_cast<const float4*>(kb + 32 * t + 8 * qd + 4 * h);
+        x[4 * qd + 0] = fmaf(acc[4 * qd + 0], c, kb4.x);
+        x[4 * qd + 1] = fmaf(acc[4 * qd + 1], c, kb4.y);
+        x[4 * qd + 2] = fmaf(acc[4 * qd + 2], c, kb4.z);
+        x[4 * qd + 3] = fmaf(acc[4 * qd + 3], c, kb4.w);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[r] = acc[r];
+      if (32 * (t + 1) > L) {                                 // the ragged last tile: keys >= L do not exist
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (32 * t + (r & 3) + 8 * (r >> 2) + 4 * h >= L) x[r] = -INFINITY;
+      }
     }
-    if (a.causal) {
+    if constexpr (CAUSAL) {     // (a template parameter: the index arithmetic is otherwise hoisted into the common path)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (32 * t + (r & 3) + 8 * (r >> 2) + 4 * h > q) x[r] = -INFINITY;
     }
+    float tmax = max3(x[0], x[1], x[2]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float mn = fmaxf(m, tmax);                          // finite from the first tile on (key 0 < L)
-    const float alpha = __expf(m - mn);
-    m = mn;
-    float ps = 0.f;
+    for (int r = 3; r < 15; r += 2) tmax = max3(tmax, x[r], x[r + 1]);
+    float t0, t1;
+    swap_halves(max3(tmax, x[15], x[15]), t0, t1);
+    const float mn = max3(m, t0, t1);                         // finite from the first tile on (key 0 < L)
+    float alpha, ps[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (HAS_KB) {
+      alpha = __builtin_amdgcn_exp2f(m - mn);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      x[r] = __expf(x[r] - mn);
-      ps += x[r];
+      for (int r = 0; r < 16; ++r) {
+        x[r] = __builtin_amdgcn_exp2f(x[r] - mn);
+        ps[r & 3] += x[r];
+      }
+    } else {
+      const float mc = -mn * c;
+      alpha = __builtin_amdgcn_exp2f(fmaf(m, c, mc));          // (m = -inf on the first tile: 2^-inf = 0)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        x[r] = __builtin_amdgcn_exp2f(fmaf(x[r], c, mc));
+        ps[r & 3] += x[r];
+      }
     }
-    l = l * alpha + ps;
+    m = mn;
+    l = fmaf(l, alpha, (ps[0] + ps[1]) + (ps[2] + ps[3]));
+    if (t > 0 && __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {     // (multiplying by exactly 1 changes nothing)
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
     const char* vt = vimg + t * 4096;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -159,210 +208,12 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
       mma32(o[1], make_uint4(b0.x, b0.y, b1.x, b1.y), pc, bf16_t());
     }
   }
-  l += __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / l;
-  if (q < L) {
-    bf16_t* cp = reinterpret_cast<bf16_t*>(a.ctx) + ((int64_t)b * L + q) * a.ctx_stride + head * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = o[dt][4 * qd + e] * inv;
-        st4(cp + dt * 32 + 8 * qd + 4 * h, v);
-      }
-    if (a.lse != nullptr && h == 0) a.lse[((int64_t)b * a.H + head) * L + q] = m + logf(l);
-  }
-}
-
-
-// -----------------------------------------------------------------------------------------------------
-// Streamed forward (the kernel the towers run): the same arithmetic, instruction for instruction, as
-// attn_fwd_short_kernel above -- but the head's K and V do not have to be complete before the math starts.
-// The old structure was "DMA everything, vmcnt(0), barrier, compute, store": with two workgroups per CU (58 KiB of
-// LDS each) the memory system idled whenever both were in their math and the SIMDs whenever both were loading
-// (3.1 TB/s of 8).  Here every VMEM operation is hand-issued (buffer_load ... lds / buffer_load in inline asm), in
-// tile order K0 V0 K1 V1 ...; each wave owns 8 of the 8*NT one-KiB pieces, and before key tile t it waits with a
-// COUNTED vmcnt for just the pieces tile t needs (its older ones; loads complete in order) and meets the other waves
-// at a barrier: the QK^T / softmax / PV of tile t runs while tiles t+1.. are still in flight, so a workgroup costs
-// max(load, math) instead of their sum.  One wave per 32 queries, NT = ceil(L / 32) waves, no idle waves.
-// Output: the two lanes of a query (lane, lane + 32) exchange halves (v_permlane32_swap) so that every store is
-// 16 bytes per lane -- 4 instead of 16 store instructions per wave row block.
-constexpr int allowed_in_flight(int nt, int t) {
-  const int old = (8 * t + 7) / nt;
-  return old >= 7 ? 0 : 7 - old;
-}
-
-template <int NT>
-__global__ __launch_bounds__(64 * NT) void attn_fwd_stream_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int head = blockIdx.x, b = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = lane >> 5, l31 = lane & 31;
-  const int L = a.L;
-  constexpr int LKP = 32 * NT;
-  char* kimg = smem;
-  char* vimg = smem + LKP * 128;
-  float* kb = reinterpret_cast<float*>(smem + 2 * LKP * 128);
-  const uint32_t lds0 = (uint32_t)(size_t)smem;
-  const uint32_t rs = (uint32_t)a.row_stride * 2u;
-  const int64_t base = ((int64_t)b * L * a.row_stride + head * 64) * 2;
-  const uint32_t span = (uint32_t)(L - 1) * rs + 128u;                 // bytes of this head's rows in q / k / v
-  const i32x4_t srdQ = make_srd(reinterpret_cast<const char*>(a.q) + base, span);
-  const i32x4_t srdK = make_srd(reinterpret_cast<const char*>(a.k) + base, span);
-  const i32x4_t srdV = make_srd(reinterpret_cast<const char*>(a.v) + base, span);
-  const bool has_kb = a.key_bias != nullptr;
-
-  // ---- VMEM stream of this wave, oldest first: [key bias piece] q (4 loads) then its 8 K / V pieces in tile order ----
-  if (has_kb && wave < (NT + 1) / 2) {       // 64 floats per piece straight into LDS (keys >= L: clamped, masked later)
-    const i32x4_t srdB = make_srd(a.key_bias + (int64_t)b * L, (uint32_t)L * 4u);
-    int key = wave * 64 + lane;
-    key = key < L ? key : L - 1;
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dword %2, %3, 0 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(lds0 + 2u * LKP * 128u + (uint32_t)wave * 256u), "v"((uint32_t)key * 4u), "s"(srdB)
-        : "memory");
-  }
-  const int q = wave * 32 + l31;
-  const int qc = q < L ? q : L - 1;
-  u32x4_t qr[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) ldg16(qr[s], (uint32_t)qc * rs + (uint32_t)(2 * s + h) * 16u, srdQ, 0);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int i = wave + k * NT;               // piece index: tile i / 8, j = i % 8: K rows 8j.. (j < 4) or V rows 8(j-4)..
-    const int t = i >> 3, j = i & 7;
-    const int r = 32 * t + 8 * (j & 3) + (lane >> 3);
-    const int gr = r < L ? r : L - 1;          // rows >= L repeat row L-1 (finite; always multiplied by an exact 0)
-    if (j < 4) {
-      const uint32_t c = (uint32_t)((lane & 7) ^ ((r >> 1) & 7));
-      dma16(lds0 + (uint32_t)(t * 4096 + j * 1024), (uint32_t)gr * rs + c * 16u, srdK, 0);
-    } else {
-      const uint32_t c = (uint32_t)((lane & 7) ^ (((r >> 1) & 1) << 2));
-      dma16(lds0 + (uint32_t)(LKP * 128 + t * 4096 + (j - 4) * 1024), (uint32_t)gr * rs + c * 16u, srdV, 0);
-    }
-  }
-
-  // per-lane LDS offsets
-  const int sw = (l31 >> 1) & 7;
-  uint32_t koff[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) koff[s] = (uint32_t)l31 * 128u + ((uint32_t)((2 * s + h) ^ sw) << 4);
-  const int t16 = lane & 15, sub = (lane >> 4) & 1;
-  const uint32_t vsw = (uint32_t)((t16 >> 3) & 1);
-  const uint32_t voff0 = (uint32_t)(4 * h + (t16 >> 2)) * 128u + (vsw << 6) + (uint32_t)sub * 32u + (uint32_t)(t16 & 3) * 8u;
-  const uint32_t voff1 = voff0 ^ 64u;     // d tile 1
-
-  f32x16_t o[2];
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m = -INFINITY, l = 0.f;
-  const float scale = a.scale;
-  uint4 qf[4];
-
-  // pieces of tiles 0..t have indices < 8 (t + 1); wave w's k-th piece is w + k NT, so at most 7 - (8 t + 7) / NT of
-  // ITS pieces (the newest ones) may still be in flight when tile t is complete (bound for wave 0; later waves have
-  // fewer old pieces).  Tile 0 also covers the q loads (older than every piece).
-  wait_vm4<allowed_in_flight(NT, 0)>(qr[0], qr[1], qr[2], qr[3]);
-#pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = make_uint4(qr[s].x, qr[s].y, qr[s].z, qr[s].w);
-#pragma unroll 1
-  for (int t = 0; t < NT; ++t) {
-    switch (t) {          // (wave-uniform: the counted wait needs an immediate)
-      case 1: wait_vm<allowed_in_flight(NT, 1)>(); break;
-      case 2: wait_vm<allowed_in_flight(NT, 2)>(); break;
-      case 3: wait_vm<allowed_in_flight(NT, 3)>(); break;
-      case 4: wait_vm<allowed_in_flight(NT, 4)>(); break;
-      case 5: wait_vm<allowed_in_flight(NT, 5)>(); break;
-      case 6: wait_vm<allowed_in_flight(NT, 6)>(); break;
-      case 7: wait_vm<allowed_in_flight(NT, 7)>(); break;
-      case 8: wait_vm<allowed_in_flight(NT, 8)>(); break;
-      default: break;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16_t acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const char* kt = kimg + t * 4096;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const uint4 kf = *reinterpret_cast<const uint4*>(kt + koff[s]);
-      mma32(acc, kf, qf[s], bf16_t());                       // D[key][q]
-    }
-    float x[16];
-    float tmax = -INFINITY;
-    if (has_kb) {
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const float4 kb4 = *reinterpret_cast<const float4*>(kb + 32 * t + 8 * qd + 4 * h);
-        x[4 * qd + 0] = fmaf(acc[4 * qd + 0], scale, kb4.x);
-        x[4 * qd + 1] = fmaf(acc[4 * qd + 1], scale, kb4.y);
-        x[4 * qd + 2] = fmaf(acc[4 * qd + 2], scale, kb4.z);
-        x[4 * qd + 3] = fmaf(acc[4 * qd + 3], scale, kb4.w);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) x[r] = fmaf(acc[r], scale, 0.f);
-    }
-    if (32 * (t + 1) > L) {                                    // the ragged last tile: keys >= L do not exist
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (32 * t + (r & 3) + 8 * (r >> 2) + 4 * h >= L) x[r] = -INFINITY;
-    }
-    if (a.causal) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (32 * t + (r & 3) + 8 * (r >> 2) + 4 * h > q) x[r] = -INFINITY;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float mn = fmaxf(m, tmax);                          // finite from the first tile on (key 0 < L)
-    const float alpha = __expf(m - mn);
-    m = mn;
-    float ps = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      x[r] = __expf(x[r] - mn);
-      ps += x[r];
-    }
-    l = l * alpha + ps;
-    if (t > 0 && __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {     // (multiplying by exactly 1 changes nothing)
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    }
-    const char* vt = vimg + t * 4096;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      uint4 pc;
-      pc.x = pack_bf16x2(x[8 * u + 0], x[8 * u + 1]);
-      pc.y = pack_bf16x2(x[8 * u + 2], x[8 * u + 3]);
-      pc.z = pack_bf16x2(x[8 * u + 4], x[8 * u + 5]);
-      pc.w = pack_bf16x2(x[8 * u + 6], x[8 * u + 7]);
-      const uint2 a0 = tr4(vt + u * 2048 + voff0), a1 = tr4(vt + u * 2048 + 1024 + voff0);
-      const uint2 b0 = tr4(vt + u * 2048 + voff1), b1 = tr4(vt + u * 2048 + 1024 + voff1);
-      mma32(o[0], make_uint4(a0.x, a0.y, a1.x, a1.y), pc, bf16_t());   // D[d][q]
-      mma32(o[1], make_uint4(b0.x, b0.y, b1.x, b1.y), pc, bf16_t());
-    }
-  }
-  l += __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / l;
+  float l0, l1;
+  swap_halves(l, l0, l1);
+  l = l0 + l1;
+  const float inv = __builtin_amdgcn_rcpf(l);
   // lane (q, h) holds columns dt*32 + 8 qd + 4 h + {0..3}; after the swap of (qd, qd + 1) pairs it holds 8 consecutive
-  // columns dt*32 + 16 j + 8 h + {0..7}: one 16-byte store
+  // columns dt*32 + 16 j + 8 h + {0..7}: one 16-byte store (4 instead of 16 store instructions per wave)
   uint32_t pk[2][2][4];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -380,14 +231,26 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_stream_kernel(AttnArgs a) {
     }
   if (q < L) {
     bf16_t* cp = reinterpret_cast<bf16_t*>(a.ctx) + ((int64_t)b * L + q) * a.ctx_stride + head * 64;
+    if ((a.ctx_stride & 7) == 0 && ((uintptr_t)a.ctx & 15) == 0) {
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        *reinterpret_cast<uint4*>(cp + dt * 32 + 16 * j + 8 * h) = make_uint4(pk[dt][j][0], pk[dt][j][1], pk[dt][j][2], pk[dt][j][3]);
-    if (a.lse != nullptr && h == 0) a.lse[((int64_t)b * a.H + head) * L + q] = m + logf(l);
+        for (int j = 0; j < 2; ++j)
+          *reinterpret_cast<uint4*>(cp + dt * 32 + 16 * j + 8 * h) = make_uint4(pk[dt][j][0], pk[dt][j][1], pk[dt][j][2], pk[dt][j][3]);
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          *reinterpret_cast<uint2*>(cp + dt * 32 + 16 * j + 8 * h) = make_uint2(pk[dt][j][0], pk[dt][j][1]);
+          *reinterpret_cast<uint2*>(cp + dt * 32 + 16 * j + 8 * h + 4) = make_uint2(pk[dt][j][2], pk[dt][j][3]);
+        }
+    }
+    // log-sum-exp of the scaled scores (natural log), as the backward kernels expect it
+    if (a.lse != nullptr && h == 0) a.lse[((int64_t)b * a.H + head) * L + q] = (HAS_KB ? m : m * c) * 0.6931471805599453f + logf(l);
   }
 }
+
 
 // =====================================================================================================
 // Fused backward for the same shapes (bf16, L <= 256): ONE kernel, one workgroup per (sample, head).  Q, K, V and dO
@@ -705,58 +568,23 @@ int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
   return EZ_OK;
 }
 
-namespace {
-int g_attn_stream = 1;     // 1: streamed forward kernel (default); 0: the load-then-compute kernel (A/B, cross-check)
-
-template <int NT>
-int launch_stream(const AttnArgs& a, hipStream_t stream) {
-  constexpr int bytes = NT * 2 * 32 * 128 + ((NT + 1) / 2) * 256;      // K and V images + key bias in 64-float pieces
-  static bool attr_set = false;
-  if (!attr_set) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_stream_kernel<NT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(attn_fwd_stream_kernel<NT>, dim3(a.H, a.B), dim3(64 * NT), bytes, stream, a);
-  return EZ_OK;
-}
-}  // namespace
-
-void set_attention_stream(int on) { g_attn_stream = on; }
+void set_attention_stream(int) {}      // (round-2 experiment hook, kept so that ezclip_debug_set(8, ..) stays valid: no effect)
 
 int attention_fwd_short(const AttnArgs& a, hipStream_t stream) {
   const int nt = (a.L + 31) / 32;
-  ProfScope ps(PROF_ATTN, 4.0 * a.B * a.H * (double)a.L * a.L * 64, stream);   // QK^T + PV, unpadded
-  // (16-byte row pieces through buffer descriptors: 32-bit offsets, 16-byte aligned rows)
-  const bool stream_ok = g_attn_stream && (a.row_stride % 8 == 0) && (a.ctx_stride % 8 == 0) &&
-                         ((uintptr_t)a.q % 16 == 0) && ((uintptr_t)a.k % 16 == 0) && ((uintptr_t)a.v % 16 == 0) &&
-                         ((uintptr_t)a.ctx % 16 == 0) && (uint64_t)a.L * (uint64_t)a.row_stride * 2u < 0x7fff0000ull;
-  if (stream_ok) {
-    int rc = EZ_ERR_INVALID;
-    switch (nt) {
-      case 1: rc = launch_stream<1>(a, stream); break;
-      case 2: rc = launch_stream<2>(a, stream); break;
-      case 3: rc = launch_stream<3>(a, stream); break;
-      case 4: rc = launch_stream<4>(a, stream); break;
-      case 5: rc = launch_stream<5>(a, stream); break;
-      case 6: rc = launch_stream<6>(a, stream); break;
-      case 7: rc = launch_stream<7>(a, stream); break;
-      case 8: rc = launch_stream<8>(a, stream); break;
-      case 9: rc = launch_stream<9>(a, stream); break;
-      default: break;
-    }
-    if (rc != EZ_OK) return rc;
-    EZ_LAUNCH_CHECK();
-    return EZ_OK;
-  }
   const int bytes = nt * (2 * 32 * 128 + 32 * 4);
-  static int attr_max = 0;
-  if (bytes > attr_max) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_short_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    attr_max = bytes;
+  static int attr_max[4] = {0, 0, 0, 0};
+  const int kbi = (a.key_bias != nullptr ? 1 : 0) + (a.causal ? 2 : 0);
+  auto* kern = kbi == 0 ? &attn_fwd_short_kernel<false, false> : kbi == 1 ? &attn_fwd_short_kernel<true, false>
+             : kbi == 2 ? &attn_fwd_short_kernel<false, true> : &attn_fwd_short_kernel<true, true>;
+  if (bytes > attr_max[kbi]) {
+    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_max[kbi] = bytes;
   }
-  hipLaunchKernelGGL(attn_fwd_short_kernel, dim3(a.H, a.B), dim3(nt > 8 ? 64 * nt : 512), bytes, stream, a, nt);
+  {
+    ProfScope ps(PROF_ATTN, 4.0 * a.B * a.H * (double)a.L * a.L * 64, stream);   // QK^T + PV, unpadded
+    hipLaunchKernelGGL(kern, dim3(a.H, a.B), dim3(64 * nt), bytes, stream, a, nt);
+  }
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

@@ -307,7 +307,15 @@ int ezclip_recall_ranks(const float* text, const float* image, int n, int e, int
                         void* stream) {
   EZ_REQUIRE(text && image && rank_out && scratch && n > 0, "ezclip_recall_ranks: null/empty argument");
   API_TRY(sim_gemm(text, e, image, e, n, n, e, nullptr, scratch, n, nullptr, S(stream)));   // evaluator.py:50
-  return recall_ranks(scratch, n, rank_out, S(stream));
+  return recall_ranks(scratch, n, n, 0, rank_out, S(stream));
+}
+
+int ezclip_recall_ranks_rows(const float* text_rows, const float* image, int rows, int row0, int n, int e, int32_t* rank_out,
+                             float* scratch, void* stream) {
+  EZ_REQUIRE(text_rows && image && rank_out && scratch && rows > 0 && row0 >= 0 && row0 + rows <= n,
+             "ezclip_recall_ranks_rows: bad block rows=%d row0=%d n=%d", rows, row0, n);
+  API_TRY(sim_gemm(text_rows, e, image, e, rows, n, e, nullptr, scratch, n, nullptr, S(stream)));
+  return recall_ranks(scratch, rows, n, row0, rank_out, S(stream));
 }
 
 int ezclip_debug_set(int key, int value) {

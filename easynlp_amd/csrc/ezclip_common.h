@@ -89,7 +89,8 @@ __device__ __forceinline__ float erf_fast(float x) {
 template <bool FAST>
 __device__ __forceinline__ float act_apply(float x, int act) {
   if (act == ACT_QUICKGELU) {
-    if (FAST) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    // exp(-1.702 x) = 2^(x * -1.702 log2(e)): one multiply in front of v_exp_f32 instead of two
+    if (FAST) return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.4554669595930157f));
     return x / (1.0f + expf(-1.702f * x));
   }
   if (act == ACT_GELU_ERF) {
@@ -104,7 +105,7 @@ __device__ __forceinline__ float act_apply(float x, int act) {
 template <bool FAST>
 __device__ __forceinline__ float act_grad(float x, int act) {
   if (act == ACT_QUICKGELU) {
-    const float e = FAST ? __expf(-1.702f * x) : expf(-1.702f * x);
+    const float e = FAST ? __builtin_amdgcn_exp2f(x * -2.4554669595930157f) : expf(-1.702f * x);
     const float s = FAST ? __builtin_amdgcn_rcpf(1.0f + e) : 1.0f / (1.0f + e);
     return s * (1.0f + 1.702f * x * (1.0f - s));
   }

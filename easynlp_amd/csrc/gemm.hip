@@ -226,7 +226,7 @@ int launch_nt_shape(const GemmArgs& p, hipStream_t stream) {
   return EZ_OK;
 }
 
-int g_gemm_variant = -1;   // -1: heuristic; 0: 128x128; 1: 256x256 (2-phase); 2: 256x256 8-phase (gemm8p.hip); 3: 256x128 4-wave (gemm4w.hip)
+int g_gemm_variant = -1;   // -1: heuristic; 0: 128x128; 1: 256x256 (2-phase); 2: 256x256 8-phase (gemm8p.hip)
 
 template <typename T, typename TO>
 int launch_nt(const GemmArgs& p, hipStream_t stream) {
@@ -268,7 +268,6 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
              (p.R == nullptr || (p.ldr % 4 == 0 && (uintptr_t)p.R % 16 == 0)) &&
              (p.U == nullptr || (p.ldu % 4 == 0 && (uintptr_t)p.U % 16 == 0));
   p.vec_ok = vec ? 1 : 0;
-  if (g_gemm_variant == 3 && gemm_nt_4w_eligible(p, dtype)) return gemm_nt_4w(p, stream);
   if (gemm_nt_uses_8p(p, dtype)) return gemm_nt_8p(p, stream);
   if (p.colsum != nullptr) {   // not the 8-phase kernel: separate column-sum pass after the GEMM
     float* cs = p.colsum;

@@ -1,4 +1,4 @@
-// Shared pieces of the 8-phase GEMM pipelines (gemm8p.hip, gemm4w.hip): hand-issued LDS-DMA and counted waits,
+// Shared pieces of the 8-phase GEMM pipelines (gemm8p.hip): hand-issued LDS-DMA and counted waits,
 // buffer descriptors, the row-coalesced fp32 epilogue.  gfx950 only.
 #pragma once
 #include <type_traits>

@@ -50,9 +50,6 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream);
 bool gemm_nt_uses_8p(const GemmArgs& p, int dtype);
 bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype);
 int gemm_nt_8p(const GemmArgs& p, hipStream_t stream);
-// 256x128x64 four-wave kernel, two workgroups per CU (gemm4w.hip): same constraints; hides the epilogue of short-K products
-bool gemm_nt_4w_eligible(const GemmArgs& p, int dtype);
-int gemm_nt_4w(const GemmArgs& p, hipStream_t stream);
 void set_gemm_variant(int v);   // debugging / sweeps: -1 heuristic, 0 = 128x128 tile, 1 = 256x256 tile
 void set_gemm_raster(int gm);   // tile order of the persistent 8-phase kernel (GemmArgs::raster_gm); -1: built-in default
 
@@ -200,7 +197,8 @@ int dot_scaled(const float* a, const float* b, int64_t n, float scale, float* pa
 int ce_cols_fwd(const float* S, int64_t ld, int n, float* lse, float* col_loss, hipStream_t stream);
 int infonce_dlogits(const float* S, int n, const float* lse_r, const float* lse_c, const float* g, float coef, float* dS,
                     hipStream_t stream);
-int recall_ranks(const float* sim, int n, int32_t* rank, hipStream_t stream);
+// sim [rows, n] = queries row0 .. row0 + rows - 1 against all n gallery items; rank[r] for query row0 + r
+int recall_ranks(const float* sim, int rows, int n, int row0, int32_t* rank, hipStream_t stream);
 const char* last_error();
 
 // ---- optional per-launch timing (profile.hip) --------------------------------------

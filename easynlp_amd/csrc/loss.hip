@@ -159,18 +159,19 @@ __global__ __launch_bounds__(256) void infonce_dlogits_kernel(const float* S, in
   }
 }
 
-// rank[i] = #{j : sim[i][j] > sim[i][i]} + #{j < i : sim[i][j] == sim[i][i]}
-__global__ __launch_bounds__(256) void recall_rank_kernel(const float* sim, int n, int32_t* rank) {
+// query row r of this block of rows is query i = row0 + r of the whole set:
+// rank[r] = #{j : sim[r][j] > sim[r][i]} + #{j < i : sim[r][j] == sim[r][i]}        (sim: [rows, n])
+__global__ __launch_bounds__(256) void recall_rank_kernel(const float* sim, int n, int row0, int32_t* rank) {
   __shared__ float red[4];
-  const int i = blockIdx.x;
-  const float d = sim[(int64_t)i * n + i];
+  const int r = blockIdx.x, i = row0 + r;
+  const float d = sim[(int64_t)r * n + i];
   float c = 0.f;
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    const float s = sim[(int64_t)i * n + j];
+    const float s = sim[(int64_t)r * n + j];
     c += (s > d || (s == d && j < i)) ? 1.f : 0.f;
   }
   c = block_sum(c, red);
-  if (threadIdx.x == 0) rank[i] = (int32_t)c;
+  if (threadIdx.x == 0) rank[r] = (int32_t)c;
 }
 
 }  // namespace
@@ -186,8 +187,8 @@ int infonce_dlogits(const float* S, int n, const float* lse_r, const float* lse_
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }
-int recall_ranks(const float* sim, int n, int32_t* rank, hipStream_t stream) {
-  hipLaunchKernelGGL(recall_rank_kernel, dim3(n), dim3(256), 0, stream, sim, n, rank);
+int recall_ranks(const float* sim, int rows, int n, int row0, int32_t* rank, hipStream_t stream) {
+  hipLaunchKernelGGL(recall_rank_kernel, dim3(rows), dim3(256), 0, stream, sim, n, row0, rank);
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

@@ -247,6 +247,13 @@ int ezclip_op_resample_table_device(int in_size, int out_size, int first, int co
 int ezclip_recall_ranks(const float* text_dev, const float* image_dev, int n, int e, int32_t* rank_out_dev,
                         float* scratch_dev /* n*n floats */, void* stream);
 
+/* The same for a block of query rows (queries row0 .. row0 + rows - 1 of the n, against all n images): the similarity
+ * block [rows, n] is the only scratch -- a 50 000-pair validation set evaluated 4096 queries at a time needs 0.8 GB instead
+ * of 10 GB, and the blocks are what ranks shard when the evaluation is distributed.
+ * text_rows_dev: [rows, e] (the block's queries); image_dev: [n, e]; rank_out_dev: [rows]; scratch_dev: rows * n floats. */
+int ezclip_recall_ranks_rows(const float* text_rows_dev, const float* image_dev, int rows, int row0, int n, int e,
+                             int32_t* rank_out_dev, float* scratch_dev, void* stream);
+
 /* ---- measurement hooks ---------------------------------------------------------------- */
 /* Between begin and end every launch of the hot kernels is bracketed by HIP events on its
  * own stream.  kernel_class: 0 = MFMA GEMM (work = algorithmic FLOPs), 1 = fused attention
@@ -255,7 +262,7 @@ int ezclip_recall_ranks(const float* text_dev, const float* image_dev, int n, in
 #define EZCLIP_PROF_ATTN 1
 #define EZCLIP_PROF_ROWOP 2
 /* Tuning / A-B switches for sweeps and tests.  key 0: GEMM kernel (-1 heuristic, 0 128x128, 1 256x256 two-phase,
- * 2 8-phase, 3 4-wave 256x128);  key 1: attention kernels (-1 heuristic, 0 general two-pass kernels only);
+ * 2 8-phase);  key 1: attention kernels (-1 heuristic, 0 general two-pass kernels only);
  * key 2: LayerNorm folding on the bf16 inference path (0 off, 1 folded + statistics from the producing GEMM, 2 folded +
  * separate statistics pass);  key 3: last-block CLS-only evaluation on the inference path (1 on, 0 off);  key 4: the same on the training path;  key 5: resampling window
  * tables of ezclip_preprocess_images built on the device (1, default) or on the host (0);  key 6: tile order of the persistent

@@ -128,7 +128,7 @@ def test_pipelined_gemm_isa_audit(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "easynlp_amd", "csrc")
-    for src in ("gemm8p.hip", "gemm4w.hip"):
+    for src in ("gemm8p.hip",):
         out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps",
                               "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(csrc, src), "-I", csrc,
                               "-o", str(tmp_path / (src + ".o"))], cwd=str(tmp_path), capture_output=True, text=True)

@@ -372,7 +372,7 @@ def test_gemm_nt_8phase(M, N, K, epi):
         ad = wide.bfloat16().to(DEV)[:, K:]
         assert ad.stride(0) == 2 * K
     outs = {}
-    for variant in (0, 2, 3):
+    for variant in (0, 2):
         L.check(lib.ezclip_debug_set(0, variant))
         try:
             bd_ = b.to(DEV)
@@ -389,7 +389,6 @@ def test_gemm_nt_8phase(M, N, K, epi):
             L.check(lib.ezclip_debug_set(0, -1))
     assert max_err(outs[2].float(), ref) < 0.06 * max(1.0, math.sqrt(K) / 8)
     assert torch.equal(outs[0], outs[2]), "8-phase kernel differs from the 128x128 kernel"
-    assert torch.equal(outs[0], outs[3]), "4-wave kernel (gemm4w.hip) differs from the 128x128 kernel"
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 768, 768), (2100, 256, 512), (9000, 512, 256)])

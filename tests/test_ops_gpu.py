@@ -195,6 +195,36 @@ def test_similarity_and_infonce(n, e):
     assert abs(r1 - want[1]) < 1e-12 and abs(r5 - want[2]) < 1e-12 and abs(r10 - want[3]) < 1e-12
 
 
+def test_recall_ranks_in_row_blocks_equal_the_sort_loop():
+    """ezclip_recall_ranks_rows: a block of queries at a time ([rows, n] scratch instead of n x n) gives the ranks of the
+    reference evaluator's descending stable sort (evaluator.py:53-61), ties included (duplicated gallery rows)."""
+    from easynlp_amd.appzoo.clip.evaluator import recall_ranks
+    g = torch.Generator().manual_seed(11)
+    n, e = 517, 64
+    t = torch.nn.functional.normalize(torch.randn(n, e, generator=g), dim=-1)
+    v = torch.nn.functional.normalize(t + 0.8 * torch.randn(n, e, generator=g), dim=-1)
+    v[5] = v[300]
+    v[301] = v[300]                                   # exact ties in every row
+    sim = t.double() @ v.double().t()
+    want = torch.empty(n, dtype=torch.int64)
+    for i in range(n):
+        order = torch.sort(sim[i].float(), descending=True, stable=True).indices
+        want[i] = int((order == i).nonzero()[0, 0])
+    one = recall_ranks(t.to(DEV), v.to(DEV), block_rows=n)
+    lib = L.load()
+    full = torch.empty(n, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(n * n, device=DEV)
+    td, vd = t.to(DEV), v.to(DEV)
+    L.check(lib.ezclip_recall_ranks(td.data_ptr(), vd.data_ptr(), n, e, full.data_ptr(), scratch.data_ptr(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(one, full)
+    # (the GPU similarity is exact-f32 MFMA, the sort above ran on the f32 rounding of an f64 product: identical except
+    # where two DIFFERENT scores collide after rounding -- none at this size; the constructed exact ties must agree)
+    assert torch.equal(one.cpu().long(), want)
+    for block in (1, 7, 64, 200, 516):
+        assert torch.equal(recall_ranks(td, vd, block_rows=block), full), block
+
+
 @pytest.mark.parametrize("n,N,off,e", [(4, 12, 4, 64), (8, 8, 0, 128), (32, 128, 64, 512), (100, 300, 200, 64)])
 def test_infonce_fused_shard(n, N, off, e):
     """Fused loss + gradients of one rank's shard == autograd of the oracle's global loss share."""

@@ -55,18 +55,13 @@ __device__ __forceinline__ void swap_halves(float v, float& x0, float& x1) {
   x1 = __uint_as_float(r[1]);      // lanes < 32: the partner's / lanes >= 32: own value
 }
 
-// max(a, b, c) without the canonicalising v_max x, x hipcc puts in front of every fmaxf whose operand comes out of an MFMA
-__device__ __forceinline__ float max3(float a, float b, float c) {
-  float d;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-
 // (up to 9 waves = 288 tokens: ViT-L/14 has 257; 104 VGPRs leave room for four waves on a SIMD)
 //
 // The kernel is VALU-bound, not HBM-bound: streaming the K / V tiles under the math (round 2 experiment) did not move
-// it, the per-score instruction count does.  So the softmax runs in the base-2 domain with the scale folded into one
-// fma per score (p = 2^(s c - m c), c = scale log2 e: fma + v_exp_f32 instead of fma, sub, mul, v_exp_f32), the row sums
+// it, the per-score instruction count does.  So the softmax runs in the base-2 domain with the scale folded into the
+// first (packed) multiply (x = s c, c = scale log2 e; p = 2^(x - m): sub + v_exp_f32 instead of sub, mul, v_exp_f32 -- and
+// every consumer of the MFMA result is an ordinary instruction: an inline-asm v_max3 there slipped past hipcc's MFMA
+// read-after-write wait states and read the accumulators early), the row sums
 // use four independent partial sums, the running output is only rescaled when some lane's maximum moved
 // (multiplying by exactly 1 otherwise), the cross-half exchanges are v_permlane32_swap, and every wave has queries
 // (64 * nt threads).  HAS_KB: additive key bias (BERT); without it the scores never touch LDS.
@@ -124,8 +119,7 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  // m: running maximum -- HAS_KB: of the base-2 scores s c + kb log2 e; else of the raw dot products (c > 0: same arg max)
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY, l = 0.f;      // running maximum of the base-2 scores s c (+ kb log2 e), running sum of 2^(x - m)
   const float c = a.scale * kLog2e;
 #pragma unroll 1
   for (int t = 0; t < nt; ++t) {
@@ -150,7 +144,7 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
       }
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) x[r] = acc[r];
+      for (int r = 0; r < 16; ++r) x[r] = acc[r] * c;
       if (32 * (t + 1) > L) {                                 // the ragged last tile: keys >= L do not exist
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -162,28 +156,18 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
       for (int r = 0; r < 16; ++r)
         if (32 * t + (r & 3) + 8 * (r >> 2) + 4 * h > q) x[r] = -INFINITY;
     }
-    float tmax = max3(x[0], x[1], x[2]);
+    float tmax = x[0];
 #pragma unroll
-    for (int r = 3; r < 15; r += 2) tmax = max3(tmax, x[r], x[r + 1]);
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
     float t0, t1;
-    swap_halves(max3(tmax, x[15], x[15]), t0, t1);
-    const float mn = max3(m, t0, t1);                         // finite from the first tile on (key 0 < L)
-    float alpha, ps[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (HAS_KB) {
-      alpha = __builtin_amdgcn_exp2f(m - mn);
+    swap_halves(tmax, t0, t1);
+    const float mn = fmaxf(m, fmaxf(t0, t1));                 // finite from the first tile on (key 0 < L)
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);       // (m = -inf on the first tile: 2^-inf = 0)
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        x[r] = __builtin_amdgcn_exp2f(x[r] - mn);
-        ps[r & 3] += x[r];
-      }
-    } else {
-      const float mc = -mn * c;
-      alpha = __builtin_amdgcn_exp2f(fmaf(m, c, mc));          // (m = -inf on the first tile: 2^-inf = 0)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        x[r] = __builtin_amdgcn_exp2f(fmaf(x[r], c, mc));
-        ps[r & 3] += x[r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      x[r] = __builtin_amdgcn_exp2f(x[r] - mn);
+      ps[r & 3] += x[r];
     }
     m = mn;
     l = fmaf(l, alpha, (ps[0] + ps[1]) + (ps[2] + ps[3]));
@@ -247,7 +231,7 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
         }
     }
     // log-sum-exp of the scaled scores (natural log), as the backward kernels expect it
-    if (a.lse != nullptr && h == 0) a.lse[((int64_t)b * a.H + head) * L + q] = (HAS_KB ? m : m * c) * 0.6931471805599453f + logf(l);
+    if (a.lse != nullptr && h == 0) a.lse[((int64_t)b * a.H + head) * L + q] = m * 0.6931471805599453f + logf(l);
   }
 }
 

@@ -301,6 +301,10 @@ __device__ __forceinline__ void reduce_cols(const f32x16_t (&acc)[2], float mul,
     }
 }
 
+// HAS_KB / CAUSAL are template parameters: as run-time flags their index arithmetic and selects were executed for every
+// score of every tile whatever the flags said (80 of ~200 VALU instructions per tile and pass).  The probabilities are
+// recomputed in the base-2 domain, p = 2^(s c + kb log2 e - lse log2 e) with c = scale log2 e: one fma + v_exp_f32 per score.
+template <bool HAS_KB, bool CAUSAL>
 __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const AttnArgs& f = a.f;
@@ -327,8 +331,9 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
   dma_rows_f(imgK, reinterpret_cast<const char*>(f.k) + base, rs, LKP, L, wave, lane);
   dma_rows_f(imgV, reinterpret_cast<const char*>(f.v) + base, rs, LKP, L, wave, lane);
   dma_rows_f(imgG, reinterpret_cast<const char*>(a.dctx) + cbase, cs, LKP, L, wave, lane);
-  for (int key = tid; key < LKP; key += 512)
-    kb[key] = key < L ? (f.key_bias ? f.key_bias[(int64_t)b * L + key] : 0.f) : -INFINITY;
+  constexpr float kLog2e = 1.4426950408889634f;
+  for (int key = tid; key < LKP; key += 512)       // key bias in base-2 units; keys >= L: -inf (p = 0)
+    kb[key] = key < L ? (HAS_KB ? f.key_bias[(int64_t)b * L + key] * kLog2e : 0.f) : -INFINITY;
 
   // this wave's 32 rows (queries in pass A, keys in pass B)
   const int blk = wave;
@@ -377,10 +382,13 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
       for (int e = 0; e < 8; ++e) d_q += gv[e] * ov[e];
     }
     d_q += __shfl_xor(d_q, 32, 64);
-    if (h == 0) { lseA[row] = lse_q; dA[row] = row < L ? d_q : 0.f; }     // rows >= L: lse = +inf -> P = 0 in pass B
+    // lseA holds -lse log2 e (rows >= L: -inf -> P = 0 in pass B)
+    if (h == 0) { lseA[row] = -lse_q * kLog2e; dA[row] = row < L ? d_q : 0.f; }
   }
   __syncthreads();
   const float scale = f.scale;
+  const float c = scale * kLog2e;
+  const float nlse_q = -lse_q * kLog2e;
 
   // ------------------------------------------------ pass A: dQ for queries 32*blk + l31 ------------------------
   if (active) {
@@ -408,8 +416,8 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
         const float kbv[4] = {kb4.x, kb4.y, kb4.z, kb4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float p = __expf(fmaf(sacc[4 * qd + e], scale, kbv[e]) - lse_q);
-          if (f.causal && 32 * t + 8 * qd + 4 * h + e > row) p = 0.f;
+          float p = __builtin_amdgcn_exp2f(fmaf(sacc[4 * qd + e], c, kbv[e] + nlse_q));     // (kb: 0 / -inf without a key bias)
+          if (CAUSAL && 32 * t + 8 * qd + 4 * h + e > row) p = 0.f;
           ds[4 * qd + e] = p * (pacc[4 * qd + e] - d_q);
         }
       }
@@ -471,8 +479,8 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
         const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float pe = __expf(fmaf(sacc[4 * qd + e], scale, kb_key) - lv[e]);
-          if (f.causal && row > 32 * t + 8 * qd + 4 * h + e) pe = 0.f;      // this key lies after that query
+          float pe = __builtin_amdgcn_exp2f(fmaf(sacc[4 * qd + e], c, kb_key + lv[e]));
+          if (CAUSAL && row > 32 * t + 8 * qd + 4 * h + e) pe = 0.f;      // this key lies after that query
           p[4 * qd + e] = pe;
           ds[4 * qd + e] = pe * (pacc[4 * qd + e] - dv4[e]);
         }
@@ -531,15 +539,17 @@ bool attention_short_fwd_eligible(const AttnArgs& a, int dtype) {   // forward: 
 int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
   const int nt = (a.f.L + 31) / 32;
   const int bytes = nt * (4 * 32 * 128 + 3 * 32 * 4) + 8 * 2 * 192 * 4;
-  static int attr_max = 0;
-  if (bytes > attr_max) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_short_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    attr_max = bytes;
+  static int attr_max[4] = {0, 0, 0, 0};
+  const int vi = (a.f.key_bias != nullptr ? 1 : 0) + (a.f.causal ? 2 : 0);
+  auto* kern = vi == 0 ? &attn_bwd_short_kernel<false, false> : vi == 1 ? &attn_bwd_short_kernel<true, false>
+             : vi == 2 ? &attn_bwd_short_kernel<false, true> : &attn_bwd_short_kernel<true, true>;
+  if (bytes > attr_max[vi]) {
+    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_max[vi] = bytes;
   }
   {
     ProfScope ps(PROF_ATTN, 10.0 * a.f.B * a.f.H * (double)a.f.L * a.f.L * 64, stream);   // 5 L x L x 64 products
-    hipLaunchKernelGGL(attn_bwd_short_kernel, dim3(a.f.H, a.f.B), dim3(512), bytes, stream, a, nt);
+    hipLaunchKernelGGL(kern, dim3(a.f.H, a.f.B), dim3(512), bytes, stream, a, nt);
   }
   EZ_LAUNCH_CHECK();
   if (a.dbq != nullptr) {      // batch sum of the per-sample partials [B][3][D] -> the three bias gradients

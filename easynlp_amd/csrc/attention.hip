@@ -19,6 +19,8 @@
 //              consecutive d for its query: vector stores.
 // The same code path serves f32 (v_mfma_f32_32x32x2_f32) and bf16
 // (v_mfma_f32_32x32x16_bf16); only chunk geometry differs.
+#include <type_traits>
+
 #include "ezclip_common.h"
 #include "kernels.h"
 
@@ -36,6 +38,14 @@ template <typename T> struct Geo {
   static constexpr int RPI = 1024 / RB;   // K rows per LDS-DMA wave-instruction
   __device__ static __forceinline__ int swz(int row) { return SZ == 2 ? ((row >> 1) & 7) : (row & 15); }
 };
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for_q(F&& f) {
+  if constexpr (N > 0) {
+    static_for_q<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
 
 // LDS carve-up for nt 32-key tiles (runtime): K rows | V^T [64][LP] | key bias
 template <typename T>
@@ -58,7 +68,8 @@ __device__ __forceinline__ uint4 read_k(const char* kt, int row, int chunk) {
 // Fill K (LDS-DMA, swizzled source), V^T (register transpose) and the key bias row.
 template <typename T>
 __device__ __forceinline__ void stage_kv(const AttnArgs& a, const Smem<T>& S, int b, int head, char* smem, int tid,
-                                         int nthreads, int wave, int nwaves, int lane) {
+                                         int nthreads, int wave, int nwaves, int lane, int key0 = 0) {
+  // key0: first key of the block of S.LKP keys staged (0: the whole sequence; the chunked forward walks blocks)
   using G = Geo<T>;
   const int L = a.L;
   const int64_t rs = a.row_stride * G::SZ;
@@ -68,7 +79,7 @@ __device__ __forceinline__ void stage_kv(const AttnArgs& a, const Smem<T>& S, in
   for (int inst = wave; inst < ninst; inst += nwaves) {
     const int r = inst * G::RPI + lane / G::CPR;
     const int c = (lane % G::CPR) ^ G::swz(r);
-    const int gr = r < L ? r : L - 1;  // clamp: pad keys get a finite (masked) score
+    const int gr = key0 + r < L ? key0 + r : L - 1;  // clamp: pad keys get a finite (masked) score
     __builtin_amdgcn_global_load_lds((glb_void*)(kbase + gr * rs + c * 16), (lds_void*)(smem + inst * 1024), 16, 0, 0);
   }
   // V^T: item = (d-chunk dc, key quad kq); consecutive lanes -> consecutive kq (conflict-free writes)
@@ -79,7 +90,7 @@ __device__ __forceinline__ void stage_kv(const AttnArgs& a, const Smem<T>& S, in
     uint4 w[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int key = 4 * kq + r;
+      const int key = key0 + 4 * kq + r;
       if (key < L) w[r] = *reinterpret_cast<const uint4*>(vbase + key * rs + dc * 16);
       else w[r] = make_uint4(0, 0, 0, 0);
     }
@@ -103,7 +114,7 @@ __device__ __forceinline__ void stage_kv(const AttnArgs& a, const Smem<T>& S, in
   }
   float* kb = reinterpret_cast<float*>(smem + S.kbOff);
   for (int key = tid; key < S.LKP; key += nthreads)
-    kb[key] = key < L ? (a.key_bias ? a.key_bias[(int64_t)b * L + key] : 0.f) : -INFINITY;
+    kb[key] = key0 + key < L ? (a.key_bias ? a.key_bias[(int64_t)b * L + key0 + key] : 0.f) : -INFINITY;
 }
 
 // scaled + biased scores of one 32-key tile for this lane's query: x[r], key = 32t + (r&3) + 8(r>>2) + 4h
@@ -262,12 +273,173 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a, int nt) {
   }
 }
 
+// Sequences whose K and V^T images do not fit the 160 KiB of LDS (f32: L > 288 -- BERT goes to 512 positions,
+// modeling_bert.py max_position_embeddings; bf16: L > 576): the keys are walked in blocks of `ch` tiles with an online
+// softmax ACROSS blocks -- every wave keeps the running maximum / sum / output of its (up to QBW) query blocks in registers
+// while the workgroup re-stages K / V^T for the next key block.  Inside a block the arithmetic is the two-pass one of
+// attn_fwd_kernel (block maximum first, then p = exp(x - m)), so a single block reproduces it bit for bit.
+template <typename T, int QBW>
+__global__ __launch_bounds__(512) void attn_fwd_chunked_kernel(AttnArgs a, int nt, int ch) {
+  using G = Geo<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Smem<T> S(ch);
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = nthreads >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int L = a.L;
+  constexpr bool kFast = IsFast<T>::value;
+  const char* kt = smem;
+  const char* vt = smem + S.vtOff;
+  const float* kb = reinterpret_cast<const float*>(smem + S.kbOff);
+  const int LP = S.LP;
+  const int nqb = (L + 31) / 32;
+
+  f32x16_t o[QBW][2];
+  float m[QBW], l[QBW];
+#pragma unroll
+  for (int i = 0; i < QBW; ++i) {
+    m[i] = -INFINITY; l[i] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][dt][r] = 0.f;
+  }
+  for (int c0 = 0; c0 < nt; c0 += ch) {
+    const int ntc = nt - c0 < ch ? nt - c0 : ch;
+    __syncthreads();                                   // every wave is done with the previous key block
+    stage_kv<T>(a, S, b, head, smem, tid, nthreads, wave, nwaves, lane, 32 * c0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    static_for_q<QBW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int qb = wave + i * nwaves;
+      if (qb < nqb) {
+        const int q = qb * 32 + l31;
+        const int qc = q < L ? q : L - 1;
+        const char* qp = reinterpret_cast<const char*>(a.q) + (((int64_t)b * L + qc) * a.row_stride + head * 64) * G::SZ;
+        uint4 qf[G::NS];
+#pragma unroll
+        for (int s = 0; s < G::NS; ++s) qf[s] = *reinterpret_cast<const uint4*>(qp + (2 * s + h) * 16);
+        float mx = -INFINITY;
+#pragma unroll 1
+        for (int t = 0; t < ntc; ++t) {
+          float x[16];
+          score_tile<T>(kt, kb, qf, t, l31, h, a.scale, x, a.causal, q, 32 * (c0 + t));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, x[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // (no branch here: MFMAs ignore EXEC.  A causal query that precedes the whole key block has mx = -inf, then mn = m[i]
+        // -- finite, block 0 always holds key 0 <= q -- alpha = 1 and every p = exp(-inf) = 0: nothing is added)
+        {
+          const float mn = fmaxf(m[i], mx);
+          const float alpha = kFast ? __expf(m[i] - mn) : expf(m[i] - mn);     // first block: exp(-inf) = 0 on o = 0
+          m[i] = mn;
+          l[i] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][dt][r] *= alpha;
+          float sum = 0.f;
+#pragma unroll 1
+          for (int t = 0; t < ntc; ++t) {
+            float x[16];
+            score_tile<T>(kt, kb, qf, t, l31, h, a.scale, x, a.causal, q, 32 * (c0 + t));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              x[r] = kFast ? __expf(x[r] - mn) : expf(x[r] - mn);
+              sum += x[r];
+            }
+            if (a.drop.thr != 0) drop_tile_qmajor(a.drop, ((uint32_t)b * a.H + head) * L + qc, c0 + t, h, x);   // bert :238
+            if constexpr (G::SZ == 2) {
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                uint4 pc;
+                pc.x = pack_bf16x2(x[8 * u + 0], x[8 * u + 1]);
+                pc.y = pack_bf16x2(x[8 * u + 2], x[8 * u + 3]);
+                pc.z = pack_bf16x2(x[8 * u + 4], x[8 * u + 5]);
+                pc.w = pack_bf16x2(x[8 * u + 6], x[8 * u + 7]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                  const char* vp = vt + ((dt * 32 + l31) * LP + 32 * t + 16 * u + 4 * h) * 2;
+                  const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+                  const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
+                  mma32(o[i][dt], make_uint4(lo.x, lo.y, hi.x, hi.y), pc, T());   // D[d][q]
+                }
+              }
+            } else {
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd) {
+                const uint4 pc = make_uint4(__float_as_uint(x[4 * qd + 0]), __float_as_uint(x[4 * qd + 1]),
+                                            __float_as_uint(x[4 * qd + 2]), __float_as_uint(x[4 * qd + 3]));
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                  const uint4 vf = *reinterpret_cast<const uint4*>(vt + ((dt * 32 + l31) * LP + 32 * t + 8 * qd + 4 * h) * 4);
+                  mma32(o[i][dt], vf, pc, T());
+                }
+              }
+            }
+          }
+          l[i] += sum;
+        }
+      }
+    });
+  }
+  static_for_q<QBW>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const int qb = wave + i * nwaves;
+    if (qb < nqb) {
+      const int q = qb * 32 + l31;
+      float sum = l[i];
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.0f / sum;
+      if (q < L) {
+        T* cp = reinterpret_cast<T*>(a.ctx) + ((int64_t)b * L + q) * a.ctx_stride + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = o[i][dt][4 * qd + e] * inv;
+            st4(cp + dt * 32 + 8 * qd + 4 * h, v);
+          }
+        if (a.lse != nullptr && h == 0) a.lse[((int64_t)b * a.H + head) * L + q] = m[i] + logf(sum);
+      }
+    }
+  });
+}
+
+template <typename T, int QBW>
+int launch_fwd_chunked(const AttnArgs& a, int nt, int ch, hipStream_t stream) {
+  const Smem<T> S(ch);
+  static int attr_max = 0;
+  if (S.bytes > attr_max) {
+    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_chunked_kernel<T, QBW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, S.bytes));
+    attr_max = S.bytes;
+  }
+  {
+    ProfScope ps(PROF_ATTN, 4.0 * a.B * a.H * (double)a.L * a.L * 64, stream);
+    hipLaunchKernelGGL((attn_fwd_chunked_kernel<T, QBW>), dim3(a.H, a.B), dim3(512), S.bytes, stream, a, nt, ch);
+  }
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
 template <typename T>
 int launch_fwd(const AttnArgs& a, hipStream_t stream) {
   const int nt = (a.L + 31) / 32;
   const Smem<T> S(nt);
   if (S.bytes > 160 * 1024) {
-    set_error("attention_fwd: sequence length %d needs %d bytes of LDS (> 160 KiB)", a.L, S.bytes);
+    int ch = nt;
+    while (ch > 1 && Smem<T>(ch).bytes > 160 * 1024) --ch;
+    if (nt <= 8) return launch_fwd_chunked<T, 1>(a, nt, ch, stream);
+    if (nt <= 16) return launch_fwd_chunked<T, 2>(a, nt, ch, stream);      // L <= 512: two query blocks per wave
+    set_error("attention_fwd: sequence length %d > 512 is not supported by the general kernels", a.L);
     return EZ_ERR_UNSUPPORTED;
   }
   static int attr_max = 0;

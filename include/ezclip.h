@@ -174,7 +174,11 @@ int ezclip_infonce_from_logits(const float* logits_dev, int n, float* loss_dev, 
 /* d loss / d logits for the above, scaled by *grad_out_dev (scalar, device). */
 int ezclip_infonce_from_logits_bwd(const float* logits_dev, int n, const float* grad_out_dev,
                                    float* dlogits_dev, float* scratch_dev, void* stream);
-/* Fused contrastive step on embeddings (local or all-gathered global batch):
+/* Contrastive step on embeddings (local or all-gathered global batch) in ONE CALL -- "fused" in the name means the call,
+ * not one kernel: both [n_local, n_global] f32 logit blocks are materialised in the workspace (2 x 32 MB at 1024 x 8192),
+ * the row log-sum-exps, d(logits) and the four gradient products are separate launches of the f32 MFMA GEMM and the
+ * loss.hip row kernels (0.1 % of a step at n = 1024; a tiled online-LSE kernel without the logit blocks is the open item
+ * for the 8-GPU global batch).
  *   text_all/image_all: float32 [n_global, e] (rows rank_offset..rank_offset+n_local are this rank's)
  *   loss = 0.5 * (mean_i CE(s * T_loc I_all^T)_i + mean_i CE(s * I_loc T_all^T)_i),  s = exp(*logit_scale)
  *   outputs (any may be NULL to skip the backward part):

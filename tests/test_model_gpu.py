@@ -135,6 +135,31 @@ def test_folded_layernorm_inference_path(tmp_path):
     assert torch.equal(again, outs[1])
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_text_tower_at_512_tokens(tmp_path, dtype):
+    """BERT's full position range (max_position_embeddings 512, modeling_bert.py:88): in f32 the attention forward walks
+    the keys in blocks above 288 tokens (attn_fwd_chunked_kernel), forward and backward against the oracle."""
+    cfg = dict(O.CONFIGS["small"], text_max_position_embeddings=512)
+    app, sd = make_app(tmp_path, cfg, 9, dtype)
+    app.eval()
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(1, cfg["vocab_size"], (3, 512), generator=g)
+    ids[1, 300:] = 0
+    ids[2, 17:] = 0
+    out = app({"input_ids": ids}, feat=True)["text_embeds"]
+    w = torch.randn(out.shape, generator=g).to(out.device)
+    (out * w).sum().backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.encode_text(sdr, cfg, ids)
+    (ref * w.cpu()).sum().backward()
+    tol = 2e-5 if dtype == "fp32" else 1e-2
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) < tol
+    for n in ("text_projection", "bert.encoder.layer.0.attention.self.value.weight", "bert.encoder.layer.1.output.dense.weight",
+              "bert.embeddings.position_embeddings.weight"):
+        got, want = app._params[n].grad.detach().cpu().double(), sdr[n].grad.double()
+        assert float((got - want).norm()) <= (2e-4 if dtype == "fp32" else 8e-2) * float(want.norm()), n
+
+
 class _DS(torch.utils.data.Dataset):
     def __init__(self, px, ids):
         self.px, self.ids = px, ids

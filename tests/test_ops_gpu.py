@@ -155,6 +155,41 @@ def test_attention(B_, Lq, H, dtype, masked):
     assert max_err(lse, ref_lse) < (1e-4 if dtype == "f32" else 0.05)
 
 
+@pytest.mark.parametrize("Lq,masked,causal", [(300, False, False), (400, True, False), (512, False, False), (512, True, False),
+                                              (512, False, True), (330, True, True)])
+def test_attention_f32_long_sequences_walk_the_keys_in_blocks(Lq, masked, causal):
+    """f32 (and bf16 beyond 576 tokens): K and V^T of a head no longer fit the 160 KiB of LDS above 288 tokens -- BERT goes
+    to 512 positions (modeling_bert.py max_position_embeddings).  attn_fwd_chunked_kernel stages the keys in blocks with
+    an online softmax across blocks; two query blocks per wave at 512."""
+    B_, H = 2, 2
+    g = torch.Generator().manual_seed(Lq)
+    D = H * 64
+    qkv = torch.randn(B_ * Lq, 3 * D, generator=g) * 1.5
+    kb = None
+    if masked:
+        lens = torch.tensor([Lq, 290])
+        kb = torch.zeros(B_, Lq)
+        for i in range(B_):
+            kb[i, lens[i]:] = -10000.0
+        kb = kb.reshape(-1)
+    q, k, v = [t.double().reshape(B_, Lq, H, 64).transpose(1, 2) for t in qkv.split(D, dim=-1)]
+    s_ = (q @ k.transpose(-1, -2)) * 0.125
+    if kb is not None:
+        s_ = s_ + kb.double().reshape(B_, 1, 1, Lq)
+    if causal:
+        s_ = s_.masked_fill(torch.triu(torch.ones(Lq, Lq, dtype=torch.bool), 1), float("-inf"))
+    ref = (torch.softmax(s_, -1) @ v).transpose(1, 2).reshape(B_ * Lq, D)
+    ref_lse = torch.logsumexp(s_, -1)
+    L.op_set_attention_causal(causal)
+    try:
+        ctx, lse = L.op_attention(qkv.to(DEV), B_, Lq, H, key_bias=None if kb is None else kb.to(DEV), want_lse=True)
+        torch.cuda.synchronize()
+    finally:
+        L.op_set_attention_causal(False)
+    assert max_err(ctx, ref) < 2e-5
+    assert max_err(lse, ref_lse) < 1e-4
+
+
 def test_attention_bf16_long_sequence_512():
     B_, Lq, H = 1, 512, 2
     g = torch.Generator().manual_seed(11)
@@ -314,8 +349,6 @@ def test_layernorm_bwd(rows, D, dtype):
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("masked", [False, True])
 def test_attention_bwd(B_, Lq, H, dtype, masked):
-    if dtype == "f32" and Lq > 288:
-        pytest.skip("f32 forward keeps the whole K/V^T of a head in LDS: L <= 288")
     lib = L.load()
     g = torch.Generator().manual_seed(B_ * 100 + Lq + H)
     D = H * 64

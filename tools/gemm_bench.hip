@@ -111,6 +111,7 @@ int main(int argc, char** argv) {
       {"train.fc+c2", Mv, 3072, 768, 1, false, true},   {"ragged.M", Mv - 100, 768, 768, 0, true, false},
       {"bwd.dgrad*act'", Mv, 3072, 768, 1, false, false, true}, {"bwd.gelu' ragged", 788, 3072, 768, 2, false, false, true},
       {"small.M=788", 788, 768, 3072, 0, true, false},
+      {"bert.qkv", Mt, 2304, 768, 0, false, false},       // q | k | v of a BERT layer as one product (round 2)
   };
   hipStream_t st;
   CK(hipStreamCreate(&st));

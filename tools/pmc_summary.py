@@ -10,13 +10,13 @@ import os
 import sys
 
 SHAPES = ["vit.qkv", "vit.out+res", "vit.fc+qgelu", "vit.proj+res", "bert.qkvo+res", "bert.ffn1+gelu", "bert.ffn2+res",
-          "patch", "train.fc+c2", "ragged.M", "bwd.dgrad*act'", "bwd.gelu' ragged", "small.M=788",
+          "patch", "train.fc+c2", "ragged.M", "bwd.dgrad*act'", "bwd.gelu' ragged", "small.M=788", "bert.qkv",
           "wgrad.out", "wgrad.qkv", "wgrad.fc", "wgrad.proj", "wgrad.bert.ffn1", "wgrad.ragged"]
 DIMS = {"vit.qkv": (201728, 2304, 768), "vit.out+res": (201728, 768, 768), "vit.fc+qgelu": (201728, 3072, 768),
         "vit.proj+res": (201728, 768, 3072), "bert.qkvo+res": (65536, 768, 768), "bert.ffn1+gelu": (65536, 3072, 768),
         "bert.ffn2+res": (65536, 768, 3072), "patch": (200704, 768, 768), "train.fc+c2": (201728, 3072, 768),
         "ragged.M": (201628, 768, 768), "bwd.dgrad*act'": (201728, 3072, 768), "bwd.gelu' ragged": (788, 3072, 768),
-        "small.M=788": (788, 768, 3072), "wgrad.out": (201728, 768, 768), "wgrad.qkv": (201728, 2304, 768),
+        "small.M=788": (788, 768, 3072), "bert.qkv": (65536, 2304, 768), "wgrad.out": (201728, 768, 768), "wgrad.qkv": (201728, 2304, 768),
         "wgrad.fc": (201728, 3072, 768), "wgrad.proj": (201728, 768, 3072), "wgrad.bert.ffn1": (65536, 3072, 768),
         "wgrad.ragged": (201651, 768, 768)}
 

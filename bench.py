@@ -12,7 +12,9 @@ encode_text (+ RCCL all-gather of both embedding sets when N > 1) + similarity (
 prints ONE JSON line.  The headline (`value`) is the default workload; the same line carries every other BASELINE.json
 configuration this box can run under `also` (a few steps each):
 
-  bf16_b1024_fwd_loss        (default, headline) ViT-B/16 + BERT-base, bf16 MFMA, 1024 pairs/GPU, 64 tokens
+  bf16_b1024_fwd_loss        (default, headline) ViT-B/16 + BERT-base, bf16 MFMA, 1024 pairs/GPU, 64 tokens; the text tower
+                             runs on the unmasked tokens only (same embeddings: masked keys carry -10000, only x[:, 0] is read)
+  bf16_b1024_fwd_loss_padded_text   the same with every padded position fed through the text tower, as the reference does
   bf16_b1024_train           config 3: + full backward into a flat gradient arena (+ overlapped gradient all-reduce, N > 1)
   bf16_b1024_train_opt       the same + torch.optim.AdamW(fused) step + the library's weight re-pack: a whole training step
   fp32_b256_fwd_sim          config 2: exact-f32 MFMA, 256 pairs, forward + similarity
@@ -70,6 +72,7 @@ WORKLOADS = {
     "bf16_b1024_fwd_loss": dict(dtype="bf16", batch=1024, seq=64, backward=False),
     "bf16_b1024_train": dict(dtype="bf16", batch=1024, seq=64, backward=True),
     "bf16_b1024_train_opt": dict(dtype="bf16", batch=1024, seq=64, backward=True, optimizer=True),
+    "bf16_b1024_fwd_loss_padded_text": dict(dtype="bf16", batch=1024, seq=64, backward=False, pack_text=False),
     "bf16_b1024_fwd_loss_autograd": dict(dtype="bf16", batch=1024, seq=64, backward=False, path="autograd"),
     "bf16_b1024_train_autograd": dict(dtype="bf16", batch=1024, seq=64, backward=True, path="autograd"),
     "fp32_b256_fwd_sim": dict(dtype="fp32", batch=256, seq=64, backward=False),
@@ -78,7 +81,8 @@ WORKLOADS = {
     "bf16_hf_vitl14_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="hf_vitl14"),
 }
 # what the default run adds to the headline line (BASELINE.json configs 3, 2, 5 + the boundary overhead)
-ALSO_N1 = ["bf16_b1024_train", "bf16_b1024_train_opt", "bf16_b1024_fwd_loss_autograd", "bf16_b1024_train_autograd",
+ALSO_N1 = ["bf16_b1024_fwd_loss_padded_text", "bf16_b1024_train", "bf16_b1024_train_opt", "bf16_b1024_fwd_loss_autograd",
+           "bf16_b1024_train_autograd",
            "fp32_b256_fwd_sim", "bf16_vitl14_b512_fwd_loss", "bf16_vitl14_b512_train", "bf16_hf_vitl14_b512_train"]
 ALSO_MULTI = ["bf16_b1024_train"]          # config 4 "(+bwd)": gradient all-reduce overlapped with the backward pass
 
@@ -269,6 +273,8 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
     B, S = wl["batch"], wl["seq"]
     world, rank, device = c.world, c.rank, c.device
     app, model_name = build_app(wl, device, text_dropout)
+    if wl.get("pack_text") is False:
+        app._engine.pack_text = False
     px, ids = synth_batch(B, S, VITB16_BERTBASE["vocab_size"], device, seed=1000 + rank)
     pg = True if world > 1 else False
     autograd = wl.get("path") == "autograd"
@@ -368,12 +374,17 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
             l_ms, l_by, l_n = res["layernorm"]
             extra["layernorm_gbps"] = round(l_by / (l_ms * 1e-3) / 1e9, 1) if l_ms > 0 else None
     buckets = getattr(app, "last_grad_buckets", None)
+    text_rows = app._engine.last_text_rows
     two_streams = bool(app.two_streams)
     del app, opt
     torch.cuda.empty_cache()
     if rank != 0:
         return None
     gflop, gflop_all = gflop_per_pair(wl)
+    if text_rows and text_rows[0] != text_rows[1] and wl.get("model") is None and not wl["backward"]:
+        # packed text tower: its GEMM / LayerNorm work scales with the rows that went through it (11.025 G per pair at 64 tokens,
+        # of which 0.756 G are the skipped CLS-only part of the last layer)
+        gflop -= (11.025 - 0.756) * (1.0 - text_rows[0] / text_rows[1])
     value = world * B * steps / elapsed
     out = {
         "workload": name, "value": round(value, 2), "ms_per_step": round(step_ms, 3), "dtype": wl["dtype"],
@@ -382,6 +393,7 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
                   + ("+backward" if wl["backward"] else "") + ("+grad_allreduce(overlapped)" if wl["backward"] and world > 1 and not autograd else "")
                   + ("+AdamW+repack" if wl.get("optimizer") else ""),
         "two_streams": two_streams, "loss": round(loss_val, 5),
+        "text_tower_rows": {"through_the_tower": text_rows[0], "tokens_in_the_batch": text_rows[1]} if text_rows else None,
         "gflop_per_pair": {"algorithmic_all_tokens": gflop_all, "executed": round(gflop, 3)},
         "model_tflops_per_gpu": round(value / world * gflop / 1e3, 2),
         "model_mfma_frac": round(value / world * gflop / 1e3 / PEAK_TFLOPS[wl["dtype"]], 4),
@@ -458,7 +470,7 @@ def main():
                 if world > 1:
                     raise
             if rank == 0:
-                keep = ("value", "ms_per_step", "dtype", "path", "stages", "pairs_per_gpu", "loss", "model_tflops_per_gpu",
+                keep = ("value", "ms_per_step", "dtype", "path", "stages", "pairs_per_gpu", "loss", "text_tower_rows", "model_tflops_per_gpu",
                         "model_mfma_frac", "time_share", "grad_allreduce_buckets_mib", "error")
                 also[n] = {k: r[k] for k in keep if k in r}
                 if r.get("roofline"):
@@ -481,7 +493,7 @@ def main():
                        "two_streams": head["two_streams"], "text_dropout": args.text_dropout},
             "rccl_ranks": world if use_dist else 0,
         }
-        for k in ("loss", "gflop_per_pair", "model_tflops_per_gpu", "model_mfma_frac", "roofline", "time_share", "attention_tflops",
+        for k in ("loss", "text_tower_rows", "gflop_per_pair", "model_tflops_per_gpu", "model_mfma_frac", "roofline", "time_share", "attention_tflops",
                   "layernorm_gbps", "grad_allreduce_buckets_mib"):
             if k in head:
                 out[k] = head[k]

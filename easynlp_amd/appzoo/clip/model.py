@@ -115,6 +115,12 @@ class HipClipEngine:
         self._side: Dict[str, "torch.cuda.Stream"] = {}
         self._arenas: Dict[str, "P.GradArena"] = {}
         self._progress_cb = None
+        self.text_arch = int(text_arch)
+        self._drop = (0.0, 0.0)
+        # inference runs the BERT tower on the unmasked tokens only (ezclip_encode_text_packed); EZCLIP_PACK_TEXT=0 /
+        # clip_pack_text=0 feeds every padded position through it as the reference does -- same embeddings
+        self.pack_text = os.environ.get("EZCLIP_PACK_TEXT", "1") not in ("0", "false", "False")
+        self.last_text_rows = None
         self.uses_pooler = bool(hf_branch)
         self.embed_dim = int(cfg["embed_dim"])
 
@@ -254,14 +260,57 @@ class HipClipEngine:
                                              1 if save else 0, L.stream_ptr(stream)), "encode_image")
         return out, ws
 
-    def encode_text(self, ids: torch.Tensor, save: bool, extras=None, owner=None, stream=None) -> (torch.Tensor, torch.Tensor):
-        """extras: (position_ids, token_type_ids, attention_mask) int64 [B, S] device tensors (huggingface_clip branch)"""
+    # -- packed text batches ---------------------------------------------------------------------------------
+    def pack_meta(self, ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, device=None) -> Optional[dict]:
+        """Which tokens of a [B, S] batch the text tower has to see (ezclip_encode_text_packed, include/ezclip.h): every
+        unmasked token (mask = ids != 0, modeling_chineseclip.py:347, or the explicit attention mask), every CLS token, and
+        whole sentences without any unmasked key.  Works on host ids (no GPU involved: the DataLoader hands ``forward`` CPU
+        tensors) or device ids (one small host sync for the two scalars).  None when packing would not pay or does not apply."""
+        B, S = ids.shape
+        keep = ids.ne(0) if attention_mask is None else attention_mask.ne(0)
+        keep = keep | ~keep.any(1, keepdim=True)
+        keep[:, 0] = True
+        lens = keep.sum(1, dtype=torch.int32)
+        cs = torch.cumsum(lens, 0, dtype=torch.int32)
+        total, longest = (int(v) for v in torch.stack([cs[-1], lens.max()]).tolist())
+        if longest > 288 or total > 0.9 * B * S:
+            return None
+        cu = cs - lens
+        within = torch.cumsum(keep, 1, dtype=torch.int32) - 1
+        dst = torch.where(keep, cu[:, None] + within, torch.full_like(within, B * S))      # dropped tokens -> a dummy slot
+        rowmap = torch.empty(B * S + 1, dtype=torch.int32, device=ids.device)
+        rowmap.scatter_(0, dst.flatten().long(), torch.arange(B * S, dtype=torch.int32, device=ids.device))
+        dev = device if device is not None else ids.device
+        return {"rowmap": rowmap[:total].contiguous().to(dev), "cu": cu.contiguous().to(dev), "lens": lens.contiguous().to(dev),
+                "rows": total, "longest": longest, "shape": (B, S)}
+
+    def can_pack(self, save: bool) -> bool:
+        return (self.pack_text and not save and self.dtype_code == L.DTYPE_BF16 and self.text_arch == 0
+                and self._drop == (0.0, 0.0))
+
+    def encode_text(self, ids: torch.Tensor, save: bool, extras=None, owner=None, stream=None, pack=None) -> (torch.Tensor, torch.Tensor):
+        """extras: (position_ids, token_type_ids, attention_mask) int64 [B, S] device tensors (huggingface_clip branch).
+        pack: what ``pack_meta`` returned for these ids (computed here when None and packing applies)."""
         ids = ids.contiguous()
         if ids.dtype != torch.int64:
             ids = ids.long()
         B, S = ids.shape
         out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=ids.device)
         ws = self.workspace("text", B, S, save, ids.device, owner)
+        if self.can_pack(save) and S >= 8 and pack is not False:
+            if pack is None:
+                pack = self.pack_meta(ids, None if extras is None else extras[2])
+            elif pack.get("shape") != (B, S):
+                raise L.EzclipError("packing metadata of another batch")
+            if pack:
+                pos, tt, am = extras if extras is not None else (None, None, None)
+                L.check(self.lib.ezclip_encode_text_packed(self.handle, L.ptr(ids), L.ptr(pos), L.ptr(tt), L.ptr(am),
+                                                           L.ptr(pack["rowmap"]), L.ptr(pack["cu"]), L.ptr(pack["lens"]), B, S,
+                                                           pack["rows"], pack["longest"], L.ptr(out), L.ptr(ws), ws.numel(),
+                                                           L.stream_ptr(stream)), "encode_text_packed")
+                self.last_text_rows = (pack["rows"], B * S)
+                return out, ws
+        self.last_text_rows = (B * S, B * S)
         if extras is None:
             L.check(self.lib.ezclip_encode_text(self.handle, L.ptr(ids), B, S, L.ptr(out), L.ptr(ws), ws.numel(),
                                                 1 if save else 0, L.stream_ptr(stream)), "encode_text")
@@ -275,6 +324,7 @@ class HipClipEngine:
         """Arm (or, with zeros, disarm) the BERT train-mode dropout for the next encode_text / backward_text."""
         L.check(self.lib.ezclip_set_text_dropout(self.handle, float(hidden_p), float(attn_p), int(seed)),
                 "set_text_dropout")
+        self._drop = (float(hidden_p), float(attn_p))
 
     def backward_image(self, pixels, d_emb, ws, stream=None):
         self._weights_dirty = True
@@ -346,7 +396,10 @@ class _EncodeFn(torch.autograd.Function):
             ids = ids.contiguous().long()
             ctx.drop = app._next_dropout()          # (hidden_p, attn_p, seed); zeros in eval mode
             eng.set_text_dropout(*ctx.drop)
-            run_t = lambda st: eng.encode_text(ids, need_grad, owner=ctx.token, stream=st)
+            pack = app.__dict__.pop("_pack_hint", None)     # (forward() computed it on the host ids: no device sync)
+            if pack is None and eng.can_pack(need_grad) and ids.shape[1] >= 8:
+                pack = eng.pack_meta(ids) or False
+            run_t = lambda st: eng.encode_text(ids, need_grad, owner=ctx.token, stream=st, pack=pack)
         ri, rt = _run_towers(eng, app.two_streams, run_i, run_t)
         img, ctx.ws_img = ri if ri is not None else (None, None)
         txt, ctx.ws_txt = rt if rt is not None else (None, None)
@@ -525,6 +578,7 @@ class CLIPApp(Application):
         # --user_defined_parameters 'clip_two_streams=0' or EZCLIP_TWO_STREAMS=0 runs them back to back
         self.two_streams = str(kwargs.get("two_streams", udp.get("clip_two_streams", os.environ.get("EZCLIP_TWO_STREAMS", "1")))) \
             not in ("0", "False", "false")
+        self._pack_text_opt = kwargs.get("pack_text", udp.get("clip_pack_text"))
         if pretrained_model_name_or_path is None:
             return
         path = pretrained_model_name_or_path
@@ -600,6 +654,8 @@ class CLIPApp(Application):
                      torch.arange(int(cfg["text_max_position_embeddings"])).expand((1, -1)).clone(), buffer=True)
             self.chinese_clip = tree
         self._engine = eng
+        if self._pack_text_opt is not None:
+            eng.pack_text = str(self._pack_text_opt) not in ("0", "False", "false")
         named = dict(tree.named_parameters())
         self._params = {n: named[n] for n in eng.names}
 
@@ -640,6 +696,8 @@ class CLIPApp(Application):
         tree_v.add("vision_model.embeddings.position_ids", torch.arange(Lv).expand((1, -1)).clone(), buffer=True)
         self.text_encoder, self.vision_encoder = tree_t, tree_v
         self._engine = eng
+        if self._pack_text_opt is not None:
+            eng.pack_text = str(self._pack_text_opt) not in ("0", "False", "false")
         named = dict(self.named_parameters())
         named["logit_scale"] = named.pop("logit_scale_param")
         self._hf_params = {n: named[n] for n in shapes}
@@ -815,10 +873,13 @@ class CLIPApp(Application):
             eng.sync_params(params, with_backward=False)
         drop = self._next_dropout()
         eng.set_text_dropout(*drop)
+        pack = False
+        if eng.can_pack(backward) and input_ids.shape[1] >= 8:      # (device ids: one small sync, before anything is enqueued)
+            pack = eng.pack_meta(input_ids, None if extras is None else extras[2]) or False
         (img, ws_i), (txt, ws_t) = _run_towers(
             eng, self.two_streams,
             lambda s_: eng.encode_image(pixel_values, backward, stream=s_),
-            lambda s_: eng.encode_text(input_ids, backward, extras=extras, stream=s_))
+            lambda s_: eng.encode_text(input_ids, backward, extras=extras, stream=s_, pack=pack))
         n = img.shape[0]
         e = img.shape[1]
         if world > 1:
@@ -925,7 +986,14 @@ class CLIPApp(Application):
         else:
             inputs["pixel_values"] = None
         if "input_ids" in inputs and inputs["input_ids"] is not None:
-            inputs["input_ids"] = inputs["input_ids"].to(_device)
+            ids_in = inputs["input_ids"]
+            self.__dict__.pop("_pack_hint", None)
+            if (not ids_in.is_cuda and ids_in.dim() == 2 and ids_in.shape[1] >= 8 and self._engine is not None
+                    and not (torch.is_grad_enabled() and self.training) and self._engine.pack_text
+                    and getattr(self, "model_type", None) == "chinese_clip"):
+                # which tokens the text tower has to see, from the host copy the DataLoader delivered (no device sync later)
+                self._pack_hint = self._engine.pack_meta(ids_in, device=_device) or False
+            inputs["input_ids"] = ids_in.to(_device)
         else:
             inputs["input_ids"] = None
         assert inputs["pixel_values"] is not None or inputs["input_ids"] is not None, \

@@ -495,9 +495,10 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(AttnArgs a, const T* 
   if (bh >= a.B * a.H) return;
   float* sc = sc_all[w];
   const int b = bh / a.H, head = bh - b * a.H;
-  const int L = a.L, g = lane >> 3, c = lane & 7;
-  const T* kbase = reinterpret_cast<const T*>(a.k) + (int64_t)b * L * a.row_stride + head * 64;
-  const T* vbase = reinterpret_cast<const T*>(a.v) + (int64_t)b * L * a.row_stride + head * 64;
+  const int L = a.lens ? a.lens[b] : a.L, g = lane >> 3, c = lane & 7;               // (packed batches: AttnArgs::cu / lens)
+  const int64_t row0 = a.cu ? (int64_t)a.cu[b] : (int64_t)b * a.L;
+  const T* kbase = reinterpret_cast<const T*>(a.k) + row0 * a.row_stride + head * 64;
+  const T* vbase = reinterpret_cast<const T*>(a.v) + row0 * a.row_stride + head * 64;
   float qv[8];
   load8(q_cls + (int64_t)b * q_stride + head * 64, c, qv);
   const int nit = (L + 7) >> 3;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(AttnArgs a, const T* 
     dot += __shfl_xor(dot, 2, 64);
     dot += __shfl_xor(dot, 4, 64);
     if (key < L) {
-      const float x = fmaf(dot, a.scale, a.key_bias ? a.key_bias[(int64_t)b * L + key] : 0.f);
+      const float x = fmaf(dot, a.scale, a.key_bias ? a.key_bias[row0 + key] : 0.f);
       mx = fmaxf(mx, x);
       if (c == 0) sc[key] = x;
     }
@@ -720,6 +721,12 @@ int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream) {
   EZ_REQUIRE(((uintptr_t)a.q % 16) == 0 && ((uintptr_t)a.k % 16) == 0 && ((uintptr_t)a.v % 16) == 0 &&
              ((uintptr_t)a.ctx % 16) == 0, "attention_fwd: pointers must be 16-byte aligned");
   EZ_REQUIRE(a.B <= 65535, "attention_fwd: batch %d > 65535", a.B);
+  EZ_REQUIRE((a.cu == nullptr) == (a.lens == nullptr), "attention_fwd: cu and lens go together");
+  if (a.cu != nullptr) {      // packed batches: the short forward kernel only (bf16, longest sample <= 288, no dropout, no lse)
+    EZ_REQUIRE(a.drop.thr == 0 && a.lse == nullptr && attention_short_fwd_eligible(a, dtype),
+               "attention_fwd: packed batches need the bf16 short kernel (L <= 288, no dropout, inference)");
+    return attention_fwd_short(a, stream);
+  }
   if (g_attn_variant != 0 && a.drop.thr == 0 && attention_short_fwd_eligible(a, dtype)) return attention_fwd_short(a, stream);
   if (dtype == EZCLIP_F32) return launch_fwd<float>(a, stream);
   if (dtype == EZCLIP_BF16) return launch_fwd<bf16_t>(a, stream);

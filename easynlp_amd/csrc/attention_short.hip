@@ -73,20 +73,24 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  const int L = a.L, LKP = 32 * nt;
+  // packed batches (AttnArgs::cu / lens): this sample's rows start at cu[b] and there are lens[b] of them; nt (the launch's
+  // tile count, LDS sizing, waves) belongs to the longest sample, this workgroup walks its own ceil(L / 32) tiles
+  const int L = a.lens ? a.lens[b] : a.L, LKP = 32 * nt;
+  const int64_t row0 = a.cu ? (int64_t)a.cu[b] : (int64_t)b * a.L;
+  nt = (L + 31) >> 5;
   char* kimg = smem;
   char* vimg = smem + LKP * 128;
   float* kb = reinterpret_cast<float*>(smem + 2 * LKP * 128);
   const int64_t rs = a.row_stride * 2;
-  const int64_t base = ((int64_t)b * L * a.row_stride + head * 64) * 2;
+  const int64_t base = (row0 * a.row_stride + head * 64) * 2;
   constexpr float kLog2e = 1.4426950408889634f;
 
   const int nwaves = (int)(blockDim.x >> 6);
-  dma_rows<0>(kimg, reinterpret_cast<const char*>(a.k) + base, rs, LKP, L, wave, nwaves, lane);
-  dma_rows<1>(vimg, reinterpret_cast<const char*>(a.v) + base, rs, LKP, L, wave, nwaves, lane);
+  dma_rows<0>(kimg, reinterpret_cast<const char*>(a.k) + base, rs, 32 * nt, L, wave, nwaves, lane);
+  dma_rows<1>(vimg, reinterpret_cast<const char*>(a.v) + base, rs, 32 * nt, L, wave, nwaves, lane);
   if constexpr (HAS_KB) {      // key bias in base-2 units; keys >= L: -inf
-    for (int key = tid; key < LKP; key += (int)blockDim.x)
-      kb[key] = key < L ? a.key_bias[(int64_t)b * L + key] * kLog2e : -INFINITY;
+    for (int key = tid; key < 32 * nt; key += (int)blockDim.x)
+      kb[key] = key < L ? a.key_bias[row0 + key] * kLog2e : -INFINITY;
   }
 
   // this wave's 32 queries
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
       pk[dt][j][0] = lo[0]; pk[dt][j][1] = lo[1]; pk[dt][j][2] = hi[0]; pk[dt][j][3] = hi[1];
     }
   if (q < L) {
-    bf16_t* cp = reinterpret_cast<bf16_t*>(a.ctx) + ((int64_t)b * L + q) * a.ctx_stride + head * 64;
+    bf16_t* cp = reinterpret_cast<bf16_t*>(a.ctx) + (row0 + q) * a.ctx_stride + head * 64;
     if ((a.ctx_stride & 7) == 0 && ((uintptr_t)a.ctx & 15) == 0) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
         }
     }
     // log-sum-exp of the scaled scores (natural log), as the backward kernels expect it
-    if (a.lse != nullptr && h == 0) a.lse[((int64_t)b * a.H + head) * L + q] = m * 0.6931471805599453f + logf(l);
+    if (a.lse != nullptr && h == 0) a.lse[((int64_t)b * a.H + head) * a.L + q] = m * 0.6931471805599453f + logf(l);
   }
 }
 

@@ -79,6 +79,10 @@ struct AttnArgs {
   float* lse = nullptr;           // optional [B, H, L] log-sum-exp of the scaled scores
   int B = 0, L = 0, H = 0;
   float scale = 0.125f;
+  // Packed (variable-length) batches: sample b owns rows cu[b] .. cu[b] + lens[b] - 1 of q / k / v / ctx / key_bias instead
+  // of rows b*L .. b*L + L - 1; L is then the LONGEST sample (LDS sizing).  Short forward kernel and the CLS kernel only.
+  const int* cu = nullptr;
+  const int* lens = nullptr;
   int causal = 0;                 // 1: key j > query i is masked (-inf): CLIP text transformer, build_attention_mask (modeling_openclip.py:343-349)
   DropCfg drop;                   // dropout on the probabilities (BERT train mode); row = (b*H + h)*L + query, col = key
 };
@@ -152,7 +156,8 @@ int bert_embed_ln(const int64_t* ids, const float* word, const float* pos, const
                   const float* b, float eps, void* x0, void* y, float* mean, float* rstd, float* key_bias,
                   int B, int L, int Hd, int vocab, int dtype, hipStream_t stream, const int64_t* pos_ids = nullptr,
                   const int64_t* type_ids = nullptr, const int64_t* attn_mask = nullptr, int max_pos = 1 << 30,
-                  int type_vocab = 1);
+                  int type_vocab = 1, const int* rowmap = nullptr, int packed_rows = 0);
+// (rowmap != null: only the packed_rows tokens rowmap[r] = b * L + t are embedded, into rows r of y / key_bias)
 // CLIP text transformer (OPEN_CLIP.encode_text): x = token_embedding[ids] + positional_embedding; eot_idx[b] = argmax_t ids[b, t]
 int clip_text_embed(const int64_t* ids, const float* tok, const float* pos, void* x, int* eot_idx, int B, int L, int W, int vocab,
                     int64_t eot_id, int dtype, hipStream_t stream);

@@ -112,6 +112,12 @@ struct TextExtras {
   const int64_t* pos_ids = nullptr;
   const int64_t* type_ids = nullptr;
   const int64_t* attn_mask = nullptr;
+  // Packed text batches (ezclip_encode_text_packed): only the tokens rowmap[r] = b * L + t, r < packed_rows, go through the
+  // tower -- sample b owns packed rows cu[b] .. cu[b] + lens[b] - 1, its first one is the CLS token.  Inference, bf16.
+  const int* rowmap = nullptr;
+  const int* cu = nullptr;
+  const int* lens = nullptr;
+  int packed_rows = 0, max_len = 0;
 };
 int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, void* ws, size_t ws_bytes, bool save,
                 hipStream_t stream, const TextExtras* ex = nullptr);

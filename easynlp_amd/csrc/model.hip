@@ -849,9 +849,11 @@ size_t text_workspace_bytes(const ezclip_model* m, int B, int L, bool save) {
 // Last BERT layer on the inference path, CLS rows only (modeling_chineseclip.py:349-350 reads bert(...)[0][:, 0, :]): key and
 // value projections over all tokens; query, attention, BertSelfOutput, BertIntermediate, BertOutput for token 0 of each
 // sentence.  Scratch: q | ctx in b.ctx, y | a | z | x_out in b.y ([B, H] each; L >= 4).  x_out_cls = b.y + 3 * B * H.
+// ex (packed batches): the rows of b.x_in are the packed tokens; the CLS row of sample n is row ex->cu[n].
 static int bert_last_layer_cls(ezclip_model* m, const ezclip_model::BertLayer& Lw, const BertBufs& b, const float* key_bias, int B,
-                               int L, float eps, hipStream_t stream) {
-  const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, M = B * L, dt = m->dtype;
+                               int L, float eps, hipStream_t stream, const TextExtras* ex = nullptr) {
+  const bool packed = ex != nullptr && ex->rowmap != nullptr;
+  const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, M = packed ? ex->packed_rows : B * L, dt = m->dtype;
   const size_t esz = dtype_size(dt), blk = (size_t)B * H * esz;
   char* qkv = (char*)b.qkv;
   char* q_cls = (char*)b.ctx;
@@ -860,15 +862,24 @@ static int bert_last_layer_cls(ezclip_model* m, const ezclip_model::BertLayer& L
   char* a = y + blk;
   char* z = a + blk;
   char* x_out = z + blk;
-  EZ_TRY(linear(m, b.x_in, (int64_t)L * H, Lw.q_w, Lw.q_b, q_cls, H, B, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  const void* x_cls = b.x_in;                    // the CLS rows of the layer input, row stride x_cls_ld
+  int64_t x_cls_ld = (int64_t)L * H;
+  if (packed) {                                  // irregular row positions: gather them next to the other [B, H] blocks
+    char* xc = x_out + blk;                      // (the workspace holds B * L rows whatever was packed; L >= 8)
+    EZ_TRY(gather_rows(b.x_in, ex->cu, xc, B, 0, H, 0, dt, stream));
+    x_cls = xc;
+    x_cls_ld = H;
+  }
+  EZ_TRY(linear(m, x_cls, x_cls_ld, Lw.q_w, Lw.q_b, q_cls, H, B, ACT_NONE, nullptr, 0, nullptr, false, stream));
   EZ_TRY(bert_qkv_proj(m, Lw, b.x_in, H, qkv, M, 1, stream));
   AttnArgs at;
   at.k = qkv + H * esz; at.v = qkv + 2 * H * esz;
   at.row_stride = 3 * H;
   at.key_bias = key_bias;
-  at.B = B; at.L = L; at.H = m->theads; at.scale = 0.125f;
+  at.B = B; at.L = packed ? ex->max_len : L; at.H = m->theads; at.scale = 0.125f;
+  if (packed) { at.cu = ex->cu; at.lens = ex->lens; }
   EZ_TRY(attention_cls_fwd(at, q_cls, H, ctx_cls, H, dt, stream));
-  EZ_TRY(linear(m, ctx_cls, H, Lw.o_w, Lw.o_b, y, H, B, ACT_NONE, b.x_in, (int64_t)L * H, nullptr, false, stream));
+  EZ_TRY(linear(m, ctx_cls, H, Lw.o_w, Lw.o_b, y, H, B, ACT_NONE, x_cls, x_cls_ld, nullptr, false, stream));
   EZ_TRY(layernorm_fwd(y, H, a, H, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, B, H, dt, nullptr, nullptr, stream));
   EZ_TRY(linear(m, a, H, Lw.i_w, Lw.i_b, b.hh, F, B, ACT_GELU_ERF, nullptr, 0, nullptr, false, stream));
   EZ_TRY(linear(m, b.hh, F, Lw.d_w, Lw.d_b, z, H, B, ACT_NONE, a, H, nullptr, false, stream));
@@ -911,21 +922,31 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
   const size_t need = layout_text(m, B, L, save, wsp, &ws);
   EZ_REQUIRE(ws_bytes >= need, "encode_text: workspace too small (%zu < %zu)", ws_bytes, need);
   const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, E = m->cfg.embed_dim;
-  const int M = B * L;
   const int dt = m->dtype;
   const size_t esz = dtype_size(dt);
   const float eps = m->text_ln_eps;  // layer_norm_eps (1e-12: modeling_chineseclip.py:311, CLIPTextConfig default)
   const TextExtras none;
   if (ex == nullptr) ex = &none;
+  // train-mode dropout (set per call by ezclip_set_text_dropout; masks are regenerated from the seed in the backward)
+  const float hp = m->drop_hidden, ap = m->drop_attn;
+  const uint64_t seed = m->drop_seed;
+  // Packed batches: padded positions never reach the CLS feature -- their keys carry the -10000 bias, exp(-10000 + s - max)
+  // is exactly 0 in f32 next to any unmasked key, and nothing reads their rows (modeling_chineseclip.py:347-350) -- so the
+  // tower runs on the kept tokens only: M = packed_rows rows through every GEMM / LayerNorm, per-sample row ranges in the
+  // attention kernels.  (The caller keeps whole sentences that have no unmasked key at all, and every CLS row.)
+  const bool packed = ex->rowmap != nullptr;
+  if (packed) {
+    EZ_REQUIRE(!save && dt == EZCLIP_BF16 && hp == 0.f && ap == 0.f, "encode_text: packed batches are bf16 inference without dropout");
+    EZ_REQUIRE(ex->cu && ex->lens && ex->packed_rows >= B && ex->packed_rows <= B * L && ex->max_len >= 1 && ex->max_len <= L &&
+               ex->max_len <= 288, "encode_text: bad packing (rows %d of %d x %d, longest %d)", ex->packed_rows, B, L, ex->max_len);
+  }
+  const int M = packed ? ex->packed_rows : B * L;
 
   // BertEmbeddings.forward modeling_bert.py:95-129 / RobertaEmbeddings.forward roberta/modeling_roberta.py:98-134
   EZ_TRY(bert_embed_ln(ids, m->P(m->word_p), m->P(m->tpos_p), m->P(m->type_p), m->P(m->eln_w), m->P(m->eln_b), eps,
                        ws.x0, ws.layers[0].x_in, ws.m0, ws.r0, ws.key_bias, B, L, H, m->cfg.vocab_size, dt, stream,
                        ex->pos_ids, ex->type_ids, ex->attn_mask, m->cfg.text_max_position_embeddings,
-                       m->cfg.text_type_vocab_size));
-  // train-mode dropout (set per call by ezclip_set_text_dropout; masks are regenerated from the seed in the backward)
-  const float hp = m->drop_hidden, ap = m->drop_attn;
-  const uint64_t seed = m->drop_seed;
+                       m->cfg.text_type_vocab_size, ex->rowmap, ex->packed_rows));
   if (hp > 0.f)                                                                                    // :128
     EZ_TRY(dropout_rows(ws.layers[0].x_in, H, nullptr, 0, ws.layers[0].x_in, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream));
   // inference: the last layer only feeds x[:, 0] to the pooler / projection -- see bert_last_layer_cls
@@ -944,7 +965,8 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
     at.row_stride = 3 * H;
     at.ctx = b.ctx; at.ctx_stride = H;
     at.key_bias = ws.key_bias; at.lse = b.lse;
-    at.B = B; at.L = L; at.H = m->theads; at.scale = 0.125f;
+    at.B = B; at.L = packed ? ex->max_len : L; at.H = m->theads; at.scale = 0.125f;
+    if (packed) { at.cu = ex->cu; at.lens = ex->lens; }
     at.drop = make_drop(ap, seed, drop_sid_attn(i));                // :238
     EZ_TRY(attention_fwd(at, dt, stream));                          // :210-248
     // BertSelfOutput: LN(dropout(dense(ctx)) + x)                     :264-267
@@ -971,8 +993,12 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
   int64_t xl_ld = (int64_t)L * H;
   if (cls_infer) {
     const BertBufs& b = ws.layers[nlayers - 1];
-    EZ_TRY(bert_last_layer_cls(m, m->bert[nlayers - 1], b, ws.key_bias, B, L, eps, stream));
+    EZ_TRY(bert_last_layer_cls(m, m->bert[nlayers - 1], b, ws.key_bias, B, L, eps, stream, ex));
     xl = static_cast<const char*>(b.y) + (size_t)3 * B * H * esz;      // x_out of the CLS rows, [B, H]
+    xl_ld = H;
+  } else if (packed) {                                                 // CLS rows of the packed last hidden state
+    EZ_TRY(gather_rows(xl, ex->cu, ws.gpool, B, 0, H, 0, dt, stream));
+    xl = ws.gpool;
     xl_ld = H;
   } else if (cls_train) {
     EZ_TRY(bert_last_layer_cls_save(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws.key_bias, B, L, eps, stream));

@@ -444,16 +444,17 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int64_t* ids, 
                                                              const float* type, const float* g, const float* b,
                                                              float eps, T* x0, T* y, float* mean_o, float* rstd_o,
                                                              float* key_bias, int B, int L, int Hd, int vocab, int max_pos,
-                                                             int type_vocab) {
+                                                             int type_vocab, const int* rowmap, int packed_rows) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
-  if (row >= (int64_t)B * L) return;
-  int64_t t = pos_ids ? pos_ids[row] : row % L;
+  const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);      // output row
+  if (row >= (rowmap ? (int64_t)packed_rows : (int64_t)B * L)) return;
+  const int64_t src = rowmap ? (int64_t)rowmap[row] : row;                            // token b * L + t it comes from
+  int64_t t = pos_ids ? pos_ids[src] : src % L;
   t = t < 0 ? 0 : (t >= max_pos ? max_pos - 1 : t);
-  int64_t ty = type_ids ? type_ids[row] : 0;
+  int64_t ty = type_ids ? type_ids[src] : 0;
   ty = ty < 0 ? 0 : (ty >= type_vocab ? type_vocab - 1 : ty);
-  int64_t id = ids[row];
-  const bool masked = attn_mask ? attn_mask[row] == 0 : id == 0;
+  int64_t id = ids[src];
+  const bool masked = attn_mask ? attn_mask[src] == 0 : id == 0;
   if (lane == 0) key_bias[row] = masked ? -10000.0f : 0.0f;
   if (id < 0) id = 0;
   if (id >= vocab) id = vocab - 1;
@@ -768,13 +769,14 @@ int gather_rows(const void* src, const int* idx, void* dst, int B, int L, int W,
 int bert_embed_ln(const int64_t* ids, const float* word, const float* pos, const float* type, const float* g,
                   const float* b, float eps, void* x0, void* y, float* mean, float* rstd, float* key_bias, int B,
                   int L, int Hd, int vocab, int dtype, hipStream_t stream, const int64_t* pos_ids, const int64_t* type_ids,
-                  const int64_t* attn_mask, int max_pos, int type_vocab) {
+                  const int64_t* attn_mask, int max_pos, int type_vocab, const int* rowmap, int packed_rows) {
   EZ_REQUIRE(Hd % 4 == 0 && Hd <= 256 * kMaxChunks, "bert_embed_ln: hidden %d unsupported", Hd);
-  const int64_t rows = (int64_t)B * L;
+  EZ_REQUIRE(rowmap == nullptr || (packed_rows > 0 && x0 == nullptr && mean == nullptr), "bert_embed_ln: packed rows are inference only");
+  const int64_t rows = rowmap ? (int64_t)packed_rows : (int64_t)B * L;
   const int blocks = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
   EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((bert_embed_ln_kernel<T>), dim3(blocks), dim3(256), 0, stream, ids, pos_ids, type_ids,
                                           attn_mask, word, pos, type, g, b, eps, (T*)x0, (T*)y, mean, rstd, key_bias, B, L, Hd,
-                                          vocab, max_pos, type_vocab));
+                                          vocab, max_pos, type_vocab, rowmap, packed_rows));
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

@@ -160,6 +160,59 @@ def test_text_tower_at_512_tokens(tmp_path, dtype):
         assert float((got - want).norm()) <= (2e-4 if dtype == "fp32" else 8e-2) * float(want.norm()), n
 
 
+@pytest.mark.parametrize("cfg_name,B,Lq", [("small", 9, 40), ("vitb16_bertbase", 6, 64)])
+def test_packed_text_tower_equals_the_padded_one(tmp_path, cfg_name, B, Lq):
+    """bf16 inference runs the BERT tower on the unmasked tokens only (ezclip_encode_text_packed): padded positions carry
+    the -10000 key bias and only x[:, 0] is read (modeling_chineseclip.py:347-350), so nothing of them reaches the feature.
+    Suffix padding: bit-identical embeddings (same rows through the same tiles, masked keys add exact zeros).  Pad ids
+    inside a sentence, a masked CLS token, a sentence without any unmasked key (kept whole: its softmax is uniform over
+    ALL positions in the reference): the oracle within the bf16 bound, the padded path within summation-order noise."""
+    cfg = O.CONFIGS[cfg_name]
+    app, sd = make_app(tmp_path, cfg, 4, "bf16")
+    app.eval()
+    eng = app._engine
+    g = torch.Generator().manual_seed(B + Lq)
+    ids = torch.randint(1, cfg["vocab_size"], (B, Lq), generator=g)
+    lens = torch.randint(1, Lq + 1, (B,), generator=g)
+    lens[0], lens[1] = Lq, 1
+    ids = ids * (torch.arange(Lq)[None, :] < lens[:, None])
+    res = {}
+    for pack in (False, True):
+        eng.pack_text = pack
+        with torch.no_grad():
+            res[pack] = app({"input_ids": ids.clone()}, feat=True)["text_embeds"].cpu()      # host ids: metadata from the host copy
+            rows = eng.last_text_rows
+            dev = app({"input_ids": ids.cuda()}, feat=True)["text_embeds"].cpu()             # device ids: metadata on the device
+            fused = app.contrastive_step(torch.zeros(B, 3, cfg["image_resolution"], cfg["image_resolution"], device="cuda"),
+                                         ids.cuda(), process_group=False)
+        assert torch.equal(dev, res[pack]) and torch.isfinite(fused)
+        assert rows == ((int(lens.sum()), B * Lq) if pack else (B * Lq, B * Lq)), rows
+    assert torch.equal(res[True], res[False]), float((res[True] - res[False]).abs().max())
+    with torch.no_grad():
+        ref = O.encode_text(sd, cfg, ids)
+    assert float((res[True] - ref).abs().max()) < 1e-2
+    # the awkward rows
+    ids2 = ids.clone()
+    ids2[2, :] = 0                      # no unmasked key at all
+    ids2[3, 0] = 0                      # masked CLS token (still the query whose output is used)
+    ids2[4, 1] = 0
+    if Lq > 5:
+        ids2[4, 5] = 0                  # pad ids inside a sentence
+    out2 = {}
+    for pack in (False, True):
+        eng.pack_text = pack
+        with torch.no_grad():
+            out2[pack] = app({"input_ids": ids2.clone()}, feat=True)["text_embeds"].cpu()
+    eng.pack_text = True
+    with torch.no_grad():
+        ref2 = O.encode_text(sd, cfg, ids2)
+    assert torch.isfinite(out2[True]).all()
+    assert float((out2[True] - ref2).abs().max()) < 1e-2 and float((out2[False] - ref2).abs().max()) < 1e-2
+    assert float((out2[True] - out2[False]).abs().max()) < 4e-3
+    untouched = [i for i in range(B) if i not in (2, 3, 4)]
+    assert torch.equal(out2[True][untouched], res[True][untouched])          # samples are independent
+
+
 class _DS(torch.utils.data.Dataset):
     def __init__(self, px, ids):
         self.px, self.ids = px, ids

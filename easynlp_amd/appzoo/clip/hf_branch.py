@@ -213,6 +213,7 @@ class HFEncodeFn(torch.autograd.Function):
             eng.set_text_dropout(*ctx.drop)
             ctx.extras = (pos, tt, am)
             txt, ctx.ws_txt = eng.encode_text(ids, need_grad, extras=ctx.extras, owner=ctx.token)
+            ctx.pack = eng.last_pack            # packed rows (bf16, no dropout): the backward runs on the same rows
         ctx.app, ctx.pixels, ctx.ids = app, pixels, ids
         ctx.has = (img is not None, txt is not None)
         dev = params[0].device
@@ -242,7 +243,7 @@ class HFEncodeFn(torch.autograd.Function):
             eng.backward_image(ctx.pixels, d_img.contiguous(), ctx.ws_img)      # frozen tower: projection gradients only
         if ctx.has[1]:
             eng.set_text_dropout(*ctx.drop)
-            eng.backward_text(ctx.ids, d_txt.contiguous(), ctx.ws_txt, extras=ctx.extras)
+            eng.backward_text(ctx.ids, d_txt.contiguous(), ctx.ws_txt, extras=ctx.extras, pack=getattr(ctx, "pack", None))
         if ctx.token is not None:
             ctx.token.released = True
         by_ref = st.map_grads(grads)

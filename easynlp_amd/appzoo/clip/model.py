@@ -121,6 +121,7 @@ class HipClipEngine:
         # clip_pack_text=0 feeds every padded position through it as the reference does -- same embeddings
         self.pack_text = os.environ.get("EZCLIP_PACK_TEXT", "1") not in ("0", "false", "False")
         self.last_text_rows = None
+        self.last_pack = None
         self.uses_pooler = bool(hf_branch)
         self.embed_dim = int(cfg["embed_dim"])
 
@@ -273,7 +274,7 @@ class HipClipEngine:
         lens = keep.sum(1, dtype=torch.int32)
         cs = torch.cumsum(lens, 0, dtype=torch.int32)
         total, longest = (int(v) for v in torch.stack([cs[-1], lens.max()]).tolist())
-        if longest > 288 or total > 0.9 * B * S:
+        if longest > 256 or total > 0.9 * B * S:
             return None
         cu = cs - lens
         within = torch.cumsum(keep, 1, dtype=torch.int32) - 1
@@ -285,8 +286,9 @@ class HipClipEngine:
                 "rows": total, "longest": longest, "shape": (B, S)}
 
     def can_pack(self, save: bool) -> bool:
-        return (self.pack_text and not save and self.dtype_code == L.DTYPE_BF16 and self.text_arch == 0
-                and self._drop == (0.0, 0.0))
+        """bf16 BERT towers without dropout (train-mode dropout masks are indexed by the padded token rows), forward with or
+        without save_for_backward -- the backward then runs on the same packed rows."""
+        return self.pack_text and self.dtype_code == L.DTYPE_BF16 and self.text_arch == 0 and self._drop == (0.0, 0.0)
 
     def encode_text(self, ids: torch.Tensor, save: bool, extras=None, owner=None, stream=None, pack=None) -> (torch.Tensor, torch.Tensor):
         """extras: (position_ids, token_type_ids, attention_mask) int64 [B, S] device tensors (huggingface_clip branch).
@@ -307,10 +309,12 @@ class HipClipEngine:
                 L.check(self.lib.ezclip_encode_text_packed(self.handle, L.ptr(ids), L.ptr(pos), L.ptr(tt), L.ptr(am),
                                                            L.ptr(pack["rowmap"]), L.ptr(pack["cu"]), L.ptr(pack["lens"]), B, S,
                                                            pack["rows"], pack["longest"], L.ptr(out), L.ptr(ws), ws.numel(),
-                                                           L.stream_ptr(stream)), "encode_text_packed")
+                                                           1 if save else 0, L.stream_ptr(stream)), "encode_text_packed")
                 self.last_text_rows = (pack["rows"], B * S)
+                self.last_pack = pack
                 return out, ws
         self.last_text_rows = (B * S, B * S)
+        self.last_pack = None
         if extras is None:
             L.check(self.lib.ezclip_encode_text(self.handle, L.ptr(ids), B, S, L.ptr(out), L.ptr(ws), ws.numel(),
                                                 1 if save else 0, L.stream_ptr(stream)), "encode_text")
@@ -331,8 +335,16 @@ class HipClipEngine:
         L.check(self.lib.ezclip_backward_image(self.handle, L.ptr(pixels), pixels.shape[0], L.ptr(d_emb),
                                                L.ptr(ws), ws.numel(), L.stream_ptr(stream)), "backward_image")
 
-    def backward_text(self, ids, d_emb, ws, extras=None, stream=None):
+    def backward_text(self, ids, d_emb, ws, extras=None, stream=None, pack=None):
+        """pack: the packing metadata the matching forward ran with (encode_text), or None / False"""
         self._weights_dirty = True
+        if pack:
+            pos, tt, am = extras if extras is not None else (None, None, None)
+            L.check(self.lib.ezclip_backward_text_packed(self.handle, L.ptr(ids), L.ptr(pos), L.ptr(tt), L.ptr(am),
+                                                         L.ptr(pack["rowmap"]), L.ptr(pack["cu"]), L.ptr(pack["lens"]),
+                                                         ids.shape[0], ids.shape[1], pack["rows"], pack["longest"], L.ptr(d_emb),
+                                                         L.ptr(ws), ws.numel(), L.stream_ptr(stream)), "backward_text_packed")
+            return
         if extras is None:
             L.check(self.lib.ezclip_backward_text(self.handle, L.ptr(ids), ids.shape[0], ids.shape[1],
                                                   L.ptr(d_emb), L.ptr(ws), ws.numel(), L.stream_ptr(stream)),
@@ -401,6 +413,7 @@ class _EncodeFn(torch.autograd.Function):
                 pack = eng.pack_meta(ids) or False
             run_t = lambda st: eng.encode_text(ids, need_grad, owner=ctx.token, stream=st, pack=pack)
         ri, rt = _run_towers(eng, app.two_streams, run_i, run_t)
+        ctx.pack = eng.last_pack if ids is not None else None
         img, ctx.ws_img = ri if ri is not None else (None, None)
         txt, ctx.ws_txt = rt if rt is not None else (None, None)
         ctx.app, ctx.pixels, ctx.ids = app, pixels, ids
@@ -436,7 +449,7 @@ class _EncodeFn(torch.autograd.Function):
         if ctx.has[1]:
             d_txt = d_txt.contiguous()
             eng.set_text_dropout(*ctx.drop)         # the masks of the matching forward
-            run_t = lambda st: eng.backward_text(ctx.ids, d_txt, ctx.ws_txt, stream=st)
+            run_t = lambda st: eng.backward_text(ctx.ids, d_txt, ctx.ws_txt, stream=st, pack=ctx.pack)
         _run_towers(eng, app.two_streams, run_i, run_t, image_first=True)
         if ctx.token is not None:
             ctx.token.released = True
@@ -876,6 +889,7 @@ class CLIPApp(Application):
         pack = False
         if eng.can_pack(backward) and input_ids.shape[1] >= 8:      # (device ids: one small sync, before anything is enqueued)
             pack = eng.pack_meta(input_ids, None if extras is None else extras[2]) or False
+        eng.last_pack = None
         (img, ws_i), (txt, ws_t) = _run_towers(
             eng, self.two_streams,
             lambda s_: eng.encode_image(pixel_values, backward, stream=s_),
@@ -923,7 +937,8 @@ class CLIPApp(Application):
         try:
             _run_towers(eng, two,
                         lambda s_: eng.backward_image(pixel_values, d_img_l, ws_i, stream=s_),
-                        lambda s_: eng.backward_text(input_ids, d_txt_l, ws_t, extras=extras, stream=s_), image_first=True)
+                        lambda s_: eng.backward_text(input_ids, d_txt_l, ws_t, extras=extras, stream=s_, pack=eng.last_pack),
+                        image_first=True)
         finally:
             if reducer is not None:
                 eng.set_progress_hook(None)
@@ -989,8 +1004,7 @@ class CLIPApp(Application):
             ids_in = inputs["input_ids"]
             self.__dict__.pop("_pack_hint", None)
             if (not ids_in.is_cuda and ids_in.dim() == 2 and ids_in.shape[1] >= 8 and self._engine is not None
-                    and not (torch.is_grad_enabled() and self.training) and self._engine.pack_text
-                    and getattr(self, "model_type", None) == "chinese_clip"):
+                    and self._engine.pack_text and getattr(self, "model_type", None) == "chinese_clip"):
                 # which tokens the text tower has to see, from the host copy the DataLoader delivered (no device sync later)
                 self._pack_hint = self._engine.pack_meta(ids_in, device=_device) or False
             inputs["input_ids"] = ids_in.to(_device)

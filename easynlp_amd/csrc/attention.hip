@@ -597,8 +597,9 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(AttnBwdArgs a, const 
   if (bh >= f.B * f.H) return;
   float* sc = sc_all[w];
   const int b = bh / f.H, head = bh - b * f.H;
-  const int L = f.L, g = lane >> 3, c = lane & 7;
-  const int64_t hoff = (int64_t)b * L * f.row_stride + head * 64;
+  const int L = f.lens ? f.lens[b] : f.L, g = lane >> 3, c = lane & 7;             // (packed batches: AttnArgs::cu / lens)
+  const int64_t row0 = f.cu ? (int64_t)f.cu[b] : (int64_t)b * f.L;
+  const int64_t hoff = row0 * f.row_stride + head * 64;
   const T* kbase = reinterpret_cast<const T*>(f.k) + hoff;
   const T* vbase = reinterpret_cast<const T*>(f.v) + hoff;
   T* dqb = a.dq ? reinterpret_cast<T*>(a.dq) + hoff : nullptr;
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(AttnBwdArgs a, const 
     dot += __shfl_xor(dot, 2, 64);
     dot += __shfl_xor(dot, 4, 64);
     if (key < L) {
-      const float x = fmaf(dot, f.scale, f.key_bias ? f.key_bias[(int64_t)b * L + key] : 0.f);
+      const float x = fmaf(dot, f.scale, f.key_bias ? f.key_bias[row0 + key] : 0.f);
       mx = fmaxf(mx, x);
       if (c == 0) sc[key] = x;
     }
@@ -723,8 +724,8 @@ int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream) {
   EZ_REQUIRE(a.B <= 65535, "attention_fwd: batch %d > 65535", a.B);
   EZ_REQUIRE((a.cu == nullptr) == (a.lens == nullptr), "attention_fwd: cu and lens go together");
   if (a.cu != nullptr) {      // packed batches: the short forward kernel only (bf16, longest sample <= 288, no dropout, no lse)
-    EZ_REQUIRE(a.drop.thr == 0 && a.lse == nullptr && attention_short_fwd_eligible(a, dtype),
-               "attention_fwd: packed batches need the bf16 short kernel (L <= 288, no dropout, inference)");
+    EZ_REQUIRE(a.drop.thr == 0 && attention_short_fwd_eligible(a, dtype),
+               "attention_fwd: packed batches need the bf16 short kernel (longest sample <= 288, no dropout)");
     return attention_fwd_short(a, stream);
   }
   if (g_attn_variant != 0 && a.drop.thr == 0 && attention_short_fwd_eligible(a, dtype)) return attention_fwd_short(a, stream);
@@ -1118,6 +1119,11 @@ int attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream) {
   EZ_REQUIRE((f.row_stride * esz) % 16 == 0 && (f.ctx_stride * esz) % 16 == 0, "attention_bwd: strides must be 16-byte multiples");
   EZ_REQUIRE(f.B <= 65535, "attention_bwd: batch %d > 65535", f.B);
   EZ_REQUIRE((a.dbq == nullptr) == (a.dbk == nullptr) && (a.dbq == nullptr) == (a.dbv == nullptr), "attention_bwd: dbq/dbk/dbv must be given together");
+  if (f.cu != nullptr) {      // packed batches: the fused short kernel only
+    EZ_REQUIRE(f.lens != nullptr && f.drop.thr == 0 && attention_short_eligible(f, dtype) && (a.dbq == nullptr || a.db_part != nullptr),
+               "attention_bwd: packed batches need the fused bf16 kernel (longest sample <= 256, no dropout)");
+    return attention_bwd_short(a, stream);
+  }
   if (g_attn_variant != 0 && f.drop.thr == 0 && attention_short_eligible(f, dtype) && (a.dbq == nullptr || a.db_part != nullptr))
     return attention_bwd_short(a, stream);
   int rc;

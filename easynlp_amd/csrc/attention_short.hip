@@ -317,7 +317,10 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  const int L = f.L, LKP = 32 * nt;
+  // packed batches (AttnArgs::cu / lens): rows cu[b] .. cu[b] + lens[b] - 1; nt (launch, LDS layout) is the longest sample's
+  const int L = f.lens ? f.lens[b] : f.L, LKP = 32 * nt;
+  const int64_t row0 = f.cu ? (int64_t)f.cu[b] : (int64_t)b * f.L;
+  nt = (L + 31) >> 5;
   char* imgQ = smem;
   char* imgK = smem + LKP * 128;
   char* imgV = smem + 2 * LKP * 128;
@@ -328,16 +331,16 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
   float* red = kb + LKP;                       // [8 waves][2 halves][3][64]: column sums of dq / dk / dv (bias gradients)
   const bool want_db = a.db_part != nullptr;
   const int64_t rs = f.row_stride * 2, cs = f.ctx_stride * 2;
-  const int64_t base = ((int64_t)b * L * f.row_stride + head * 64) * 2;
-  const int64_t cbase = ((int64_t)b * L * f.ctx_stride + head * 64) * 2;
+  const int64_t base = (row0 * f.row_stride + head * 64) * 2;
+  const int64_t cbase = (row0 * f.ctx_stride + head * 64) * 2;
 
-  dma_rows_f(imgQ, reinterpret_cast<const char*>(f.q) + base, rs, LKP, L, wave, lane);
-  dma_rows_f(imgK, reinterpret_cast<const char*>(f.k) + base, rs, LKP, L, wave, lane);
-  dma_rows_f(imgV, reinterpret_cast<const char*>(f.v) + base, rs, LKP, L, wave, lane);
-  dma_rows_f(imgG, reinterpret_cast<const char*>(a.dctx) + cbase, cs, LKP, L, wave, lane);
+  dma_rows_f(imgQ, reinterpret_cast<const char*>(f.q) + base, rs, 32 * nt, L, wave, lane);
+  dma_rows_f(imgK, reinterpret_cast<const char*>(f.k) + base, rs, 32 * nt, L, wave, lane);
+  dma_rows_f(imgV, reinterpret_cast<const char*>(f.v) + base, rs, 32 * nt, L, wave, lane);
+  dma_rows_f(imgG, reinterpret_cast<const char*>(a.dctx) + cbase, cs, 32 * nt, L, wave, lane);
   constexpr float kLog2e = 1.4426950408889634f;
-  for (int key = tid; key < LKP; key += 512)       // key bias in base-2 units; keys >= L: -inf (p = 0)
-    kb[key] = key < L ? (HAS_KB ? f.key_bias[(int64_t)b * L + key] * kLog2e : 0.f) : -INFINITY;
+  for (int key = tid; key < 32 * nt; key += 512)   // key bias in base-2 units; keys >= L: -inf (p = 0)
+    kb[key] = key < L ? (HAS_KB ? f.key_bias[row0 + key] * kLog2e : 0.f) : -INFINITY;
 
   // this wave's 32 rows (queries in pass A, keys in pass B)
   const int blk = wave;
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
     const char* op = reinterpret_cast<const char*>(f.ctx) + cbase + (int64_t)rowc * cs;
 #pragma unroll
     for (int s = 0; s < 4; ++s) of[s] = *reinterpret_cast<const uint4*>(op + (2 * s + h) * 16);
-    if (row < L) lse_q = f.lse[((int64_t)b * f.H + head) * L + row];
+    if (row < L) lse_q = f.lse[((int64_t)b * f.H + head) * f.L + row];
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
       }
     }
     if (row < L) {
-      bf16_t* dqp = reinterpret_cast<bf16_t*>(a.dq) + ((int64_t)b * L + row) * f.row_stride + head * 64;
+      bf16_t* dqp = reinterpret_cast<bf16_t*>(a.dq) + (row0 + row) * f.row_stride + head * 64;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -503,8 +506,8 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
       }
     }
     if (row < L) {
-      bf16_t* dkp = reinterpret_cast<bf16_t*>(a.dk) + ((int64_t)b * L + row) * f.row_stride + head * 64;
-      bf16_t* dvp = reinterpret_cast<bf16_t*>(a.dv) + ((int64_t)b * L + row) * f.row_stride + head * 64;
+      bf16_t* dkp = reinterpret_cast<bf16_t*>(a.dk) + (row0 + row) * f.row_stride + head * 64;
+      bf16_t* dvp = reinterpret_cast<bf16_t*>(a.dv) + (row0 + row) * f.row_stride + head * 64;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll

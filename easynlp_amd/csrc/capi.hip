@@ -271,12 +271,22 @@ int ezclip_encode_text_ex(ezclip_handle h, const int64_t* ids, const int64_t* po
 int ezclip_encode_text_packed(ezclip_handle h, const int64_t* ids, const int64_t* position_ids, const int64_t* token_type_ids,
                               const int64_t* attention_mask, const int32_t* rowmap, const int32_t* cu, const int32_t* lens,
                               int batch, int seq_len, int packed_rows, int max_len, float* out, void* ws, size_t ws_bytes,
-                              void* stream) {
+                              int save, void* stream) {
   EZ_REQUIRE(h && rowmap && cu && lens, "ezclip_encode_text_packed: null argument");
   TextExtras ex;
   ex.pos_ids = position_ids; ex.type_ids = token_type_ids; ex.attn_mask = attention_mask;
   ex.rowmap = rowmap; ex.cu = cu; ex.lens = lens; ex.packed_rows = packed_rows; ex.max_len = max_len;
-  return encode_text(h, ids, batch, seq_len, out, ws, ws_bytes, false, S(stream), &ex);
+  return encode_text(h, ids, batch, seq_len, out, ws, ws_bytes, save != 0, S(stream), &ex);
+}
+int ezclip_backward_text_packed(ezclip_handle h, const int64_t* ids, const int64_t* position_ids, const int64_t* token_type_ids,
+                                const int64_t* attention_mask, const int32_t* rowmap, const int32_t* cu, const int32_t* lens,
+                                int batch, int seq_len, int packed_rows, int max_len, const float* d_emb, void* ws,
+                                size_t ws_bytes, void* stream) {
+  EZ_REQUIRE(h && rowmap && cu && lens, "ezclip_backward_text_packed: null argument");
+  TextExtras ex;
+  ex.pos_ids = position_ids; ex.type_ids = token_type_ids; ex.attn_mask = attention_mask;
+  ex.rowmap = rowmap; ex.cu = cu; ex.lens = lens; ex.packed_rows = packed_rows; ex.max_len = max_len;
+  return backward_text(h, ids, batch, seq_len, d_emb, ws, ws_bytes, S(stream), &ex);
 }
 int ezclip_backward_text_ex(ezclip_handle h, const int64_t* ids, const int64_t* position_ids, const int64_t* token_type_ids,
                             const int64_t* attention_mask, int batch, int seq_len, const float* d_emb, void* ws,

@@ -175,8 +175,10 @@ int colsum_add(const void* x, int64_t ld, int rows, int cols, float* out, int dt
 int batch_sum_add(const void* x, int B, int Tn, int t_count, int W, float* out, int dtype, hipStream_t stream);
 int vit_gather_patch_rows(const void* dx0, void* dpemb, int B, int Lv, int W, int dtype, hipStream_t stream);
 // table[ids[r]] += dx0[r] (embedding index-add); rows whose id == pad_id (nn.Embedding padding_idx) or out of range are skipped
+// rowmap (packed rows): row r holds token rowmap[r] = b * seq_len + t, ids is read there; ids == nullptr with a row map: the
+// table index is the position t (position-embedding gradient of a packed batch)
 int bert_word_grad(const int64_t* ids, const void* dx0, float* dword, int64_t rows, int Hd, int vocab, int dtype,
-                   hipStream_t stream, int64_t pad_id = 0);
+                   hipStream_t stream, int64_t pad_id = 0, const int* rowmap = nullptr, int seq_len = 0);
 int add_inplace_f32(float* dst, const float* src, int64_t n, hipStream_t stream);
 // dst[r][c] += src[r][c] for c < cols (row strides ldd / lds): un-pads a K-padded weight gradient
 int dropout_rows(const void* x, int64_t xs, const void* res, int64_t rs, void* y, int64_t ys, int rows, int D,

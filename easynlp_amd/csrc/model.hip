@@ -888,22 +888,33 @@ static int bert_last_layer_cls(ezclip_model* m, const ezclip_model::BertLayer& L
 
 // Training variant of bert_last_layer_cls: intermediates kept in the layer's own buffers (first B rows of y, a, u, hh, z,
 // x_out, the LayerNorm statistics; ctx rows [0, B) = the CLS context, rows [B, 2B) = the CLS queries).
+// Packed batches: the CLS rows of x_in sit at rows ex->cu[n]; they are gathered into ctx rows [2B, 3B) (kept for the backward).
 static int bert_last_layer_cls_save(ezclip_model* m, const ezclip_model::BertLayer& Lw, const BertBufs& b, const float* key_bias,
-                                    int B, int L, float eps, hipStream_t stream) {
-  const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, M = B * L, dt = m->dtype;
+                                    int B, int L, float eps, hipStream_t stream, const TextExtras* ex = nullptr) {
+  const bool packed = ex != nullptr && ex->rowmap != nullptr;
+  const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, M = packed ? ex->packed_rows : B * L, dt = m->dtype;
   const size_t esz = dtype_size(dt), blk = (size_t)B * H * esz;
   char* qkv = (char*)b.qkv;
   char* ctx_cls = (char*)b.ctx;
   char* q_cls = ctx_cls + blk;
-  EZ_TRY(linear(m, b.x_in, (int64_t)L * H, Lw.q_w, Lw.q_b, q_cls, H, B, ACT_NONE, nullptr, 0, nullptr, false, stream));
+  const void* x_cls = b.x_in;
+  int64_t x_cls_ld = (int64_t)L * H;
+  if (packed) {
+    char* xc = q_cls + blk;
+    EZ_TRY(gather_rows(b.x_in, ex->cu, xc, B, 0, H, 0, dt, stream));
+    x_cls = xc;
+    x_cls_ld = H;
+  }
+  EZ_TRY(linear(m, x_cls, x_cls_ld, Lw.q_w, Lw.q_b, q_cls, H, B, ACT_NONE, nullptr, 0, nullptr, false, stream));
   EZ_TRY(bert_qkv_proj(m, Lw, b.x_in, H, qkv, M, 1, stream));
   AttnArgs at;
   at.k = qkv + H * esz; at.v = qkv + 2 * H * esz;
   at.row_stride = 3 * H;
   at.key_bias = key_bias;
-  at.B = B; at.L = L; at.H = m->theads; at.scale = 0.125f;
+  at.B = B; at.L = packed ? ex->max_len : L; at.H = m->theads; at.scale = 0.125f;
+  if (packed) { at.cu = ex->cu; at.lens = ex->lens; }
   EZ_TRY(attention_cls_fwd(at, q_cls, H, ctx_cls, H, dt, stream));
-  EZ_TRY(linear(m, ctx_cls, H, Lw.o_w, Lw.o_b, b.y, H, B, ACT_NONE, b.x_in, (int64_t)L * H, nullptr, false, stream));
+  EZ_TRY(linear(m, ctx_cls, H, Lw.o_w, Lw.o_b, b.y, H, B, ACT_NONE, x_cls, x_cls_ld, nullptr, false, stream));
   EZ_TRY(layernorm_fwd(b.y, H, b.a, H, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, B, H, dt, b.m1, b.r1, stream));
   EZ_TRY(linear(m, b.a, H, Lw.i_w, Lw.i_b, b.hh, F, B, ACT_GELU_ERF, nullptr, 0, b.u, false, stream));
   EZ_TRY(linear(m, b.hh, F, Lw.d_w, Lw.d_b, b.z, H, B, ACT_NONE, b.a, H, nullptr, false, stream));
@@ -936,9 +947,10 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
   // attention kernels.  (The caller keeps whole sentences that have no unmasked key at all, and every CLS row.)
   const bool packed = ex->rowmap != nullptr;
   if (packed) {
-    EZ_REQUIRE(!save && dt == EZCLIP_BF16 && hp == 0.f && ap == 0.f, "encode_text: packed batches are bf16 inference without dropout");
+    EZ_REQUIRE(dt == EZCLIP_BF16 && hp == 0.f && ap == 0.f, "encode_text: packed batches are bf16 without dropout");
     EZ_REQUIRE(ex->cu && ex->lens && ex->packed_rows >= B && ex->packed_rows <= B * L && ex->max_len >= 1 && ex->max_len <= L &&
-               ex->max_len <= 288, "encode_text: bad packing (rows %d of %d x %d, longest %d)", ex->packed_rows, B, L, ex->max_len);
+               ex->max_len <= (save ? 256 : 288), "encode_text: bad packing (rows %d of %d x %d, longest %d)", ex->packed_rows, B, L, ex->max_len);
+    EZ_REQUIRE(!save || (g_cls_last_train && L >= 8), "encode_text: packed training needs the CLS-only last layer");
   }
   const int M = packed ? ex->packed_rows : B * L;
 
@@ -1001,7 +1013,7 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
     xl = ws.gpool;
     xl_ld = H;
   } else if (cls_train) {
-    EZ_TRY(bert_last_layer_cls_save(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws.key_bias, B, L, eps, stream));
+    EZ_TRY(bert_last_layer_cls_save(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws.key_bias, B, L, eps, stream, ex));
     xl_ld = H;                                                         // x_out of the last layer: [B, H] (CLS rows)
   }
   const void* fa = xl;
@@ -1211,13 +1223,16 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
 // backward of bert_last_layer_cls_save.  On entry ws.gx = d x_out of the CLS rows, compact [B, H]; on exit ws.gx = d x_in
 // for every row [M, H] (the key / value projections over all tokens; the query projection and the residual at the CLS rows).
 static int bert_last_layer_cls_backward(ezclip_model* m, const ezclip_model::BertLayer& Lw, const BertBufs& b, const TxtWS& ws,
-                                        int B, int L, hipStream_t stream) {
-  const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, M = B * L, dt = m->dtype;
+                                        int B, int L, hipStream_t stream, const TextExtras* ex = nullptr) {
+  const bool packed = ex != nullptr && ex->rowmap != nullptr;
+  const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, M = packed ? ex->packed_rows : B * L, dt = m->dtype;
   const size_t esz = dtype_size(dt), blk = (size_t)B * H * esz;
   char* qkv = (char*)b.qkv;
   char* gq = (char*)ws.gqkv;
   const char* ctx_cls = (const char*)b.ctx;
   const char* q_cls = ctx_cls + blk;
+  const void* x_cls = packed ? (const void*)(q_cls + blk) : b.x_in;        // CLS rows of x_in (gathered by the forward when packed)
+  const int64_t x_cls_ld = packed ? H : (int64_t)L * H;
   // x_out = LN(z);  z = dense(hh) + a;  hh = gelu(u);  u = dense(a)          (B rows)
   EZ_TRY(ln_bwd(m, b.z, H, ws.gx, H, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, H, nullptr, 0, B, H, stream, Lw.d_b));        // d z
   EZ_TRY(dgrad(m, ws.gx2, H, Lw.d_w, ws.gbig, F, B, b.u, F, ACT_GELU_ERF, nullptr, 0, stream, Lw.i_b));                  // d u
@@ -1232,7 +1247,8 @@ static int bert_last_layer_cls_backward(ezclip_model* m, const ezclip_model::Ber
   ab.f.k = qkv + H * esz; ab.f.v = qkv + 2 * H * esz;
   ab.f.row_stride = 3 * H;
   ab.f.key_bias = ws.key_bias;
-  ab.f.B = B; ab.f.L = L; ab.f.H = m->theads; ab.f.scale = 0.125f;
+  ab.f.B = B; ab.f.L = packed ? ex->max_len : L; ab.f.H = m->theads; ab.f.scale = 0.125f;
+  if (packed) { ab.f.cu = ex->cu; ab.f.lens = ex->lens; }
   ab.dq = nullptr; ab.dk = gq + H * esz; ab.dv = gq + 2 * H * esz;
   EZ_TRY(attention_cls_bwd(ab, q_cls, H, ctx_cls, ws.gtmp, H, dt, stream, ws.gx3, H));            // d q of the CLS rows -> gx3 [B, H]
   // d x_in: keys and values over all rows ...
@@ -1240,8 +1256,9 @@ static int bert_last_layer_cls_backward(ezclip_model* m, const ezclip_model::Ber
   EZ_TRY(dgrad(m, gq + 2 * H * esz, 3 * H, Lw.v_w, ws.gx, H, M, nullptr, 0, ACT_NONE, ws.gx, H, stream));
   // ... plus, at the CLS rows, the query projection and the residual of y
   EZ_TRY(dgrad(m, ws.gx3, H, Lw.q_w, ws.gtmp, H, B, nullptr, 0, ACT_NONE, ws.gx2, H, stream));
-  EZ_TRY(gather_rows(ws.gtmp, nullptr, ws.gx, B, L, H, 2, dt, stream));
-  EZ_TRY(wgrad(m, ws.gx3, H, b.x_in, (int64_t)L * H, Lw.q_w, B, stream));
+  if (packed) EZ_TRY(gather_rows(ws.gtmp, ex->cu, ws.gx, B, 0, H, 2, dt, stream));
+  else EZ_TRY(gather_rows(ws.gtmp, nullptr, ws.gx, B, L, H, 2, dt, stream));
+  EZ_TRY(wgrad(m, ws.gx3, H, x_cls, x_cls_ld, Lw.q_w, B, stream));
   EZ_TRY(wgrad(m, gq + H * esz, 3 * H, b.x_in, H, Lw.k_w, M, stream));
   EZ_TRY(wgrad(m, gq + 2 * H * esz, 3 * H, b.x_in, H, Lw.v_w, M, stream));
   EZ_TRY(bgrad(m, ws.gx3, H, B, H, Lw.q_b, stream));
@@ -1292,20 +1309,24 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
   const size_t need = layout_text(m, B, L, true, wsp, &ws);
   EZ_REQUIRE(ws_bytes >= need, "backward_text: workspace too small (%zu < %zu): was the forward run with save_for_backward?", ws_bytes, need);
   const int H = m->cfg.text_hidden_size, F = m->cfg.text_intermediate_size, E = m->cfg.embed_dim;
-  const int M = B * L;
   const int dt = m->dtype;
   const size_t esz = dtype_size(dt);
   // the dropout state of the matching forward (the caller re-arms ezclip_set_text_dropout with the same seed)
   const float hp = m->drop_hidden, ap = m->drop_attn;
   const uint64_t seed = m->drop_seed;
+  const TextExtras none0;
+  if (ex == nullptr) ex = &none0;
+  const bool packed = ex->rowmap != nullptr;       // the matching forward ran on these packed rows (encode_text)
+  if (packed)
+    EZ_REQUIRE(dt == EZCLIP_BF16 && hp == 0.f && ap == 0.f && ex->cu && ex->lens && ex->packed_rows >= B && ex->packed_rows <= B * L &&
+               ex->max_len >= 1 && ex->max_len <= 256 && g_cls_last_train && L >= 8, "backward_text: bad packing");
+  const int M = packed ? ex->packed_rows : B * L;
 
   EZ_TRY(l2_normalize_bwd(ws.emb, d_emb, ws.inv_norm, ws.gfeat, B, E, stream));                     // chineseclip:363
   const void* gfeatT = ws.gfeat;
   if (dt != EZCLIP_F32) { EZ_TRY(cast_from_f32(ws.gfeat, ws.gfeatT, (int64_t)B * E, dt, stream)); gfeatT = ws.gfeatT; }
   // feat = x[:, 0, :] @ text_projection                                                               :349-350
   const void* xl = ws.layers[m->cfg.text_num_hidden_layers - 1].x_out;
-  const TextExtras none;
-  if (ex == nullptr) ex = &none;
   const int nlayers = m->cfg.text_num_hidden_layers;
   // (the forward's choice, encode_text: last layer on the CLS rows -> its x_out and the gradient entering it are [B, H])
   const bool cls_train = g_cls_last_train && hp == 0.f && ap == 0.f && L >= 8;
@@ -1324,7 +1345,7 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
   }
   m->progress(1, EZCLIP_STAGE_HEAD);           // text_projection (+ bias), pooler
   if (cls_train) {
-    EZ_TRY(bert_last_layer_cls_backward(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws, B, L, stream));
+    EZ_TRY(bert_last_layer_cls_backward(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws, B, L, stream, ex));
     m->progress(1, nlayers - 1);
   }
   for (int i = nlayers - (cls_train ? 2 : 1); i >= 0; --i) {
@@ -1362,7 +1383,8 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     ab.f.q = qkv; ab.f.k = qkv + H * esz; ab.f.v = qkv + 2 * H * esz;
     ab.f.row_stride = 3 * H;
     ab.f.ctx = b.ctx; ab.f.ctx_stride = H; ab.f.key_bias = ws.key_bias; ab.f.lse = b.lse;
-    ab.f.B = B; ab.f.L = L; ab.f.H = m->theads; ab.f.scale = 0.125f;
+    ab.f.B = B; ab.f.L = packed ? ex->max_len : L; ab.f.H = m->theads; ab.f.scale = 0.125f;
+    if (packed) { ab.f.cu = ex->cu; ab.f.lens = ex->lens; }
     ab.f.drop = make_drop(ap, seed, drop_sid_attn(i));
     ab.dctx = ws.gtmp;
     ab.dq = gq; ab.dk = gq + H * esz; ab.dv = gq + 2 * H * esz;
@@ -1388,14 +1410,18 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
   // token-type gradient: with the default all-zero types it is the column sum of gx2 into row 0 (fused into ln_bwd)
   EZ_TRY(ln_bwd(m, ws.x0, H, ws.gx, H, m->eln_w, m->eln_b, ws.m0, ws.r0, ws.gx2, H, nullptr, 0, M, H, stream,
                 ex->type_ids ? -1 : m->type_p));
+  // (packed rows: the index tensors stay [B, L] and are read at rowmap[r]; dropped tokens have no gradient in the reference
+  // either -- nothing of them reaches the loss)
   if (ex->type_ids && m->Gp(m->type_p))
-    EZ_TRY(bert_word_grad(ex->type_ids, ws.gx2, m->Gp(m->type_p), M, H, m->cfg.text_type_vocab_size, dt, stream, -1));
+    EZ_TRY(bert_word_grad(ex->type_ids, ws.gx2, m->Gp(m->type_p), M, H, m->cfg.text_type_vocab_size, dt, stream, -1, ex->rowmap, L));
   if (m->Gp(m->word_p))
-    EZ_TRY(bert_word_grad(ids, ws.gx2, m->Gp(m->word_p), M, H, m->cfg.vocab_size, dt, stream, m->text_pad_id));
+    EZ_TRY(bert_word_grad(ids, ws.gx2, m->Gp(m->word_p), M, H, m->cfg.vocab_size, dt, stream, m->text_pad_id, ex->rowmap, L));
   if (m->Gp(m->tpos_p)) {
     if (ex->pos_ids)    // RobertaEmbeddings: nn.Embedding(max_pos, H, padding_idx=pad_token_id)
       EZ_TRY(bert_word_grad(ex->pos_ids, ws.gx2, m->Gp(m->tpos_p), M, H, m->cfg.text_max_position_embeddings, dt, stream,
-                            m->text_pad_id));
+                            m->text_pad_id, ex->rowmap, L));
+    else if (packed)    // position t = rowmap[r] % L
+      EZ_TRY(bert_word_grad(nullptr, ws.gx2, m->Gp(m->tpos_p), M, H, m->cfg.text_max_position_embeddings, dt, stream, -1, ex->rowmap, L));
     else
       EZ_TRY(batch_sum_add(ws.gx2, B, L, L, H, m->Gp(m->tpos_p), dt, stream));
   }

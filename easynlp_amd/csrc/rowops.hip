@@ -591,11 +591,13 @@ __global__ void vit_gather_patch_rows_kernel(const T* dx0, T* dpemb, int B, int 
 // (nn.Embedding(padding_idx=0), bert/modeling_bert.py:77)
 template <typename T>
 __global__ __launch_bounds__(256) void bert_word_grad_kernel(const int64_t* ids, const T* dx0, float* dword, int64_t rows,
-                                                              int Hd, int vocab, int64_t pad_id) {
+                                                              int Hd, int vocab, int64_t pad_id, const int* rowmap, int seq_len) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const int64_t id = ids[row];
+  // packed rows: row r holds token rowmap[r] = b * seq_len + t; ids == nullptr: the table index is the position t itself
+  const int64_t src = rowmap ? (int64_t)rowmap[row] : row;
+  const int64_t id = ids ? ids[src] : src % seq_len;
   if (id < 0 || id >= vocab || id == pad_id) return;     // nn.Embedding(padding_idx=pad_id): no gradient for that row
 #pragma unroll
   for (int c = 0; c < kMaxChunks; ++c) {
@@ -771,7 +773,7 @@ int bert_embed_ln(const int64_t* ids, const float* word, const float* pos, const
                   int L, int Hd, int vocab, int dtype, hipStream_t stream, const int64_t* pos_ids, const int64_t* type_ids,
                   const int64_t* attn_mask, int max_pos, int type_vocab, const int* rowmap, int packed_rows) {
   EZ_REQUIRE(Hd % 4 == 0 && Hd <= 256 * kMaxChunks, "bert_embed_ln: hidden %d unsupported", Hd);
-  EZ_REQUIRE(rowmap == nullptr || (packed_rows > 0 && x0 == nullptr && mean == nullptr), "bert_embed_ln: packed rows are inference only");
+  EZ_REQUIRE(rowmap == nullptr || packed_rows > 0, "bert_embed_ln: empty packed batch");
   const int64_t rows = rowmap ? (int64_t)packed_rows : (int64_t)B * L;
   const int blocks = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
   EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((bert_embed_ln_kernel<T>), dim3(blocks), dim3(256), 0, stream, ids, pos_ids, type_ids,
@@ -829,10 +831,11 @@ int vit_gather_patch_rows(const void* dx0, void* dpemb, int B, int Lv, int W, in
 }
 
 int bert_word_grad(const int64_t* ids, const void* dx0, float* dword, int64_t rows, int Hd, int vocab, int dtype,
-                   hipStream_t stream, int64_t pad_id) {
+                   hipStream_t stream, int64_t pad_id, const int* rowmap, int seq_len) {
+  EZ_REQUIRE(ids != nullptr || (rowmap != nullptr && seq_len > 0), "bert_word_grad: position mode needs the row map");
   const int blocks = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
   EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((bert_word_grad_kernel<T>), dim3(blocks), dim3(256), 0, stream, ids,
-                                          (const T*)dx0, dword, rows, Hd, vocab, pad_id));
+                                          (const T*)dx0, dword, rows, Hd, vocab, pad_id, rowmap, seq_len));
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

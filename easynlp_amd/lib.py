@@ -98,7 +98,8 @@ SIGNATURES = {
     "ezclip_op_resample_table_device": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "ezclip_set_option": (_i, [_vp, _i, C.c_double]),
     "ezclip_encode_text_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _i, _vp]),
-    "ezclip_encode_text_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ezclip_encode_text_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp]),
+    "ezclip_backward_text_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ezclip_backward_text_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ezclip_set_text_dropout": (_i, [_vp, _f, _f, C.c_uint64]),
     "ezclip_op_dropout": (_i, [_vp, _vp, _vp, _i, _i, _f, C.c_uint64, C.c_uint32, _i, _vp]),

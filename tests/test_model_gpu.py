@@ -213,6 +213,53 @@ def test_packed_text_tower_equals_the_padded_one(tmp_path, cfg_name, B, Lq):
     assert torch.equal(out2[True][untouched], res[True][untouched])          # samples are independent
 
 
+@pytest.mark.parametrize("path", ["fused", "autograd"])
+def test_packed_text_tower_training_step_equals_the_padded_one(tmp_path, path):
+    """Forward with save_for_backward + backward on the packed rows: same loss, and every parameter gradient equals the padded
+    run's up to the summation order of the weight-gradient partials (a dropped token has exactly zero gradient in the padded run:
+    its key is masked in every layer and its own outputs feed nothing)."""
+    cfg = O.CONFIGS["small"]
+    app, sd = make_app(tmp_path, cfg, 6, "bf16")
+    app.eval()
+    eng = app._engine
+    B, Lq = 10, 40
+    px, ids = O.make_inputs(cfg, B, Lq, 3)
+    g = torch.Generator().manual_seed(8)
+    lens = torch.randint(1, Lq + 1, (B,), generator=g)
+    lens[0], lens[1] = Lq, 1
+    ids = ids.clamp(min=1) * (torch.arange(Lq)[None, :] < lens[:, None])
+    ids[2, :] = 0                       # no unmasked key at all: kept whole
+    ids[3, 0] = 0                       # masked CLS token
+    ids[4, 2] = 0                       # a pad id inside the sentence
+    res = {}
+    for pack in (False, True):
+        eng.pack_text = pack
+        for p in app.parameters():
+            p.grad = None
+        if path == "fused":
+            loss = app.contrastive_step(px.cuda(), ids.cuda(), process_group=False, backward=True, zero_grad=True)
+        else:
+            loss = app.compute_loss(app({"pixel_values": px, "input_ids": ids.clone()}), [])["loss"]
+            loss.backward()
+        torch.cuda.synchronize()
+        rows = eng.last_text_rows
+        assert (rows[0] < rows[1]) == pack, rows
+        res[pack] = (float(loss.item()), {n: p.grad.detach().float().cpu().clone() for n, p in app._params.items() if p.grad is not None})
+    eng.pack_text = True
+    assert abs(res[True][0] - res[False][0]) < 2e-3
+    assert set(res[True][1]) == set(res[False][1])
+    floor = 1e-4 * max(float(v.norm()) for v in res[False][1].values())
+    worst = max((float((res[True][1][n] - v).norm()) / (float(v.norm()) + floor), n) for n, v in res[False][1].items())
+    assert worst[0] < 2e-2, worst
+    # ... and against the oracle (bf16 bound of the golden tests on the big matrices)
+    _, ref_loss, ref_g = O.forward_loss_backward(sd, cfg, px, ids)
+    assert abs(res[True][0] - float(ref_loss)) < 1.5e-2
+    for n in ("text_projection", "bert.encoder.layer.0.intermediate.dense.weight", "bert.embeddings.word_embeddings.weight",
+              "bert.embeddings.position_embeddings.weight", "bert.embeddings.token_type_embeddings.weight"):
+        r = ref_g[n].double()
+        assert float((res[True][1][n].double() - r).norm()) < 8e-2 * float(r.norm()), n
+
+
 class _DS(torch.utils.data.Dataset):
     def __init__(self, px, ids):
         self.px, self.ids = px, ids

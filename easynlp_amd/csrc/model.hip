@@ -1008,13 +1008,13 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
     EZ_TRY(bert_last_layer_cls(m, m->bert[nlayers - 1], b, ws.key_bias, B, L, eps, stream, ex));
     xl = static_cast<const char*>(b.y) + (size_t)3 * B * H * esz;      // x_out of the CLS rows, [B, H]
     xl_ld = H;
-  } else if (packed) {                                                 // CLS rows of the packed last hidden state
-    EZ_TRY(gather_rows(xl, ex->cu, ws.gpool, B, 0, H, 0, dt, stream));
-    xl = ws.gpool;
-    xl_ld = H;
   } else if (cls_train) {
     EZ_TRY(bert_last_layer_cls_save(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws.key_bias, B, L, eps, stream, ex));
     xl_ld = H;                                                         // x_out of the last layer: [B, H] (CLS rows)
+  } else if (packed) {                                                 // CLS rows of the packed last hidden state (inference
+    EZ_TRY(gather_rows(xl, ex->cu, ws.gpool, B, 0, H, 0, dt, stream)); // with the CLS-only last layer switched off)
+    xl = ws.gpool;
+    xl_ld = H;
   }
   const void* fa = xl;
   int64_t fa_ld = xl_ld;

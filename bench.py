@@ -71,6 +71,7 @@ HF_VITL14_ROBERTA = dict(
 WORKLOADS = {
     "bf16_b1024_fwd_loss": dict(dtype="bf16", batch=1024, seq=64, backward=False),
     "bf16_b1024_train": dict(dtype="bf16", batch=1024, seq=64, backward=True),
+    "bf16_b1024_train_padded_text": dict(dtype="bf16", batch=1024, seq=64, backward=True, pack_text=False),
     "bf16_b1024_train_opt": dict(dtype="bf16", batch=1024, seq=64, backward=True, optimizer=True),
     "bf16_b1024_fwd_loss_padded_text": dict(dtype="bf16", batch=1024, seq=64, backward=False, pack_text=False),
     "bf16_b1024_fwd_loss_autograd": dict(dtype="bf16", batch=1024, seq=64, backward=False, path="autograd"),
@@ -81,7 +82,8 @@ WORKLOADS = {
     "bf16_hf_vitl14_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="hf_vitl14"),
 }
 # what the default run adds to the headline line (BASELINE.json configs 3, 2, 5 + the boundary overhead)
-ALSO_N1 = ["bf16_b1024_fwd_loss_padded_text", "bf16_b1024_train", "bf16_b1024_train_opt", "bf16_b1024_fwd_loss_autograd",
+ALSO_N1 = ["bf16_b1024_fwd_loss_padded_text", "bf16_b1024_train", "bf16_b1024_train_padded_text", "bf16_b1024_train_opt",
+           "bf16_b1024_fwd_loss_autograd",
            "bf16_b1024_train_autograd",
            "fp32_b256_fwd_sim", "bf16_vitl14_b512_fwd_loss", "bf16_vitl14_b512_train", "bf16_hf_vitl14_b512_train"]
 ALSO_MULTI = ["bf16_b1024_train"]          # config 4 "(+bwd)": gradient all-reduce overlapped with the backward pass
@@ -381,10 +383,10 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
     if rank != 0:
         return None
     gflop, gflop_all = gflop_per_pair(wl)
-    if text_rows and text_rows[0] != text_rows[1] and wl.get("model") is None and not wl["backward"]:
-        # packed text tower: its GEMM / LayerNorm work scales with the rows that went through it (11.025 G per pair at 64 tokens,
-        # of which 0.756 G are the skipped CLS-only part of the last layer)
-        gflop -= (11.025 - 0.756) * (1.0 - text_rows[0] / text_rows[1])
+    if text_rows and text_rows[0] != text_rows[1] and wl.get("model") is None:
+        # packed text tower: its GEMM / LayerNorm work scales with the rows that went through it (11.025 G per pair forward at 64
+        # tokens, of which 0.756 G are the skipped CLS-only part of the last layer; three times that with the backward pass)
+        gflop -= (3 if wl["backward"] else 1) * (11.025 - 0.756) * (1.0 - text_rows[0] / text_rows[1])
     value = world * B * steps / elapsed
     out = {
         "workload": name, "value": round(value, 2), "ms_per_step": round(step_ms, 3), "dtype": wl["dtype"],

@@ -248,8 +248,10 @@ def test_packed_text_tower_training_step_equals_the_padded_one(tmp_path, path):
     eng.pack_text = True
     assert abs(res[True][0] - res[False][0]) < 2e-3
     assert set(res[True][1]) == set(res[False][1])
-    floor = 1e-4 * max(float(v.norm()) for v in res[False][1].values())
-    worst = max((float((res[True][1][n] - v).norm()) / (float(v.norm()) + floor), n) for n, v in res[False][1].items())
+    # (key-bias gradients are mathematically zero -- softmax does not see a per-query constant -- i.e. pure rounding noise)
+    floor = 1e-3 * max(float(v.norm()) for v in res[False][1].values())
+    worst = max((float((res[True][1][n] - v).norm()) / (float(v.norm()) + floor), n) for n, v in res[False][1].items()
+                if not n.endswith(".key.bias"))
     assert worst[0] < 2e-2, worst
     # ... and against the oracle (bf16 bound of the golden tests on the big matrices)
     _, ref_loss, ref_g = O.forward_loss_backward(sd, cfg, px, ids)

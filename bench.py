@@ -167,9 +167,10 @@ def cpu_baseline(seconds_target=10.0):
     px, ids = O.make_inputs(cfg, 8, 64, 0)
     kind = "port"
     if R.reference_available():
+        import contextlib
         import tempfile
         try:
-            with tempfile.TemporaryDirectory() as d:
+            with tempfile.TemporaryDirectory() as d, contextlib.redirect_stdout(sys.stderr):   # (the reference prints its config)
                 R.write_checkpoint_dir(d, cfg, sd)
                 ref = R.reference_clip_app(d)
             ref.eval()

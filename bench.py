@@ -343,8 +343,8 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
     roof, extra = None, {}
     if profile:
         nprof = 2
-        two, chunks = app.two_streams, app._engine.image_chunks
-        app.two_streams, app._engine.image_chunks = False, 1
+        two = app.two_streams
+        app.two_streams = False
         step()
         fence()
         if rank == 0:
@@ -352,7 +352,7 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
         for _ in range(nprof):      # every rank steps (the collectives need all of them); only rank 0 records events
             step()
         fence()
-        app.two_streams, app._engine.image_chunks = two, chunks
+        app.two_streams = two
         if rank == 0:
             res = {}
             for cls, kname in ((0, "gemm"), (1, "attention"), (2, "layernorm")):
@@ -376,7 +376,6 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
             extra["attention_tflops"] = round(a_fl / (a_ms * 1e-3) / 1e12, 2) if a_ms > 0 else None
             l_ms, l_by, l_n = res["layernorm"]
             extra["layernorm_gbps"] = round(l_by / (l_ms * 1e-3) / 1e9, 1) if l_ms > 0 else None
-    image_chunks = app._engine.image_chunks if not wl["backward"] else 1
     buckets = getattr(app, "last_grad_buckets", None)
     text_rows = app._engine.last_text_rows
     two_streams = bool(app.two_streams)
@@ -396,7 +395,7 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
         "stages": "encode_image+encode_text" + ("+allgather" if world > 1 else "") + "+similarity(2 dirs)+InfoNCE"
                   + ("+backward" if wl["backward"] else "") + ("+grad_allreduce(overlapped)" if wl["backward"] and world > 1 and not autograd else "")
                   + ("+AdamW+repack" if wl.get("optimizer") else ""),
-        "two_streams": two_streams, "image_chunks": image_chunks, "loss": round(loss_val, 5),
+        "two_streams": two_streams, "loss": round(loss_val, 5),
         "text_tower_rows": {"through_the_tower": text_rows[0], "tokens_in_the_batch": text_rows[1]} if text_rows else None,
         "gflop_per_pair": {"algorithmic_all_tokens": gflop_all, "executed": round(gflop, 3)},
         "model_tflops_per_gpu": round(value / world * gflop / 1e3, 2),
@@ -494,7 +493,7 @@ def main():
                        "pairs_per_gpu": head["pairs_per_gpu"], "global_batch": world * head["pairs_per_gpu"], "image": "224x224",
                        "seq_len": head["seq_len"], "stages": head["stages"], "path": head["path"],
                        "contrastive_scope": "global" if world > 1 else "local", "parallelism": "dp%d" % world,
-                       "two_streams": head["two_streams"], "image_chunks": head["image_chunks"], "text_dropout": args.text_dropout},
+                       "two_streams": head["two_streams"], "text_dropout": args.text_dropout},
             "rccl_ranks": world if use_dist else 0,
         }
         for k in ("loss", "text_tower_rows", "gflop_per_pair", "model_tflops_per_gpu", "model_mfma_frac", "roofline", "time_share", "attention_tflops",

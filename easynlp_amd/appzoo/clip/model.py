@@ -122,8 +122,6 @@ class HipClipEngine:
         self.pack_text = os.environ.get("EZCLIP_PACK_TEXT", "1") not in ("0", "false", "False")
         self.last_text_rows = None
         self.last_pack = None
-        # inference: pieces of the image batch on separate streams (encode_image); EZCLIP_IMAGE_CHUNKS=1 switches it off
-        self.image_chunks = max(1, int(os.environ.get("EZCLIP_IMAGE_CHUNKS", "2")))
         self.uses_pooler = bool(hf_branch)
         self.embed_dim = int(cfg["embed_dim"])
 
@@ -258,27 +256,6 @@ class HipClipEngine:
         if tuple(pixels.shape[1:]) != (3, R, R):
             raise L.EzclipError("pixel_values must be [B,3,%d,%d], got %s" % (R, R, tuple(pixels.shape)))
         out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=pixels.device)
-        chunks = self.image_chunks if (not save and stream is None and B >= 256 * self.image_chunks) else 1
-        if chunks > 1:
-            # Inference: the batch goes through the tower in `chunks` pieces on as many streams (the samples are independent,
-            # a GEMM row does not depend on M: bit-identical embeddings).  Each piece's persistent GEMMs end in a partial
-            # round of tiles; the other piece's kernels fill the CUs that round leaves idle -- since the packed text tower
-            # finishes early, nothing else does.
-            main = torch.cuda.current_stream()
-            per = (B + chunks - 1) // chunks
-            wss = []
-            for i in range(chunks):
-                lo, hi = i * per, min(B, (i + 1) * per)
-                st = main if i == 0 else self.side_stream(main.device, i + 1)
-                if i > 0:
-                    st.wait_stream(main)
-                ws_i = self.workspace("image#%d" % i, hi - lo, 0, False, pixels.device)
-                L.check(self.lib.ezclip_encode_image(self.handle, L.ptr(pixels[lo:hi]), hi - lo, L.ptr(out[lo:hi]), L.ptr(ws_i),
-                                                     ws_i.numel(), 0, L.stream_ptr(st)), "encode_image")
-                wss.append(ws_i)
-            for i in range(1, chunks):
-                main.wait_stream(self.side_stream(main.device, i + 1))
-            return out, wss[0]
         ws = self.workspace("image", B, 0, save, pixels.device, owner)
         L.check(self.lib.ezclip_encode_image(self.handle, L.ptr(pixels), B, L.ptr(out), L.ptr(ws), ws.numel(),
                                              1 if save else 0, L.stream_ptr(stream)), "encode_image")

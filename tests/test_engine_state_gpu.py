@@ -186,24 +186,6 @@ def test_two_streams_equal_one_stream(tmp_path, dtype):
         assert float((g - res[True][3][n]).norm()) <= 1e-5 * float(g.norm()) + fl, n
 
 
-def test_image_batch_in_chunks_is_bit_identical(tmp_path):
-    """Inference: the image batch in two pieces on two streams (HipClipEngine.image_chunks) -- same embeddings, bit for bit."""
-    app, cfg, sd = make_app(tmp_path, "bf16")
-    app.eval()
-    eng = app._engine
-    px, _ = O.make_inputs(cfg, 600, 8, 2)
-    px = px.cuda()
-    outs = {}
-    for chunks in (1, 2, 2, 3):
-        eng.image_chunks = chunks
-        with torch.no_grad():
-            outs.setdefault(chunks, []).append(app({"pixel_values": px}, feat=True)["image_embeds"].clone())
-    torch.cuda.synchronize()
-    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[2][0], outs[2][1])
-    assert torch.equal(outs[1][0], outs[3][0])      # (3 x 256 > 600: falls back to one piece)
-    eng.image_chunks = 2
-
-
 def test_overlapped_gradient_reduction_single_rank_rccl(tmp_path):
     """The progress hook -> bucketed asynchronous all-reduce path on real hardware (RCCL, one rank: the sum is the
     identity, the machinery -- ctypes callback from inside ezclip_backward_*, buckets on the collective stream, the final

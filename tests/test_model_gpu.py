@@ -258,8 +258,13 @@ def test_packed_text_tower_training_step_equals_the_padded_one(tmp_path, path):
     assert abs(res[True][0] - float(ref_loss)) < 1.5e-2
     for n in ("text_projection", "bert.encoder.layer.0.intermediate.dense.weight", "bert.embeddings.word_embeddings.weight",
               "bert.embeddings.position_embeddings.weight", "bert.embeddings.token_type_embeddings.weight"):
-        r = ref_g[n].double()
-        assert float((res[True][1][n].double() - r).norm()) < 8e-2 * float(r.norm()), n
+        r, got = ref_g[n].double(), res[True][1][n].double()
+        if n.endswith("word_embeddings.weight"):
+            # nn.Embedding(padding_idx=0) (modeling_bert.py:77): torch gives row 0 no gradient; the oracle's plain indexing does
+            # (only visible here, where pad tokens are queries that reach the loss)
+            assert float(got[0].abs().max()) == 0.0
+            r, got = r[1:], got[1:]
+        assert float((got - r).norm()) < 8e-2 * float(r.norm()), n
 
 
 class _DS(torch.utils.data.Dataset):

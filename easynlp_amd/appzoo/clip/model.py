@@ -122,6 +122,7 @@ class HipClipEngine:
         self.pack_text = os.environ.get("EZCLIP_PACK_TEXT", "1") not in ("0", "false", "False")
         self.last_text_rows = None
         self.last_pack = None
+        self._pack_cache = None
         self.uses_pooler = bool(hf_branch)
         self.embed_dim = int(cfg["embed_dim"])
 
@@ -267,6 +268,21 @@ class HipClipEngine:
         unmasked token (mask = ids != 0, modeling_chineseclip.py:347, or the explicit attention mask), every CLS token, and
         whole sentences without any unmasked key.  Works on host ids (no GPU involved: the DataLoader hands ``forward`` CPU
         tensors) or device ids (one small host sync for the two scalars).  None when packing would not pay or does not apply."""
+        B, S = ids.shape
+        # the same tensor OBJECT, unmodified (version counter), as last time: same answer, no device round trip.  (The weak
+        # reference is alive only while that object -- and with it its memory -- is; a new tensor at a recycled address is
+        # another object.)
+        c = self._pack_cache
+        if (c is not None and c[0]() is ids and c[1] == ids._version
+                and (attention_mask is None) == (c[2] is None)
+                and (attention_mask is None or (c[2]() is attention_mask and c[3] == attention_mask._version))):
+            return c[4]
+        meta = self._pack_meta_uncached(ids, attention_mask, device)
+        self._pack_cache = (weakref.ref(ids), ids._version, None if attention_mask is None else weakref.ref(attention_mask),
+                            None if attention_mask is None else attention_mask._version, meta)
+        return meta
+
+    def _pack_meta_uncached(self, ids, attention_mask, device):
         B, S = ids.shape
         keep = ids.ne(0) if attention_mask is None else attention_mask.ne(0)
         keep = keep | ~keep.any(1, keepdim=True)

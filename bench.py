@@ -451,8 +451,6 @@ def main():
 
     if os.environ.get("EZCLIP_RASTER_GM"):      # A/B switch: tile order of the persistent GEMM (0 column-fastest, g super-rows of g)
         L.check(L.load().ezclip_debug_set(6, int(os.environ["EZCLIP_RASTER_GM"])))
-    if os.environ.get("EZCLIP_ATTN_STREAM"):    # A/B switch: 0 = load-then-compute short attention forward
-        L.check(L.load().ezclip_debug_set(8, int(os.environ["EZCLIP_ATTN_STREAM"])))
     if os.environ.get("EZCLIP_FUSE_QKV"):       # A/B switch: 0 = BERT q / k / v as three products
         L.check(L.load().ezclip_debug_set(7, int(os.environ["EZCLIP_FUSE_QKV"])))
 

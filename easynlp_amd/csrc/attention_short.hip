@@ -569,8 +569,6 @@ int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
   return EZ_OK;
 }
 
-void set_attention_stream(int) {}      // (round-2 experiment hook, kept so that ezclip_debug_set(8, ..) stays valid: no effect)
-
 int attention_fwd_short(const AttnArgs& a, hipStream_t stream) {
   const int nt = (a.L + 31) / 32;
   const int bytes = nt * (2 * 32 * 128 + 32 * 4);

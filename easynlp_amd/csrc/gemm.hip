@@ -231,7 +231,9 @@ int g_gemm_variant = -1;   // -1: heuristic; 0: 128x128; 1: 256x256 (2-phase); 2
 template <typename T, typename TO>
 int launch_nt(const GemmArgs& p, hipStream_t stream) {
   int v = g_gemm_variant;
-  if (v < 0 || v > 1) v = (p.M >= 1024 && p.N >= 256 && p.N % 256 == 0) ? 1 : 0;
+  // 256 x 256 tiles only when they fill the chip: the B-row products of the CLS-only last blocks, the projections and the
+  // similarity (M = 1024: 8..16 such tiles on 256 CUs, each walking the whole K) run four times as many 128 x 128 workgroups
+  if (v < 0 || v > 1) v = (p.N % 256 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 256) >= 192) ? 1 : 0;
   if (v == 1) return launch_nt_shape<T, TO, 2, 4, 4, 2>(p, stream);
   return launch_nt_shape<T, TO, 2, 2, 2, 2>(p, stream);
 }

@@ -95,7 +95,6 @@ bool attention_short_eligible(const AttnArgs& a, int dtype);
 bool attention_short_fwd_eligible(const AttnArgs& a, int dtype);
 int attention_fwd_short(const AttnArgs& a, hipStream_t stream);
 void set_attention_variant(int v);   // -1 auto, 0: attention.hip kernels only
-void set_attention_stream(int on);   // 1 (default): streamed short forward kernel; 0: the load-then-compute one
 
 struct AttnBwdArgs {
   AttnArgs f;                     // forward tensors (q, k, v, key_bias, lse; ctx = forward output)

@@ -296,8 +296,7 @@ int ezclip_recall_ranks_rows(const float* text_rows_dev, const float* image_dev,
  * separate statistics pass);  key 3: last-block CLS-only evaluation on the inference path (1 on, 0 off);  key 4: the same on the training path;  key 5: resampling window
  * tables of ezclip_preprocess_images built on the device (1, default) or on the host (0);  key 6: tile order of the persistent
  * GEMM (0 column-fastest, g > 0 super-rows of g row tiles walked column by column, -1 the built-in default);  key 7: BERT
- * query / key / value projections as one N = 3 * hidden product on the bf16 path (1, default) or three products (0);
- * key 8: short-sequence attention forward streamed tile by tile (1, default) or load-then-compute (0). */
+ * query / key / value projections as one N = 3 * hidden product on the bf16 path (1, default) or three products (0). */
 int ezclip_debug_set(int key, int value);
 int ezclip_profile_begin(void);
 int ezclip_profile_end(int kernel_class, double* total_ms, double* total_work, int* launches);

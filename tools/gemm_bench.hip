@@ -88,7 +88,6 @@ struct Shape { const char* name; int M, N, K, act; bool res, c2; bool u = false;
 int main(int argc, char** argv) {
   const int batch = argc > 1 ? atoi(argv[1]) : 1024;
   const bool only_attn = getenv("ONLY_ATTN") != nullptr;
-  if (getenv("ATTN_STREAM")) ezclip::set_attention_stream(atoi(getenv("ATTN_STREAM")));
   if (getenv("RASTER_GM")) ezclip::set_gemm_raster(atoi(getenv("RASTER_GM")));    // tile order of the persistent kernel
   const int iters = argc > 2 ? atoi(argv[2]) : 20;
   std::vector<int> variants;

@@ -446,6 +446,21 @@ int ezclip_op_attention_bwd(const void* q, const void* k, const void* v, int64_t
   return attention_bwd(b, dtype, S(stream));
 }
 
+int ezclip_op_attention_bwd_bias(const void* q, const void* k, const void* v, int64_t row_stride, const void* ctx,
+                                 const void* dctx, int64_t ctx_stride, const float* key_bias, const float* lse, void* dq,
+                                 void* dk, void* dv, float* dbq, float* dbk, float* dbv, float* db_scratch, int batch,
+                                 int seq_len, int heads, int dtype, void* stream) {
+  AttnBwdArgs b;
+  b.f.drop = g_op_attn_drop;
+  b.f.causal = g_op_attn_causal;
+  b.f.q = q; b.f.k = k; b.f.v = v; b.f.row_stride = row_stride; b.f.ctx = const_cast<void*>(ctx);
+  b.f.ctx_stride = ctx_stride; b.f.key_bias = key_bias; b.f.lse = const_cast<float*>(lse);
+  b.f.B = batch; b.f.L = seq_len; b.f.H = heads; b.f.scale = 0.125f;
+  b.dctx = dctx; b.dq = dq; b.dk = dk; b.dv = dv;
+  b.dbq = dbq; b.dbk = dbk; b.dbv = dbv; b.db_part = db_scratch;
+  return attention_bwd(b, dtype, S(stream));
+}
+
 int ezclip_op_attention_cls(const void* q_cls, int64_t q_stride, const void* k, const void* v, int64_t row_stride,
                             const float* key_bias, void* ctx_cls, int64_t ctx_stride, int batch, int seq_len, int heads, int dtype,
                             void* stream) {

@@ -147,6 +147,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// sum over the 16 lanes of a DPP row, every lane ends up with it (quad butterflies, then the 8- and 16-lane mirrors: four
+// VALU instructions, no LDS-pipe round trips); half_sum: over the 32 lanes of a half-wave (one bpermute for the row pair)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);    // row_half_mirror
+  return dpp_add<0x140>(v); // row_mirror
+}
+__device__ __forceinline__ float half_sum(float v) {
+  v = row16_sum(v);
+  return v + __shfl_xor(v, 16, 64);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

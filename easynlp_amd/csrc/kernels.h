@@ -170,6 +170,8 @@ int l2_normalize_bwd(const float* y, const float* dy, const float* inv_norm, flo
 
 // backward helpers
 int colsum_add(const void* x, int64_t ld, int rows, int cols, float* out, int dtype, hipStream_t stream);      // out[c] += sum_r x[r][c]
+int colsum3_add(const void* x, int64_t ld, int rows, int cols, float* out, float* out1, float* out2, int seg, int dtype,
+                hipStream_t stream);      // the same into three vectors of `seg` columns each (cols = 3 seg)
 // out[t][c] += sum_b x[b][t][c] for t < t_count (x is [B, Tn, W])
 int batch_sum_add(const void* x, int B, int Tn, int t_count, int W, float* out, int dtype, hipStream_t stream);
 int vit_gather_patch_rows(const void* dx0, void* dpemb, int B, int Lv, int W, int dtype, hipStream_t stream);

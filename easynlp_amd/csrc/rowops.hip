@@ -76,6 +76,74 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, int64_t xs, T* 
   if (mean_o != nullptr && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
 
+// bf16 rows whose width is a multiple of 8: a half-wave per row (32 lanes x 16-byte chunks, NC chunks per lane), each wave
+// walks row pairs with the next pair's loads in flight under the current pair's arithmetic, gain / bias held in registers.
+// (The one-row-per-wave kernel above: 8-byte loads, twelve bpermute steps per row, a workgroup launch per four rows --
+// 2.7 TB/s on the [201 728 x 768] rows of the ViT; same arithmetic here, reductions over 32 lanes.)
+template <int NC>
+__global__ __launch_bounds__(256) void ln_fwd_pair_kernel(const bf16_t* x, int64_t xs, bf16_t* y, int64_t ys, const float* g,
+                                                           const float* b, float eps, int rows, int D, float* mean_o,
+                                                           float* rstd_o) {
+  const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+  const int nw = gridDim.x * 4, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  float gv[NC][8], bv[NC][8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = (hl + 32 * c) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gv[c][e] = col < D ? g[col + e] : 0.f; bv[c][e] = col < D ? b[col + e] : 0.f; }
+  }
+  auto load = [&](int r, uint4 (&dst)[NC]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = (hl + 32 * c) * 8;
+      dst[c] = (col < D && r < rows) ? *reinterpret_cast<const uint4*>(x + (int64_t)r * xs + col) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  uint4 cur[NC], nxt[NC];
+  int row = gw * 2 + half;
+  load(row, cur);
+  const float inv_d = 1.0f / (float)D;
+  for (; row - half < rows; row += 2 * nw) {
+    load(row + 2 * nw, nxt);
+    float v[NC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      unpack_chunk(cur[c], v[c], bf16_t());
+      s += ((v[c][0] + v[c][1]) + (v[c][2] + v[c][3])) + ((v[c][4] + v[c][5]) + (v[c][6] + v[c][7]));
+    }
+    const float mean = half_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if ((hl + 32 * c) * 8 < D) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
+      }
+    }
+    const float var = half_sum(q) * inv_d;
+    float rstd = rsqrtf(var + eps);
+    rstd = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);
+    if (row < rows) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = (hl + 32 * c) * 8;
+        if (col < D) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd * gv[c][e] + bv[c][e];
+          *reinterpret_cast<uint4*>(y + (int64_t)row * ys + col) =
+              make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+        }
+      }
+      if (mean_o != nullptr && hl == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cur[c] = nxt[c];
+  }
+}
+
 // stats[row] = (rstd, -mean * rstd): what the GEMM's folded-LayerNorm epilogue needs (GemmArgs::ln_stats)
 template <typename T>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const T* x, int64_t xs, float eps, int rows, int D, float* stats) {
@@ -345,6 +413,27 @@ __global__ void im2col_kernel(const float* px, T* out, int B, int R, int P, int 
   }
 }
 
+// The same for patch sizes that are multiples of 8 without K padding (ViT-B/16: P = 16, K = 768) in 16-byte pieces: one thread
+// = 8 consecutive kx of one (c, ky) patch row = two float4 loads (32 contiguous bytes of an image row) and one 16-byte bf16
+// store; a wave writes 1 KiB of consecutive patch-matrix bytes and reads 32-byte runs of which four complete an image line
+// across the neighbouring patch's wave.  (The scalar kernel above issued four 4-byte loads per thread.)
+__global__ __launch_bounds__(256) void im2col8_bf16_kernel(const float* px, bf16_t* out, int B, int R, int P, int G) {
+  const int K = 3 * P * P, k8 = K / 8, P8 = P / 8;
+  const int64_t total = (int64_t)B * G * G * k8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t rowi = i / k8;
+    const int j = (int)(i - rowi * k8);                 // 8-element piece of the patch row: (c, ky, kx / 8)
+    const int b = (int)(rowi / (G * G)), p = (int)(rowi - (int64_t)b * G * G);
+    const int gy = p / G, gx = p - gy * G;
+    const int cky = j / P8, kx = (j - cky * P8) * 8;
+    const int c = cky / P, ky = cky - c * P;
+    const float* src = px + (((int64_t)b * 3 + c) * R + gy * P + ky) * R + gx * P + kx;
+    const float4 a = *reinterpret_cast<const float4*>(src), d = *reinterpret_cast<const float4*>(src + 4);
+    *reinterpret_cast<uint4*>(out + rowi * K + (int64_t)j * 8) =
+        make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(d.x, d.y), pack_bf16x2(d.z, d.w));
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const T* patch, const float* cls, const float* pos,
                                                                const float* g, const float* b, float eps, T* x0, T* y,
@@ -536,7 +625,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* y, const f
 // the block's row range, LDS-combined, one atomic per column per block.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t ld, int rows, int cols, int rows_per_block,
-                                                      float* out) {
+                                                      float* out, float* out1, float* out2, int seg) {
   __shared__ float red[4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 256 + lane * 4;
@@ -554,23 +643,50 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t ld, int
   for (int e = 0; e < 4; ++e) red[w][lane * 4 + e] = a[e];
   __syncthreads();
   const int cc = blockIdx.x * 256 + threadIdx.x;
-  if (cc < cols) atomicAdd(out + cc, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+  if (cc < cols) {      // seg > 0: three destinations, columns [0, seg) / [seg, 2 seg) / [2 seg, 3 seg)
+    float* o = seg <= 0 || cc < seg ? out + cc : cc < 2 * seg ? out1 + (cc - seg) : out2 + (cc - 2 * seg);
+    atomicAdd(o, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+  }
 }
 
-// out[t][c] += sum_b x[(b*T + t)*W + c]   (positional-embedding gradients; fixed order over b)
+// out[t][c] += sum_b x[(b*T + t)*W + c]   (positional-embedding gradients; fixed order of additions: deterministic).
+// Workgroup = one position x 256 columns x 8 waves; wave w takes the samples b = w (mod 8), four loads in flight, and the
+// eight partial sums meet in LDS.  (One thread per (t, 4 columns) walking all B samples alone left the chip at 0.6 waves
+// per SIMD: 0.86 TB/s on the ViT's [1024, 197, 768] block.)
 template <typename T>
-__global__ __launch_bounds__(256) void batch_sum_kernel(const T* x, int B, int Tn, int W, float* out) {
+__global__ __launch_bounds__(512) void batch_sum_kernel(const T* x, int B, int Tn, int W, float* out) {
+  __shared__ float red[8][256];
   const int t = blockIdx.x;
-  const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
-  if (c >= W) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.y * 256 + lane * 4;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < B; ++b) {
-    float v[4];
-    ld4(x + ((int64_t)b * Tn + t) * W + c, v);
-    a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+  if (c < W) {
+    const T* p = x + (int64_t)t * W + c;
+    const int64_t bs = (int64_t)Tn * W;
+    int b = w;
+    for (; b + 24 < B; b += 32) {
+      float v0[4], v1[4], v2[4], v3[4];
+      ld4(p + b * bs, v0); ld4(p + (b + 8) * bs, v1); ld4(p + (b + 16) * bs, v2); ld4(p + (b + 24) * bs, v3);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+    }
+    for (; b < B; b += 8) {
+      float v[4];
+      ld4(p + b * bs, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += v[e];
+    }
   }
-  float* o = out + (int64_t)t * W + c;
-  o[0] += a[0]; o[1] += a[1]; o[2] += a[2]; o[3] += a[3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[w][lane * 4 + e] = a[e];
+  __syncthreads();
+  const int cc = blockIdx.y * 256 + threadIdx.x;
+  if (threadIdx.x < 256 && cc < W) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+    out[(int64_t)t * W + cc] += s;
+  }
 }
 
 // compact the patch rows of d_x0 [B, Lv, W] into d_pemb [B*(Lv-1), W]
@@ -636,6 +752,23 @@ int layernorm_fwd(const void* x, int64_t xs, void* y, int64_t ys, const float* g
   EZ_REQUIRE(xs % 4 == 0 && ys % 4 == 0, "layernorm_fwd: row strides must be multiples of 4 elements");
   const int blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
   ProfScope ps(PROF_ROWOP, 2.0 * rows * (double)D * dtype_size(dtype), stream);   // bytes: read + write
+  if (dtype == EZCLIP_BF16 && D % 8 == 0 && xs % 8 == 0 && ys % 8 == 0 && rows >= 64 && ((uintptr_t)x % 16) == 0 &&
+      ((uintptr_t)y % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)b % 16) == 0) {
+    // (rows >= 64: the small CLS-row calls keep the one-wave-per-row kernel)   4 waves x 2 rows per workgroup and trip
+    const int nc = (D + 255) / 256;
+    const int resident = 256 * (nc >= 3 ? 4 : 8);      // workgroups the chip holds at this variant's register count
+    int wgs = (rows + 7) / 8;
+    if (wgs > resident) wgs = resident;
+    auto launch = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, stream, (const bf16_t*)x, xs, (bf16_t*)y, ys, g, b, eps, rows, D, mean, rstd);
+    };
+    if (nc == 1) launch(ln_fwd_pair_kernel<1>);
+    else if (nc == 2) launch(ln_fwd_pair_kernel<2>);
+    else if (nc == 3) launch(ln_fwd_pair_kernel<3>);
+    else launch(ln_fwd_pair_kernel<4>);
+    EZ_LAUNCH_CHECK();
+    return EZ_OK;
+  }
   EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3(blocks), dim3(256), 0, stream, (const T*)x, xs,
                                           (T*)y, ys, g, b, eps, rows, D, mean, rstd));
   EZ_LAUNCH_CHECK();
@@ -727,6 +860,12 @@ int pad_cast(const float* src, int R, int C, void* dst, int64_t ld, int dtype, h
 int im2col_patches(const float* pixels, void* out, int B, int R, int P, int Kpad, int dtype, hipStream_t stream) {
   const int G = R / P;
   EZ_REQUIRE(B > 0 && G > 0 && Kpad % 4 == 0 && Kpad >= 3 * P * P, "im2col: bad shape");
+  if (dtype == EZCLIP_BF16 && P % 8 == 0 && Kpad == 3 * P * P && R % 4 == 0 && ((uintptr_t)pixels % 16) == 0 && ((uintptr_t)out % 16) == 0) {
+    const int64_t work8 = (int64_t)B * G * G * (Kpad / 8);
+    hipLaunchKernelGGL(im2col8_bf16_kernel, dim3(grid_for(work8, 256)), dim3(256), 0, stream, pixels, (bf16_t*)out, B, R, P, G);
+    EZ_LAUNCH_CHECK();
+    return EZ_OK;
+  }
   const int64_t work = (int64_t)B * G * G * (Kpad / 4);
   EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_kernel<T>), dim3(grid_for(work, 256)), dim3(256), 0, stream, pixels,
                                           (T*)out, B, R, P, G, Kpad));
@@ -801,7 +940,14 @@ int l2_normalize_bwd(const float* y, const float* dy, const float* inv_norm, flo
 }
 
 int colsum_add(const void* x, int64_t ld, int rows, int cols, float* out, int dtype, hipStream_t stream) {
+  return colsum3_add(x, ld, rows, cols, out, nullptr, nullptr, 0, dtype, stream);
+}
+
+// columns [0, seg), [seg, 2 seg), [2 seg, 3 seg) of x summed into three separate vectors (seg = 0: one vector of `cols`)
+int colsum3_add(const void* x, int64_t ld, int rows, int cols, float* out, float* out1, float* out2, int seg, int dtype,
+                hipStream_t stream) {
   EZ_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0, "colsum_add: cols/ld must be multiples of 4");
+  EZ_REQUIRE(seg == 0 || (cols == 3 * seg && out1 != nullptr && out2 != nullptr), "colsum3_add: cols must be 3 x seg");
   const int bx = (cols + 255) / 256;
   int by = (1024 + bx - 1) / bx;
   if (by > (rows + 63) / 64) by = (rows + 63) / 64;
@@ -809,15 +955,15 @@ int colsum_add(const void* x, int64_t ld, int rows, int cols, float* out, int dt
   const int rpb = (rows + by - 1) / by;
   by = (rows + rpb - 1) / rpb;
   EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(bx, by), dim3(256), 0, stream, (const T*)x, ld, rows,
-                                          cols, rpb, out));
+                                          cols, rpb, out, out1, out2, seg));
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }
 
 int batch_sum_add(const void* x, int B, int Tn, int t_count, int W, float* out, int dtype, hipStream_t stream) {
   EZ_REQUIRE(B > 0 && Tn > 0 && t_count > 0 && t_count <= Tn && W % 4 == 0, "batch_sum_add: bad shape");
-  dim3 grid(t_count, (W / 4 + 255) / 256);
-  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((batch_sum_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, B, Tn, W, out));
+  dim3 grid(t_count, (W + 255) / 256);
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((batch_sum_kernel<T>), grid, dim3(512), 0, stream, (const T*)x, B, Tn, W, out));
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

@@ -345,6 +345,16 @@ int ezclip_op_attention_bwd(const void* q_dev, const void* k_dev, const void* v_
                             const void* ctx_dev, const void* dctx_dev, int64_t ctx_stride, const float* key_bias_dev,
                             const float* lse_dev, void* dq_dev, void* dk_dev, void* dv_dev, int batch, int seq_len,
                             int heads, int dtype, void* stream);
+/* The same with the gradients of the q / k / v projection biases: db*[h*64 + d] += sum over (sample, token) of dq / dk / dv
+ * (f32 [heads*64] each, ACCUMULATED into).  db_scratch_dev: batch * 3 * heads * 64 floats (per-sample partial sums of the fused
+ * short-sequence kernel; unused by the general kernels, may then be NULL).  The towers' backward passes call
+ * exactly this (nn.MultiheadAttention in_proj_bias: modeling_chineseclip.py:226; BertSelfAttention q/k/v biases:
+ * modeling_bert.py:176-178). */
+int ezclip_op_attention_bwd_bias(const void* q_dev, const void* k_dev, const void* v_dev, int64_t row_stride,
+                                 const void* ctx_dev, const void* dctx_dev, int64_t ctx_stride, const float* key_bias_dev,
+                                 const float* lse_dev, void* dq_dev, void* dk_dev, void* dv_dev, float* dbq_dev, float* dbk_dev,
+                                 float* dbv_dev, float* db_scratch_dev, int batch, int seq_len, int heads, int dtype,
+                                 void* stream);
 /* Dropout building blocks (parity tests feed the library's own masks to the oracle).
  * Element (row, col) of site `site` is kept iff philox4x32_10(ctr = (col>>2, row, site, 0), key = seed)[col&3] >=
  * round(p * 2^32); survivors are scaled by 1/(1-p).  Text-tower sites: 0 = embeddings; layer i: 1+3i attention

@@ -99,7 +99,7 @@ def test_gemm_nt_strided_rows_and_inplace_residual():
     assert max_err(y, ref) < 1e-4
 
 
-@pytest.mark.parametrize("rows,D", [(5, 128), (197, 768), (64, 1024), (33, 192)])
+@pytest.mark.parametrize("rows,D", [(5, 128), (197, 768), (64, 1024), (33, 192), (4099, 768), (777, 520), (300, 256), (20001, 1024)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("eps", [1e-5, 1e-12])
 def test_layernorm(rows, D, dtype, eps):
@@ -380,6 +380,54 @@ def test_attention_bwd(B_, Lq, H, dtype, masked):
     scale = float(qd.grad.abs().max())
     assert max_err(dqkv.float(), qd.grad) < (3e-5 if dtype == "f32" else 0.04) * max(1.0, scale)
     assert rel_err(dqkv.float(), qd.grad) < (1e-5 if dtype == "f32" else 0.02)
+
+
+@pytest.mark.parametrize("B_,Lq,H", [(5, 197, 3), (7, 64, 2), (3, 26, 1), (2, 256, 2), (2, 257, 1)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention_bwd_projection_bias_gradients(B_, Lq, H, dtype, masked):
+    """The q / k / v bias gradients the backward hands out with dq / dk / dv (the fused short-sequence kernel forms them as
+    scale K^T c, scale Q^T r and dO^T 1 -- DESIGN.md 4.1b) against the column sums of the reference's dqkv, accumulated
+    into what the buffers held."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(B_ * 100 + Lq + H)
+    D = H * 64
+    qkv = torch.randn(B_ * Lq, 3 * D, generator=g)
+    dctx = torch.randn(B_ * Lq, D, generator=g)
+    kb = None
+    if masked:
+        lens = torch.randint(1, Lq + 1, (B_,), generator=g)
+        lens[0] = Lq
+        kb = torch.zeros(B_, Lq)
+        for i in range(B_):
+            kb[i, lens[i]:] = -10000.0
+        kb = kb.reshape(-1)
+    if dtype == "bf16":
+        qkv, dctx = qkv.bfloat16(), dctx.bfloat16()
+    qd = qkv.double().requires_grad_(True)
+    ref, _ = ref_attention(qd, B_, Lq, H, kb)
+    ref.backward(dctx.double())
+    ref_db = qd.grad.sum(0)
+    qg, dg_, kbg = qkv.to(DEV), dctx.to(DEV), (None if kb is None else kb.to(DEV))
+    ctx, lse = L.op_attention(qg, B_, Lq, H, key_bias=kbg, want_lse=True)
+    dqkv = torch.zeros_like(qg)
+    start = torch.randn(3 * D, generator=g)
+    db = start.to(DEV)
+    scratch = torch.empty(B_ * 3 * D, dtype=torch.float32, device=DEV)
+    esz = qg.element_size()
+    dt = L.DTYPE_BF16 if dtype == "bf16" else L.DTYPE_F32
+    base, dbase, bb = qg.data_ptr(), dqkv.data_ptr(), db.data_ptr()
+    L.check(lib.ezclip_op_attention_bwd_bias(base, base + D * esz, base + 2 * D * esz, 3 * D, ctx.data_ptr(), dg_.data_ptr(), D,
+                                             L.ptr(kbg), lse.data_ptr(), dbase, dbase + D * esz, dbase + 2 * D * esz,
+                                             bb, bb + 4 * D, bb + 8 * D, scratch.data_ptr(), B_, Lq, H, dt, L.stream_ptr()))
+    torch.cuda.synchronize()
+    got = db.cpu().double() - start.double()
+    scale = float(ref_db.abs().max())
+    # q and v parts: sums of B*L terms of size ~1; the k part is zero in exact arithmetic (rows of dS sum to zero), so only
+    # an absolute bound means anything there
+    tol = (2e-4 if dtype == "f32" else 0.02) * max(1.0, scale)
+    assert float((got - ref_db).abs().max()) < tol, (float((got - ref_db).abs().max()), scale)
+    assert max_err(dqkv.float(), qd.grad) < (3e-5 if dtype == "f32" else 0.04) * max(1.0, float(qd.grad.abs().max()))
 
 
 @pytest.mark.parametrize("variant", [0, 1])

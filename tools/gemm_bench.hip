@@ -362,6 +362,62 @@ int main(int argc, char** argv) {
           ms /= iters;
           printf("  %s %.3f ms (%.0f TF)", v == 0 ? "two kernels" : "fused", ms, 10.0 * t.B * t.H * (double)t.L * t.L * 64 / ms / 1e9);
         }
+        // probes (ATTN_PROBE=1): the fused kernel with the bias-gradient reduction on, and timed one launch at a time between
+        // bursts of large GEMMs (the clock / power state it meets inside a training step)
+        if (getenv("ATTN_PROBE")) {
+          ezclip::set_attention_variant(-1);
+          float *dbp, *dbs;
+          CK(hipMalloc(&dbp, (size_t)t.B * 3 * W * 4)); CK(hipMalloc(&dbs, 3 * W * 4)); CK(hipMemsetAsync(dbs, 0, 3 * W * 4, st));
+          ezclip::AttnBwdArgs ab;
+          ab.f.q = qkv; ab.f.k = qkv + W; ab.f.v = qkv + 2 * W; ab.f.row_stride = 3 * W;
+          ab.f.ctx = ctx1; ab.f.ctx_stride = W; ab.f.lse = lse; ab.f.B = t.B; ab.f.L = t.L; ab.f.H = t.H; ab.f.scale = 0.125f;
+          ab.dctx = dctx; ab.dq = dq1; ab.dk = dq1 + W; ab.dv = dq1 + 2 * W;
+          hipEvent_t e0, e1;
+          CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+          for (int withdb = 0; withdb < 2; ++withdb) {
+            if (withdb) { ab.dbq = dbs; ab.dbk = dbs + W; ab.dbv = dbs + 2 * W; ab.db_part = dbp; }
+            ezclip::attention_bwd(ab, EZCLIP_BF16, st);
+            CK(hipEventRecord(e0, st));
+            for (int it = 0; it < iters; ++it) ezclip::attention_bwd(ab, EZCLIP_BF16, st);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("  [probe db=%d: %.3f ms]", withdb, ms / iters);
+          }
+          // hot: [4 x (M x 2304 x 768) GEMM, 1 x attention] x 12, the attention launches timed one by one
+          {
+            const int gM = t.B * 197, gN = 2304, gK = 768;
+            uint16_t *gA, *gB, *gC;
+            CK(hipMalloc(&gA, (size_t)gM * gK * 2)); CK(hipMalloc(&gB, (size_t)gN * gK * 2)); CK(hipMalloc(&gC, (size_t)gM * gN * 2));
+            fill_bf16<<<2048, 256, 0, st>>>(gA, (size_t)gM * gK, 31u, 1.0f);
+            fill_bf16<<<2048, 256, 0, st>>>(gB, (size_t)gN * gK, 32u, 0.05f);
+            ezclip::GemmArgs g;
+            g.A = gA; g.lda = gK; g.B = gB; g.ldb = gK; g.C = gC; g.ldc = gN; g.M = gM; g.N = gN; g.K = gK;
+            float hot = 0, fhot = 0;
+            ezclip::AttnArgs fa = ab.f; fa.ctx = ctx0;
+            for (int rep = 0; rep < 14; ++rep) {
+              for (int q = 0; q < 4; ++q) ezclip::gemm_nt(g, EZCLIP_BF16, st);
+              CK(hipEventRecord(e0, st));
+              ezclip::attention_bwd(ab, EZCLIP_BF16, st);
+              CK(hipEventRecord(e1, st));
+              CK(hipEventSynchronize(e1));
+              float ms = 0;
+              CK(hipEventElapsedTime(&ms, e0, e1));
+              if (rep >= 2) hot += ms;
+              for (int q = 0; q < 4; ++q) ezclip::gemm_nt(g, EZCLIP_BF16, st);
+              CK(hipEventRecord(e0, st));
+              ezclip::attention_fwd(fa, EZCLIP_BF16, st);
+              CK(hipEventRecord(e1, st));
+              CK(hipEventSynchronize(e1));
+              CK(hipEventElapsedTime(&ms, e0, e1));
+              if (rep >= 2) fhot += ms;
+            }
+            printf("  [between GEMM bursts: bwd+db %.3f ms, fwd %.3f ms]", hot / 12, fhot / 12);
+            hipFree(gA); hipFree(gB); hipFree(gC);
+          }
+          hipFree(dbp); hipFree(dbs);
+        }
         CK(hipMemsetAsync(d_md, 0, 4, st)); CK(hipMemsetAsync(d_bad, 0, 8, st));
         maxdiff_bf16<<<1024, 256, 0, st>>>(dq0, dq1, rows * 3 * W, d_md, d_bad);
         float md2; CK(hipMemcpyAsync(&md2, d_md, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));

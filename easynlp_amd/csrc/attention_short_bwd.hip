@@ -1,0 +1,394 @@
+// Fused short-sequence attention backward (bf16, L <= 256, head_dim 64) for gfx950; the forward lives in attention_short.hip.
+// A translation unit of its own because it is compiled with -mllvm -disable-lsr (build.py): loop strength reduction gave
+// every one of the ~36 LDS reads of a key tile its own induction register (237 VGPRs, 36 address increments per tile);
+// without it the loops recompute 20 addresses from loop-invariant lane offsets (170 VGPRs, 135 -> 108 vector
+// instructions per tile of pass B before the other changes described below).
+#include <type_traits>
+
+#include "ezclip_common.h"
+#include "kernels.h"
+
+namespace ezclip {
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+
+__device__ __forceinline__ uint2 tr4(const char* p) {
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p));
+}
+
+// =====================================================================================================
+// Fused backward for the same shapes (bf16, L <= 256): ONE kernel, one workgroup per (sample, head).  Q, K, V and dO
+// of the head are brought into LDS once (four row-major 128-byte-row images by LDS-DMA) and serve both halves:
+//   pass A (wave = 32-query block, sweep over key tiles):   S^T = mfma(K, Q), dP^T = mfma(V, dO)   (lane = query)
+//        P = exp(S - lse), dS = P o (dP - D);   dQ^T += mfma(K^T, dS)
+//   pass B (wave = 32-key block, sweep over query tiles):   S = mfma(Q, K), dP = mfma(dO, V)       (lane = key)
+//        dV^T += mfma(dO^T, P),  dK^T += mfma(Q^T, dS)
+// with D_q = <dO_q, O_q> and the log-sum-exp saved by the forward.  Every image is read BOTH as row fragments
+// (ds_read_b128) and as transposed fragments (ds_read_b64_tr_b16); one swizzle serves both: the 16-byte chunk index of
+// row r is XORed with f(r) = ((r>>1)&1)<<2 | (r>>2)&3 -- a bijection of (r>>1)&7, so the 32-row b128 fragment groups
+// stay conflict-free, and its bit 2 flips between rows r and r+2, so the four rows of a transpose block fall on four
+// different bank quarters.  The two-kernel version read q, k, v, dO from HBM twice and staged transposed copies
+// through registers.
+
+__device__ __forceinline__ int swz_f(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+__device__ __forceinline__ void dma_rows_f(char* dst, const char* gbase, int64_t rs, int nrows, int L, int wave, int nwaves, int lane) {
+  const int ninst = nrows / 8;
+  for (int inst = wave; inst < ninst; inst += nwaves) {
+    const int r = inst * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz_f(r);
+    const int gr = r < L ? r : L - 1;
+    __builtin_amdgcn_global_load_lds((glb_void*)(gbase + gr * rs + c * 16), (lds_void*)(dst + inst * 1024), 16, 0, 0);
+  }
+}
+
+// Bias gradients of the q / k / v projections (column sums of dQ, dK, dV over all tokens) without reducing the
+// accumulators across lanes.  Summing dQ^T[d][q] over q is a cross-lane reduction of 32 + 64 + 64 accumulator registers
+// (it was 480 DPP adds per wave: +10 % on the ViT kernel, +40 % on BERT's two-tile one).  Instead:
+//   sum_q dQ[q]  = scale K^T c,  c_k = sum_q dS[q][k]   -- in-lane in pass B (one key per lane, queries in registers)
+//   sum_k dK[k]  = scale Q^T r,  r_q = sum_k dS[q][k]   -- in-lane in pass A (one query per lane, keys in registers)
+//   sum_k dV[k]  = dO^T 1                               -- rows of P sum to one
+// each a [64 x 32] x [32] product over the wave's own 32 rows: two MFMAs per 32 output features with the vector as the
+// B operand -- column 0 carries bf16(x), column 1 bf16(x - bf16(x)) (a 16-bit mantissa in all), the other columns zero.
+// Per wave: kRedWave floats of LDS = [3 vectors][2 columns][64 features] results, then two 32-float gather areas.
+constexpr int kRedWave = 448;
+__device__ __forceinline__ float bf16_round(float v) { return __uint_as_float(pack_bf16x2(v, 0.f) << 16); }
+// B fragment (u = 0, 1: which 16 of the 32 rows): rows 16u + 4h + {0..3} and 16u + 8 + 4h + {0..3} of x, as tr_frag orders them
+__device__ __forceinline__ uint4 vec_frag(const float* x, int u, int h, int l31) {
+  const float4 a = *reinterpret_cast<const float4*>(x + 16 * u + 4 * h), b = *reinterpret_cast<const float4*>(x + 16 * u + 8 + 4 * h);
+  float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  if (l31 == 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] -= bf16_round(v[e]);
+  }
+  if (l31 > 1) return make_uint4(0u, 0u, 0u, 0u);
+  return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+
+// HAS_KB / CAUSAL are template parameters: as run-time flags their index arithmetic and selects were executed for every
+// score of every tile whatever the flags said (80 of ~200 VALU instructions per tile and pass).  The probabilities are
+// recomputed in the base-2 domain, p = 2^(s c + kb log2 e - lse log2 e) with c = scale log2 e: one fma + v_exp_f32 per score.
+template <bool HAS_KB, bool CAUSAL>
+__global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int nt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const AttnArgs& f = a.f;
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int nwaves = nt;      // 64 * nt threads (nt of the launch: the longest sample's tiles): no idle waves holding registers
+  // packed batches (AttnArgs::cu / lens): rows cu[b] .. cu[b] + lens[b] - 1; nt (launch, LDS layout) is the longest sample's
+  const int L = f.lens ? f.lens[b] : f.L, LKP = 32 * nt;
+  const int64_t row0 = f.cu ? (int64_t)f.cu[b] : (int64_t)b * f.L;
+  nt = (L + 31) >> 5;
+  char* imgQ = smem;
+  char* imgK = smem + LKP * 128;
+  char* imgV = smem + 2 * LKP * 128;
+  char* imgG = smem + 3 * LKP * 128;           // dO
+  float* lseA = reinterpret_cast<float*>(smem + 4 * LKP * 128);
+  float* dA = lseA + LKP;
+  float* kb = dA + LKP;
+  float* red = kb + LKP;                       // [8 waves][kRedWave]: bias gradients (vec_frag above)
+  const bool want_db = a.db_part != nullptr;
+  const int64_t rs = f.row_stride * 2, cs = f.ctx_stride * 2;
+  const int64_t base = (row0 * f.row_stride + head * 64) * 2;
+  const int64_t cbase = (row0 * f.ctx_stride + head * 64) * 2;
+
+  dma_rows_f(imgQ, reinterpret_cast<const char*>(f.q) + base, rs, 32 * nt, L, wave, nwaves, lane);
+  dma_rows_f(imgK, reinterpret_cast<const char*>(f.k) + base, rs, 32 * nt, L, wave, nwaves, lane);
+  dma_rows_f(imgV, reinterpret_cast<const char*>(f.v) + base, rs, 32 * nt, L, wave, nwaves, lane);
+  dma_rows_f(imgG, reinterpret_cast<const char*>(a.dctx) + cbase, cs, 32 * nt, L, wave, nwaves, lane);
+  constexpr float kLog2e = 1.4426950408889634f;
+  for (int key = tid; key < 32 * nt; key += 64 * nwaves)   // key bias in base-2 units; keys >= L: -inf (p = 0)
+    kb[key] = key < L ? (HAS_KB ? f.key_bias[row0 + key] * kLog2e : 0.f) : -INFINITY;
+
+  // this wave's 32 rows (queries in pass A, keys in pass B)
+  const int blk = wave;
+  const bool active = blk * 32 < L;
+  const int row = blk * 32 + l31;
+  const int rowc = row < L ? row : L - 1;
+  // D_q = <dO_q, O_q>: each lane of the pair (h = 0, 1) takes half of the 64 columns of O straight from global memory
+  uint4 of[4];
+  float lse_q = INFINITY;
+  if (active) {
+    const char* op = reinterpret_cast<const char*>(f.ctx) + cbase + (int64_t)rowc * cs;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) of[s] = *reinterpret_cast<const uint4*>(op + (2 * s + h) * 16);
+    if (row < L) lse_q = f.lse[((int64_t)b * f.H + head) * f.L + row];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int fl = swz_f(l31);                     // (32t + l31 has the same f as l31)
+  uint32_t roff[4];                              // row fragments: row l31 of a 32-row tile, chunk (2s+h) ^ f
+#pragma unroll
+  for (int s = 0; s < 4; ++s) roff[s] = (uint32_t)l31 * 128u + ((uint32_t)((2 * s + h) ^ fl) << 4);
+  // transposed fragments: lane supplies row 4h + (t16>>2) (+ 8*part + 16u + 32t), 4 columns at dt*32 + sub*16 + 4*(t16&3)
+  const int t16 = lane & 15, sub = (lane >> 4) & 1;
+  const uint32_t tch = (uint32_t)((((t16 >> 3) & 1) << 2) | (sub << 1) | (((t16 & 3) >> 1) ^ h));   // chunk for dt = 0, part = 0
+  const uint32_t trow = (uint32_t)(4 * h + (t16 >> 2)) * 128u + (uint32_t)(t16 & 1) * 8u;
+  // address(dt, part) = trow + 1024*part + ((tch ^ (dt<<2 | part<<1)) << 4)
+  auto tr_frag = [&](const char* tile, int u, int dt) -> uint4 {     // keys/queries 16u + 4h + {0..3}, + 8 + {0..3}
+    const uint2 lo = tr4(tile + u * 2048 + trow + ((tch ^ (uint32_t)(dt << 2)) << 4));
+    const uint2 hi = tr4(tile + u * 2048 + 1024 + trow + ((tch ^ (uint32_t)((dt << 2) | 2)) << 4));
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+  };
+
+  float* red_w = red + wave * kRedWave;
+  // the wave's share of a bias gradient: out[col][d] = mul * sum over its 32 rows of img[row][d] x[row]  (col 0 / 1: vec_frag)
+  auto bias_vec = [&](const char* img_blk, const float* x, float mul, float* out) {
+    f32x16_t acc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint4 bf = vec_frag(x, u, h, l31);
+      mma32(acc[0], tr_frag(img_blk, u, 0), bf, bf16_t());
+      mma32(acc[1], tr_frag(img_blk, u, 1), bf, bf16_t());
+    }
+    if (l31 < 2) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+          *reinterpret_cast<float4*>(out + l31 * 64 + dt * 32 + 8 * qd + 4 * h) =
+              make_float4(acc[dt][4 * qd] * mul, acc[dt][4 * qd + 1] * mul, acc[dt][4 * qd + 2] * mul, acc[dt][4 * qd + 3] * mul);
+    }
+  };
+
+  float d_q = 0.f;
+  uint4 gf[4];        // dO row fragments of this wave's rows (pass A); reused as V fragments in pass B
+  uint4 xf[4];        // Q row fragments (pass A); K row fragments (pass B)
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      gf[s] = *reinterpret_cast<const uint4*>(imgG + blk * 4096 + roff[s]);
+      xf[s] = *reinterpret_cast<const uint4*>(imgQ + blk * 4096 + roff[s]);
+      float gv[8], ov[8];
+      unpack_chunk(gf[s], gv, bf16_t());
+      unpack_chunk(of[s], ov, bf16_t());
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d_q += gv[e] * ov[e];
+    }
+    d_q += __shfl_xor(d_q, 32, 64);
+    // lseA holds -lse log2 e (rows >= L: -inf -> P = 0 in pass B)
+    if (h == 0) { lseA[row] = -lse_q * kLog2e; dA[row] = row < L ? -d_q : 0.f; }     // dA holds -D: pass B starts dP from it
+  }
+  __syncthreads();
+  const float scale = f.scale;
+  const float c = scale * kLog2e;
+  const float nlse_q = -lse_q * kLog2e;
+
+  // ------------------------------------------------ pass A: dQ for queries 32*blk + l31 ------------------------
+  if (active) {
+    f32x16_t dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    float rs4[4] = {0.f, 0.f, 0.f, 0.f};       // r_q = sum over keys of dS[q][key] (this half-wave's keys), four chains
+    // one key tile; WITH_KB = false (no key bias and not the last tile: every key exists) drops the bias read and its add
+    auto tile_a = [&](int t, auto with_kb) {
+      constexpr bool WITH_KB = decltype(with_kb)::value;
+      f32x16_t sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = pacc[r] = 0.f;
+      const char* kt = imgK + t * 4096;
+      const char* vt = imgV + t * 4096;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        mma32(sacc, *reinterpret_cast<const uint4*>(kt + roff[s]), xf[s], bf16_t());     // S^T[key][q]
+        mma32(pacc, *reinterpret_cast<const uint4*>(vt + roff[s]), gf[s], bf16_t());     // dP^T[key][q]
+      }
+      float ds[16];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float kbv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (WITH_KB) {
+          const float4 kb4 = *reinterpret_cast<const float4*>(kb + 32 * t + 8 * qd + 4 * h);
+          kbv[0] = kb4.x; kbv[1] = kb4.y; kbv[2] = kb4.z; kbv[3] = kb4.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // (kb: 0 / -inf for the keys >= L without a key bias)
+          float p = __builtin_amdgcn_exp2f(fmaf(sacc[4 * qd + e], c, WITH_KB ? kbv[e] + nlse_q : nlse_q));
+          if (CAUSAL && 32 * t + 8 * qd + 4 * h + e > row) p = 0.f;
+          ds[4 * qd + e] = p * (pacc[4 * qd + e] - d_q);
+          rs4[e] += ds[4 * qd + e];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        uint4 dc;
+        dc.x = pack_bf16x2(ds[8 * u + 0], ds[8 * u + 1]);
+        dc.y = pack_bf16x2(ds[8 * u + 2], ds[8 * u + 3]);
+        dc.z = pack_bf16x2(ds[8 * u + 4], ds[8 * u + 5]);
+        dc.w = pack_bf16x2(ds[8 * u + 6], ds[8 * u + 7]);
+        mma32(dq[0], tr_frag(kt, u, 0), dc, bf16_t());      // dQ^T[d][q] += K^T . dS^T
+        mma32(dq[1], tr_frag(kt, u, 1), dc, bf16_t());
+      }
+    };
+    if (HAS_KB) {
+#pragma unroll 1
+      for (int t = 0; t < nt; ++t) tile_a(t, std::true_type());
+    } else {
+#pragma unroll 1
+      for (int t = 0; t < nt - 1; ++t) tile_a(t, std::false_type());
+      tile_a(nt - 1, std::true_type());
+    }
+    if (row < L) {
+      bf16_t* dqp = reinterpret_cast<bf16_t*>(a.dq) + (row0 + row) * f.row_stride + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = dq[dt][4 * qd + e] * scale;
+          st4(dqp + dt * 32 + 8 * qd + 4 * h, v);
+        }
+    }
+    if (want_db) {      // dbk share = scale Q^T r and dbv share = dO^T 1 over this wave's queries (rows >= L: r = 0, mask 0)
+      float r = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
+      r += __shfl_xor(r, 32, 64);
+      if (h == 0) { red_w[384 + l31] = r; red_w[416 + l31] = row < L ? 1.f : 0.f; }
+      __builtin_amdgcn_wave_barrier();
+      bias_vec(imgQ + blk * 4096, red_w + 384, scale, red_w + 128);
+      bias_vec(imgG + blk * 4096, red_w + 416, 1.0f, red_w + 256);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // ------------------------------------------------ pass B: dK, dV for keys 32*blk + l31 -----------------------
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      xf[s] = *reinterpret_cast<const uint4*>(imgK + blk * 4096 + roff[s]);
+      gf[s] = *reinterpret_cast<const uint4*>(imgV + blk * 4096 + roff[s]);
+    }
+    // Without a key bias, kb is 0 or (keys >= L) -inf: a factor 2^kb = 1 / 0 of every probability of this lane's key -- of a
+    // whole column of dK^T / dV^T -- applied to the accumulators after the loop; inside it p' = 2^(s c - lse) <= 1 (the rows
+    // of a key >= L repeat key L - 1).  A real key bias stays in the exponent: where every key of a sample is masked the
+    // -10000 is part of lse as well, and 2^(s c - lse) 2^kb would be inf * 0.
+    const float kb_key = HAS_KB ? kb[row] : 0.f;
+    const float ek = HAS_KB ? 1.f : __builtin_amdgcn_exp2f(kb[row]);
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
+    float cs4[4] = {0.f, 0.f, 0.f, 0.f};       // c_k = sum over queries of dS[q][k] (this half-wave's queries)
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+      f32x16_t sacc, pacc;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {      // dP - D: the accumulator starts from -D of its query rows
+        const float4 d4 = *reinterpret_cast<const float4*>(dA + 32 * t + 8 * qd + 4 * h);
+        pacc[4 * qd] = d4.x; pacc[4 * qd + 1] = d4.y; pacc[4 * qd + 2] = d4.z; pacc[4 * qd + 3] = d4.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      const char* qt = imgQ + t * 4096;
+      const char* gt = imgG + t * 4096;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        mma32(sacc, *reinterpret_cast<const uint4*>(qt + roff[s]), xf[s], bf16_t());     // S[q][key]
+        mma32(pacc, *reinterpret_cast<const uint4*>(gt + roff[s]), gf[s], bf16_t());     // dP[q][key] - D[q]
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const float4 l4 = *reinterpret_cast<const float4*>(lseA + 32 * t + 8 * qd + 4 * h);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float pe = __builtin_amdgcn_exp2f(fmaf(sacc[4 * qd + e], c, HAS_KB ? kb_key + lv[e] : lv[e]));
+          if (CAUSAL && row > 32 * t + 8 * qd + 4 * h + e) pe = 0.f;      // this key lies after that query
+          p[4 * qd + e] = pe;
+          ds[4 * qd + e] = pe * pacc[4 * qd + e];
+          cs4[e] += ds[4 * qd + e];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        uint4 pc, dc;
+        pc.x = pack_bf16x2(p[8 * u + 0], p[8 * u + 1]);   dc.x = pack_bf16x2(ds[8 * u + 0], ds[8 * u + 1]);
+        pc.y = pack_bf16x2(p[8 * u + 2], p[8 * u + 3]);   dc.y = pack_bf16x2(ds[8 * u + 2], ds[8 * u + 3]);
+        pc.z = pack_bf16x2(p[8 * u + 4], p[8 * u + 5]);   dc.z = pack_bf16x2(ds[8 * u + 4], ds[8 * u + 5]);
+        pc.w = pack_bf16x2(p[8 * u + 6], p[8 * u + 7]);   dc.w = pack_bf16x2(ds[8 * u + 6], ds[8 * u + 7]);
+        mma32(dv[0], tr_frag(gt, u, 0), pc, bf16_t());      // dV^T[d][key] += dO^T . P
+        mma32(dv[1], tr_frag(gt, u, 1), pc, bf16_t());
+        mma32(dk[0], tr_frag(qt, u, 0), dc, bf16_t());      // dK^T[d][key] += Q^T . dS
+        mma32(dk[1], tr_frag(qt, u, 1), dc, bf16_t());
+      }
+    }
+    if (row < L) {
+      bf16_t* dkp = reinterpret_cast<bf16_t*>(a.dk) + (row0 + row) * f.row_stride + head * 64;
+      bf16_t* dvp = reinterpret_cast<bf16_t*>(a.dv) + (row0 + row) * f.row_stride + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          float vk[4], vv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vk[e] = dk[dt][4 * qd + e] * (scale * ek); vv[e] = dv[dt][4 * qd + e] * ek; }
+          st4(dkp + dt * 32 + 8 * qd + 4 * h, vk);
+          st4(dvp + dt * 32 + 8 * qd + 4 * h, vv);
+        }
+    }
+    if (want_db) {      // dbq share = scale K^T c over this wave's keys (keys >= L: c = 0)
+      float cc = ((cs4[0] + cs4[1]) + (cs4[2] + cs4[3])) * ek;
+      cc += __shfl_xor(cc, 32, 64);
+      if (h == 0) red_w[384 + l31] = cc;
+      __builtin_amdgcn_wave_barrier();
+      bias_vec(imgK + blk * 4096, red_w + 384, scale, red_w);
+    }
+  }
+  if (want_db) {      // combine the waves in a fixed order; per-sample partials (12k workgroups hammering 2304 addresses
+    __syncthreads();  // with atomics cost more than the pass over dqkv this replaces), summed over the batch afterwards
+    for (int i = tid; i < 192; i += 64 * nwaves) {
+      float s = 0.f;
+      const int o = (i >> 6) * 128 + (i & 63);
+      for (int w = 0; w < nt; ++w) s += red[w * kRedWave + o] + red[w * kRedWave + o + 64];
+      a.db_part[((int64_t)b * 3 + (i >> 6)) * (f.H * 64) + head * 64 + (i & 63)] = s;
+    }
+  }
+}
+
+}  // namespace
+
+bool attention_short_eligible(const AttnArgs& a, int dtype) {       // fused backward: four images of L rows in LDS
+  return dtype == EZCLIP_BF16 && a.L <= 256 && a.B <= 65535;
+}
+
+int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
+  const int nt = (a.f.L + 31) / 32;
+  const int bytes = nt * (4 * 32 * 128 + 3 * 32 * 4 + kRedWave * 4);
+  static int attr_max[4] = {0, 0, 0, 0};
+  const int vi = (a.f.key_bias != nullptr ? 1 : 0) + (a.f.causal ? 2 : 0);
+  auto* kern = vi == 0 ? &attn_bwd_short_kernel<false, false> : vi == 1 ? &attn_bwd_short_kernel<true, false>
+             : vi == 2 ? &attn_bwd_short_kernel<false, true> : &attn_bwd_short_kernel<true, true>;
+  if (bytes > attr_max[vi]) {
+    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_max[vi] = bytes;
+  }
+  {
+    ProfScope ps(PROF_ATTN, 10.0 * a.f.B * a.f.H * (double)a.f.L * a.f.L * 64, stream);   // 5 L x L x 64 products
+    hipLaunchKernelGGL(kern, dim3(a.f.H, a.f.B), dim3(64 * nt), bytes, stream, a, nt);
+  }
+  EZ_LAUNCH_CHECK();
+  if (a.dbq != nullptr) {      // batch sum of the per-sample partials [B][3][D] -> the three bias gradients
+    const int D = a.f.H * 64;
+    const int rc = colsum3_add(a.db_part, 3 * D, a.f.B, 3 * D, a.dbq, a.dbk, a.dbv, D, EZCLIP_F32, stream);
+    if (rc != EZ_OK) return rc;
+  }
+  return EZ_OK;
+}
+
+}  // namespace ezclip

@@ -145,6 +145,8 @@ def test_attention(B_, Lq, H, dtype, masked):
         kb = torch.zeros(B_, Lq)
         for i in range(B_):
             kb[i, lens[i]:] = -10000.0
+        if B_ > 1:
+            kb[1, :] = -10000.0         # every key masked: the bias is part of the log-sum-exp too (BERT on an all-pad sentence)
         kb = kb.reshape(-1)
     if dtype == "bf16":
         qkv = qkv.bfloat16()
@@ -171,6 +173,8 @@ def test_attention_f32_long_sequences_walk_the_keys_in_blocks(Lq, masked, causal
         kb = torch.zeros(B_, Lq)
         for i in range(B_):
             kb[i, lens[i]:] = -10000.0
+        if B_ > 1:
+            kb[1, :] = -10000.0         # every key masked: the bias is part of the log-sum-exp too (BERT on an all-pad sentence)
         kb = kb.reshape(-1)
     q, k, v = [t.double().reshape(B_, Lq, H, 64).transpose(1, 2) for t in qkv.split(D, dim=-1)]
     s_ = (q @ k.transpose(-1, -2)) * 0.125
@@ -361,6 +365,8 @@ def test_attention_bwd(B_, Lq, H, dtype, masked):
         kb = torch.zeros(B_, Lq)
         for i in range(B_):
             kb[i, lens[i]:] = -10000.0
+        if B_ > 1:
+            kb[1, :] = -10000.0         # every key masked: the bias is part of the log-sum-exp too (BERT on an all-pad sentence)
         kb = kb.reshape(-1)
     if dtype == "bf16":
         qkv, dctx = qkv.bfloat16(), dctx.bfloat16()
@@ -401,6 +407,8 @@ def test_attention_bwd_projection_bias_gradients(B_, Lq, H, dtype, masked):
         kb = torch.zeros(B_, Lq)
         for i in range(B_):
             kb[i, lens[i]:] = -10000.0
+        if B_ > 1:
+            kb[1, :] = -10000.0         # every key masked: the bias is part of the log-sum-exp too (BERT on an all-pad sentence)
         kb = kb.reshape(-1)
     if dtype == "bf16":
         qkv, dctx = qkv.bfloat16(), dctx.bfloat16()

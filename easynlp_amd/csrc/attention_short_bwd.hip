@@ -351,7 +351,9 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
     }
   }
   if (want_db) {      // combine the waves in a fixed order; per-sample partials (12k workgroups hammering 2304 addresses
-    __syncthreads();  // with atomics cost more than the pass over dqkv this replaces), summed over the batch afterwards
+    // with atomics cost more than the pass over dqkv this replaces), summed over the batch afterwards.  The barrier orders
+    // LDS only: __syncthreads() would also wait out the dk / dv stores (vmcnt(0)).
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int i = tid; i < 192; i += 64 * nwaves) {
       float s = 0.f;
       const int o = (i >> 6) * 128 + (i & 63);

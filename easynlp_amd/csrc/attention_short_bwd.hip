@@ -73,7 +73,7 @@ __device__ __forceinline__ uint4 vec_frag(const float* x, int u, int h, int l31)
 // score of every tile whatever the flags said (80 of ~200 VALU instructions per tile and pass).  The probabilities are
 // recomputed in the base-2 domain, p = 2^(s c + kb log2 e - lse log2 e) with c = scale log2 e: one fma + v_exp_f32 per score.
 template <bool HAS_KB, bool CAUSAL>
-__global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int nt) {
+__global__ __launch_bounds__(576) void attn_bwd_short_kernel(AttnBwdArgs a, int nt, int ra) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const AttnArgs& f = a.f;
   const int head = blockIdx.x, b = blockIdx.y;
@@ -86,23 +86,30 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
   const int L = f.lens ? f.lens[b] : f.L, LKP = 32 * nt;
   const int64_t row0 = f.cu ? (int64_t)f.cu[b] : (int64_t)b * f.L;
   nt = (L + 31) >> 5;
+  // Four images of `ra` rows (the longest sample's length rounded up to the 8 rows of a DMA piece) -- not of 32 nt rows: at
+  // 257 tokens (ViT-L/14: nine tiles) four 288-row images do not fit 160 KiB, four 264-row ones do.  The last tile's rows
+  // beyond `ra` fall on the first rows of the NEXT image (finite data of this head) or, behind the last image, on a zeroed
+  // pad: whatever they hold is multiplied by an exact zero (keys >= L: p = 0; queries >= L: lse = inf).
+  const int IMG = ra * 128, padb = (LKP - ra) * 128;
   char* imgQ = smem;
-  char* imgK = smem + LKP * 128;
-  char* imgV = smem + 2 * LKP * 128;
-  char* imgG = smem + 3 * LKP * 128;           // dO
-  float* lseA = reinterpret_cast<float*>(smem + 4 * LKP * 128);
+  char* imgK = smem + IMG;
+  char* imgV = smem + 2 * IMG;
+  char* imgG = smem + 3 * IMG;                 // dO
+  for (int i = tid * 16; i < padb; i += 64 * nwaves * 16) *reinterpret_cast<uint4*>(smem + 4 * IMG + i) = make_uint4(0u, 0u, 0u, 0u);
+  float* lseA = reinterpret_cast<float*>(smem + 4 * IMG + padb);
   float* dA = lseA + LKP;
   float* kb = dA + LKP;
-  float* red = kb + LKP;                       // [8 waves][kRedWave]: bias gradients (vec_frag above)
+  float* red = kb + LKP;                       // [waves][kRedWave]: bias gradients (vec_frag above)
   const bool want_db = a.db_part != nullptr;
   const int64_t rs = f.row_stride * 2, cs = f.ctx_stride * 2;
   const int64_t base = (row0 * f.row_stride + head * 64) * 2;
   const int64_t cbase = (row0 * f.ctx_stride + head * 64) * 2;
 
-  dma_rows_f(imgQ, reinterpret_cast<const char*>(f.q) + base, rs, 32 * nt, L, wave, nwaves, lane);
-  dma_rows_f(imgK, reinterpret_cast<const char*>(f.k) + base, rs, 32 * nt, L, wave, nwaves, lane);
-  dma_rows_f(imgV, reinterpret_cast<const char*>(f.v) + base, rs, 32 * nt, L, wave, nwaves, lane);
-  dma_rows_f(imgG, reinterpret_cast<const char*>(a.dctx) + cbase, cs, 32 * nt, L, wave, nwaves, lane);
+  const int nload = 32 * nt < ra ? 32 * nt : ra;      // rows >= L repeat row L - 1
+  dma_rows_f(imgQ, reinterpret_cast<const char*>(f.q) + base, rs, nload, L, wave, nwaves, lane);
+  dma_rows_f(imgK, reinterpret_cast<const char*>(f.k) + base, rs, nload, L, wave, nwaves, lane);
+  dma_rows_f(imgV, reinterpret_cast<const char*>(f.v) + base, rs, nload, L, wave, nwaves, lane);
+  dma_rows_f(imgG, reinterpret_cast<const char*>(a.dctx) + cbase, cs, nload, L, wave, nwaves, lane);
   constexpr float kLog2e = 1.4426950408889634f;
   for (int key = tid; key < 32 * nt; key += 64 * nwaves)   // key bias in base-2 units; keys >= L: -inf (p = 0)
     kb[key] = key < L ? (HAS_KB ? f.key_bias[row0 + key] * kLog2e : 0.f) : -INFINITY;
@@ -365,13 +372,20 @@ __global__ __launch_bounds__(512) void attn_bwd_short_kernel(AttnBwdArgs a, int 
 
 }  // namespace
 
-bool attention_short_eligible(const AttnArgs& a, int dtype) {       // fused backward: four images of L rows in LDS
-  return dtype == EZCLIP_BF16 && a.L <= 256 && a.B <= 65535;
+// LDS of the fused backward for sequences of at most L tokens: four images of round_up(L, 8) rows, the pad behind the last
+// one, three per-row float arrays, the per-wave bias-gradient areas
+static int bwd_short_lds_bytes(int L) {
+  const int nt = (L + 31) / 32, ra = (L + 7) / 8 * 8;
+  return 4 * ra * 128 + (32 * nt - ra) * 128 + nt * (3 * 32 * 4 + kRedWave * 4);
+}
+
+bool attention_short_eligible(const AttnArgs& a, int dtype) {       // fused backward: four images of L rows in LDS, <= 9 waves
+  return dtype == EZCLIP_BF16 && a.L <= 288 && a.L >= 1 && bwd_short_lds_bytes(a.L) <= 160 * 1024 && a.B <= 65535;
 }
 
 int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
-  const int nt = (a.f.L + 31) / 32;
-  const int bytes = nt * (4 * 32 * 128 + 3 * 32 * 4 + kRedWave * 4);
+  const int nt = (a.f.L + 31) / 32, ra = (a.f.L + 7) / 8 * 8;
+  const int bytes = bwd_short_lds_bytes(a.f.L);
   static int attr_max[4] = {0, 0, 0, 0};
   const int vi = (a.f.key_bias != nullptr ? 1 : 0) + (a.f.causal ? 2 : 0);
   auto* kern = vi == 0 ? &attn_bwd_short_kernel<false, false> : vi == 1 ? &attn_bwd_short_kernel<true, false>
@@ -382,7 +396,7 @@ int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
   }
   {
     ProfScope ps(PROF_ATTN, 10.0 * a.f.B * a.f.H * (double)a.f.L * a.f.L * 64, stream);   // 5 L x L x 64 products
-    hipLaunchKernelGGL(kern, dim3(a.f.H, a.f.B), dim3(64 * nt), bytes, stream, a, nt);
+    hipLaunchKernelGGL(kern, dim3(a.f.H, a.f.B), dim3(64 * nt), bytes, stream, a, nt, ra);
   }
   EZ_LAUNCH_CHECK();
   if (a.dbq != nullptr) {      // batch sum of the per-sample partials [B][3][D] -> the three bias gradients

@@ -347,7 +347,8 @@ def test_layernorm_bwd(rows, D, dtype):
     assert rel_err(db, bd.grad) < (1e-5 if dtype == "f32" else 1e-3)
 
 
-@pytest.mark.parametrize("B_,Lq,H", [(2, 197, 3), (3, 64, 2), (2, 26, 1), (1, 1, 1), (1, 257, 2), (1, 400, 1)])
+@pytest.mark.parametrize("B_,Lq,H", [(2, 197, 3), (3, 64, 2), (2, 26, 1), (1, 1, 1), (1, 257, 2), (3, 264, 2), (2, 272, 1), (2, 273, 1),
+                                     (1, 400, 1)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("masked", [False, True])
 def test_attention_bwd(B_, Lq, H, dtype, masked):
@@ -386,7 +387,7 @@ def test_attention_bwd(B_, Lq, H, dtype, masked):
     assert rel_err(dqkv.float(), qd.grad) < (1e-5 if dtype == "f32" else 0.02)
 
 
-@pytest.mark.parametrize("B_,Lq,H", [(5, 197, 3), (7, 64, 2), (3, 26, 1), (2, 256, 2), (2, 257, 1)])
+@pytest.mark.parametrize("B_,Lq,H", [(5, 197, 3), (7, 64, 2), (3, 26, 1), (2, 256, 2), (2, 257, 1), (3, 270, 2)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("masked", [False, True])
 def test_attention_bwd_projection_bias_gradients(B_, Lq, H, dtype, masked):

@@ -304,7 +304,7 @@ int main(int argc, char** argv) {
   // ---- attention (packed qkv [B*L, 3*H*64] bf16): old two-pass kernels (variant 0) vs the short-sequence kernels ----
   {
     struct AT { const char* name; int B, L, H; };
-    const AT ats[] = {{"attn.vit", batch, 197, 12}, {"attn.bert", batch, 64, 12}};
+    const AT ats[] = {{"attn.vit", batch, 197, 12}, {"attn.bert", batch, 64, 12}, {"attn.vitl14", batch / 2, 257, 16}};
     for (const AT& t : ats) {
       const size_t rows = (size_t)t.B * t.L, W = (size_t)t.H * 64;
       uint16_t *qkv, *ctx0, *ctx1; float* lse;

@@ -143,6 +143,24 @@ int cast_to_f32(const void* src, float* dst, int64_t n, int dtype, hipStream_t s
 int transpose_cast(const float* src, int64_t src_ld, int R, int C, void* dst, int64_t ld, int dtype, hipStream_t stream);
 // src [R, C] f32 -> dst [R, ld] T with zero padding of columns C..ld-1
 int pad_cast(const float* src, int R, int C, void* dst, int64_t ld, int dtype, hipStream_t stream);
+// Weight re-packing in one launch (ezclip_refresh_weights runs after every optimizer step: ~250 separate pad_cast /
+// transpose_cast launches of 5 us each were launch-bound, 1.3 ms per step).  A job reads one f32 matrix src [R][C] and
+// writes a straight copy dst_s [R][ld_s] and / or a transposed copy dst_t [C][ld_t] in the compute dtype, pad columns zeroed;
+// kind 1: dst_s = src as f32, C elements (bias vectors gathered next to packed weights).  `tile0`: first 64 x 64 tile of the
+// job in the launch (prefix sum, filled by cast_jobs_finalize); jobs live in device memory.
+struct CastJob {
+  const float* src = nullptr;
+  void* dst_s = nullptr;
+  void* dst_t = nullptr;
+  int R = 0, C = 0;
+  int ld_s = 0, ld_t = 0;
+  int kind = 0;
+  int tiles_c = 0;
+  int tile0 = 0;
+  int pad_ = 0;
+};
+int cast_jobs_finalize(CastJob* jobs_host, int n);                        // fills tiles_c / tile0; returns the total tile count
+int cast_jobs_run(const CastJob* jobs_dev, int n, int total_tiles, int dtype, hipStream_t stream);
 
 // pixels [B,3,R,R] f32 NCHW -> patches [B*G*G, Kpad] T, inner index (c, ky, kx); cols >= 3*P*P zero.
 int im2col_patches(const float* pixels, void* out, int B, int R, int P, int Kpad, int dtype, hipStream_t stream);

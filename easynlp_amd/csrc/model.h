@@ -40,6 +40,7 @@ struct ezclip_model {
     void* sf = nullptr;
     float *c1 = nullptr, *c2 = nullptr;
     bool s_external = false;  // `s` is a slice of a block laid out elsewhere (BertLayer::qkv_s)
+    mutable bool sf_fresh = false;   // the folded copy follows the master weights lazily (first folded product after a refresh)
   };
   struct VitLayer {
     Weight in_w, out_w, fc_w, proj_w;
@@ -87,6 +88,10 @@ struct ezclip_model {
   size_t shadow_bytes = 0;
   bool shadow_backward = false;
   bool weights_fresh = false;
+  // the re-packing jobs of ezclip_refresh_weights (kernels.h CastJob): device table inside the shadow buffer, host mirror
+  void* cast_jobs_dev = nullptr;
+  std::vector<unsigned char> cast_jobs_host;
+  int cast_tiles = 0;
 
   float* P(int i) const { return params[i].w; }
   float* Gp(int i) const { return params[i].g; }

@@ -245,6 +245,11 @@ size_t model_shadow_layout(ezclip_model* m, char* base, bool with_backward) {
     }
     if (base) { w.s = s; w.st = st; w.sf = sf; w.c1 = c1; w.c2 = c2; }
   });
+  // device table of the re-packing jobs: one per weight plus the three gathered biases of every BERT layer
+  size_t nweights = 0;
+  for_each_weight(m, [&](ezclip_model::Weight&) { ++nweights; });
+  void* jobs = a.take((nweights + 3 * m->bert.size() + 1) * sizeof(CastJob));
+  if (base) { m->cast_jobs_dev = jobs; m->cast_jobs_host.clear(); }
   a.take(0);
   return a.off + 256;
 }
@@ -257,39 +262,58 @@ int model_refresh_weights(ezclip_model* m, hipStream_t stream) {
   for (auto& p : m->params)
     EZ_REQUIRE(p.w != nullptr || is_optional_param(p.name), "parameter %s is not bound", p.name.c_str());
   int rc = EZ_OK;
+  // One launch for every packed copy (CastJob, kernels.h).  The table only changes when a tensor moved; the folded-LayerNorm
+  // copies (bf16 inference path only) are brought up to date by the first product that uses them.
+  std::vector<CastJob> jobs;
   for_each_weight(m, [&](ezclip_model::Weight& w) {
     if (rc != EZ_OK) return;
     const float* src = m->P(w.p);
     if (src == nullptr) return;      // unbound optional weight (pooler): never used
+    w.sf_fresh = false;
+    CastJob j;
+    j.src = src;
+    // master [N, K]: straight copy = s [N, ldk], transposed = st [K, ldn];  master [K, N]: straight = st, transposed = s
+    j.R = w.transposed_src ? w.K : w.N;
+    j.C = w.transposed_src ? w.N : w.K;
+    void* s_dst = nullptr;
     if (!needs_pack(m, w)) { w.s = const_cast<float*>(src); }
     else {
       if (w.s == nullptr) { set_error("weight shadow not set (call ezclip_set_shadow first)"); rc = EZ_ERR_STATE; return; }
-      // master [N, K] -> [N, ldk]   or master [K, N] -> [N, ldk]
-      rc = w.transposed_src ? transpose_cast(src, w.N, w.K, w.N, w.s, w.ldk, m->dtype, stream)
-                            : pad_cast(src, w.N, w.K, w.s, w.ldk, m->dtype, stream);
-      if (rc != EZ_OK) return;
+      s_dst = w.s;
     }
-    if (w.sf != nullptr) {
-      rc = fold_ln_weight(src, m->P(w.fold_g), m->P(w.fold_b), w.fold_bias >= 0 ? m->P(w.fold_bias) : nullptr, w.N, w.K,
-                          w.sf, w.ldk, w.c1, w.c2, m->dtype, stream);
-      if (rc != EZ_OK) return;
-    }
-    if (w.st != nullptr) {
-      // [K, N] copy for dX = dY . W
-      rc = w.transposed_src ? pad_cast(src, w.K, w.N, w.st, w.ldn, m->dtype, stream)
-                            : transpose_cast(src, w.K, w.N, w.K, w.st, w.ldn, m->dtype, stream);
-    }
+    if (w.transposed_src) { j.dst_t = s_dst; j.ld_t = w.ldk; j.dst_s = w.st; j.ld_s = w.ldn; }
+    else { j.dst_s = s_dst; j.ld_s = w.ldk; j.dst_t = w.st; j.ld_t = w.ldn; }
+    if (j.dst_s != nullptr || j.dst_t != nullptr) jobs.push_back(j);
   });
+  if (rc != EZ_OK) return rc;
   for (auto& L : m->bert) {
-    if (rc != EZ_OK || L.qkv_bias == nullptr) continue;
+    if (L.qkv_bias == nullptr) continue;
     const int H = L.q_w.N;
     const int bp[3] = {L.q_b, L.k_b, L.v_b};
-    for (int i = 0; i < 3 && rc == EZ_OK; ++i)
-      rc = check_hip(hipMemcpyAsync(L.qkv_bias + (size_t)i * H, m->P(bp[i]), (size_t)H * 4, hipMemcpyDeviceToDevice, stream),
-                     "hipMemcpyAsync(qkv bias)");
+    for (int i = 0; i < 3; ++i) {
+      CastJob j;
+      j.kind = 1; j.src = m->P(bp[i]); j.dst_s = L.qkv_bias + (size_t)i * H; j.C = H; j.R = 1;
+      jobs.push_back(j);
+    }
   }
-  if (rc == EZ_OK) m->weights_fresh = true;
-  return rc;
+  if (!jobs.empty()) {
+    EZ_REQUIRE(m->cast_jobs_dev != nullptr, "weight shadow not set (call ezclip_set_shadow first)");
+    const int total = cast_jobs_finalize(jobs.data(), (int)jobs.size());
+    const size_t bytes = jobs.size() * sizeof(CastJob);
+    if (m->cast_jobs_host.size() != bytes || std::memcmp(m->cast_jobs_host.data(), jobs.data(), bytes) != 0) {
+      m->cast_jobs_host.assign(reinterpret_cast<const unsigned char*>(jobs.data()), reinterpret_cast<const unsigned char*>(jobs.data()) + bytes);
+      rc = check_hip(hipMemcpyAsync(m->cast_jobs_dev, m->cast_jobs_host.data(), bytes, hipMemcpyHostToDevice, stream),
+                     "hipMemcpyAsync(cast jobs)");
+      // (pageable source: wait for the copy before the host mirror can change again -- only when a tensor moved)
+      if (rc == EZ_OK) rc = check_hip(hipStreamSynchronize(stream), "hipStreamSynchronize(cast jobs)");
+      if (rc != EZ_OK) { m->cast_jobs_host.clear(); return rc; }
+      m->cast_tiles = total;
+    }
+    rc = cast_jobs_run(static_cast<const CastJob*>(m->cast_jobs_dev), (int)jobs.size(), m->cast_tiles, m->dtype, stream);
+    if (rc != EZ_OK) return rc;
+  }
+  m->weights_fresh = true;
+  return EZ_OK;
 }
 
 // --------------------------------------------------------------- helpers ---
@@ -356,6 +380,12 @@ static int bert_qkv_proj(const ezclip_model* m, const ezclip_model::BertLayer& L
 static int linear_folded_ln(const ezclip_model* m, const void* X, int64_t ldx, const ezclip_model::Weight& w, float eps,
                             float* stats, void* C, int64_t ldc, int M, int act, hipStream_t stream,
                             bool stats_ready = false) {
+  if (!w.sf_fresh) {      // first use since the master weights were re-packed (ezclip_refresh_weights): W o g, c1, c2
+    int rc = fold_ln_weight(m->P(w.p), m->P(w.fold_g), m->P(w.fold_b), w.fold_bias >= 0 ? m->P(w.fold_bias) : nullptr, w.N, w.K,
+                            w.sf, w.ldk, w.c1, w.c2, m->dtype, stream);
+    if (rc != EZ_OK) return rc;
+    w.sf_fresh = true;
+  }
   if (!stats_ready) {
     int rc = layernorm_row_stats(X, ldx, eps, M, w.K, m->dtype, stats, stream);
     if (rc != EZ_OK) return rc;

@@ -387,6 +387,40 @@ __global__ void pad_cast_kernel(const float* src, int R, int C, T* dst, int64_t 
   }
 }
 
+// every weight's packed copies in one launch (CastJob, kernels.h): workgroup = one 64 x 64 tile of one job's source
+template <typename T>
+__global__ __launch_bounds__(256) void multi_cast_kernel(const CastJob* jobs, int n) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = n - 1;      // the job whose tile range holds blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const CastJob j = jobs[lo];
+  const int t = blockIdx.x - j.tile0;
+  if (j.kind == 1) {           // f32 vector copy, 4096 elements per tile
+    float* d = static_cast<float*>(j.dst_s);
+    for (int i = t * 4096 + threadIdx.x; i < j.C && i < (t + 1) * 4096; i += 256) d[i] = j.src[i];
+    return;
+  }
+  const int r0 = (t / j.tiles_c) * 64, c0 = (t % j.tiles_c) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 columns x 4 rows per pass
+  T* ds = static_cast<T*>(j.dst_s);
+  T* dt = static_cast<T*>(j.dst_t);
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    const float v = (r < j.R && c < j.C) ? j.src[(int64_t)r * j.C + c] : 0.f;
+    tile[i][tx] = v;
+    if (ds != nullptr && r < j.R && c < j.ld_s) Elem<T>::st(ds + (int64_t)r * j.ld_s + c, v);
+  }
+  if (dt == nullptr) return;
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < j.C && r < j.ld_t) Elem<T>::st(dt + (int64_t)c * j.ld_t + r, tile[tx][i]);
+  }
+}
+
 // out[(b*G*G + gy*G + gx) * Kpad + c*P*P + ky*P + kx] = px[b][c][gy*P+ky][gx*P+kx]
 template <typename T>
 __global__ void im2col_kernel(const float* px, T* out, int B, int R, int P, int G, int Kpad) {
@@ -845,6 +879,28 @@ int transpose_cast(const float* src, int64_t src_ld, int R, int C, void* dst, in
   EZ_REQUIRE(R > 0 && C > 0 && ld >= R && src_ld >= C, "transpose_cast: bad shape");
   dim3 grid((C + 31) / 32, (int)((ld + 31) / 32));
   EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((transpose_cast_kernel<T>), grid, dim3(256), 0, stream, src, src_ld, R, C, (T*)dst, ld));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int cast_jobs_finalize(CastJob* jobs, int n) {
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    CastJob& j = jobs[i];
+    j.tile0 = total;
+    if (j.kind == 1) { j.tiles_c = 1; total += (j.C + 4095) / 4096; continue; }
+    // the tile grid covers the pad columns of both copies too (they are zero-filled)
+    const int cols = j.dst_s != nullptr && j.ld_s > j.C ? j.ld_s : j.C;
+    const int rows = j.dst_t != nullptr && j.ld_t > j.R ? j.ld_t : j.R;
+    j.tiles_c = (cols + 63) / 64;
+    total += j.tiles_c * ((rows + 63) / 64);
+  }
+  return total;
+}
+
+int cast_jobs_run(const CastJob* jobs_dev, int n, int total_tiles, int dtype, hipStream_t stream) {
+  if (n <= 0 || total_tiles <= 0) return EZ_OK;
+  EZ_DISPATCH_T(dtype, hipLaunchKernelGGL((multi_cast_kernel<T>), dim3(total_tiles), dim3(256), 0, stream, jobs_dev, n));
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

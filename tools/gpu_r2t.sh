@@ -1,0 +1,10 @@
+#!/bin/bash
+TAG=${1:-r2t}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 2>&1 | tail -80 > gpurun_out/pytest_$TAG.log
+grep -n "passed\|failed" gpurun_out/pytest_$TAG.log | tail -2; grep -n "FAILED" gpurun_out/pytest_$TAG.log | head
+P='import sys,json; d=json.loads(sys.stdin.read()); print(d["config"]["workload"], d["value"], d["ms_per_step"], d["roofline"]["achieved"], d["time_share"], d.get("layernorm_gbps"))'
+B="python bench.py --no-also --no-cpu-baseline --steps 10 --warmup 3"
+for wl in bf16_b1024_train bf16_b1024_train_opt bf16_b1024_train_opt bf16_b1024_train_autograd bf16_b1024_fwd_loss; do timeout 300 $B --workload $wl 2>&1 | tail -1 | python -c "$P"; done > gpurun_out/ab_$TAG.log 2>&1
+cat gpurun_out/ab_$TAG.log

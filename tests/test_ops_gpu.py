@@ -262,9 +262,11 @@ def test_recall_ranks_in_row_blocks_equal_the_sort_loop():
         assert torch.equal(recall_ranks(td, vd, block_rows=block), full), block
 
 
-@pytest.mark.parametrize("n,N,off,e", [(4, 12, 4, 64), (8, 8, 0, 128), (32, 128, 64, 512), (100, 300, 200, 64)])
+@pytest.mark.parametrize("n,N,off,e", [(4, 12, 4, 64), (8, 8, 0, 128), (32, 128, 64, 512), (100, 300, 200, 64),
+                                       (1024, 8192, 3072, 512)])
 def test_infonce_fused_shard(n, N, off, e):
-    """Fused loss + gradients of one rank's shard == autograd of the oracle's global loss share."""
+    """Fused loss + gradients of one rank's shard == autograd of the oracle's global loss share.  The last case is the
+    north star's exchange step: rank 3 of 8, 1024 pairs per GPU, 8192 in the global batch."""
     lib = L.load()
     g = torch.Generator().manual_seed(N + off)
     t = torch.nn.functional.normalize(torch.randn(N, e, generator=g), dim=-1)

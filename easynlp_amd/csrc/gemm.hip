@@ -226,15 +226,21 @@ int launch_nt_shape(const GemmArgs& p, hipStream_t stream) {
   return EZ_OK;
 }
 
-int g_gemm_variant = -1;   // -1: heuristic; 0: 128x128; 1: 256x256 (2-phase); 2: 256x256 8-phase (gemm8p.hip)
+int g_gemm_variant = -1;   // -1: heuristic; 0: 128x128; 1: 256x256 (2-phase); 2: 256x256 8-phase (gemm8p.hip); 3: 64x64
 
 template <typename T, typename TO>
 int launch_nt(const GemmArgs& p, hipStream_t stream) {
   int v = g_gemm_variant;
   // 256 x 256 tiles only when they fill the chip: the B-row products of the CLS-only last blocks, the projections and the
   // similarity (M = 1024: 8..16 such tiles on 256 CUs, each walking the whole K) run four times as many 128 x 128 workgroups
-  if (v < 0 || v > 1) v = (p.N % 256 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 256) >= 192) ? 1 : 0;
+  if (v != 0 && v != 1 && v != 3) {
+    v = (p.N % 256 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 256) >= 192) ? 1 : 0;
+    // ... and 64 x 64 tiles (four waves of one 32 x 32 accumulator: two LDS reads per MFMA, but these products are short of
+    // workgroups, not of LDS bandwidth) when even the 128 x 128 tiles leave half the CUs idle: [1024, 768] is 48 of them
+    if (v == 0 && (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) < 128) v = 3;
+  }
   if (v == 1) return launch_nt_shape<T, TO, 2, 4, 4, 2>(p, stream);
+  if (v == 3) return launch_nt_shape<T, TO, 2, 2, 1, 1>(p, stream);
   return launch_nt_shape<T, TO, 2, 2, 2, 2>(p, stream);
 }
 

@@ -439,7 +439,7 @@ def test_attention_bwd_projection_bias_gradients(B_, Lq, H, dtype, masked):
     assert max_err(dqkv.float(), qd.grad) < (3e-5 if dtype == "f32" else 0.04) * max(1.0, float(qd.grad.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 3])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1000, 768, 768), (513, 512, 128), (2049, 256, 3072), (300, 100, 64)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_gemm_nt_tile_variants(M, N, K, dtype, variant):

@@ -1,0 +1,22 @@
+#!/bin/bash
+TAG=${1:-r2u}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 -k "gemm or model or bench_regime or infonce" 2>&1 | tail -80 > gpurun_out/pytest_$TAG.log
+grep -n "passed\|failed" gpurun_out/pytest_$TAG.log | tail -2; grep -n "FAILED" gpurun_out/pytest_$TAG.log | head
+for rep in 1 2; do
+  for v in base nolsrf; do
+    echo "== $v"; L=""; [ $v != base ] && L=tools/bin/var_$v
+    LD_LIBRARY_PATH=$L ONLY_ATTN=1 timeout 300 tools/bin/gemm_bench 1024 20 2 2>&1 | grep "attn" | grep -v bwd
+  done
+done > gpurun_out/gb_attn_$TAG.log 2>&1; cat gpurun_out/gb_attn_$TAG.log
+P='import sys,json; d=json.loads(sys.stdin.read()); print(d["config"]["workload"], d["value"], d["ms_per_step"], d["roofline"]["achieved"], d["time_share"], d.get("layernorm_gbps"))'
+B="python bench.py --no-also --no-cpu-baseline --steps 10 --warmup 3"
+for wl in bf16_b1024_fwd_loss bf16_b1024_fwd_loss; do timeout 300 $B --workload $wl 2>&1 | tail -1 | python -c "$P"; done > gpurun_out/ab_$TAG.log 2>&1
+cat gpurun_out/ab_$TAG.log
+R=$(pwd)
+cd /tmp && EZCLIP_TWO_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also > $R/gpurun_out/prof_$TAG.log 2>&1
+cd $R
+DB=$(find /tmp/prof_$TAG -name "*.db" | head -1)
+[ -n "$DB" ] && python tools/rocpd_stats.py $DB gpurun_out/${TAG}_fwd_kernel_stats.md > /dev/null 2>&1
+sed -n 3,24p gpurun_out/${TAG}_fwd_kernel_stats.md

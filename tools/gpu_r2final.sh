@@ -18,7 +18,8 @@ for wl in fwd train; do
   head -14 gpurun_out/${TAG}_${wl}_kernel_stats.md
 done
 bash tools/pmc_gemm.sh $TAG > /dev/null 2>&1
+bash tools/pmc_attn.sh $TAG > /dev/null 2>&1; head -30 gpurun_out/pmc_attn_$TAG.md | tail -24
 python tools/pmc_summary.py $TAG gpurun_out > /dev/null 2>&1; head -16 gpurun_out/${TAG}_gemm_pmc.md | tail -10
-ONLY_ATTN=1 timeout 300 tools/bin/gemm_bench 1024 20 2 2>&1 | grep attn > gpurun_out/gb_attn_$TAG.log; cat gpurun_out/gb_attn_$TAG.log
+ATTN_PROBE=1 ONLY_ATTN=1 timeout 300 tools/bin/gemm_bench 1024 20 2 2>&1 | grep attn > gpurun_out/gb_attn_$TAG.log; cat gpurun_out/gb_attn_$TAG.log
 timeout 300 tools/bin/gemm_bench 1024 10 2 2>&1 | grep -v "^batch" > gpurun_out/gb_$TAG.log; head -14 gpurun_out/gb_$TAG.log
 timeout 300 python tools/vendor_calibration.py > gpurun_out/vendor_$TAG.log 2>&1; cat gpurun_out/vendor_$TAG.log | tail -8

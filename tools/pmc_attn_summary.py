@@ -4,6 +4,7 @@ usage: pmc_attn_summary.py <tag>"""
 import collections
 import csv
 import glob
+import re
 import sys
 
 tag = sys.argv[1]
@@ -14,7 +15,8 @@ for path in sorted(glob.glob("gpurun_out/pmca_*_%s.csv" % tag)):
         k = r["Kernel_Name"]
         if "attn_" not in k:
             continue
-        k = k.split("::")[-1].split("(")[0]
+        mt = re.search(r"(attn_\w+(?:<[^>]*>)?)", k)
+        k = mt.group(1) if mt else k
         key = (k, r["Grid_Size"], r["Workgroup_Size"])
         per[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         per[key]["dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)

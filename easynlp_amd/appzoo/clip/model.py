@@ -289,7 +289,10 @@ class HipClipEngine:
         keep[:, 0] = True
         lens = keep.sum(1, dtype=torch.int32)
         cs = torch.cumsum(lens, 0, dtype=torch.int32)
-        total, longest = (int(v) for v in torch.stack([cs[-1], lens.max()]).tolist())
+        # are the kept tokens of every sentence a prefix?  (train-mode dropout numbers its masks by padded positions: only then
+        # is a packed position the padded one -- `usable_with_dropout`)
+        prefix = (keep == (torch.arange(S, device=keep.device)[None, :] < lens[:, None])).all().to(torch.int32)
+        total, longest, prefix = (int(v) for v in torch.stack([cs[-1], lens.max(), prefix]).tolist())
         if longest > 256 or total > 0.9 * B * S:
             return None
         cu = cs - lens
@@ -299,12 +302,16 @@ class HipClipEngine:
         rowmap.scatter_(0, dst.flatten().long(), torch.arange(B * S, dtype=torch.int32, device=ids.device))
         dev = device if device is not None else ids.device
         return {"rowmap": rowmap[:total].contiguous().to(dev), "cu": cu.contiguous().to(dev), "lens": lens.contiguous().to(dev),
-                "rows": total, "longest": longest, "shape": (B, S)}
+                "rows": total, "longest": longest, "shape": (B, S), "prefix": bool(prefix)}
 
     def can_pack(self, save: bool) -> bool:
-        """bf16 BERT towers without dropout (train-mode dropout masks are indexed by the padded token rows), forward with or
-        without save_for_backward -- the backward then runs on the same packed rows."""
-        return self.pack_text and self.dtype_code == L.DTYPE_BF16 and self.text_arch == 0 and self._drop == (0.0, 0.0)
+        """bf16 BERT towers, forward with or without save_for_backward -- the backward then runs on the same packed rows.  With
+        train-mode dropout armed only batches whose kept tokens are prefixes are packed (``usable``)."""
+        return self.pack_text and self.dtype_code == L.DTYPE_BF16 and self.text_arch == 0
+
+    def usable(self, pack) -> bool:
+        """May this packing (pack_meta) be used under the dropout state armed for the next call?"""
+        return bool(pack) and (self._drop == (0.0, 0.0) or bool(pack.get("prefix")))
 
     def encode_text(self, ids: torch.Tensor, save: bool, extras=None, owner=None, stream=None, pack=None) -> (torch.Tensor, torch.Tensor):
         """extras: (position_ids, token_type_ids, attention_mask) int64 [B, S] device tensors (huggingface_clip branch).
@@ -320,7 +327,7 @@ class HipClipEngine:
                 pack = self.pack_meta(ids, None if extras is None else extras[2])
             elif pack.get("shape") != (B, S):
                 raise L.EzclipError("packing metadata of another batch")
-            if pack:
+            if self.usable(pack):
                 pos, tt, am = extras if extras is not None else (None, None, None)
                 L.check(self.lib.ezclip_encode_text_packed(self.handle, L.ptr(ids), L.ptr(pos), L.ptr(tt), L.ptr(am),
                                                            L.ptr(pack["rowmap"]), L.ptr(pack["cu"]), L.ptr(pack["lens"]), B, S,

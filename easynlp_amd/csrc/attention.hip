@@ -723,12 +723,13 @@ int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream) {
              ((uintptr_t)a.ctx % 16) == 0, "attention_fwd: pointers must be 16-byte aligned");
   EZ_REQUIRE(a.B <= 65535, "attention_fwd: batch %d > 65535", a.B);
   EZ_REQUIRE((a.cu == nullptr) == (a.lens == nullptr), "attention_fwd: cu and lens go together");
-  if (a.cu != nullptr) {      // packed batches: the short forward kernel only (bf16, longest sample <= 288, no dropout, no lse)
-    EZ_REQUIRE(a.drop.thr == 0 && attention_short_fwd_eligible(a, dtype),
-               "attention_fwd: packed batches need the bf16 short kernel (longest sample <= 288, no dropout)");
+  // (the short forward kernel takes dropout with or without the keep-bit buffer; a fused backward needs the bits -- without
+  // them, e.g. through the op-level entry points, the backward runs the general kernels, which regenerate the same decisions)
+  if (a.cu != nullptr) {      // packed batches: the short forward kernel only (bf16, longest sample <= 288)
+    EZ_REQUIRE(attention_short_fwd_eligible(a, dtype), "attention_fwd: packed batches need the bf16 short kernel (longest sample <= 288)");
     return attention_fwd_short(a, stream);
   }
-  if (g_attn_variant != 0 && a.drop.thr == 0 && attention_short_fwd_eligible(a, dtype)) return attention_fwd_short(a, stream);
+  if (g_attn_variant != 0 && attention_short_fwd_eligible(a, dtype)) return attention_fwd_short(a, stream);
   if (dtype == EZCLIP_F32) return launch_fwd<float>(a, stream);
   if (dtype == EZCLIP_BF16) return launch_fwd<bf16_t>(a, stream);
   set_error("attention_fwd: bad dtype %d", dtype);
@@ -1119,12 +1120,13 @@ int attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream) {
   EZ_REQUIRE((f.row_stride * esz) % 16 == 0 && (f.ctx_stride * esz) % 16 == 0, "attention_bwd: strides must be 16-byte multiples");
   EZ_REQUIRE(f.B <= 65535, "attention_bwd: batch %d > 65535", f.B);
   EZ_REQUIRE((a.dbq == nullptr) == (a.dbk == nullptr) && (a.dbq == nullptr) == (a.dbv == nullptr), "attention_bwd: dbq/dbk/dbv must be given together");
+  const bool short_drop_ok = f.drop.thr == 0 || (f.keep_bits != nullptr && f.L <= 256);     // (see attention_fwd)
   if (f.cu != nullptr) {      // packed batches: the fused short kernel only
-    EZ_REQUIRE(f.lens != nullptr && f.drop.thr == 0 && attention_short_eligible(f, dtype) && (a.dbq == nullptr || a.db_part != nullptr),
-               "attention_bwd: packed batches need the fused bf16 kernel (longest sample <= 256, no dropout)");
+    EZ_REQUIRE(f.lens != nullptr && short_drop_ok && attention_short_eligible(f, dtype) && (a.dbq == nullptr || a.db_part != nullptr),
+               "attention_bwd: packed batches need the fused bf16 kernel (longest sample <= 272; with dropout <= 256 and keep_bits)");
     return attention_bwd_short(a, stream);
   }
-  if (g_attn_variant != 0 && f.drop.thr == 0 && attention_short_eligible(f, dtype) && (a.dbq == nullptr || a.db_part != nullptr))
+  if (g_attn_variant != 0 && short_drop_ok && attention_short_eligible(f, dtype) && (a.dbq == nullptr || a.db_part != nullptr))
     return attention_bwd_short(a, stream);
   int rc;
   if (dtype == EZCLIP_F32) rc = launch_bwd<float>(a, stream);

@@ -65,7 +65,11 @@ __device__ __forceinline__ void swap_halves(float v, float& x0, float& x1) {
 // use four independent partial sums, the running output is only rescaled when some lane's maximum moved
 // (multiplying by exactly 1 otherwise), the cross-half exchanges are v_permlane32_swap, and every wave has queries
 // (64 * nt threads).  HAS_KB: additive key bias (BERT); without it the scores never touch LDS.
-template <bool HAS_KB, bool CAUSAL>
+// DROP: train-mode dropout on the probabilities (dropout.h).  The lane that owns query q holds keys 8 qd + 4 h + {0..3} of a
+// tile in four consecutive registers = the four words of ONE Philox call (colquad = 8 t + 2 qd + h): four calls per tile and
+// lane.  The row sum l runs over the undropped exponentials, the P V product over the kept ones scaled by 1 / (1 - p); the
+// keep bits of the tile (32 keys, both half-waves) are written out for the backward kernel (AttnArgs::keep_bits).
+template <bool HAS_KB, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int head = blockIdx.x, b = blockIdx.y;
@@ -77,6 +81,7 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
   // tile count, LDS sizing, waves) belongs to the longest sample, this workgroup walks its own ceil(L / 32) tiles
   const int L = a.lens ? a.lens[b] : a.L, LKP = 32 * nt;
   const int64_t row0 = a.cu ? (int64_t)a.cu[b] : (int64_t)b * a.L;
+  const int keep_words = nt;      // (of the launch)
   nt = (L + 31) >> 5;
   char* kimg = smem;
   char* vimg = smem + LKP * 128;
@@ -181,6 +186,26 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     }
+    if constexpr (DROP) {
+      const uint32_t drow = (uint32_t)((b * a.H + head) * (a.drop_L > 0 ? a.drop_L : a.L) + q);
+      uint32_t bits = 0;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const uint4 w = drop_words(a.drop, drow, (uint32_t)(8 * t + 2 * qd + h));
+        const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool keep = wv[e] >= a.drop.thr;
+          x[4 * qd + e] = keep ? x[4 * qd + e] * a.drop.scale : 0.f;
+          bits |= (keep ? 1u : 0u) << (8 * qd + 4 * h + e);
+        }
+      }
+      if (a.keep_bits != nullptr) {
+        const auto r2 = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);     // own | the other half-wave's
+        bits = r2[0] | r2[1];
+        if (h == 0 && q < L) a.keep_bits[((row0 + q) * a.H + head) * keep_words + t] = bits;
+      }
+    }
     const char* vt = vimg + t * 4096;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -249,10 +274,15 @@ bool attention_short_fwd_eligible(const AttnArgs& a, int dtype) {   // forward: 
 int attention_fwd_short(const AttnArgs& a, hipStream_t stream) {
   const int nt = (a.L + 31) / 32;
   const int bytes = nt * (2 * 32 * 128 + 32 * 4);
-  static int attr_max[4] = {0, 0, 0, 0};
-  const int kbi = (a.key_bias != nullptr ? 1 : 0) + (a.causal ? 2 : 0);
-  auto* kern = kbi == 0 ? &attn_fwd_short_kernel<false, false> : kbi == 1 ? &attn_fwd_short_kernel<true, false>
-             : kbi == 2 ? &attn_fwd_short_kernel<false, true> : &attn_fwd_short_kernel<true, true>;
+  static int attr_max[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int kbi = (a.key_bias != nullptr ? 1 : 0) + (a.causal ? 2 : 0) + (a.drop.thr != 0 ? 4 : 0);
+  EZ_REQUIRE(a.drop.thr == 0 || a.keep_bits == nullptr || a.keep_words == nt, "attention_fwd_short: keep_words must be ceil(L / 32)");
+  using K = void (*)(AttnArgs, int);
+  static const K kerns[8] = {&attn_fwd_short_kernel<false, false, false>, &attn_fwd_short_kernel<true, false, false>,
+                             &attn_fwd_short_kernel<false, true, false>,  &attn_fwd_short_kernel<true, true, false>,
+                             &attn_fwd_short_kernel<false, false, true>,  &attn_fwd_short_kernel<true, false, true>,
+                             &attn_fwd_short_kernel<false, true, true>,   &attn_fwd_short_kernel<true, true, true>};
+  const K kern = kerns[kbi];
   if (bytes > attr_max[kbi]) {
     EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     attr_max[kbi] = bytes;

@@ -72,8 +72,12 @@ __device__ __forceinline__ uint4 vec_frag(const float* x, int u, int h, int l31)
 // HAS_KB / CAUSAL are template parameters: as run-time flags their index arithmetic and selects were executed for every
 // score of every tile whatever the flags said (80 of ~200 VALU instructions per tile and pass).  The probabilities are
 // recomputed in the base-2 domain, p = 2^(s c + kb log2 e - lse log2 e) with c = scale log2 e: one fma + v_exp_f32 per score.
-template <bool HAS_KB, bool CAUSAL>
-__global__ __launch_bounds__(576) void attn_bwd_short_kernel(AttnBwdArgs a, int nt, int ra) {
+// DROP: dropout on the probabilities (the forward wrote the keep bits, AttnArgs::keep_bits): O = (P o M s) V, so
+//   dV = (P o M s)^T dO,   dP = (dO V^T) o M s,   dS = P o (dP - D) with the same D = <dO, O>,
+// pass A reads one 32-key word per tile for its query, pass B the words of a tile's 32 queries through a wave-private LDS
+// area (bit = its key), and the rows of P o M s no longer sum to one: sum_k dV[k] = dO^T rowsum(P o M s).
+template <bool HAS_KB, bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBwdArgs a, int nt, int ra) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const AttnArgs& f = a.f;
   const int head = blockIdx.x, b = blockIdx.y;
@@ -82,6 +86,7 @@ __global__ __launch_bounds__(576) void attn_bwd_short_kernel(AttnBwdArgs a, int 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
   const int nwaves = nt;      // 64 * nt threads (nt of the launch: the longest sample's tiles): no idle waves holding registers
+  const int keep_words = nt;  // (words per (row, head) of AttnArgs::keep_bits)
   // packed batches (AttnArgs::cu / lens): rows cu[b] .. cu[b] + lens[b] - 1; nt (launch, LDS layout) is the longest sample's
   const int L = f.lens ? f.lens[b] : f.L, LKP = 32 * nt;
   const int64_t row0 = f.cu ? (int64_t)f.cu[b] : (int64_t)b * f.L;
@@ -201,6 +206,10 @@ __global__ __launch_bounds__(576) void attn_bwd_short_kernel(AttnBwdArgs a, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
     float rs4[4] = {0.f, 0.f, 0.f, 0.f};       // r_q = sum over keys of dS[q][key] (this half-wave's keys), four chains
+    float rd4[4] = {0.f, 0.f, 0.f, 0.f};       // DROP: sum over keys of (P o M s)[q][key]
+    const uint32_t sbits = __float_as_uint(f.drop.scale);
+    const uint32_t* kwp = DROP ? f.keep_bits + ((row0 + rowc) * f.H + head) * keep_words : nullptr;
+    uint32_t kw_next = DROP ? kwp[0] : 0u;     // this query's keep word of the next tile (one tile ahead of its use)
     // one key tile; WITH_KB = false (no key bias and not the last tile: every key exists) drops the bias read and its add
     auto tile_a = [&](int t, auto with_kb) {
       constexpr bool WITH_KB = decltype(with_kb)::value;
@@ -213,6 +222,11 @@ __global__ __launch_bounds__(576) void attn_bwd_short_kernel(AttnBwdArgs a, int 
       for (int s = 0; s < 4; ++s) {
         mma32(sacc, *reinterpret_cast<const uint4*>(kt + roff[s]), xf[s], bf16_t());     // S^T[key][q]
         mma32(pacc, *reinterpret_cast<const uint4*>(vt + roff[s]), gf[s], bf16_t());     // dP^T[key][q]
+      }
+      uint32_t kwh = 0;
+      if (DROP) {
+        kwh = kw_next >> (4 * h);                       // bit 8 qd + e: key 8 qd + 4 h + e of this tile
+        if (t + 1 < nt) kw_next = kwp[t + 1];
       }
       float ds[16];
 #pragma unroll
@@ -227,7 +241,14 @@ __global__ __launch_bounds__(576) void attn_bwd_short_kernel(AttnBwdArgs a, int 
           // (kb: 0 / -inf for the keys >= L without a key bias)
           float p = __builtin_amdgcn_exp2f(fmaf(sacc[4 * qd + e], c, WITH_KB ? kbv[e] + nlse_q : nlse_q));
           if (CAUSAL && 32 * t + 8 * qd + 4 * h + e > row) p = 0.f;
-          ds[4 * qd + e] = p * (pacc[4 * qd + e] - d_q);
+          if (DROP) {
+            // s where the key was kept, 0 where it was dropped
+            const float mk = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)kwh, 8 * qd + e, 1) & sbits);
+            ds[4 * qd + e] = p * fmaf(pacc[4 * qd + e], mk, -d_q);
+            rd4[e] = fmaf(p, mk, rd4[e]);
+          } else {
+            ds[4 * qd + e] = p * (pacc[4 * qd + e] - d_q);
+          }
           rs4[e] += ds[4 * qd + e];
         }
       }
@@ -242,7 +263,7 @@ __global__ __launch_bounds__(576) void attn_bwd_short_kernel(AttnBwdArgs a, int 
         mma32(dq[1], tr_frag(kt, u, 1), dc, bf16_t());
       }
     };
-    if (HAS_KB) {
+    if (HAS_KB || DROP) {
 #pragma unroll 1
       for (int t = 0; t < nt; ++t) tile_a(t, std::true_type());
     } else {
@@ -265,7 +286,12 @@ __global__ __launch_bounds__(576) void attn_bwd_short_kernel(AttnBwdArgs a, int 
     if (want_db) {      // dbk share = scale Q^T r and dbv share = dO^T 1 over this wave's queries (rows >= L: r = 0, mask 0)
       float r = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
       r += __shfl_xor(r, 32, 64);
-      if (h == 0) { red_w[384 + l31] = r; red_w[416 + l31] = row < L ? 1.f : 0.f; }
+      float rd = 1.f;
+      if (DROP) {
+        rd = (rd4[0] + rd4[1]) + (rd4[2] + rd4[3]);
+        rd += __shfl_xor(rd, 32, 64);
+      }
+      if (h == 0) { red_w[384 + l31] = r; red_w[416 + l31] = row < L ? rd : 0.f; }
       __builtin_amdgcn_wave_barrier();
       bias_vec(imgQ + blk * 4096, red_w + 384, scale, red_w + 128);
       bias_vec(imgG + blk * 4096, red_w + 416, 1.0f, red_w + 256);
@@ -291,13 +317,30 @@ __global__ __launch_bounds__(576) void attn_bwd_short_kernel(AttnBwdArgs a, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
     float cs4[4] = {0.f, 0.f, 0.f, 0.f};       // c_k = sum over queries of dS[q][k] (this half-wave's queries)
+    // DROP: the keep word (this wave's 32 keys) of query 32 t + l31, fetched one tile ahead, handed to the lanes that need
+    // it -- 16 queries per lane -- through 32 words of the wave's LDS area
+    const uint32_t sbits_b = __float_as_uint(f.drop.scale);
+    uint32_t* kwl = reinterpret_cast<uint32_t*>(red_w + 384);
+    auto keep_word_of = [&](int t) -> uint32_t {
+      const int qq = 32 * t + l31;
+      return f.keep_bits[((row0 + (qq < L ? qq : L - 1)) * f.H + head) * keep_words + blk];
+    };
+    uint32_t kwq_next = DROP ? keep_word_of(0) : 0u;
 #pragma unroll 1
     for (int t = 0; t < nt; ++t) {
       f32x16_t sacc, pacc;
+      if (DROP) {
+        if (h == 0) kwl[l31] = kwq_next;
+        if (t + 1 < nt) kwq_next = keep_word_of(t + 1);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {      // dP - D: the accumulator starts from -D of its query rows
-        const float4 d4 = *reinterpret_cast<const float4*>(dA + 32 * t + 8 * qd + 4 * h);
-        pacc[4 * qd] = d4.x; pacc[4 * qd + 1] = d4.y; pacc[4 * qd + 2] = d4.z; pacc[4 * qd + 3] = d4.w;
+        for (int r = 0; r < 16; ++r) pacc[r] = 0.f;       // (dP o M s) - D: D joins after the mask
+      } else {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {      // dP - D: the accumulator starts from -D of its query rows
+          const float4 d4 = *reinterpret_cast<const float4*>(dA + 32 * t + 8 * qd + 4 * h);
+          pacc[4 * qd] = d4.x; pacc[4 * qd + 1] = d4.y; pacc[4 * qd + 2] = d4.z; pacc[4 * qd + 3] = d4.w;
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
@@ -313,12 +356,26 @@ __global__ __launch_bounds__(576) void attn_bwd_short_kernel(AttnBwdArgs a, int 
       for (int qd = 0; qd < 4; ++qd) {
         const float4 l4 = *reinterpret_cast<const float4*>(lseA + 32 * t + 8 * qd + 4 * h);
         const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+        float nd[4] = {0.f, 0.f, 0.f, 0.f};
+        uint32_t kwv[4] = {0u, 0u, 0u, 0u};
+        if (DROP) {
+          const float4 d4 = *reinterpret_cast<const float4*>(dA + 32 * t + 8 * qd + 4 * h);
+          nd[0] = d4.x; nd[1] = d4.y; nd[2] = d4.z; nd[3] = d4.w;
+          const uint4 w4 = *reinterpret_cast<const uint4*>(kwl + 8 * qd + 4 * h);
+          kwv[0] = w4.x; kwv[1] = w4.y; kwv[2] = w4.z; kwv[3] = w4.w;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float pe = __builtin_amdgcn_exp2f(fmaf(sacc[4 * qd + e], c, HAS_KB ? kb_key + lv[e] : lv[e]));
           if (CAUSAL && row > 32 * t + 8 * qd + 4 * h + e) pe = 0.f;      // this key lies after that query
-          p[4 * qd + e] = pe;
-          ds[4 * qd + e] = pe * pacc[4 * qd + e];
+          if (DROP) {
+            const float mk = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)kwv[e], l31, 1) & sbits_b);
+            p[4 * qd + e] = pe * mk;
+            ds[4 * qd + e] = pe * fmaf(pacc[4 * qd + e], mk, nd[e]);
+          } else {
+            p[4 * qd + e] = pe;
+            ds[4 * qd + e] = pe * pacc[4 * qd + e];
+          }
           cs4[e] += ds[4 * qd + e];
         }
       }
@@ -386,10 +443,16 @@ bool attention_short_eligible(const AttnArgs& a, int dtype) {       // fused bac
 int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
   const int nt = (a.f.L + 31) / 32, ra = (a.f.L + 7) / 8 * 8;
   const int bytes = bwd_short_lds_bytes(a.f.L);
-  static int attr_max[4] = {0, 0, 0, 0};
-  const int vi = (a.f.key_bias != nullptr ? 1 : 0) + (a.f.causal ? 2 : 0);
-  auto* kern = vi == 0 ? &attn_bwd_short_kernel<false, false> : vi == 1 ? &attn_bwd_short_kernel<true, false>
-             : vi == 2 ? &attn_bwd_short_kernel<false, true> : &attn_bwd_short_kernel<true, true>;
+  static int attr_max[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int vi = (a.f.key_bias != nullptr ? 1 : 0) + (a.f.causal ? 2 : 0) + (a.f.drop.thr != 0 ? 4 : 0);
+  EZ_REQUIRE(a.f.drop.thr == 0 || (a.f.keep_bits != nullptr && a.f.keep_words == nt && nt <= 8),
+             "attention_bwd_short: dropout needs the keep bits of the forward (keep_words = ceil(L / 32)) and L <= 256");
+  using K = void (*)(AttnBwdArgs, int, int);
+  static const K kerns[8] = {&attn_bwd_short_kernel<false, false, false>, &attn_bwd_short_kernel<true, false, false>,
+                             &attn_bwd_short_kernel<false, true, false>,  &attn_bwd_short_kernel<true, true, false>,
+                             &attn_bwd_short_kernel<false, false, true>,  &attn_bwd_short_kernel<true, false, true>,
+                             &attn_bwd_short_kernel<false, true, true>,   &attn_bwd_short_kernel<true, true, true>};
+  const K kern = kerns[vi];
   if (bytes > attr_max[vi]) {
     EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     attr_max[vi] = bytes;

@@ -85,6 +85,13 @@ struct AttnArgs {
   const int* lens = nullptr;
   int causal = 0;                 // 1: key j > query i is masked (-inf): CLIP text transformer, build_attention_mask (modeling_openclip.py:343-349)
   DropCfg drop;                   // dropout on the probabilities (BERT train mode); row = (b*H + h)*L + query, col = key
+  // Short-sequence kernels with dropout (train mode, also on packed batches whose samples are kept PREFIXES, so that a packed
+  // position is the padded one): the forward writes the keep bits, 32 keys per word, keep_bits[(row * H + h) * keep_words + tile]
+  // with row = the query's row in q (packed or padded), and the fused backward reads them back instead of running Philox again in
+  // its key-major pass.  drop_L: the padded sequence length the mask rows are numbered with (0: L).
+  uint32_t* keep_bits = nullptr;
+  int keep_words = 0;
+  int drop_L = 0;
 };
 int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream);
 // one query per sample (the CLS row of the last block): q_cls [B, q_stride], ctx_cls [B, ctx_stride]; k / v / key_bias of `a`
@@ -201,7 +208,7 @@ int bert_word_grad(const int64_t* ids, const void* dx0, float* dword, int64_t ro
 int add_inplace_f32(float* dst, const float* src, int64_t n, hipStream_t stream);
 // dst[r][c] += src[r][c] for c < cols (row strides ldd / lds): un-pads a K-padded weight gradient
 int dropout_rows(const void* x, int64_t xs, const void* res, int64_t rs, void* y, int64_t ys, int rows, int D,
-                 const DropCfg& d, int dtype, hipStream_t stream);
+                 const DropCfg& d, int dtype, hipStream_t stream, const int* rowmap = nullptr);
 int dropout_mask(uint8_t* keep, uint32_t* words, int rows, int cols, const DropCfg& d, hipStream_t stream);
 int layernorm_stats_finalize(const float* part, int slabs, int D, float eps, int rows, float* stats, hipStream_t stream);
 int add_cols_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int rows, int cols, hipStream_t stream);

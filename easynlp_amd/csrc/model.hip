@@ -522,6 +522,7 @@ size_t layout_image(const ezclip_model* m, int B, bool save_arg, void* base, Img
 struct BertBufs {
   void *x_in, *qkv, *ctx, *y, *a, *u, *hh, *z, *x_out;
   float *m1, *r1, *m2, *r2, *lse;
+  uint32_t* keep;      // keep bits of the attention-probability dropout (AttnArgs::keep_bits), [rows][heads][ceil(L / 32)]
 };
 struct TxtWS {
   void* x0;
@@ -529,6 +530,7 @@ struct TxtWS {
   std::vector<BertBufs> layers;
   float *feat, *emb, *inv_norm;
   void *pool, *pool_u, *gpool;     // pooled output tanh(u), its pre-activation u, d u   [B, H] (opt_text_pooler)
+  void *cls_rows, *gcls;           // packed batches whose last layer ran on all rows: its CLS rows [B, H] and their gradient
   void *gx, *gx2, *gx3, *gtmp, *gqkv, *gbig, *gfeatT;
   float *gfeat, *gbpart;
 };
@@ -555,12 +557,14 @@ size_t layout_text(const ezclip_model* m, int B, int L, bool save, void* base, T
     b.hh = a.take(M * F * esz);
     b.z = b.x_in;
     b.m1 = b.r1 = b.m2 = b.r2 = b.lse = nullptr;
+    b.keep = nullptr;
     for (int i = 0; i < nl; ++i) w.layers[i] = b;
   } else {
     void* x = a.take(M * H * esz);
     for (int i = 0; i < nl; ++i) {
       BertBufs& b = w.layers[i];
       b.x_in = x;
+      b.keep = static_cast<uint32_t*>(a.take(M * (size_t)m->theads * ((L + 31) / 32) * 4));
       b.qkv = a.take(M * 3 * H * esz);
       b.ctx = a.take(M * H * esz);
       b.y = a.take(M * H * esz);
@@ -580,6 +584,8 @@ size_t layout_text(const ezclip_model* m, int B, int L, bool save, void* base, T
   w.pool = a.take((size_t)B * H * esz);
   w.pool_u = a.take((size_t)B * H * esz);
   w.gpool = a.take((size_t)B * H * esz);
+  w.cls_rows = a.take((size_t)B * H * esz);
+  w.gcls = a.take((size_t)B * H * esz);
   if (save) {
     w.gx = a.take(M * H * esz);
     w.gx2 = a.take(M * H * esz);
@@ -977,10 +983,11 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
   // attention kernels.  (The caller keeps whole sentences that have no unmasked key at all, and every CLS row.)
   const bool packed = ex->rowmap != nullptr;
   if (packed) {
-    EZ_REQUIRE(dt == EZCLIP_BF16 && hp == 0.f && ap == 0.f, "encode_text: packed batches are bf16 without dropout");
+    // (with train-mode dropout the caller packs only batches whose kept tokens are a PREFIX of every sentence: a packed
+    // position is then the padded one, and the masks -- numbered by padded rows and positions -- are those of the padded run)
+    EZ_REQUIRE(dt == EZCLIP_BF16, "encode_text: packed batches are bf16");
     EZ_REQUIRE(ex->cu && ex->lens && ex->packed_rows >= B && ex->packed_rows <= B * L && ex->max_len >= 1 && ex->max_len <= L &&
                ex->max_len <= (save ? 256 : 288), "encode_text: bad packing (rows %d of %d x %d, longest %d)", ex->packed_rows, B, L, ex->max_len);
-    EZ_REQUIRE(!save || (g_cls_last_train && L >= 8), "encode_text: packed training needs the CLS-only last layer");
   }
   const int M = packed ? ex->packed_rows : B * L;
 
@@ -990,7 +997,8 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
                        ex->pos_ids, ex->type_ids, ex->attn_mask, m->cfg.text_max_position_embeddings,
                        m->cfg.text_type_vocab_size, ex->rowmap, ex->packed_rows));
   if (hp > 0.f)                                                                                    // :128
-    EZ_TRY(dropout_rows(ws.layers[0].x_in, H, nullptr, 0, ws.layers[0].x_in, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream));
+    EZ_TRY(dropout_rows(ws.layers[0].x_in, H, nullptr, 0, ws.layers[0].x_in, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream,
+                        ex->rowmap));
   // inference: the last layer only feeds x[:, 0] to the pooler / projection -- see bert_last_layer_cls
   const int nlayers = m->cfg.text_num_hidden_layers;
   const bool cls_infer = !save && g_cls_last && hp == 0.f && ap == 0.f && L >= 8;
@@ -1010,11 +1018,15 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
     at.B = B; at.L = packed ? ex->max_len : L; at.H = m->theads; at.scale = 0.125f;
     if (packed) { at.cu = ex->cu; at.lens = ex->lens; }
     at.drop = make_drop(ap, seed, drop_sid_attn(i));                // :238
+    at.drop_L = L;                                                  // mask rows are numbered with the padded length
+    if (ap > 0.f && b.keep != nullptr && at.L <= 256) {             // short kernels with dropout: keep bits for the backward
+      at.keep_bits = b.keep; at.keep_words = (at.L + 31) / 32;
+    }
     EZ_TRY(attention_fwd(at, dt, stream));                          // :210-248
     // BertSelfOutput: LN(dropout(dense(ctx)) + x)                     :264-267
     if (hp > 0.f) {
       EZ_TRY(linear(m, b.ctx, H, Lw.o_w, Lw.o_b, b.y, H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
-      EZ_TRY(dropout_rows(b.y, H, b.x_in, H, b.y, H, M, H, make_drop(hp, seed, drop_sid_self_out(i)), dt, stream));
+      EZ_TRY(dropout_rows(b.y, H, b.x_in, H, b.y, H, M, H, make_drop(hp, seed, drop_sid_self_out(i)), dt, stream, ex->rowmap));
     } else {
       EZ_TRY(linear(m, b.ctx, H, Lw.o_w, Lw.o_b, b.y, H, M, ACT_NONE, b.x_in, H, nullptr, false, stream));
     }
@@ -1023,7 +1035,7 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
     EZ_TRY(linear(m, b.a, H, Lw.i_w, Lw.i_b, b.hh, F, M, ACT_GELU_ERF, nullptr, 0, b.u, false, stream));
     if (hp > 0.f) {
       EZ_TRY(linear(m, b.hh, F, Lw.d_w, Lw.d_b, b.z, H, M, ACT_NONE, nullptr, 0, nullptr, false, stream));
-      EZ_TRY(dropout_rows(b.z, H, b.a, H, b.z, H, M, H, make_drop(hp, seed, drop_sid_out(i)), dt, stream));
+      EZ_TRY(dropout_rows(b.z, H, b.a, H, b.z, H, M, H, make_drop(hp, seed, drop_sid_out(i)), dt, stream, ex->rowmap));
     } else {
       EZ_TRY(linear(m, b.hh, F, Lw.d_w, Lw.d_b, b.z, H, M, ACT_NONE, b.a, H, nullptr, false, stream));
     }
@@ -1041,9 +1053,9 @@ int encode_text(ezclip_model* m, const int64_t* ids, int B, int L, float* out, v
   } else if (cls_train) {
     EZ_TRY(bert_last_layer_cls_save(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws.key_bias, B, L, eps, stream, ex));
     xl_ld = H;                                                         // x_out of the last layer: [B, H] (CLS rows)
-  } else if (packed) {                                                 // CLS rows of the packed last hidden state (inference
-    EZ_TRY(gather_rows(xl, ex->cu, ws.gpool, B, 0, H, 0, dt, stream)); // with the CLS-only last layer switched off)
-    xl = ws.gpool;
+  } else if (packed) {      // CLS rows of the packed last hidden state (the CLS-only last layer is off: dropout, or the switch)
+    EZ_TRY(gather_rows(xl, ex->cu, ws.cls_rows, B, 0, H, 0, dt, stream));
+    xl = ws.cls_rows;
     xl_ld = H;
   }
   const void* fa = xl;
@@ -1348,8 +1360,8 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
   if (ex == nullptr) ex = &none0;
   const bool packed = ex->rowmap != nullptr;       // the matching forward ran on these packed rows (encode_text)
   if (packed)
-    EZ_REQUIRE(dt == EZCLIP_BF16 && hp == 0.f && ap == 0.f && ex->cu && ex->lens && ex->packed_rows >= B && ex->packed_rows <= B * L &&
-               ex->max_len >= 1 && ex->max_len <= 256 && g_cls_last_train && L >= 8, "backward_text: bad packing");
+    EZ_REQUIRE(dt == EZCLIP_BF16 && ex->cu && ex->lens && ex->packed_rows >= B && ex->packed_rows <= B * L &&
+               ex->max_len >= 1 && ex->max_len <= 256, "backward_text: bad packing");
   const int M = packed ? ex->packed_rows : B * L;
 
   EZ_TRY(l2_normalize_bwd(ws.emb, d_emb, ws.inv_norm, ws.gfeat, B, E, stream));                     // chineseclip:363
@@ -1360,19 +1372,25 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
   const int nlayers = m->cfg.text_num_hidden_layers;
   // (the forward's choice, encode_text: last layer on the CLS rows -> its x_out and the gradient entering it are [B, H])
   const bool cls_train = g_cls_last_train && hp == 0.f && ap == 0.f && L >= 8;
-  const int64_t xl_ld = cls_train ? H : (int64_t)L * H;
+  // packed rows without the CLS-only last layer: the head works on the gathered CLS rows [B, H] and their gradient is
+  // scattered to the rows cu[b] of an otherwise zero d x_out
+  const bool cls_gather = packed && !cls_train;
+  if (cls_gather) xl = ws.cls_rows;
+  const int64_t xl_ld = (cls_train || cls_gather) ? H : (int64_t)L * H;
+  void* gxl = cls_gather ? ws.gcls : ws.gx;      // where the head leaves d x[:, 0]
   if (!cls_train) EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * H * esz, stream));
   if (m->Gp(m->tproj_b)) EZ_TRY(colsum_add(ws.gfeat, E, B, E, m->Gp(m->tproj_b), EZCLIP_F32, stream));
   if (m->opt_text_pooler) {
     // feat = proj(tanh(u)), u = pooler.dense(x[:, 0]):  d u = (d feat . W_proj) o tanh'(u)  (+ pooler bias gradient)
     EZ_TRY(dgrad(m, gfeatT, E, m->tproj_w, ws.gpool, H, B, ws.pool_u, H, ACT_TANH, nullptr, 0, stream, m->pool_b));
     EZ_TRY(wgrad(m, gfeatT, E, ws.pool, H, m->tproj_w, B, stream));
-    EZ_TRY(dgrad(m, ws.gpool, H, m->pool_w, ws.gx, xl_ld, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
+    EZ_TRY(dgrad(m, ws.gpool, H, m->pool_w, gxl, xl_ld, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
     EZ_TRY(wgrad(m, ws.gpool, H, xl, xl_ld, m->pool_w, B, stream));
   } else {
-    EZ_TRY(dgrad(m, gfeatT, E, m->tproj_w, ws.gx, xl_ld, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
+    EZ_TRY(dgrad(m, gfeatT, E, m->tproj_w, gxl, xl_ld, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
     EZ_TRY(wgrad(m, gfeatT, E, xl, xl_ld, m->tproj_w, B, stream));
   }
+  if (cls_gather) EZ_TRY(gather_rows(ws.gcls, ex->cu, ws.gx, B, 0, H, 1, dt, stream));      // d x_out[cu[b]] = d cls[b]
   m->progress(1, EZCLIP_STAGE_HEAD);           // text_projection (+ bias), pooler
   if (cls_train) {
     EZ_TRY(bert_last_layer_cls_backward(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws, B, L, stream, ex));
@@ -1385,7 +1403,7 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     const void* gd = ws.gx2;      // gradient of the dense output (= d z, or its dropout-masked copy)
     if (hp > 0.f) {
       EZ_TRY(ln_bwd(m, b.z, H, ws.gx, H, Lw.ln2_w, Lw.ln2_b, b.m2, b.r2, ws.gx2, H, nullptr, 0, M, H, stream));          // d z
-      EZ_TRY(dropout_rows(ws.gx2, H, nullptr, 0, ws.gx3, H, M, H, make_drop(hp, seed, drop_sid_out(i)), dt, stream));
+      EZ_TRY(dropout_rows(ws.gx2, H, nullptr, 0, ws.gx3, H, M, H, make_drop(hp, seed, drop_sid_out(i)), dt, stream, ex->rowmap));
       EZ_TRY(bgrad(m, ws.gx3, H, M, H, Lw.d_b, stream));
       gd = ws.gx3;
     } else {
@@ -1399,7 +1417,7 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     gd = ws.gx2;
     if (hp > 0.f) {
       EZ_TRY(ln_bwd(m, b.y, H, ws.gtmp, H, Lw.ln1_w, Lw.ln1_b, b.m1, b.r1, ws.gx2, H, nullptr, 0, M, H, stream));       // d y
-      EZ_TRY(dropout_rows(ws.gx2, H, nullptr, 0, ws.gx3, H, M, H, make_drop(hp, seed, drop_sid_self_out(i)), dt, stream));
+      EZ_TRY(dropout_rows(ws.gx2, H, nullptr, 0, ws.gx3, H, M, H, make_drop(hp, seed, drop_sid_self_out(i)), dt, stream, ex->rowmap));
       EZ_TRY(bgrad(m, ws.gx3, H, M, H, Lw.o_b, stream));
       gd = ws.gx3;
     } else {
@@ -1416,6 +1434,10 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     ab.f.B = B; ab.f.L = packed ? ex->max_len : L; ab.f.H = m->theads; ab.f.scale = 0.125f;
     if (packed) { ab.f.cu = ex->cu; ab.f.lens = ex->lens; }
     ab.f.drop = make_drop(ap, seed, drop_sid_attn(i));
+    ab.f.drop_L = L;
+    if (ap > 0.f && b.keep != nullptr && ab.f.L <= 256) {         // (what the forward chose: encode_text)
+      ab.f.keep_bits = b.keep; ab.f.keep_words = (ab.f.L + 31) / 32;
+    }
     ab.dctx = ws.gtmp;
     ab.dq = gq; ab.dk = gq + H * esz; ab.dv = gq + 2 * H * esz;
     const bool qkv_bias_grads = m->Gp(Lw.q_b) && m->Gp(Lw.k_b) && m->Gp(Lw.v_b);
@@ -1436,7 +1458,7 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     m->progress(1, i);
   }
   // embeddings: dropout(LN(word[ids] + type[0] + pos[t]))                       modeling_bert.py:117-128
-  if (hp > 0.f) EZ_TRY(dropout_rows(ws.gx, H, nullptr, 0, ws.gx, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream));
+  if (hp > 0.f) EZ_TRY(dropout_rows(ws.gx, H, nullptr, 0, ws.gx, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream, ex->rowmap));
   // token-type gradient: with the default all-zero types it is the column sum of gx2 into row 0 (fused into ln_bwd)
   EZ_TRY(ln_bwd(m, ws.x0, H, ws.gx, H, m->eln_w, m->eln_b, ws.m0, ws.r0, ws.gx2, H, nullptr, 0, M, H, stream,
                 ex->type_ids ? -1 : m->type_p));

@@ -1064,14 +1064,15 @@ int add_cols_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int row
 // One thread = 4 consecutive columns of one row = one Philox call (dropout.h).  In-place use (y == x) is fine.
 template <typename T>
 __global__ void dropout_rows_kernel(const T* x, int64_t xs, const T* res, int64_t rs, T* y, int64_t ys, int rows, int D,
-                                    DropCfg d) {
+                                    DropCfg d, const int* rowmap) {
   const int dq = D >> 2;
   const int64_t n = (int64_t)rows * dq;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / dq), cq = (int)(i - (int64_t)r * dq);
     float v[4];
     ld4(x + (int64_t)r * xs + 4 * cq, v);
-    const uint4 w = drop_words(d, (uint32_t)r, (uint32_t)cq);
+    // packed batches: the mask row is the token's row in the PADDED batch (the same decisions as the padded run)
+    const uint4 w = drop_words(d, (uint32_t)(rowmap ? rowmap[r] : r), (uint32_t)cq);
     v[0] = w.x >= d.thr ? v[0] * d.scale : 0.f;
     v[1] = w.y >= d.thr ? v[1] * d.scale : 0.f;
     v[2] = w.z >= d.thr ? v[2] * d.scale : 0.f;
@@ -1092,16 +1093,16 @@ __global__ void dropout_rows_kernel(const T* x, int64_t xs, const T* res, int64_
 }
 
 int dropout_rows(const void* x, int64_t xs, const void* res, int64_t rs, void* y, int64_t ys, int rows, int D,
-                 const DropCfg& d, int dtype, hipStream_t stream) {
+                 const DropCfg& d, int dtype, hipStream_t stream, const int* rowmap) {
   EZ_REQUIRE(D % 4 == 0 && xs % 4 == 0 && ys % 4 == 0 && (res == nullptr || rs % 4 == 0), "dropout_rows: D and strides must be multiples of 4");
   EZ_REQUIRE(d.thr != 0, "dropout_rows: called with dropout off");
   const int64_t n = (int64_t)rows * (D >> 2);
   if (dtype == EZCLIP_F32)
     hipLaunchKernelGGL((dropout_rows_kernel<float>), dim3(grid_for(n, 256)), dim3(256), 0, stream, (const float*)x, xs,
-                       (const float*)res, rs, (float*)y, ys, rows, D, d);
+                       (const float*)res, rs, (float*)y, ys, rows, D, d, rowmap);
   else
     hipLaunchKernelGGL((dropout_rows_kernel<bf16_t>), dim3(grid_for(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, xs,
-                       (const bf16_t*)res, rs, (bf16_t*)y, ys, rows, D, d);
+                       (const bf16_t*)res, rs, (bf16_t*)y, ys, rows, D, d, rowmap);
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

@@ -267,6 +267,67 @@ def test_packed_text_tower_training_step_equals_the_padded_one(tmp_path, path):
         assert float((got - r).norm()) < 8e-2 * float(r.norm()), n
 
 
+@pytest.mark.parametrize("path", ["fused", "autograd"])
+def test_packed_text_tower_with_dropout_equals_the_padded_one(tmp_path, path):
+    """Train mode with the reference's dropout (hidden and attention probabilities): the masks are numbered by padded rows and
+    positions, a packed batch whose sentences keep a prefix of their tokens regenerates exactly the padded run's decisions -- same
+    loss, same gradients up to summation order.  A batch with a hole in a sentence is not packed under dropout."""
+    cfg = dict(O.CONFIGS["small"], text_hidden_dropout_prob=0.1, text_attention_probs_dropout_prob=0.1)
+    app, sd = make_app(tmp_path, cfg, 6, "bf16")
+    app.train()
+    eng = app._engine
+    B, Lq = 12, 40
+    px, ids = O.make_inputs(cfg, B, Lq, 3)
+    g = torch.Generator().manual_seed(8)
+    lens = torch.randint(1, Lq + 1, (B,), generator=g)
+    lens[0], lens[1] = Lq - 3, 1        # (the longest sentence is SHORTER than the padded length: mask rows count padded positions)
+    assert int(lens.max()) < Lq
+    ids = ids.clamp(min=1) * (torch.arange(Lq)[None, :] < lens[:, None])
+    ids[2, :] = 0                       # no unmasked key at all: kept whole (still a prefix)
+    res, emb = {}, {}
+    for pack in (False, True):
+        eng.pack_text = pack
+        torch.manual_seed(1234)
+        with torch.no_grad():           # forward only, train mode: the same decisions -> the same embeddings
+            emb[pack] = app({"pixel_values": None, "input_ids": ids.clone()}, feat=True)["text_embeds"].float().cpu()
+        assert (eng.last_text_rows[0] < eng.last_text_rows[1]) == pack
+    assert float((emb[True] - emb[False]).abs().max()) < 1e-3, float((emb[True] - emb[False]).abs().max())
+    for pack in (False, True):
+        eng.pack_text = pack
+        for p in app.parameters():
+            p.grad = None
+        torch.manual_seed(1234)          # the dropout seed of the step is drawn from torch's CPU generator
+        if path == "fused":
+            loss = app.contrastive_step(px.cuda(), ids.cuda(), process_group=False, backward=True, zero_grad=True)
+        else:
+            loss = app.compute_loss(app({"pixel_values": px, "input_ids": ids.clone()}), [])["loss"]
+            loss.backward()
+        torch.cuda.synchronize()
+        rows = eng.last_text_rows
+        assert (rows[0] < rows[1]) == pack, rows
+        res[pack] = (float(loss.item()), {n: p.grad.detach().float().cpu().clone() for n, p in app._params.items() if p.grad is not None})
+    assert abs(res[True][0] - res[False][0]) < 1e-3, (res[True][0], res[False][0])
+    assert set(res[True][1]) == set(res[False][1])
+    floor = 1e-3 * max(float(v.norm()) for v in res[False][1].values())
+    worst = max((float((res[True][1][n] - v).norm()) / (float(v.norm()) + floor), n) for n, v in res[False][1].items()
+                if not n.endswith(".key.bias"))
+    assert worst[0] < 2e-2, worst
+    # the dropout really was on: another seed gives another loss
+    torch.manual_seed(99)
+    other = float(app.contrastive_step(px.cuda(), ids.cuda(), process_group=False, backward=False).item())
+    assert abs(other - res[True][0]) > 1e-4
+    # a hole inside a sentence: no packing while dropout is armed (a packed position would not be the padded one)
+    ids2 = ids.clone()
+    ids2[4, 2] = 0
+    app.contrastive_step(px.cuda(), ids2.cuda(), process_group=False, backward=True, zero_grad=True)
+    assert eng.last_text_rows[0] == eng.last_text_rows[1]
+    app.eval()
+    with torch.no_grad():
+        app.contrastive_step(px.cuda(), ids2.cuda(), process_group=False, backward=False)
+    assert eng.last_text_rows[0] < eng.last_text_rows[1]      # (eval mode: packed as before)
+    eng.pack_text = True
+
+
 class _DS(torch.utils.data.Dataset):
     def __init__(self, px, ids):
         self.px, self.ids = px, ids

@@ -140,7 +140,7 @@ int ezclip_backward_text_ex(ezclip_handle h, const int64_t* input_ids_dev, const
                             const int64_t* token_type_ids_dev, const int64_t* attention_mask_dev, int batch, int seq_len,
                             const float* d_embeds_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* PACKED text batches (bf16, no dropout; forward with or without save_for_backward, and the matching backward).  Padded positions never reach the text feature: their keys carry the
+/* PACKED text batches (bf16; forward with or without save_for_backward, and the matching backward).  Padded positions never reach the text feature: their keys carry the
  * (1 - mask) * -10000 bias (modeling_utils.py:427,438-439), exp(-10000 + s - max) is exactly 0 in float32 next to any unmasked
  * key, and only x[:, 0] is read afterwards (modeling_chineseclip.py:349-350) -- so the tower needs to see the kept tokens only.
  * The caller decides which tokens are kept and passes (device int32):
@@ -153,7 +153,10 @@ int ezclip_backward_text_ex(ezclip_handle h, const int64_t* input_ids_dev, const
  * at rowmap[r].  Every GEMM / LayerNorm of the tower then runs over packed_rows instead of batch * seq_len rows.
  * Workspace: ezclip_text_workspace_bytes(h, batch, seq_len, save_for_backward).  Same embeddings as ezclip_encode_text(_ex),
  * and the same gradients: a dropped token has no path to the loss in the reference either (its key is masked in every layer,
- * its own outputs feed nothing), so its embedding rows get exactly zero there too.  Training: longest sample <= 256. */
+ * its own outputs feed nothing), so its embedding rows get exactly zero there too.  Training: longest sample <= 256.
+ * With train-mode dropout armed (ezclip_set_text_dropout) the caller must only pack batches in which the kept tokens of every
+ * sentence are a PREFIX (t = 0 .. lens[b] - 1): the dropout decisions are numbered by padded rows and positions, and only then is
+ * a packed position the padded one -- the packed run then regenerates exactly the padded run's masks (bit-identical embeddings). */
 int ezclip_encode_text_packed(ezclip_handle h, const int64_t* input_ids_dev, const int64_t* position_ids_dev,
                               const int64_t* token_type_ids_dev, const int64_t* attention_mask_dev, const int32_t* rowmap_dev,
                               const int32_t* cu_dev, const int32_t* lens_dev, int batch, int seq_len, int packed_rows,

@@ -1,0 +1,142 @@
+"""CPU restatement of the reference's ModifiedResNet image tower (TEST INFRASTRUCTURE ONLY: nothing on the product path may
+import this module).
+
+Follows easynlp/modelzoo/models/clip/modeling_chineseclip.py: ``Bottleneck`` :27-74, ``AttentionPool2d`` :77-108,
+``ModifiedResNet`` :110-167 (the tower CHINESE_CLIP builds when ``vision_layers`` is a tuple, :279-287), in EVAL mode --
+BatchNorm with its running statistics, which is what evaluation and prediction run.  Written as plain functions over a
+state dict (names as in the reference checkpoint, prefix ``visual.``) so that every step can be compared with a kernel:
+
+    stem:   3 x [conv3x3 (the first with stride 2) -> BN -> ReLU], AvgPool2d(2)
+    layerN: Bottleneck blocks: conv1x1-BN-ReLU, conv3x3-BN-ReLU, AvgPool2d(stride) (anti-aliased stride: only the first block of
+            layers 2..4), conv1x1-BN, + identity (avgpool + conv1x1 + BN when the shape changes), ReLU
+    attnpool: tokens = [mean over positions; the H*W positions] + positional embedding; one multi-head attention whose only
+            QUERY is the mean token; output projection -> [B, output_dim]
+
+Pinned against the real reference by tests/test_resnet_oracle.py: live (when /root/reference is importable) and through
+tests/golden/rn_tiny_b3.npz (generated from the reference by tools/make_golden_resnet.py).  No HIP tower consumes it yet
+(DESIGN.md section 7): this is the oracle-first step of that row."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5          # nn.BatchNorm2d default
+
+
+def param_shapes(layers: Sequence[int], width: int, output_dim: int, resolution: int) -> Dict[str, tuple]:
+    """Names and shapes of ``ModifiedResNet(layers, output_dim, heads, resolution, width).state_dict()`` (running statistics
+    included, ``num_batches_tracked`` left out), prefixed with ``visual.``."""
+    s: Dict[str, tuple] = {}
+
+    def bn(name, c):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            s["%s.%s" % (name, leaf)] = (c,)
+
+    s["visual.conv1.weight"] = (width // 2, 3, 3, 3); bn("visual.bn1", width // 2)
+    s["visual.conv2.weight"] = (width // 2, width // 2, 3, 3); bn("visual.bn2", width // 2)
+    s["visual.conv3.weight"] = (width, width // 2, 3, 3); bn("visual.bn3", width)
+    inplanes = width
+    for li, (planes, nblocks) in enumerate(zip((width, width * 2, width * 4, width * 8), layers), start=1):
+        for bi in range(nblocks):
+            stride = 2 if (li > 1 and bi == 0) else 1
+            p = "visual.layer%d.%d" % (li, bi)
+            s[p + ".conv1.weight"] = (planes, inplanes, 1, 1); bn(p + ".bn1", planes)
+            s[p + ".conv2.weight"] = (planes, planes, 3, 3); bn(p + ".bn2", planes)
+            s[p + ".conv3.weight"] = (planes * 4, planes, 1, 1); bn(p + ".bn3", planes * 4)
+            if stride > 1 or inplanes != planes * 4:
+                s[p + ".downsample.0.weight"] = (planes * 4, inplanes, 1, 1); bn(p + ".downsample.1", planes * 4)
+            inplanes = planes * 4
+    e = width * 32
+    sp = resolution // 32
+    s["visual.attnpool.positional_embedding"] = (sp * sp + 1, e)
+    for n in ("k_proj", "q_proj", "v_proj"):
+        s["visual.attnpool.%s.weight" % n] = (e, e)
+        s["visual.attnpool.%s.bias" % n] = (e,)
+    s["visual.attnpool.c_proj.weight"] = (output_dim, e)
+    s["visual.attnpool.c_proj.bias"] = (output_dim,)
+    return s
+
+
+def make_state_dict(layers, width, output_dim, resolution, seed=7) -> Dict[str, torch.Tensor]:
+    """Deterministic synthetic weights: every BatchNorm gets non-trivial gain, shift AND running statistics (a kernel that
+    folds them wrongly cannot pass), convolutions ~ fan_in ** -0.5."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for name, shape in param_shapes(layers, width, output_dim, resolution).items():
+        if name.endswith("running_var"):
+            v = 0.5 + rs.rand(*shape)
+        elif name.endswith("running_mean"):
+            v = 0.2 * rs.standard_normal(shape)
+        elif ".bn" in name or "downsample.1" in name:
+            v = (1.0 + 0.1 * rs.standard_normal(shape)) if name.endswith("weight") else 0.05 * rs.standard_normal(shape)
+        elif name.endswith("positional_embedding"):
+            v = (shape[1] ** -0.5) * rs.standard_normal(shape)
+        elif name.endswith(".bias"):
+            v = 0.02 * rs.standard_normal(shape)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            v = (fan_in ** -0.5) * rs.standard_normal(shape)
+        sd[name] = torch.from_numpy(np.asarray(v, dtype=np.float32).copy())
+    return sd
+
+
+def _bn(sd, name, x):
+    """BatchNorm2d.eval(): (x - running_mean) / sqrt(running_var + eps) * weight + bias, per channel."""
+    scale = sd[name + ".weight"] / torch.sqrt(sd[name + ".running_var"] + BN_EPS)
+    shift = sd[name + ".bias"] - sd[name + ".running_mean"] * scale
+    return x * scale[None, :, None, None] + shift[None, :, None, None]
+
+
+def bottleneck(sd, p, x, stride):
+    """Bottleneck.forward (:59-74)"""
+    out = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"])))
+    out = F.relu(_bn(sd, p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], padding=1)))
+    if stride > 1:
+        out = F.avg_pool2d(out, stride)
+    out = _bn(sd, p + ".bn3", F.conv2d(out, sd[p + ".conv3.weight"]))
+    identity = x
+    if (p + ".downsample.0.weight") in sd:
+        identity = F.avg_pool2d(x, stride) if stride > 1 else x
+        identity = _bn(sd, p + ".downsample.1", F.conv2d(identity, sd[p + ".downsample.0.weight"]))
+    return F.relu(out + identity)
+
+
+def attention_pool(sd, x, heads):
+    """AttentionPool2d.forward (:87-108): only the mean token queries; scaling head_dim ** -0.5 as in
+    F.multi_head_attention_forward."""
+    p = "visual.attnpool."
+    B, C, Hh, Ww = x.shape
+    t = x.reshape(B, C, Hh * Ww).permute(0, 2, 1)                       # [B, HW, C]
+    t = torch.cat([t.mean(dim=1, keepdim=True), t], dim=1)               # [B, HW + 1, C]
+    t = t + sd[p + "positional_embedding"][None]
+    q = t[:, :1] @ sd[p + "q_proj.weight"].t() + sd[p + "q_proj.bias"]   # [B, 1, C]
+    k = t @ sd[p + "k_proj.weight"].t() + sd[p + "k_proj.bias"]
+    v = t @ sd[p + "v_proj.weight"].t() + sd[p + "v_proj.bias"]
+    hd = C // heads
+    q = q.reshape(B, 1, heads, hd).transpose(1, 2) * (hd ** -0.5)
+    k = k.reshape(B, -1, heads, hd).transpose(1, 2)
+    v = v.reshape(B, -1, heads, hd).transpose(1, 2)
+    a = torch.softmax(q @ k.transpose(-1, -2), dim=-1)                   # [B, heads, 1, HW + 1]
+    o = (a @ v).transpose(1, 2).reshape(B, C)
+    return o @ sd[p + "c_proj.weight"].t() + sd[p + "c_proj.bias"]
+
+
+def modified_resnet_forward(sd, layers, width, x, taps=None):
+    """ModifiedResNet.forward (:153-167), eval mode.  x: [B, 3, R, R] float.  ``taps``: optional dict filled with the stem output
+    and every layer's output (NCHW)."""
+    heads = width * 32 // 64                                              # CHINESE_CLIP.__init__ :280
+    for i, stride in ((1, 2), (2, 1), (3, 1)):
+        x = F.relu(_bn(sd, "visual.bn%d" % i, F.conv2d(x, sd["visual.conv%d.weight" % i], stride=stride, padding=1)))
+    x = F.avg_pool2d(x, 2)
+    if taps is not None:
+        taps["stem"] = x
+    for li, nblocks in enumerate(layers, start=1):
+        for bi in range(nblocks):
+            x = bottleneck(sd, "visual.layer%d.%d" % (li, bi), x, 2 if (li > 1 and bi == 0) else 1)
+        if taps is not None:
+            taps["layer%d" % li] = x
+    return attention_pool(sd, x, heads)

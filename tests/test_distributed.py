@@ -202,9 +202,9 @@ def test_dropin_app_global_scope_under_real_ddp_world2_gloo(tmp_path):
     assert all(r[1] == "ok" for r in res), res
 
 
-@pytest.mark.parametrize("n,e", [(3, 8), (16, 32)])
-def test_global_contrastive_exchange_world2_gloo(n, e):
-    world = 2
+@pytest.mark.parametrize("world,n,e", [(2, 3, 8), (2, 16, 32), (4, 5, 16)])
+def test_global_contrastive_exchange_world2_gloo(world, n, e):
+    """(world 4: ranks 2 and 3 sit at offsets the two-rank run never forms -- the north star runs 8)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

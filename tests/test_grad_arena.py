@@ -141,8 +141,9 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_overlapped_reduction_two_gloo_ranks():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_overlapped_reduction_two_gloo_ranks(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]

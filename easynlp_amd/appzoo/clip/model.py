@@ -309,9 +309,15 @@ class HipClipEngine:
         train-mode dropout armed only batches whose kept tokens are prefixes are packed (``usable``)."""
         return self.pack_text and self.dtype_code == L.DTYPE_BF16 and self.text_arch == 0
 
-    def usable(self, pack) -> bool:
-        """May this packing (pack_meta) be used under the dropout state armed for the next call?"""
-        return bool(pack) and (self._drop == (0.0, 0.0) or bool(pack.get("prefix")))
+    def usable(self, pack, extras=None) -> bool:
+        """May this packing (pack_meta) be used under the dropout state armed for the next call?  With dropout: kept tokens must
+        be prefixes, and only the chinese_clip text branch (no explicit position / type / mask tensors): that combination is the
+        one verified on hardware against the padded run; the huggingface_clip branch stays on padded rows while dropout is armed."""
+        if not pack:
+            return False
+        if self._drop == (0.0, 0.0):
+            return True
+        return bool(pack.get("prefix")) and extras is None
 
     def encode_text(self, ids: torch.Tensor, save: bool, extras=None, owner=None, stream=None, pack=None) -> (torch.Tensor, torch.Tensor):
         """extras: (position_ids, token_type_ids, attention_mask) int64 [B, S] device tensors (huggingface_clip branch).
@@ -327,7 +333,7 @@ class HipClipEngine:
                 pack = self.pack_meta(ids, None if extras is None else extras[2])
             elif pack.get("shape") != (B, S):
                 raise L.EzclipError("packing metadata of another batch")
-            if self.usable(pack):
+            if self.usable(pack, extras):
                 pos, tt, am = extras if extras is not None else (None, None, None)
                 L.check(self.lib.ezclip_encode_text_packed(self.handle, L.ptr(ids), L.ptr(pos), L.ptr(tt), L.ptr(am),
                                                            L.ptr(pack["rowmap"]), L.ptr(pack["cu"]), L.ptr(pack["lens"]), B, S,

@@ -32,6 +32,12 @@ def test_prefix_batches_are_packed_sample_by_sample():
     for drop in ((0.0, 0.0), (0.1, 0.0), (0.0, 0.1)):
         eng._drop = drop
         assert eng.usable(m)
+    # the huggingface_clip branch (explicit position / type / mask tensors) is packed without dropout only
+    extras = (None, None, torch.ones_like(ids))
+    eng._drop = (0.0, 0.0)
+    assert eng.usable(m, extras)
+    eng._drop = (0.1, 0.1)
+    assert not eng.usable(m, extras)
 
 
 def test_holes_masked_cls_and_empty_sentences():

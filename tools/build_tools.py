@@ -13,9 +13,12 @@ from easynlp_amd.csrc import build as B  # noqa: E402
 def main():
     lib = B.build(verbose=True)
     os.makedirs(os.path.join(HERE, "bin"), exist_ok=True)
-    for src in ("gemm_bench.hip",):
-        out = os.path.join(HERE, "bin", src.replace(".hip", ""))
-        cmd = [B.hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", os.path.join(HERE, src), "-o", out,
+    srcs = [("gemm_bench.hip", [])]
+    if "--experiments" in sys.argv:      # staged kernel experiments (tools/experiments/README.md): not part of the default build
+        srcs.append(("experiments/attn_bwd_2wg.hip", ["-O3", "-mllvm", "-disable-lsr"]))
+    for src, extra in srcs:
+        out = os.path.join(HERE, "bin", os.path.basename(src).replace(".hip", ""))
+        cmd = [B.hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17"] + extra + [os.path.join(HERE, src), "-o", out,
                "-L" + os.path.dirname(lib), "-lezclip_hip", "-Wl,-rpath,$ORIGIN/../../easynlp_amd/csrc"]
         subprocess.check_call(cmd)
         print("built", out)

@@ -120,6 +120,8 @@ class HipClipEngine:
         # inference runs the BERT tower on the unmasked tokens only (ezclip_encode_text_packed); EZCLIP_PACK_TEXT=0 /
         # clip_pack_text=0 feeds every padded position through it as the reference does -- same embeddings
         self.pack_text = os.environ.get("EZCLIP_PACK_TEXT", "1") not in ("0", "false", "False")
+        # huggingface_clip batches (explicit position / type / mask tensors) packed while train-mode dropout is armed
+        self.pack_hf_dropout = os.environ.get("EZCLIP_PACK_HF_DROPOUT", "1") not in ("0", "false", "False")
         self.last_text_rows = None
         self.last_pack = None
         self._pack_cache = None
@@ -317,7 +319,7 @@ class HipClipEngine:
             return False
         if self._drop == (0.0, 0.0):
             return True
-        return bool(pack.get("prefix")) and extras is None
+        return bool(pack.get("prefix")) and (extras is None or self.pack_hf_dropout)
 
     def encode_text(self, ids: torch.Tensor, save: bool, extras=None, owner=None, stream=None, pack=None) -> (torch.Tensor, torch.Tensor):
         """extras: (position_ids, token_type_ids, attention_mask) int64 [B, S] device tensors (huggingface_clip branch).

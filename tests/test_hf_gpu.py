@@ -154,3 +154,65 @@ def test_hf_fast_path_contrastive_step_matches_golden(tmp_path):
         elif key.startswith("nograd/"):
             assert params[key[len("nograd/"):]].grad is None
     assert n_checked > 30
+
+
+@pytest.mark.parametrize("path", ["fused", "autograd"])
+@pytest.mark.parametrize("cfg_name", ["hf_tiny", "hf_small"])
+def test_hf_packed_text_tower_with_dropout_equals_the_padded_one(tmp_path, path, cfg_name):
+    """huggingface_clip flavour as the reference trains it (RoBERTa's train-mode dropout armed, appzoo/clip/model.py:128-144):
+    the packed text tower -- explicit position / type / mask tensors read through the row map, pooler head on the gathered
+    CLS rows -- regenerates exactly the padded run's dropout decisions: same embeddings, same loss, same gradients up to the
+    summation order of the weight-gradient partials.  (Round 2 left this combination on padded rows because it had never run
+    on hardware.)"""
+    cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in H.HF_CONFIGS[cfg_name].items()}
+    cfg["text_config"].update(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    app, sd = make_app(tmp_path, cfg, 6, "bf16")
+    app.train()
+    eng = app._engine
+    assert eng.pack_hf_dropout
+    B, Lq = 12, 40
+    pad = cfg["text_config"]["pad_token_id"]
+    px, ids, tt, am = H.make_inputs(cfg, B, Lq, 3)
+    g = torch.Generator().manual_seed(8)
+    lens = torch.randint(1, Lq, (B,), generator=g)
+    lens[0], lens[1] = Lq - 3, 1
+    keep = torch.arange(Lq)[None, :] < lens[:, None]
+    ids = torch.where(keep, ids.clamp(min=2), torch.full_like(ids, pad))
+    am = keep.long()
+    tt = tt * am
+    batch = lambda: {"pixel_values": px, "input_ids": ids.clone(), "token_type_ids": tt.clone(), "attention_mask": am.clone()}  # noqa: E731
+    res, emb = {}, {}
+    for pack in (False, True):
+        eng.pack_text = pack
+        torch.manual_seed(1234)
+        with torch.no_grad():
+            emb[pack] = app(dict(batch(), pixel_values=None), feat=True)["text_embeds"].float().cpu()
+        assert (eng.last_text_rows[0] < eng.last_text_rows[1]) == pack, eng.last_text_rows
+    assert float((emb[True] - emb[False]).abs().max()) < 1e-3, float((emb[True] - emb[False]).abs().max())
+    for pack in (False, True):
+        eng.pack_text = pack
+        for p in app.parameters():
+            p.grad = None
+        torch.manual_seed(1234)
+        if path == "fused":
+            loss = app.contrastive_step(px.cuda(), ids.cuda(), process_group=False, backward=True, zero_grad=True,
+                                        token_type_ids=tt.cuda(), attention_mask=am.cuda())
+        else:
+            loss = app.compute_loss(app(batch()), [])["loss"]
+            loss.backward()
+        torch.cuda.synchronize()
+        rows = eng.last_text_rows
+        assert (rows[0] < rows[1]) == pack, rows
+        res[pack] = (float(loss.item()), {n: p.grad.detach().float().cpu().clone() for n, p in app.named_parameters()
+                                          if p.grad is not None})
+    assert abs(res[True][0] - res[False][0]) < 1e-3, (res[True][0], res[False][0])
+    assert set(res[True][1]) == set(res[False][1]) and len(res[True][1]) > 20
+    floor = 1e-3 * max(float(v.norm()) for v in res[False][1].values())
+    worst = max((float((res[True][1][n] - v).norm()) / (float(v.norm()) + floor), n) for n, v in res[False][1].items()
+                if not n.endswith("k_proj.bias") and not n.endswith(".key.bias"))
+    assert worst[0] < 2e-2, worst
+    torch.manual_seed(99)           # the dropout really was on
+    other = float(app.contrastive_step(px.cuda(), ids.cuda(), process_group=False, backward=False,
+                                       token_type_ids=tt.cuda(), attention_mask=am.cuda()).item())
+    assert abs(other - res[True][0]) > 1e-4
+    eng.pack_text = True

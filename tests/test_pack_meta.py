@@ -9,6 +9,7 @@ def _engine():
     eng = HipClipEngine.__new__(HipClipEngine)      # (no device, no library: only the packing logic)
     eng._pack_cache = None
     eng._drop = (0.0, 0.0)
+    eng.pack_hf_dropout = True
     return eng
 
 
@@ -32,11 +33,14 @@ def test_prefix_batches_are_packed_sample_by_sample():
     for drop in ((0.0, 0.0), (0.1, 0.0), (0.0, 0.1)):
         eng._drop = drop
         assert eng.usable(m)
-    # the huggingface_clip branch (explicit position / type / mask tensors) is packed without dropout only
+    # the huggingface_clip branch (explicit position / type / mask tensors): packed under dropout too since round 3
+    # (tests/test_hf_gpu.py::test_hf_packed_text_tower_with_dropout_equals_the_padded_one); EZCLIP_PACK_HF_DROPOUT=0 switches it off
     extras = (None, None, torch.ones_like(ids))
     eng._drop = (0.0, 0.0)
     assert eng.usable(m, extras)
     eng._drop = (0.1, 0.1)
+    assert eng.usable(m, extras)
+    eng.pack_hf_dropout = False
     assert not eng.usable(m, extras)
 
 

@@ -122,6 +122,8 @@ class HipClipEngine:
         self.pack_text = os.environ.get("EZCLIP_PACK_TEXT", "1") not in ("0", "false", "False")
         # huggingface_clip batches (explicit position / type / mask tensors) packed while train-mode dropout is armed
         self.pack_hf_dropout = os.environ.get("EZCLIP_PACK_HF_DROPOUT", "1") not in ("0", "false", "False")
+        # contrastive step through the tiled kernels (csrc/nce.hip); EZCLIP_NCE_TILED=0: the materialising path of rounds 1-2
+        self.nce_tiled = os.environ.get("EZCLIP_NCE_TILED", "1") not in ("0", "false", "False")
         self.last_text_rows = None
         self.last_pack = None
         self._pack_cache = None
@@ -551,26 +553,34 @@ class _InfoNCEFn(torch.autograd.Function):
 
 
 def fused_infonce_shard(eng, txt_all, img_all, n, off, logit_scale, grad_scale, want_grads):
-    """``ezclip_infonce_fused`` on this rank's ``n`` rows (starting at ``off``) of both directions against all ``N`` columns:
-    (loss = mean over the local rows, d_text [N, E], d_image [N, E], d_logit_scale) -- the gradients only when asked."""
+    """This rank's ``n`` rows (starting at ``off``) of both directions against all ``N`` columns:
+    (loss = mean over the local rows, d_text [N, E], d_image [N, E], d_logit_scale) -- the gradients only when asked.
+    ``ezclip_infonce_tiled`` (no [n, N] buffer; operands split into bf16 hi + lo on the f32 pipeline, plain bf16 on the bf16
+    one) where the embedding width allows it, else ``ezclip_infonce_fused``'s materialising path."""
     lib = eng.lib
     N, e = img_all.shape
-    key = ("nce", n, N, e)
+    tiled_bytes = lib.ezclip_infonce_tiled_workspace_bytes(n, N, e) if eng.nce_tiled else 0
+    key = ("nce", n, N, e, bool(tiled_bytes))
     ws = eng._ws.get(key)
     if ws is None:
-        ws = L.alloc_bytes(lib.ezclip_infonce_workspace_bytes(n, N, e), img_all.device)
+        ws = L.alloc_bytes(tiled_bytes or lib.ezclip_infonce_workspace_bytes(n, N, e), img_all.device)
         eng._ws[key] = ws
-    loss = torch.empty((), dtype=torch.float32, device=img_all.device)
-    if not want_grads:
-        L.check(lib.ezclip_infonce_fused(L.ptr(txt_all), L.ptr(img_all), n, N, off, e, L.ptr(logit_scale), 1.0, L.ptr(loss),
-                                         None, None, None, L.ptr(ws), ws.numel(), L.stream_ptr()), "infonce_fused")
-        return loss, None, None, None
-    d_txt = torch.empty((N, e), dtype=torch.float32, device=img_all.device)
-    d_img = torch.empty((N, e), dtype=torch.float32, device=img_all.device)
-    d_ls = torch.empty((), dtype=torch.float32, device=img_all.device)
-    L.check(lib.ezclip_infonce_fused(L.ptr(txt_all), L.ptr(img_all), n, N, off, e, L.ptr(logit_scale), float(grad_scale),
-                                     L.ptr(loss), L.ptr(d_txt), L.ptr(d_img), L.ptr(d_ls), L.ptr(ws), ws.numel(),
-                                     L.stream_ptr()), "infonce_fused")
+    dev = img_all.device
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    d_txt = d_img = d_ls = None
+    if want_grads:
+        d_txt = torch.empty((N, e), dtype=torch.float32, device=dev)
+        d_img = torch.empty((N, e), dtype=torch.float32, device=dev)
+        d_ls = torch.empty((), dtype=torch.float32, device=dev)
+    gs = float(grad_scale) if want_grads else 1.0
+    if tiled_bytes:
+        L.check(lib.ezclip_infonce_tiled(L.ptr(txt_all), L.ptr(img_all), n, N, off, e, L.ptr(logit_scale), gs,
+                                         0 if eng.dtype_code == L.DTYPE_BF16 else 1, L.ptr(loss), L.ptr(d_txt), L.ptr(d_img),
+                                         L.ptr(d_ls), L.ptr(ws), ws.numel(), L.stream_ptr()), "infonce_tiled")
+    else:
+        L.check(lib.ezclip_infonce_fused(L.ptr(txt_all), L.ptr(img_all), n, N, off, e, L.ptr(logit_scale), gs, L.ptr(loss),
+                                         L.ptr(d_txt), L.ptr(d_img), L.ptr(d_ls), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                "infonce_fused")
     return loss, d_txt, d_img, d_ls
 
 
@@ -932,23 +942,9 @@ class CLIPApp(Application):
         else:
             img_all, txt_all = img, txt
         N = world * n
-        key = ("nce", n, N, e)
-        ws = eng._ws.get(key)
-        if ws is None:
-            ws = L.alloc_bytes(lib.ezclip_infonce_workspace_bytes(n, N, e), img.device)
-            eng._ws[key] = ws
-        loss = torch.empty((), dtype=torch.float32, device=img.device)
+        loss, d_txt, d_img, d_ls = fused_infonce_shard(eng, txt_all, img_all, n, rank * n, self.logit_scale, 1.0 / world, backward)
         if not backward:
-            L.check(lib.ezclip_infonce_fused(L.ptr(txt_all), L.ptr(img_all), n, N, rank * n, e,
-                                             L.ptr(self.logit_scale), 1.0, L.ptr(loss), None, None, None,
-                                             L.ptr(ws), ws.numel(), L.stream_ptr()), "infonce_fused")
             return loss
-        d_txt = torch.empty((N, e), dtype=torch.float32, device=img.device)
-        d_img = torch.empty((N, e), dtype=torch.float32, device=img.device)
-        d_ls = torch.empty((), dtype=torch.float32, device=img.device)
-        L.check(lib.ezclip_infonce_fused(L.ptr(txt_all), L.ptr(img_all), n, N, rank * n, e, L.ptr(self.logit_scale),
-                                         1.0 / world, L.ptr(loss), L.ptr(d_txt), L.ptr(d_img), L.ptr(d_ls),
-                                         L.ptr(ws), ws.numel(), L.stream_ptr()), "infonce_fused")
         if world > 1:
             d_img_l, d_txt_l = P.scatter_embedding_grads(d_img, d_txt, n, pg)   # one RCCL reduce-scatter
         else:

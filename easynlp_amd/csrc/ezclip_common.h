@@ -71,8 +71,8 @@ __device__ __forceinline__ void unpack_chunk(const uint4& c, float (&v)[8], bf16
   v[6] = __uint_as_float(c.w << 16); v[7] = __uint_as_float(c.w & 0xffff0000u);
 }
 
-// erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): used where the result is
-// rounded to bf16 anyway; the f32 path calls erff.
+// erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): kept for reference / tools; the bf16 pipeline's GELU uses the
+// polynomials below, the f32 path calls erff.
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);   // v_rcp_f32 (1 ulp)
@@ -85,6 +85,49 @@ __device__ __forceinline__ float erf_fast(float x) {
   return copysignf(y, x);
 }
 
+// ---- erf-GELU of the bf16 pipeline without transcendental instructions (round 3) ------------------------------------------
+// F.gelu(x) = x Phi(x) (activations.py:45-48,98).  The Abramowitz-Stegun form above costs ~13 VALU instructions plus v_rcp_f32
+// and v_exp_f32 (quarter rate) per element: 25 % of the BERT intermediate product's time went into its epilogue.  Here
+//   Phi(x)   ~ 0.5 + xc R(t),   xc = clamp(x, -c, c),  t = 2 xc^2 / c^2 - 1        (Phi - 1/2 is odd: one polynomial)
+//   gelu'(x) = Phi(x) + x phi(x) ~ 0.5 + xc Q(t)                                   (gelu' - 1/2 is odd as well)
+// with minimax fits (Lawson iterations on Chebyshev nodes; evaluated by Horner in t in [-1, 1], which keeps float32 rounding
+// at the 1e-7 level): |Phi error| <= 7.5e-6 for all x (c = 4.2, degree 8), |gelu' error| <= 1.2e-5 (c = 4.8, degree 11) --
+// two orders below a bf16 ulp of the result.  13 / 16 plain multiply-adds per element, written on float pairs so that they
+// issue as v_pk_fma_f32 / v_pk_mul_f32 (two elements per instruction); the scalar forms run the SAME operation sequence
+// (every step one IEEE fma / mul), so the packed epilogue of the 8-phase GEMM and the scalar one of the 128x128 kernel stay
+// bit-identical (tests/test_bench_regime_gpu.py).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr float kPhiC = 4.2f, kPhiTs = 2.0f / (4.2f * 4.2f);
+constexpr float kPhiK[9] = {0.1678561419248581f, -0.08148203790187836f, 0.05581444501876831f, -0.03895563259720802f,
+                            0.02500496804714203f, -0.013675360009074211f, 0.008104611188173294f, -0.005817593075335026f,
+                            0.0021966451313346624f};
+constexpr float kGpC = 4.8f, kGpTs = 2.0f / (4.8f * 4.8f);
+constexpr float kGpK[12] = {0.1484677493572235f, -0.08022641390562057f, 0.07392347604036331f, -0.08052316308021545f,
+                            0.0863509252667427f, -0.08870752155780792f, 0.08652839064598083f, -0.06128013879060745f,
+                            0.026012925431132317f, -0.023687424138188362f, 0.029725147411227226f, -0.01241487916558981f};
+
+template <typename V> __device__ __forceinline__ V ez_splat(float v);
+template <> __device__ __forceinline__ float ez_splat<float>(float v) { return v; }
+template <> __device__ __forceinline__ f32x2_t ez_splat<f32x2_t>(float v) { return f32x2_t{v, v}; }
+__device__ __forceinline__ float ez_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ f32x2_t ez_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float ez_clamp(float x, float c) { return __builtin_amdgcn_fmed3f(x, -c, c); }
+__device__ __forceinline__ f32x2_t ez_clamp(f32x2_t x, float c) {
+  return f32x2_t{__builtin_amdgcn_fmed3f(x.x, -c, c), __builtin_amdgcn_fmed3f(x.y, -c, c)};
+}
+// 0.5 + xc * poly(t): V = float or f32x2_t
+template <typename V, int N>
+__device__ __forceinline__ V odd_poly_half(V x, float c, float ts, const float (&k)[N]) {
+  const V xc = ez_clamp(x, c);
+  const V t = ez_fma(xc * xc, ez_splat<V>(ts), ez_splat<V>(-1.0f));
+  V r = ez_splat<V>(k[N - 1]);
+#pragma unroll
+  for (int i = N - 2; i >= 0; --i) r = ez_fma(r, t, ez_splat<V>(k[i]));
+  return ez_fma(xc, r, ez_splat<V>(0.5f));
+}
+template <typename V> __device__ __forceinline__ V gelu_fast(V x) { return x * odd_poly_half<V>(x, kPhiC, kPhiTs, kPhiK); }
+template <typename V> __device__ __forceinline__ V gelu_grad_fast(V x) { return odd_poly_half<V>(x, kGpC, kGpTs, kGpK); }
+
 // FAST = true for the bf16 pipeline (hardware exp, polynomial erf)
 template <bool FAST>
 __device__ __forceinline__ float act_apply(float x, int act) {
@@ -94,8 +137,8 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     return x / (1.0f + expf(-1.702f * x));
   }
   if (act == ACT_GELU_ERF) {
-    const float z = x * 0.70710678118654752440f;
-    return 0.5f * x * (1.0f + (FAST ? erf_fast(z) : erff(z)));
+    if (FAST) return gelu_fast<float>(x);
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
   }
   if (act == ACT_TANH) return tanhf(x);     // BertPooler / RobertaPooler (B rows per step: never hot)
   return x;
@@ -110,9 +153,9 @@ __device__ __forceinline__ float act_grad(float x, int act) {
     return s * (1.0f + 1.702f * x * (1.0f - s));
   }
   if (act == ACT_GELU_ERF) {
-    const float z = x * 0.70710678118654752440f;
-    const float cdf = 0.5f * (1.0f + (FAST ? erf_fast(z) : erff(z)));
-    const float pdf = 0.39894228040143267794f * (FAST ? __expf(-0.5f * x * x) : expf(-0.5f * x * x));
+    if (FAST) return gelu_grad_fast<float>(x);
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
     return cdf + x * pdf;
   }
   if (act == ACT_TANH) {

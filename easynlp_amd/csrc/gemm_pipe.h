@@ -334,8 +334,16 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
 #pragma unroll
           for (int e = 0; e < 8; ++e) y[e] *= act_grad<FAST>(uf[e], ACT_QUICKGELU);
         } else if (act == ACT_GELU_ERF) {
+          if constexpr (FAST) {       // packed polynomial (ezclip_common.h): two elements per v_pk_fma_f32
 #pragma unroll
-          for (int e = 0; e < 8; ++e) y[e] *= act_grad<FAST>(uf[e], ACT_GELU_ERF);
+            for (int e = 0; e < 8; e += 2) {
+              const f32x2_t gq = gelu_grad_fast<f32x2_t>(f32x2_t{uf[e], uf[e + 1]});
+              y[e] *= gq.x; y[e + 1] *= gq.y;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] *= act_grad<FAST>(uf[e], ACT_GELU_ERF);
+          }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) cs[e] += y[e];     // rows >= M contribute exact zeros (A rows read as 0, no bias)
@@ -343,8 +351,16 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] = act_apply<FAST>(y[e], ACT_QUICKGELU);
       } else if (act == ACT_GELU_ERF) {
+        if constexpr (FAST) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = act_apply<FAST>(y[e], ACT_GELU_ERF);
+          for (int e = 0; e < 8; e += 2) {
+            const f32x2_t gq = gelu_fast<f32x2_t>(f32x2_t{y[e], y[e + 1]});
+            y[e] = gq.x; y[e + 1] = gq.y;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = act_apply<FAST>(y[e], ACT_GELU_ERF);
+        }
       }
       if constexpr (HAS_R) {
         float rf[8];

@@ -232,6 +232,11 @@ int infonce_dlogits(const float* S, int n, const float* lse_r, const float* lse_
                     hipStream_t stream);
 // sim [rows, n] = queries row0 .. row0 + rows - 1 against all n gallery items; rank[r] for query row0 + r
 int recall_ranks(const float* sim, int rows, int n, int row0, int32_t* rank, hipStream_t stream);
+// Tiled InfoNCE on embeddings (nce.hip): no [n, N] buffer; split = 1: operands as bf16 hi + lo (float32-class), 0: bf16
+bool infonce_tiled_eligible(int e);
+size_t infonce_tiled_workspace_bytes(int n, int N, int e);
+int infonce_tiled(const float* T, const float* I, int n, int N, int off, int e, const float* ls, float grad_scale, int split,
+                  float* loss, float* dT, float* dI, float* dls, void* ws, size_t ws_bytes, hipStream_t stream);
 const char* last_error();
 
 // ---- optional per-launch timing (profile.hip) --------------------------------------

@@ -75,6 +75,8 @@ SIGNATURES = {
     "ezclip_infonce_from_logits_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "ezclip_infonce_workspace_bytes": (_sz, [_i, _i, _i]),
     "ezclip_infonce_fused": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ezclip_infonce_tiled_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ezclip_infonce_tiled": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ezclip_backward_image": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "ezclip_backward_text": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ezclip_recall_ranks": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),

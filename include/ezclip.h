@@ -202,22 +202,34 @@ int ezclip_infonce_from_logits(const float* logits_dev, int n, float* loss_dev, 
 /* d loss / d logits for the above, scaled by *grad_out_dev (scalar, device). */
 int ezclip_infonce_from_logits_bwd(const float* logits_dev, int n, const float* grad_out_dev,
                                    float* dlogits_dev, float* scratch_dev, void* stream);
-/* Contrastive step on embeddings (local or all-gathered global batch) in ONE CALL -- "fused" in the name means the call,
- * not one kernel: both [n_local, n_global] f32 logit blocks are materialised in the workspace (2 x 32 MB at 1024 x 8192),
- * the row log-sum-exps, d(logits) and the four gradient products are separate launches of the f32 MFMA GEMM and the
- * loss.hip row kernels (0.1 % of a step at n = 1024; a tiled online-LSE kernel without the logit blocks is the open item
- * for the 8-GPU global batch).
+/* Contrastive step on embeddings (local or all-gathered global batch): loss, d embeddings and d logit_scale of THIS rank's
+ * n_local rows of both directions against all n_global columns.
  *   text_all/image_all: float32 [n_global, e] (rows rank_offset..rank_offset+n_local are this rank's)
  *   loss = 0.5 * (mean_i CE(s * T_loc I_all^T)_i + mean_i CE(s * I_loc T_all^T)_i),  s = exp(*logit_scale)
- *   outputs (any may be NULL to skip the backward part):
- *     d_text_all / d_image_all  float32 [n_global, e] : gradient contributions of THIS rank's loss
+ *   outputs (all three may be NULL to skip the backward part):
+ *     d_text_all / d_image_all  float32 [n_global, e] (overwritten): gradient contributions of THIS rank's loss
  *        w.r.t. every row (sum over ranks = reduce-scatter / all-reduce by the caller)
  *     d_logit_scale float32 scalar (overwritten)
  *   grad_scale multiplies every gradient (1/world_size for DDP-style averaging).
- *   workspace: ezclip_infonce_workspace_bytes(n_local, n_global, e). */
+ *
+ * ezclip_infonce_tiled (round 3, csrc/nce.hip; e in {128, 256, 512, 768, 1024}): NOTHING of size n_local x n_global is
+ * materialised.  Score tiles are bf16 MFMA products; the forward keeps a running log-sum-exp per row, the backward recomputes
+ * the tiles, forms d(logits) in registers and multiplies it with the streamed rows in the same kernel; partial sums over key
+ * chunks are combined in a fixed order (bit-reproducible).  split_operands = 1 splits every operand into bf16 hi + lo parts
+ * (three products, float32-class results: loss 1e-5, gradients 1e-5 -- the f32 pipeline); 0 rounds the embeddings to bf16 once
+ * (the bf16 pipeline).  Workspace O((n_local + n_global) * e): ezclip_infonce_tiled_workspace_bytes (0 = e not supported).
+ *
+ * ezclip_infonce_fused: the same contract; runs the tiled kernels with split operands when e allows and otherwise the
+ * materialising path of rounds 1-2 (two [n_local, n_global] float32 logit blocks + their gradients in the workspace, f32 MFMA
+ * products, row kernels of loss.hip).  workspace: ezclip_infonce_workspace_bytes(n_local, n_global, e). */
 size_t ezclip_infonce_workspace_bytes(int n_local, int n_global, int e);
 int ezclip_infonce_fused(const float* text_all_dev, const float* image_all_dev, int n_local, int n_global,
                          int rank_offset, int e, const float* logit_scale_dev, float grad_scale,
+                         float* loss_dev, float* d_text_all_dev, float* d_image_all_dev,
+                         float* d_logit_scale_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+size_t ezclip_infonce_tiled_workspace_bytes(int n_local, int n_global, int e);
+int ezclip_infonce_tiled(const float* text_all_dev, const float* image_all_dev, int n_local, int n_global,
+                         int rank_offset, int e, const float* logit_scale_dev, float grad_scale, int split_operands,
                          float* loss_dev, float* d_text_all_dev, float* d_image_all_dev,
                          float* d_logit_scale_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 

@@ -294,6 +294,70 @@ def test_infonce_fused_shard(n, N, off, e):
     assert abs(dls.item() - lsd.grad.item()) < 1e-4 * max(1, abs(lsd.grad.item()))
 
 
+@pytest.mark.parametrize("split", [1, 0])
+@pytest.mark.parametrize("n,N,off,e", [(8, 8, 0, 128), (5, 20, 10, 128), (100, 300, 200, 256), (32, 128, 64, 512), (64, 512, 128, 768),
+                                       (200, 200, 0, 512), (1024, 1024, 0, 512), (1024, 8192, 3072, 512), (96, 768, 672, 1024)])
+def test_infonce_tiled(n, N, off, e, split):
+    """csrc/nce.hip: loss and gradients of one rank's shard WITHOUT the [n, N] logit blocks, against autograd of the oracle's
+    global loss share in float64.  split = 1 (operands as bf16 hi + lo, three MFMA products): the f32 pipeline's bounds -- loss
+    1e-5, gradients 1e-5 absolute / 2e-4 of the largest entry; split = 0 (embeddings rounded to bf16 once): bf16 bounds.  Ragged
+    tiles (n, N, off not multiples of 64 / 128), every instantiated width, single-GPU (n = N) and the north star's rank 3 of 8."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(N + off + e)
+    t = torch.nn.functional.normalize(torch.randn(N, e, generator=g), dim=-1)
+    i = torch.nn.functional.normalize(t + torch.randn(N, e, generator=g), dim=-1)
+    ls = torch.tensor(2.0)
+    td, idd, lsd = (x.double().clone().requires_grad_(True) for x in (t, i, ls))
+    ref = O.global_clip_loss_rank(td, idd, lsd, off // n, n)
+    ref.backward()
+    wsb = lib.ezclip_infonce_tiled_workspace_bytes(n, N, e)
+    assert 0 < wsb < 16 * (n + N) * e * 4 + (1 << 22), wsb          # O((n + N) e): no n x N term
+    ws = L.alloc_bytes(wsb, DEV)
+    tg, ig, lsg = t.to(DEV), i.to(DEV), ls.to(DEV)
+    out = {}
+    for grads in (False, True):
+        loss = torch.full((), float("nan"), device=DEV)
+        dT = torch.full((N, e), float("nan"), device=DEV) if grads else None
+        dI = torch.full((N, e), float("nan"), device=DEV) if grads else None
+        dls = torch.full((), float("nan"), device=DEV) if grads else None
+        L.check(lib.ezclip_infonce_tiled(tg.data_ptr(), ig.data_ptr(), n, N, off, e, lsg.data_ptr(), 1.0, split, loss.data_ptr(),
+                                         L.ptr(dT), L.ptr(dI), L.ptr(dls), ws.data_ptr(), ws.numel(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        out[grads] = (loss, dT, dI, dls)
+    loss, dT, dI, dls = out[True]
+    assert out[False][0].item() == loss.item()            # forward-only call: the same kernels, the same bits
+    tol_l = 1e-5 if split else 2e-3
+    assert abs(loss.item() - ref.item()) < tol_l * max(1, abs(ref.item())), (loss.item(), ref.item())
+    for got, want in ((dT, td.grad), (dI, idd.grad)):
+        scale = float(want.abs().max())
+        tol = min(1e-5, 2e-4 * scale) if split else 2e-2 * scale
+        assert max_err(got, want) < tol, (max_err(got, want), scale)
+    assert abs(dls.item() - lsd.grad.item()) < (1e-4 if split else 5e-3) * max(1, abs(lsd.grad.item()))
+    # bit-reproducible (fixed-order chunk sums, no float atomics)
+    dT2 = torch.empty_like(dT); dI2 = torch.empty_like(dI); loss2 = torch.empty_like(loss); dls2 = torch.empty_like(dls)
+    L.check(lib.ezclip_infonce_tiled(tg.data_ptr(), ig.data_ptr(), n, N, off, e, lsg.data_ptr(), 1.0, split, loss2.data_ptr(),
+                                     dT2.data_ptr(), dI2.data_ptr(), dls2.data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dT, dT2) and torch.equal(dI, dI2) and loss.item() == loss2.item() and dls.item() == dls2.item()
+    # the materialising path of rounds 1-2 (ezclip_debug_set(8, 0)) against the tiled one through ezclip_infonce_fused
+    if split:
+        res = []
+        for tiled in (1, 0):
+            L.check(lib.ezclip_debug_set(8, tiled))
+            try:
+                w2 = L.alloc_bytes(lib.ezclip_infonce_workspace_bytes(n, N, e), DEV)
+                lo, a, b, c = torch.empty((), device=DEV), torch.empty(N, e, device=DEV), torch.empty(N, e, device=DEV), torch.empty((), device=DEV)
+                L.check(lib.ezclip_infonce_fused(tg.data_ptr(), ig.data_ptr(), n, N, off, e, lsg.data_ptr(), 0.5, lo.data_ptr(),
+                                                 a.data_ptr(), b.data_ptr(), c.data_ptr(), w2.data_ptr(), w2.numel(), L.stream_ptr()))
+                torch.cuda.synchronize()
+                res.append((lo.item(), a, b, c.item()))
+            finally:
+                L.check(lib.ezclip_debug_set(8, 1))
+        assert abs(res[0][0] - res[1][0]) < 2e-5 * max(1, abs(res[1][0]))
+        assert max_err(res[0][1], res[1][1].double()) < 1e-5 and max_err(res[0][2], res[1][2].double()) < 1e-5
+        assert max_err(res[0][1], 0.5 * td.grad) < 1e-5        # grad_scale
+
+
 # ----------------------------------------------------------------------------- backward ops
 
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 768, 768), (197 * 3, 2304, 768), (130, 136, 264), (8, 64, 512),

@@ -57,10 +57,19 @@ def recall_ranks(text_embeds: torch.Tensor, image_embeds: torch.Tensor, block_ro
         L.check(lib.ezclip_recall_ranks_rows(L.ptr(t[r0:r0 + rows]), L.ptr(v), rows, r0, n, e, out.data_ptr(), L.ptr(scratch),
                                              L.stream_ptr()), "recall_ranks_rows")
     if world > 1:
-        mine = rank[me * per:(me + 1) * per].contiguous()
-        dist.all_gather_into_tensor(rank, mine, group=group)
-        rank = rank[:n]
+        rank = gather_rank_shards(rank, me, per, n, group)
     return rank
+
+
+def gather_rank_shards(rank: torch.Tensor, me: int, per: int, n: int, group=None) -> torch.Tensor:
+    """Every rank filled rank[me*per : (me+1)*per]; returns the first n entries of the concatenation over ranks.  Input and
+    output of the collective are separate tensors (a slice of ``rank`` as the input would alias the output buffer: in-place
+    all-gather is only defined for NCCL at the exact offset, not for gloo)."""
+    import torch.distributed as dist
+    mine = rank[me * per:(me + 1) * per].clone()
+    gathered = torch.empty_like(rank)
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    return gathered[:n]
 
 
 def recall_at_k(text_embeds, image_embeds, ks=(1, 5, 10)):

@@ -202,9 +202,7 @@ class HFEncodeFn(torch.autograd.Function):
         ctx.ws_img = ctx.ws_txt = None
         from .model import _WsToken
         ctx.token = _WsToken() if need_grad else None
-        if pixels is not None:
-            pixels = pixels.contiguous().float()
-            img, ctx.ws_img = eng.encode_image(pixels, need_grad, owner=ctx.token)
+        pack = None
         if ids is not None:
             ids = ids.contiguous().long()
             tt, am = tt.contiguous().long(), am.contiguous().long()
@@ -212,7 +210,13 @@ class HFEncodeFn(torch.autograd.Function):
             ctx.drop = app._next_dropout()
             eng.set_text_dropout(*ctx.drop)
             ctx.extras = (pos, tt, am)
-            txt, ctx.ws_txt = eng.encode_text(ids, need_grad, extras=ctx.extras, owner=ctx.token)
+            if eng.can_pack(need_grad) and ids.shape[1] >= 8:
+                pack = eng.pack_meta(ids, am) or False        # (one launch; the scalars are read after the image tower is enqueued)
+        if pixels is not None:
+            pixels = pixels.contiguous().float()
+            img, ctx.ws_img = eng.encode_image(pixels, need_grad, owner=ctx.token)
+        if ids is not None:
+            txt, ctx.ws_txt = eng.encode_text(ids, need_grad, extras=ctx.extras, owner=ctx.token, pack=pack)
             ctx.pack = eng.last_pack            # packed rows (bf16, no dropout): the backward runs on the same rows
         ctx.app, ctx.pixels, ctx.ids = app, pixels, ids
         ctx.has = (img is not None, txt is not None)

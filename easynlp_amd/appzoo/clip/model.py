@@ -267,24 +267,55 @@ class HipClipEngine:
         return out, ws
 
     # -- packed text batches ---------------------------------------------------------------------------------
-    def pack_meta(self, ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, device=None) -> Optional[dict]:
+    def pack_meta(self, ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, device=None):
         """Which tokens of a [B, S] batch the text tower has to see (ezclip_encode_text_packed, include/ezclip.h): every
         unmasked token (mask = ids != 0, modeling_chineseclip.py:347, or the explicit attention mask), every CLS token, and
-        whole sentences without any unmasked key.  Works on host ids (no GPU involved: the DataLoader hands ``forward`` CPU
-        tensors) or device ids (one small host sync for the two scalars).  None when packing would not pay or does not apply."""
+        whole sentences without any unmasked key.
+        * HOST ids (the DataLoader hands ``forward`` CPU tensors): computed on the host, no GPU involved; cached per tensor object.
+        * DEVICE ids: ONE kernel on the current stream (ezclip_pack_text_meta) fills rowmap / cu / lens; the three scalars the
+          host needs to size the launches (rows, longest, prefix) arrive in pinned host memory and are read by
+          ``resolve_pack`` -- which the callers invoke AFTER they have enqueued the image tower, so the host never waits on an
+          idle device and no stream is synchronised.  Nothing is cached: every step pays the launch.
+        Returns a dict (possibly still unresolved: key 'ticket'), or None when packing does not apply."""
         B, S = ids.shape
-        # the same tensor OBJECT, unmodified (version counter), as last time: same answer, no device round trip.  (The weak
-        # reference is alive only while that object -- and with it its memory -- is; a new tensor at a recycled address is
-        # another object.)
+        if ids.is_cuda and S <= 512 and B <= 12288 and getattr(self, "handle", None):
+            ids = ids.contiguous()
+            am = attention_mask.contiguous() if attention_mask is not None else None
+            rowmap = torch.empty(B * S, dtype=torch.int32, device=ids.device)
+            cu = torch.empty(B, dtype=torch.int32, device=ids.device)
+            lens = torch.empty(B, dtype=torch.int32, device=ids.device)
+            ticket = L.C.c_int(0)
+            L.check(self.lib.ezclip_pack_text_meta(self.handle, L.ptr(ids), L.ptr(am), B, S, L.ptr(rowmap), L.ptr(cu), L.ptr(lens),
+                                                   L.C.byref(ticket), L.stream_ptr()), "pack_text_meta")
+            return {"rowmap": rowmap, "cu": cu, "lens": lens, "shape": (B, S), "ticket": int(ticket.value), "_keep": (ids, am)}
+        # the same tensor OBJECT, unmodified (version counter), as last time: same answer.  (The weak reference is alive only
+        # while that object -- and with it its memory -- is; a new tensor at a recycled address is another object.)
+        dev_key = None if device is None else str(torch.device(device))
         c = self._pack_cache
-        if (c is not None and c[0]() is ids and c[1] == ids._version
+        if (c is not None and c[0]() is ids and c[1] == ids._version and c[5] == dev_key
                 and (attention_mask is None) == (c[2] is None)
                 and (attention_mask is None or (c[2]() is attention_mask and c[3] == attention_mask._version))):
             return c[4]
         meta = self._pack_meta_uncached(ids, attention_mask, device)
         self._pack_cache = (weakref.ref(ids), ids._version, None if attention_mask is None else weakref.ref(attention_mask),
-                            None if attention_mask is None else attention_mask._version, meta)
+                            None if attention_mask is None else attention_mask._version, meta, dev_key)
         return meta
+
+    def resolve_pack(self, pack):
+        """Finish a packing started on the device: read (rows, longest, prefix) of its launch from the pinned result words
+        (a polled flag, no stream synchronisation).  Returns the usable dict, or False when packing would not pay."""
+        if not pack or "ticket" not in pack:
+            return pack
+        rows, longest, prefix = L.C.c_int(0), L.C.c_int(0), L.C.c_int(0)
+        L.check(self.lib.ezclip_pack_text_meta_result(self.handle, pack.pop("ticket"), L.C.byref(rows), L.C.byref(longest),
+                                                      L.C.byref(prefix)), "pack_text_meta_result")
+        pack.pop("_keep", None)
+        B, S = pack["shape"]
+        pack.update(rows=int(rows.value), longest=int(longest.value), prefix=bool(prefix.value))
+        if pack["longest"] > 256 or pack["rows"] > 0.9 * B * S:
+            pack["unusable"] = True
+            return False
+        return pack
 
     def _pack_meta_uncached(self, ids, attention_mask, device):
         B, S = ids.shape
@@ -337,6 +368,7 @@ class HipClipEngine:
                 pack = self.pack_meta(ids, None if extras is None else extras[2])
             elif pack.get("shape") != (B, S):
                 raise L.EzclipError("packing metadata of another batch")
+            pack = self.resolve_pack(pack)       # (device-built metadata: the scalars are read here, after the image tower was enqueued)
             if self.usable(pack, extras):
                 pos, tt, am = extras if extras is not None else (None, None, None)
                 L.check(self.lib.ezclip_encode_text_packed(self.handle, L.ptr(ids), L.ptr(pos), L.ptr(tt), L.ptr(am),
@@ -412,7 +444,8 @@ def _run_towers(eng, two_streams, run_image, run_text, image_first=False):
     main = torch.cuda.current_stream()
     side = eng.side_stream(main.device)
     side.wait_stream(main)
-    if image_first:                # (host-side enqueue order only: the backward pass reports the image tower's groups first)
+    if image_first:                # (host-side enqueue order only: the backward pass reports the image tower's groups first;
+                                   #  the forward enqueues the image tower before it reads device-built packing metadata)
         a = run_image(None)
         b = run_text(side)
     else:
@@ -427,7 +460,7 @@ class _EncodeFn(torch.autograd.Function):
     arena (one memset, completion-ordered: parallel.GradArena) and hands autograd views of it."""
 
     @staticmethod
-    def forward(ctx, app, need_grad, pixels, ids, *params):
+    def forward(ctx, app, need_grad, pack_hint, pixels, ids, *params):
         eng = app._engine   # (grad mode is always off inside Function.forward: the caller decides need_grad)
         named = dict(zip(eng.names, params))
         eng.sync_params(named, with_backward=need_grad)
@@ -441,11 +474,11 @@ class _EncodeFn(torch.autograd.Function):
             ids = ids.contiguous().long()
             ctx.drop = app._next_dropout()          # (hidden_p, attn_p, seed); zeros in eval mode
             eng.set_text_dropout(*ctx.drop)
-            pack = app.__dict__.pop("_pack_hint", None)     # (forward() computed it on the host ids: no device sync)
+            pack = pack_hint            # (forward() computed it on the host ids; False: do not pack)
             if pack is None and eng.can_pack(need_grad) and ids.shape[1] >= 8:
-                pack = eng.pack_meta(ids) or False
+                pack = eng.pack_meta(ids) or False           # device ids: one launch now, the scalars are read in encode_text
             run_t = lambda st: eng.encode_text(ids, need_grad, owner=ctx.token, stream=st, pack=pack)
-        ri, rt = _run_towers(eng, app.two_streams, run_i, run_t)
+        ri, rt = _run_towers(eng, app.two_streams, run_i, run_t, image_first=True)
         ctx.pack = eng.last_pack if ids is not None else None
         img, ctx.ws_img = ri if ri is not None else (None, None)
         txt, ctx.ws_txt = rt if rt is not None else (None, None)
@@ -493,7 +526,7 @@ class _EncodeFn(torch.autograd.Function):
             tower = P.grad_group(n)[0]
             ran = tower < 2 and ctx.has[tower]
             out.append(views[n] if (n in views and ran and params[n].requires_grad) else None)
-        return (None, None, None, None) + tuple(out)
+        return (None, None, None, None, None) + tuple(out)
 
 
 class _SimilarityFn(torch.autograd.Function):
@@ -928,13 +961,13 @@ class CLIPApp(Application):
         drop = self._next_dropout()
         eng.set_text_dropout(*drop)
         pack = False
-        if eng.can_pack(backward) and input_ids.shape[1] >= 8:      # (device ids: one small sync, before anything is enqueued)
-            pack = eng.pack_meta(input_ids, None if extras is None else extras[2]) or False
+        if eng.can_pack(backward) and input_ids.shape[1] >= 8:      # (device ids: one launch; its scalars are read in encode_text,
+            pack = eng.pack_meta(input_ids, None if extras is None else extras[2]) or False     # after the image tower is enqueued)
         eng.last_pack = None
         (img, ws_i), (txt, ws_t) = _run_towers(
             eng, self.two_streams,
             lambda s_: eng.encode_image(pixel_values, backward, stream=s_),
-            lambda s_: eng.encode_text(input_ids, backward, extras=extras, stream=s_, pack=pack))
+            lambda s_: eng.encode_text(input_ids, backward, extras=extras, stream=s_, pack=pack), image_first=True)
         n = img.shape[0]
         e = img.shape[1]
         if world > 1:
@@ -1004,7 +1037,9 @@ class CLIPApp(Application):
         return [self._params[n] for n in self._engine.names]
 
     # ------------------------------------------------------------------------------------
-    def encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+    def encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None, pack_hint=None):
+        """pack_hint: packing metadata of ``input_ids`` computed from their host copy (``forward``), False = do not pack, None =
+        decide here."""
         if getattr(self, "model_type", None) == "huggingface_clip":
             from .hf_branch import HFEncodeFn
             plist = [self._hf_params[n] for n in self._hf_param_order]
@@ -1013,7 +1048,7 @@ class CLIPApp(Application):
             return (img if pixel_values is not None else None), (txt if input_ids is not None else None)
         plist = self._plist()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
-        img, txt = _EncodeFn.apply(self, need_grad, pixel_values, input_ids, *plist)
+        img, txt = _EncodeFn.apply(self, need_grad, pack_hint, pixel_values, input_ids, *plist)
         return (img if pixel_values is not None else None), (txt if input_ids is not None else None)
 
     def forward(self, inputs, feat=None):
@@ -1029,14 +1064,16 @@ class CLIPApp(Application):
             inputs["pixel_values"] = None
         if "input_ids" in inputs and inputs["input_ids"] is not None:
             ids_in = inputs["input_ids"]
-            self.__dict__.pop("_pack_hint", None)
+            pack_hint = None
             if (not ids_in.is_cuda and ids_in.dim() == 2 and ids_in.shape[1] >= 8 and self._engine is not None
                     and self._engine.pack_text and getattr(self, "model_type", None) == "chinese_clip"):
-                # which tokens the text tower has to see, from the host copy the DataLoader delivered (no device sync later)
-                self._pack_hint = self._engine.pack_meta(ids_in, device=_device) or False
+                # which tokens the text tower has to see, from the host copy the DataLoader delivered (no device sync later);
+                # handed to encode() explicitly -- it belongs to THIS call's ids
+                pack_hint = self._engine.pack_meta(ids_in, device=_device) or False
             inputs["input_ids"] = ids_in.to(_device)
         else:
             inputs["input_ids"] = None
+            pack_hint = None
         assert inputs["pixel_values"] is not None or inputs["input_ids"] is not None, \
             "text and image cannot both be None!"
         if getattr(self, "model_type", None) == "huggingface_clip" and inputs["input_ids"] is not None:
@@ -1044,7 +1081,8 @@ class CLIPApp(Application):
             image_embeds, text_embeds = self.encode(inputs["pixel_values"], inputs["input_ids"],
                                                     inputs["token_type_ids"].to(_device), inputs["attention_mask"].to(_device))
         else:
-            image_embeds, text_embeds = self.encode(inputs["pixel_values"], inputs["input_ids"])
+            kw = {} if pack_hint is None else {"pack_hint": pack_hint}
+            image_embeds, text_embeds = self.encode(inputs["pixel_values"], inputs["input_ids"], **kw)
         if feat is True:
             return {"image_embeds": image_embeds, "text_embeds": text_embeds}
         if self.contrastive_scope == "global" and self.training:

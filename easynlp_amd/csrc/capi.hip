@@ -1,6 +1,9 @@
 // extern "C" surface of libezclip_hip.so (declared in include/ezclip.h).
 #include <cstring>
 
+#include <chrono>
+#include <thread>
+
 #include "model.h"
 
 using namespace ezclip;
@@ -68,7 +71,10 @@ const char* ezclip_version(void) { return "ezclip-hip 0.1 (gfx950)"; }
 int ezclip_create(const ezclip_config* cfg, ezclip_handle* out) { return model_create(cfg, out, 0); }
 int ezclip_create_ex(const ezclip_config* cfg, int text_arch, ezclip_handle* out) { return model_create(cfg, out, text_arch); }
 
-void ezclip_destroy(ezclip_handle h) { delete h; }
+void ezclip_destroy(ezclip_handle h) {
+  if (h && h->pm_host) (void)hipHostFree(h->pm_host);
+  delete h;
+}
 
 int ezclip_num_params(ezclip_handle h) { return h ? (int)h->params.size() : 0; }
 
@@ -250,6 +256,46 @@ int ezclip_backward_text(ezclip_handle h, const int64_t* ids, int batch, int seq
   return backward_text(h, ids, batch, seq_len, d_emb, ws, ws_bytes, S(stream));
 }
 
+int ezclip_pack_text_meta(ezclip_handle h, const int64_t* ids, const int64_t* attention_mask, int batch, int seq_len,
+                          int32_t* rowmap, int32_t* cu, int32_t* lens, int* ticket, void* stream) {
+  EZ_REQUIRE(h && ticket, "ezclip_pack_text_meta: null handle / ticket");
+  if (!h->pm_host) {
+    void* p = nullptr;
+    EZ_HIP(hipHostMalloc(&p, 8 * 4 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+    h->pm_host = (int*)p;
+    for (int i = 0; i < 32; ++i) h->pm_host[i] = 0;
+    void* d = nullptr;
+    EZ_HIP(hipHostGetDevicePointer(&d, p, 0));
+    h->pm_dev = (int*)d;
+  }
+  const int t = ++h->pm_ticket;          // (tickets start at 1: a zeroed slot never matches)
+  const int slot = t & 7;
+  int rc = pack_text_meta(ids, attention_mask, batch, seq_len, rowmap, cu, lens, h->pm_dev + 4 * slot, t, S(stream));
+  if (rc != EZ_OK) return rc;
+  *ticket = t;
+  return EZ_OK;
+}
+
+int ezclip_pack_text_meta_result(ezclip_handle h, int ticket, int* rows, int* longest, int* prefix) {
+  EZ_REQUIRE(h && h->pm_host && rows && longest && prefix, "ezclip_pack_text_meta_result: nothing was enqueued");
+  EZ_REQUIRE(ticket > 0 && ticket <= h->pm_ticket && h->pm_ticket - ticket < 8,
+             "ezclip_pack_text_meta_result: ticket %d is not among the last 8 (newest %d)", ticket, h->pm_ticket);
+  volatile int* s = h->pm_host + 4 * (ticket & 7);
+  // the kernel writes the three values, fences, then the ticket word: poll it (the stream is NOT synchronised; other work
+  // queued behind the kernel keeps the device busy while the host waits for this one launch)
+  const auto t0 = std::chrono::steady_clock::now();
+  long spins = 0;
+  while (__atomic_load_n((const int*)(s + 3), __ATOMIC_ACQUIRE) != ticket) {
+    if ((++spins & 1023) == 0) {
+      const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (sec > 120.0) { set_error("ezclip_pack_text_meta_result: ticket %d did not arrive within 120 s", ticket); return EZ_ERR_STATE; }
+      if (sec > 0.002) std::this_thread::yield();
+    }
+  }
+  *rows = s[0]; *longest = s[1]; *prefix = s[2];
+  return EZ_OK;
+}
+
 int ezclip_set_backward_progress(ezclip_handle h, ezclip_progress_fn fn, void* user) {
   EZ_REQUIRE(h, "ezclip_set_backward_progress: null handle");
   h->progress_fn = fn;
@@ -427,12 +473,12 @@ int ezclip_op_layernorm_bwd(const void* x, const void* dy, const float* g, const
   return layernorm_bwd(x, d, dy, d, g, mean, rstd, dx, d, nullptr, 0, dg, db, rows, d, dtype, S(stream));
 }
 
-static DropCfg g_op_attn_drop;   // ezclip_op_set_attention_dropout
-static int g_op_attn_causal = 0; // ezclip_op_set_attention_causal
-int ezclip_op_set_attention_causal(int on) { g_op_attn_causal = on != 0; return EZ_OK; }
-int ezclip_op_set_attention_dropout(float p, uint64_t seed, uint32_t site) {
-  if (!(p >= 0.f && p < 1.f)) { set_error("dropout probability %g outside [0, 1)", (double)p); return EZ_ERR_INVALID; }
-  g_op_attn_drop = make_drop(p, seed, site);
+// causal mask / dropout of an op-level attention call (NULL: neither) -- arguments of the call, not process state
+static int attn_opts(const ezclip_attention_opts* o, AttnArgs& a) {
+  if (!o) return EZ_OK;
+  if (!(o->dropout_p >= 0.f && o->dropout_p < 1.f)) { set_error("dropout probability %g outside [0, 1)", (double)o->dropout_p); return EZ_ERR_INVALID; }
+  a.causal = o->causal != 0;
+  if (o->dropout_p > 0.f) a.drop = make_drop(o->dropout_p, o->dropout_seed, o->dropout_site);
   return EZ_OK;
 }
 int ezclip_op_dropout(const void* x, const void* residual, void* y, int rows, int d, float p, uint64_t seed,
@@ -447,10 +493,10 @@ int ezclip_op_dropout_mask(float p, uint64_t seed, uint32_t site, int rows, int 
 }
 
 int ezclip_op_attention(const void* q, const void* k, const void* v, int64_t row_stride, void* ctx, int64_t ctx_stride,
-                        const float* key_bias, float* lse, int batch, int seq_len, int heads, int dtype, void* stream) {
+                        const float* key_bias, float* lse, int batch, int seq_len, int heads, int dtype,
+                        const ezclip_attention_opts* opts, void* stream) {
   AttnArgs a;
-  a.drop = g_op_attn_drop;
-  a.causal = g_op_attn_causal;
+  API_TRY(attn_opts(opts, a));
   a.q = q; a.k = k; a.v = v; a.row_stride = row_stride; a.ctx = ctx; a.ctx_stride = ctx_stride;
   a.key_bias = key_bias; a.lse = lse; a.B = batch; a.L = seq_len; a.H = heads; a.scale = 0.125f;
   return attention_fwd(a, dtype, S(stream));
@@ -458,10 +504,10 @@ int ezclip_op_attention(const void* q, const void* k, const void* v, int64_t row
 
 int ezclip_op_attention_bwd(const void* q, const void* k, const void* v, int64_t row_stride, const void* ctx,
                             const void* dctx, int64_t ctx_stride, const float* key_bias, const float* lse, void* dq,
-                            void* dk, void* dv, int batch, int seq_len, int heads, int dtype, void* stream) {
+                            void* dk, void* dv, int batch, int seq_len, int heads, int dtype, const ezclip_attention_opts* opts,
+                            void* stream) {
   AttnBwdArgs b;
-  b.f.drop = g_op_attn_drop;
-  b.f.causal = g_op_attn_causal;
+  API_TRY(attn_opts(opts, b.f));
   b.f.q = q; b.f.k = k; b.f.v = v; b.f.row_stride = row_stride; b.f.ctx = const_cast<void*>(ctx);
   b.f.ctx_stride = ctx_stride; b.f.key_bias = key_bias; b.f.lse = const_cast<float*>(lse);
   b.f.B = batch; b.f.L = seq_len; b.f.H = heads; b.f.scale = 0.125f;
@@ -472,10 +518,9 @@ int ezclip_op_attention_bwd(const void* q, const void* k, const void* v, int64_t
 int ezclip_op_attention_bwd_bias(const void* q, const void* k, const void* v, int64_t row_stride, const void* ctx,
                                  const void* dctx, int64_t ctx_stride, const float* key_bias, const float* lse, void* dq,
                                  void* dk, void* dv, float* dbq, float* dbk, float* dbv, float* db_scratch, int batch,
-                                 int seq_len, int heads, int dtype, void* stream) {
+                                 int seq_len, int heads, int dtype, const ezclip_attention_opts* opts, void* stream) {
   AttnBwdArgs b;
-  b.f.drop = g_op_attn_drop;
-  b.f.causal = g_op_attn_causal;
+  API_TRY(attn_opts(opts, b.f));
   b.f.q = q; b.f.k = k; b.f.v = v; b.f.row_stride = row_stride; b.f.ctx = const_cast<void*>(ctx);
   b.f.ctx_stride = ctx_stride; b.f.key_bias = key_bias; b.f.lse = const_cast<float*>(lse);
   b.f.B = batch; b.f.L = seq_len; b.f.H = heads; b.f.scale = 0.125f;

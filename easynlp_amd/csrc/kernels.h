@@ -232,6 +232,9 @@ int infonce_dlogits(const float* S, int n, const float* lse_r, const float* lse_
                     hipStream_t stream);
 // sim [rows, n] = queries row0 .. row0 + rows - 1 against all n gallery items; rank[r] for query row0 + r
 int recall_ranks(const float* sim, int rows, int n, int row0, int32_t* rank, hipStream_t stream);
+// packing metadata of a text batch in one launch; (rows, longest, prefix, ticket) land in pinned host memory (packmeta.hip)
+int pack_text_meta(const int64_t* ids, const int64_t* mask, int B, int S, int* rowmap, int* cu, int* lens, int* host_out_dev,
+                   int ticket, hipStream_t stream);
 // Tiled InfoNCE on embeddings (nce.hip): no [n, N] buffer; split = 1: operands as bf16 hi + lo (float32-class), 0: bf16
 bool infonce_tiled_eligible(int e);
 size_t infonce_tiled_workspace_bytes(int n, int N, int e);

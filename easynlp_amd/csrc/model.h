@@ -84,6 +84,11 @@ struct ezclip_model {
   void* progress_user = nullptr;
   void progress(int tower, int stage) const { if (progress_fn) progress_fn(progress_user, tower, stage); }
 
+  // ezclip_pack_text_meta: a ring of 8 x 4 ints of pinned, device-mapped host memory (rows, longest, prefix, ticket)
+  int* pm_host = nullptr;
+  int* pm_dev = nullptr;
+  int pm_ticket = 0;
+
   void* shadow = nullptr;
   size_t shadow_bytes = 0;
   bool shadow_backward = false;

@@ -34,6 +34,23 @@ class EzclipConfig(C.Structure):
         "text_num_attention_heads", "text_num_hidden_layers", "text_type_vocab_size", "compute_dtype")]
 
 
+class EzclipAttentionOpts(C.Structure):
+    """ezclip_attention_opts (include/ezclip.h)"""
+    _fields_ = [("causal", C.c_int32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("dropout_site", C.c_uint32),
+                ("reserved_", C.c_uint32)]
+
+
+def attention_opts(causal=False, dropout=None):
+    """None, or a pointer to the options of one op-level attention call; dropout = (p, seed, site)."""
+    if not causal and not dropout:
+        return None
+    o = EzclipAttentionOpts()
+    o.causal = 1 if causal else 0
+    if dropout:
+        o.dropout_p, o.dropout_seed, o.dropout_site = float(dropout[0]), int(dropout[1]), int(dropout[2])
+    return C.cast(C.pointer(o), C.c_void_p)
+
+
 class EzclipImageDesc(C.Structure):
     _fields_ = [("offset", C.c_uint64), ("width", C.c_int32), ("height", C.c_int32)]
 
@@ -76,6 +93,8 @@ SIGNATURES = {
     "ezclip_infonce_workspace_bytes": (_sz, [_i, _i, _i]),
     "ezclip_infonce_fused": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ezclip_infonce_tiled_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ezclip_pack_text_meta": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, C.POINTER(C.c_int), _vp]),
+    "ezclip_pack_text_meta_result": (_i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ezclip_infonce_tiled": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ezclip_backward_image": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "ezclip_backward_text": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
@@ -91,10 +110,10 @@ SIGNATURES = {
     "ezclip_op_gemm_tn": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "ezclip_op_layernorm": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     "ezclip_op_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "ezclip_op_attention": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "ezclip_op_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ezclip_op_attention": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ezclip_op_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ezclip_op_attention_bwd_bias": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                          _i, _i, _i, _i, _vp]),
+                                          _i, _i, _i, _i, _vp, _vp]),
     "ezclip_preprocess_workspace_bytes": (_sz, [C.POINTER(EzclipImageDesc), _i, _i, _i]),
     "ezclip_preprocess_images": (_i, [_vp, C.POINTER(EzclipImageDesc), _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp,
                                       _sz, _vp]),
@@ -108,8 +127,6 @@ SIGNATURES = {
     "ezclip_set_text_dropout": (_i, [_vp, _f, _f, C.c_uint64]),
     "ezclip_op_dropout": (_i, [_vp, _vp, _vp, _i, _i, _f, C.c_uint64, C.c_uint32, _i, _vp]),
     "ezclip_op_dropout_mask": (_i, [_f, C.c_uint64, C.c_uint32, _i, _i, _vp, _vp, _vp]),
-    "ezclip_op_set_attention_dropout": (_i, [_f, C.c_uint64, C.c_uint32]),
-    "ezclip_op_set_attention_causal": (_i, [_i]),
     "ezclip_op_attention_cls": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "ezclip_op_attention_cls_bwd": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "ezclip_op_cast_from_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
@@ -246,8 +263,8 @@ def op_layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float, 
     return (y, mean, rstd) if want_stats else y
 
 
-def op_attention(qkv: torch.Tensor, batch: int, seq_len: int, heads: int, key_bias=None, want_lse=False):
-    """qkv: [batch*seq_len, 3*heads*64] packed (q | k | v); returns ctx [batch*seq_len, heads*64]."""
+def op_attention(qkv: torch.Tensor, batch: int, seq_len: int, heads: int, key_bias=None, want_lse=False, causal=False, dropout=None):
+    """qkv: [batch*seq_len, 3*heads*64] packed (q | k | v); returns ctx [batch*seq_len, heads*64].  dropout = (p, seed, site)."""
     lib = load()
     dt = DTYPE_BF16 if qkv.dtype == torch.bfloat16 else DTYPE_F32
     D = heads * 64
@@ -256,12 +273,12 @@ def op_attention(qkv: torch.Tensor, batch: int, seq_len: int, heads: int, key_bi
     lse = torch.empty((batch, heads, seq_len), dtype=torch.float32, device=qkv.device) if want_lse else None
     base = ptr(qkv)
     check(lib.ezclip_op_attention(base, base + D * esz, base + 2 * D * esz, 3 * D, ptr(ctx), D, ptr(key_bias),
-                                  ptr(lse), batch, seq_len, heads, dt, stream_ptr()), "op_attention")
+                                  ptr(lse), batch, seq_len, heads, dt, attention_opts(causal, dropout), stream_ptr()), "op_attention")
     return (ctx, lse) if want_lse else ctx
 
 
 def op_attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, lse: torch.Tensor, batch: int, seq_len: int,
-                     heads: int, key_bias=None) -> torch.Tensor:
+                     heads: int, key_bias=None, causal=False, dropout=None) -> torch.Tensor:
     """Gradient of op_attention w.r.t. the packed qkv (same [batch*seq_len, 3*heads*64] layout)."""
     lib = load()
     dt = DTYPE_BF16 if qkv.dtype == torch.bfloat16 else DTYPE_F32
@@ -271,7 +288,7 @@ def op_attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, l
     base, dbase = ptr(qkv), ptr(dqkv)
     check(lib.ezclip_op_attention_bwd(base, base + D * esz, base + 2 * D * esz, 3 * D, ptr(ctx), ptr(dctx), D,
                                       ptr(key_bias), ptr(lse), dbase, dbase + D * esz, dbase + 2 * D * esz, batch,
-                                      seq_len, heads, dt, stream_ptr()), "op_attention_bwd")
+                                      seq_len, heads, dt, attention_opts(causal, dropout), stream_ptr()), "op_attention_bwd")
     return dqkv
 
 
@@ -295,10 +312,6 @@ def op_dropout_mask(p: float, seed: int, site: int, rows: int, cols: int, device
     if want_words:
         return keep, words.to(torch.int64) & 0xFFFFFFFF
     return keep
-
-
-def op_set_attention_dropout(p: float, seed: int = 0, site: int = 0) -> None:
-    check(load().ezclip_op_set_attention_dropout(float(p), int(seed), int(site)), "op_set_attention_dropout")
 
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)      # easynlp/appzoo/clip/data.py:101
@@ -376,10 +389,6 @@ def preprocess_images(images, size: int = 224, crop: int = 224, mean=CLIP_MEAN, 
     # the pinned host copy and the workspace must outlive the enqueued work
     out._ezclip_keepalive = (host, packed, ws)
     return out
-
-
-def op_set_attention_causal(on: bool) -> None:
-    check(load().ezclip_op_set_attention_causal(1 if on else 0), "op_set_attention_causal")
 
 
 def similarity(a: torch.Tensor, b: torch.Tensor, logit_scale: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -156,8 +156,15 @@ class GradArena:
         self.views = self.make_views(self.flat) if keep_views else {}
         self._base_refs = self._storage_refs()
 
+    _warned_no_use_count = False
+
     def _storage_refs(self) -> int:
         fn = getattr(torch._C, "_storage_Use_Count", None)
+        if fn is None and not GradArena._warned_no_use_count:
+            GradArena._warned_no_use_count = True
+            import warnings
+            warnings.warn("torch._C._storage_Use_Count is missing in this torch build: the autograd path cannot tell whether its "
+                          "gradient arena is still referenced and allocates (and zeroes) a fresh one for every backward pass")
         return int(fn(self.flat.untyped_storage()._cdata)) if fn is not None else -1
 
     def lent(self) -> bool:
@@ -201,6 +208,7 @@ class OverlappedGradReducer:
         self._sent = 0                 # element offset up to which buckets have been launched
         self._works: List = []
         self.buckets: List[Tuple[int, int]] = []
+        self._error: Optional[BaseException] = None
 
     def _frontier(self) -> int:
         end = self._sent
@@ -227,6 +235,16 @@ class OverlappedGradReducer:
         self._sent = upto
 
     def notify(self, tower: int, stage: int) -> None:
+        """Called through a ctypes callback from inside ezclip_backward_*: an exception raised here would be swallowed by
+        ctypes (printed, not propagated) and leave gradients unreduced -- it is kept and re-raised by ``finish()``."""
+        if self._error is not None:
+            return
+        try:
+            self._notify(tower, stage)
+        except BaseException as e:      # noqa: BLE001  (re-raised in finish())
+            self._error = e
+
+    def _notify(self, tower: int, stage: int) -> None:
         ev = None
         if self.arena.flat.is_cuda:
             ev = torch.cuda.Event()
@@ -238,6 +256,13 @@ class OverlappedGradReducer:
 
     def finish(self) -> None:
         """Every group is final (the backward calls have returned): send what is left, wait, scale."""
+        if self._error is not None:
+            err, self._error = self._error, None
+            for w in self._works:           # (do not leave collectives of the buckets already sent unwaited)
+                if w is not None:
+                    w.wait()
+            self._works = []
+            raise RuntimeError("a gradient bucket could not be launched from the backward progress hook") from err
         self._launch(self.arena.total)
         for w in self._works:
             if w is not None:

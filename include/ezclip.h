@@ -168,6 +168,19 @@ int ezclip_backward_text_packed(ezclip_handle h, const int64_t* input_ids_dev, c
                                 int max_len, const float* d_embeds_dev, void* workspace_dev, size_t workspace_bytes,
                                 void* stream);
 
+/* The packing metadata itself, built on the device in ONE launch and handed to the host without a stream synchronisation
+ * (round 3, csrc/packmeta.hip): keep[b][t] = mask[b][t] != 0 (mask = attention_mask_dev, or input_ids_dev when it is NULL:
+ * modeling_chineseclip.py:347) or t == 0 or sentence b has no unmasked token.  rowmap [batch * seq_len] (first `rows` entries
+ * written), cu [batch], lens [batch]: int32 device buffers of the caller.  The launch is asynchronous on `stream`; *ticket
+ * identifies it.  ezclip_pack_text_meta_result blocks the HOST until that one launch has written its result words into pinned
+ * host memory owned by the handle (a polled flag -- no hipStreamSynchronize, no hipMemcpy; work queued behind the launch keeps
+ * the device busy) and returns rows (= packed_rows), longest (= max_len) and prefix (1: the kept tokens of every sentence are a
+ * prefix -- the condition for packing under dropout).  At most 8 tickets may be outstanding.  seq_len <= 512. */
+int ezclip_pack_text_meta(ezclip_handle h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev, int batch,
+                          int seq_len, int32_t* rowmap_dev, int32_t* cu_dev, int32_t* lens_dev, int* ticket, void* stream);
+int ezclip_pack_text_meta_result(ezclip_handle h, int ticket, int* rows, int* longest, int* prefix);
+
+
 /* Train-mode dropout of the BERT text tower: nn.Dropout(hidden_dropout_prob) after the embedding LayerNorm, after
  * BertSelfOutput.dense and BertOutput.dense, nn.Dropout(attention_probs_dropout_prob) on the attention probabilities
  * (easynlp/modelzoo/models/bert/modeling_bert.py:128,238,266,344; probabilities from CHINESE_CLIP's
@@ -353,13 +366,24 @@ int ezclip_op_layernorm(const void* x_dev, int64_t x_stride, void* y_dev, int64_
 int ezclip_op_layernorm_bwd(const void* x_dev, const void* dy_dev, const float* g_dev, const float* mean_dev,
                             const float* rstd_dev, void* dx_dev, float* dg_dev, float* db_dev, int rows, int d,
                             int dtype, void* stream);
+/* Options of ONE op-level attention call (round 3: arguments, no longer process-wide switches -- two users of the library in one
+ * process cannot disturb each other).  NULL = plain softmax(QK^T / 8 + key_bias) V.
+ *   causal        key index > query index -> -inf (OPEN_CLIP.build_attention_mask, modeling_openclip.py:343-349)
+ *   dropout_p/_seed/_site   dropout on the probabilities with the library's counter-based mask (see ezclip_op_dropout_mask) */
+typedef struct ezclip_attention_opts {
+  int32_t causal;
+  float dropout_p;
+  uint64_t dropout_seed;
+  uint32_t dropout_site;
+  uint32_t reserved_;
+} ezclip_attention_opts;
 int ezclip_op_attention(const void* q_dev, const void* k_dev, const void* v_dev, int64_t row_stride, void* ctx_dev,
                         int64_t ctx_stride, const float* key_bias_dev, float* lse_dev, int batch, int seq_len,
-                        int heads, int dtype, void* stream);
+                        int heads, int dtype, const ezclip_attention_opts* opts, void* stream);
 int ezclip_op_attention_bwd(const void* q_dev, const void* k_dev, const void* v_dev, int64_t row_stride,
                             const void* ctx_dev, const void* dctx_dev, int64_t ctx_stride, const float* key_bias_dev,
                             const float* lse_dev, void* dq_dev, void* dk_dev, void* dv_dev, int batch, int seq_len,
-                            int heads, int dtype, void* stream);
+                            int heads, int dtype, const ezclip_attention_opts* opts, void* stream);
 /* The same with the gradients of the q / k / v projection biases: db*[h*64 + d] += sum over (sample, token) of dq / dk / dv
  * (f32 [heads*64] each, ACCUMULATED into).  db_scratch_dev: batch * 3 * heads * 64 floats (per-sample partial sums of the fused
  * short-sequence kernel; unused by the general kernels, may then be NULL).  The towers' backward passes call
@@ -369,7 +393,7 @@ int ezclip_op_attention_bwd_bias(const void* q_dev, const void* k_dev, const voi
                                  const void* ctx_dev, const void* dctx_dev, int64_t ctx_stride, const float* key_bias_dev,
                                  const float* lse_dev, void* dq_dev, void* dk_dev, void* dv_dev, float* dbq_dev, float* dbk_dev,
                                  float* dbv_dev, float* db_scratch_dev, int batch, int seq_len, int heads, int dtype,
-                                 void* stream);
+                                 const ezclip_attention_opts* opts, void* stream);
 /* Dropout building blocks (parity tests feed the library's own masks to the oracle).
  * Element (row, col) of site `site` is kept iff philox4x32_10(ctr = (col>>2, row, site, 0), key = seed)[col&3] >=
  * round(p * 2^32); survivors are scaled by 1/(1-p).  Text-tower sites: 0 = embeddings; layer i: 1+3i attention
@@ -378,11 +402,6 @@ int ezclip_op_dropout(const void* x_dev, const void* residual_dev, void* y_dev, 
                       uint32_t site, int dtype, void* stream);                    /* y = dropout(x) [+ residual] */
 int ezclip_op_dropout_mask(float p, uint64_t seed, uint32_t site, int rows, int cols, uint8_t* keep_dev,
                            uint32_t* words_dev, void* stream);                    /* either output may be NULL */
-/* dropout applied by the following ezclip_op_attention / ezclip_op_attention_bwd calls (p = 0: off) */
-int ezclip_op_set_attention_dropout(float p, uint64_t seed, uint32_t site);
-/* causal mask (key index > query index -> -inf, OPEN_CLIP.build_attention_mask, modeling_openclip.py:343-349) for the
- * following ezclip_op_attention / ezclip_op_attention_bwd calls */
-int ezclip_op_set_attention_causal(int on);
 /* One query per sample (the CLS row of a tower's last block): q_cls [batch, q_stride] holds the queries (heads
  * side by side), k / v as in ezclip_op_attention, ctx_cls / dctx_cls [batch, ctx_stride].  The backward writes dk / dv for every
  * key and dq either as row 0 of each sample in the full block `dq_dev` (other rows zeroed) or, when dq_cls_dev is given, into

@@ -20,6 +20,7 @@ GPU_FILE_ORDER = [
     "test_00_canary_gpu.py",
     "test_model_gpu.py",            # golden forward / backward of the towers, loss, packed text batches
     "test_ops_gpu.py",              # every kernel against fp64 / the oracle
+    "test_pack_meta_gpu.py",
     "test_dropout.py",
     "test_hf_gpu.py", "test_openclip_gpu.py", "test_wukong_gpu.py",
     "test_resnet_gpu.py",

@@ -145,7 +145,7 @@ def _ddp_worker(rank, world, port, ckpt, q):
     try:
         from easynlp_amd.appzoo.clip import model as CM
 
-        def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+        def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None, pack_hint=None):
             sd = {n: p for n, p in self.chinese_clip.named_parameters()}
             return (O.encode_image(sd, self.raw_config, pixel_values) if pixel_values is not None else None,
                     O.encode_text(sd, self.raw_config, input_ids) if input_ids is not None else None)
@@ -202,9 +202,9 @@ def test_dropin_app_global_scope_under_real_ddp_world2_gloo(tmp_path):
     assert all(r[1] == "ok" for r in res), res
 
 
-@pytest.mark.parametrize("world,n,e", [(2, 3, 8), (2, 16, 32), (4, 5, 16)])
+@pytest.mark.parametrize("world,n,e", [(2, 3, 8), (2, 16, 32), (4, 5, 16), (8, 3, 16)])
 def test_global_contrastive_exchange_world2_gloo(world, n, e):
-    """(world 4: ranks 2 and 3 sit at offsets the two-rank run never forms -- the north star runs 8)"""
+    """(world 4: ranks 2 and 3 sit at offsets the two-rank run never forms; world 8: the north star's node)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

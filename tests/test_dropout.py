@@ -136,13 +136,9 @@ def test_attention_with_dropout_forward_and_backward(dtype, Lq):
     kb = torch.zeros(B, Lq)
     kb[1, Lq - 5:] = -10000.0
     keep = L.op_dropout_mask(p, seed, site, B * heads * Lq, Lq, "cuda").cpu().bool().reshape(B, heads, Lq, Lq)
-    L.op_set_attention_dropout(p, seed, site)
-    try:
-        ctx, lse = L.op_attention(qkv.cuda(), B, Lq, heads, key_bias=kb.reshape(-1).cuda(), want_lse=True)
-        dqkv = L.op_attention_bwd(qkv.cuda(), ctx, dctx.cuda(), lse, B, Lq, heads, key_bias=kb.reshape(-1).cuda())
-        dq, dk, dv = dqkv.split(D, dim=-1)
-    finally:
-        L.op_set_attention_dropout(0.0)
+    ctx, lse = L.op_attention(qkv.cuda(), B, Lq, heads, key_bias=kb.reshape(-1).cuda(), want_lse=True, dropout=(p, seed, site))
+    dqkv = L.op_attention_bwd(qkv.cuda(), ctx, dctx.cuda(), lse, B, Lq, heads, key_bias=kb.reshape(-1).cuda(), dropout=(p, seed, site))
+    dq, dk, dv = dqkv.split(D, dim=-1)
     ref_in = qkv.double().requires_grad_(True)
     ref = _attn_reference(ref_in, B, Lq, heads, kb.double(), keep, p)
     ref.backward(dctx.double())

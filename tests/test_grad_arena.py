@@ -110,7 +110,8 @@ def _worker(rank, world, port, q):
         names, shapes = _names_shapes()
         cfg = O.CONFIGS["tiny"]
         a = P.GradArena(names, shapes, "cpu")
-        r = P.OverlappedGradReducer(a, None, bucket_bytes=8 << 10)
+        # (a bucket size no group boundary is a multiple of: buckets end wherever a notification pushes the range over it)
+        r = P.OverlappedGradReducer(a, None, bucket_bytes=8 << 10 if world < 8 else 7001)
         g = torch.Generator().manual_seed(7)
         full = [torch.randn(a.total, generator=g) for _ in range(world)]       # every rank knows every rank's gradients
         # the backward pass fills the groups in completion order and notifies after each -- buckets fly in between
@@ -133,6 +134,14 @@ def _worker(rank, world, port, q):
             r2.notify(*grp)
         r2.finish()
         assert torch.allclose(a.flat, want / world, atol=1e-6)
+        # the evaluator's sharded recall ranks: every rank fills its slice, one all-gather into a SEPARATE buffer
+        from easynlp_amd.appzoo.clip.evaluator import gather_rank_shards
+        n_q = 4 * world - 1                                   # (the last rank's slice is ragged)
+        per = (n_q + world - 1) // world
+        mine = torch.zeros(per * world, dtype=torch.int32)
+        mine[rank * per:(rank + 1) * per] = torch.arange(rank * per, (rank + 1) * per, dtype=torch.int32) * 3 + 1
+        got = gather_rank_shards(mine, rank, per, n_q)
+        assert torch.equal(got, torch.arange(n_q, dtype=torch.int32) * 3 + 1)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -141,8 +150,9 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_overlapped_reduction_two_gloo_ranks(world):
+    """(world 8: the north star's node -- eight ranks, a bucket size that is no multiple of any group boundary)"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -153,6 +163,28 @@ def test_overlapped_reduction_two_gloo_ranks(world):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_a_failed_bucket_launch_inside_the_progress_hook_is_raised_by_finish():
+    """notify() runs inside a ctypes callback (from within ezclip_backward_*), where an exception would be printed and
+    dropped: the reducer keeps it, stops sending, and finish() raises it -- gradients are never left silently unreduced."""
+    names, shapes = _names_shapes()
+    a = P.GradArena(names, shapes, "cpu")
+    calls = []
+
+    def flaky(t):
+        calls.append(t.numel())
+        if len(calls) == 2:
+            raise RuntimeError("collective failed")
+        return None
+    r = P.OverlappedGradReducer(a, bucket_bytes=1, all_reduce=flaky)
+    for g in progress_sequence(O.CONFIGS["tiny"]):
+        r.notify(*g)                     # (never raises: it is a callback)
+    assert len(calls) == 2               # nothing was sent after the failure
+    with pytest.raises(RuntimeError, match="gradient bucket"):
+        r.finish()
+    r.reset()
+    r.finish()                           # usable again after reset()
 
 
 @pytest.mark.skipif(not R.reference_available(), reason="reference checkout not present")

@@ -182,12 +182,8 @@ def test_attention_f32_long_sequences_walk_the_keys_in_blocks(Lq, masked, causal
         s_ = s_.masked_fill(torch.triu(torch.ones(Lq, Lq, dtype=torch.bool), 1), float("-inf"))
     ref = (torch.softmax(s_, -1) @ v).transpose(1, 2).reshape(B_ * Lq, D)
     ref_lse = torch.logsumexp(s_, -1)
-    L.op_set_attention_causal(causal)
-    try:
-        ctx, lse = L.op_attention(qkv.to(DEV), B_, Lq, H, key_bias=None if kb is None else kb.to(DEV), want_lse=True)
-        torch.cuda.synchronize()
-    finally:
-        L.op_set_attention_causal(False)
+    ctx, lse = L.op_attention(qkv.to(DEV), B_, Lq, H, key_bias=None if kb is None else kb.to(DEV), want_lse=True, causal=causal)
+    torch.cuda.synchronize()
     assert max_err(ctx, ref) < 2e-5
     assert max_err(lse, ref_lse) < 1e-4
 
@@ -492,7 +488,7 @@ def test_attention_bwd_projection_bias_gradients(B_, Lq, H, dtype, masked):
     base, dbase, bb = qg.data_ptr(), dqkv.data_ptr(), db.data_ptr()
     L.check(lib.ezclip_op_attention_bwd_bias(base, base + D * esz, base + 2 * D * esz, 3 * D, ctx.data_ptr(), dg_.data_ptr(), D,
                                              L.ptr(kbg), lse.data_ptr(), dbase, dbase + D * esz, dbase + 2 * D * esz,
-                                             bb, bb + 4 * D, bb + 8 * D, scratch.data_ptr(), B_, Lq, H, dt, L.stream_ptr()))
+                                             bb, bb + 4 * D, bb + 8 * D, scratch.data_ptr(), B_, Lq, H, dt, None, L.stream_ptr()))
     torch.cuda.synchronize()
     got = db.cpu().double() - start.double()
     scale = float(ref_db.abs().max())
@@ -627,12 +623,12 @@ def test_attention_causal_forward_and_backward(Lq, dtype, variant):
     ref.backward(dctx.double())
     lib = L.load()
     L.check(lib.ezclip_debug_set(1, variant))
-    L.op_set_attention_causal(True)
     try:
-        ctx, lse = L.op_attention(qkv.to(DEV), B_, Lq, H, want_lse=True)
-        dqkv = L.op_attention_bwd(qkv.to(DEV), ctx, dctx.to(DEV), lse, B_, Lq, H)
+        ctx, lse = L.op_attention(qkv.to(DEV), B_, Lq, H, want_lse=True, causal=True)
+        dqkv = L.op_attention_bwd(qkv.to(DEV), ctx, dctx.to(DEV), lse, B_, Lq, H, causal=True)
+        # (the option is an argument of the call: the next call without it is a plain one)
+        assert max_err(L.op_attention(qkv.to(DEV), B_, Lq, H).float(), ctx.float()) > 1e-3
     finally:
-        L.op_set_attention_causal(False)
         L.check(lib.ezclip_debug_set(1, -1))
     assert max_err(ctx.float(), ref.detach()) < (2e-5 if dtype == "f32" else 3e-2)
     assert rel_err(dqkv.float(), qd.grad) < (1e-5 if dtype == "f32" else 2e-2)

@@ -1,0 +1,95 @@
+"""ezclip_pack_text_meta (csrc/packmeta.hip): the packing metadata of a text batch built by ONE device launch, against the host
+computation (`HipClipEngine._pack_meta_uncached`, itself pinned by tests/test_pack_meta.py) -- rowmap, cu, lens word for word, and
+the three scalars the host reads back from pinned memory without a stream synchronisation."""
+import pytest
+import torch
+
+from easynlp_amd import lib as L
+from easynlp_amd.appzoo.clip import CLIPApp
+from oracle import clip_oracle as O
+from oracle import ref_harness as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine(tmp_path_factory):
+    d = tmp_path_factory.mktemp("ckpt")
+    cfg = O.CONFIGS["tiny"]
+    R.write_checkpoint_dir(str(d), cfg, O.make_state_dict(cfg, 1))
+    app = CLIPApp(str(d), user_defined_parameters={"clip_compute_dtype": "bf16"}).cuda()
+    return app._engine
+
+
+def _batch(B, S, seed, kind):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1, 1000, (B, S), generator=g)
+    lens = torch.randint(1, S + 1, (B,), generator=g)
+    ids = ids * (torch.arange(S)[None, :] < lens[:, None])
+    if kind == "holes":
+        ids = ids * (torch.rand(B, S, generator=g) > 0.15)
+        ids[0, 0] = 0                       # a masked CLS token is kept all the same
+        if B > 2:
+            ids[2, :] = 0                   # no unmasked key at all: the sentence is kept whole
+    return ids
+
+
+@pytest.mark.parametrize("kind", ["prefix", "holes"])
+@pytest.mark.parametrize("B,S", [(1, 8), (5, 40), (7, 64), (33, 77), (1024, 64), (3000, 24), (64, 200), (9, 512)])
+def test_device_metadata_equals_the_host_computation(engine, B, S, kind):
+    ids = _batch(B, S, B * 1000 + S, kind)
+    want = engine._pack_meta_uncached(ids, None, "cpu")
+    keep = ids.ne(0)
+    keep = keep | ~keep.any(1, keepdim=True)
+    keep[:, 0] = True
+    lens = keep.sum(1)
+    got = engine.pack_meta(ids.cuda())
+    assert "ticket" in got                              # launched, not yet read back
+    res = engine.resolve_pack(got)
+    rows, longest = int(lens.sum()), int(lens.max())
+    prefix = bool((keep == (torch.arange(S)[None, :] < lens[:, None])).all())
+    if want is None:                                    # packing would not pay / longest > 256: the host says so as well
+        assert res is False and (longest > 256 or rows > 0.9 * B * S)
+    else:
+        assert res["rows"] == want["rows"] == rows and res["longest"] == want["longest"] == longest
+        assert res["prefix"] == want["prefix"] == prefix
+        assert torch.equal(res["rowmap"][:rows].cpu(), want["rowmap"][:rows].cpu())
+    assert torch.equal(got["lens"].cpu(), lens.int()) and torch.equal(got["cu"].cpu(), (lens.cumsum(0) - lens).int())
+    assert got["rows"] == rows and got["longest"] == longest and got["prefix"] == prefix
+
+
+def test_explicit_attention_mask_and_many_tickets_in_flight(engine):
+    B, S = 50, 48
+    ids = torch.randint(1, 1000, (B, S))
+    packs, wants = [], []
+    for k in range(8):                                  # eight launches before the first result is read
+        am = (torch.arange(S)[None, :] < torch.randint(1, S, (B, 1), generator=torch.Generator().manual_seed(k))).long()
+        packs.append(engine.pack_meta(ids.cuda(), am.cuda()))
+        wants.append(engine._pack_meta_uncached(ids, am, "cpu"))
+    for p, w in zip(packs, wants):
+        r = engine.resolve_pack(p)
+        assert r["rows"] == w["rows"] and r["longest"] == w["longest"] and r["prefix"] is True
+        assert torch.equal(r["rowmap"][:r["rows"]].cpu(), w["rowmap"].cpu()) and torch.equal(r["cu"].cpu(), w["cu"].cpu())
+    with pytest.raises(L.EzclipError):                  # a ninth outstanding ticket would reuse a result slot
+        old = dict(packs[0], ticket=1)
+        for _ in range(8):
+            engine.resolve_pack(engine.pack_meta(ids.cuda()))
+        engine.resolve_pack(old)
+
+
+def test_no_stream_synchronisation_is_needed_to_read_the_result(engine):
+    """The result words are polled in pinned host memory: they arrive although a long kernel queued BEHIND the metadata
+    launch is still running (a stream synchronisation would have waited for it)."""
+    ids = _batch(1024, 64, 3, "prefix").cuda()
+    a = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+    pack = engine.pack_meta(ids)
+    done = torch.cuda.Event()
+    for _ in range(20):
+        a = a @ a * 1e-4                                # ~20 x 1.1 TFLOP behind the launch
+    done.record()
+    res = engine.resolve_pack(pack)
+    still_running = not done.query()
+    torch.cuda.synchronize()
+    assert res["rows"] == int(ids.ne(0).sum().item()) or res["rows"] > 0
+    assert still_running, "the queued GEMMs finished before the metadata was read: the check is inconclusive on this box"

@@ -52,7 +52,7 @@ def test_reference_and_dropin_predictor_and_evaluator_agree(tmp_path, monkeypatc
             outs.append(P.preprocess(np.repeat(a[:, :, None], 3, axis=2) if a.ndim == 2 else a, size=size, crop=crop))
         return torch.from_numpy(np.stack(outs))
 
-    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None, pack_hint=None):
         sd = {n: p for n, p in self.chinese_clip.named_parameters()}
         return (O.encode_image(sd, self.raw_config, pixel_values) if pixel_values is not None else None,
                 O.encode_text(sd, self.raw_config, input_ids) if input_ids is not None else None)
@@ -140,7 +140,7 @@ def test_reference_and_dropin_wukong_predictor_agree(tmp_path, monkeypatch):
     def oracle_preprocess(images, size=224, crop=224, mean=L.CLIP_MEAN, std=L.CLIP_STD, device="cpu"):
         return torch.from_numpy(np.stack([P.preprocess(np.asarray(im), size=size, crop=crop) for im in images]))
 
-    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None, pack_hint=None):
         fo = WK.wukong_forward({"model." + n: p for n, p in self.model.named_parameters()}, self.raw_config, pixel_values, input_ids)
         return fo["image_features"], fo["text_features"]
 
@@ -225,7 +225,7 @@ def test_reference_and_dropin_text2video_predictor_and_evaluator_agree(tmp_path,
             outs.append(P.preprocess(np.repeat(a[:, :, None], 3, axis=2) if a.ndim == 2 else a, size=size, crop=crop))
         return torch.from_numpy(np.stack(outs))
 
-    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None, pack_hint=None):
         sd = {n: p for n, p in self.open_clip.named_parameters()}
         img = O.l2_normalize(O.vit_forward(sd, OC.chinese_style_config(cfg), pixel_values)) if pixel_values is not None else None
         txt = O.l2_normalize(OC.text_forward(sd, cfg, input_ids)) if input_ids is not None else None
@@ -272,7 +272,7 @@ def test_forward_contract_matches_the_reference_app(tmp_path, monkeypatch):
     cfg = O.CONFIGS["tiny"]
     R.write_checkpoint_dir(str(tmp_path), cfg, O.make_state_dict(cfg, 2))
 
-    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None, pack_hint=None):
         sd = {n: p for n, p in self.chinese_clip.named_parameters()}
         return (O.encode_image(sd, self.raw_config, pixel_values) if pixel_values is not None else None,
                 O.encode_text(sd, self.raw_config, input_ids) if input_ids is not None else None)
@@ -375,7 +375,7 @@ def test_open_clip_flavour_predictor_and_dataset_agree_with_the_reference(tmp_pa
             outs.append(P.preprocess(np.repeat(a[:, :, None], 3, axis=2) if a.ndim == 2 else a, size=size, crop=crop))
         return torch.from_numpy(np.stack(outs))
 
-    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None, pack_hint=None):
         sd = {n: p for n, p in self.open_clip.named_parameters()}
         img = O.l2_normalize(O.vit_forward(sd, OC.chinese_style_config(cfg), pixel_values)) if pixel_values is not None else None
         txt = O.l2_normalize(OC.text_forward(sd, cfg, input_ids)) if input_ids is not None else None
@@ -425,7 +425,7 @@ def test_huggingface_flavour_predictor_agrees_with_the_reference(tmp_path, monke
             outs.append(P.preprocess(np.repeat(a[:, :, None], 3, axis=2) if a.ndim == 2 else a, size=size, crop=crop))
         return torch.from_numpy(np.stack(outs))
 
-    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+    def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None, pack_hint=None):
         sd = dict(self._hf_params)
         img = txt = None
         if input_ids is not None:       # (hf_clip_forward wants both modalities: feed a dummy image / text for the other side)

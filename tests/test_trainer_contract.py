@@ -133,7 +133,7 @@ def oracle_preprocess(images, size=224, crop=224, mean=L.CLIP_MEAN, std=L.CLIP_S
         a = np.asarray(im)
         outs.append(P.preprocess(np.repeat(a[:, :, None], 3, axis=2) if a.ndim == 2 else a, size=size, crop=crop))
     return torch.from_numpy(np.stack(outs))
-def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+def oracle_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None, pack_hint=None):
     if FLAVOUR == "wukong":
         fo = WK.wukong_forward({"model." + n: p for n, p in self.model.named_parameters()}, cfg, pixel_values, input_ids)
         return fo["image_features"], fo["text_features"]

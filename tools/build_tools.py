@@ -14,8 +14,6 @@ def main():
     lib = B.build(verbose=True)
     os.makedirs(os.path.join(HERE, "bin"), exist_ok=True)
     srcs = [("gemm_bench.hip", [])]
-    if "--experiments" in sys.argv:      # staged kernel experiments (tools/experiments/README.md): not part of the default build
-        srcs.append(("experiments/attn_bwd_2wg.hip", ["-O3", "-mllvm", "-disable-lsr"]))
     for src, extra in srcs:
         out = os.path.join(HERE, "bin", os.path.basename(src).replace(".hip", ""))
         cmd = [B.hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17"] + extra + [os.path.join(HERE, src), "-o", out,

@@ -592,7 +592,12 @@ def fused_infonce_shard(eng, txt_all, img_all, n, off, logit_scale, grad_scale, 
     one) where the embedding width allows it, else ``ezclip_infonce_fused``'s materialising path."""
     lib = eng.lib
     N, e = img_all.shape
-    tiled_bytes = lib.ezclip_infonce_tiled_workspace_bytes(n, N, e) if eng.nce_tiled else 0
+    # bf16 pipeline: always tiled (bf16 operands).  f32 pipeline: the exact-f32 materialising path while the two logit blocks
+    # are small (its gradient bound of 1e-4 rel-L2 per parameter sits below what split-bf16 operands hold after the towers'
+    # backward: 2^-16 per product, amplified by the cancellation in sum_j (p_ij - d_ij) x_j); tiled with split operands beyond
+    # 2^24 logits per block
+    want_tiled = eng.nce_tiled and (eng.dtype_code == L.DTYPE_BF16 or n * N >= (1 << 24))
+    tiled_bytes = lib.ezclip_infonce_tiled_workspace_bytes(n, N, e) if want_tiled else 0
     key = ("nce", n, N, e, bool(tiled_bytes))
     ws = eng._ws.get(key)
     if ws is None:

@@ -39,7 +39,6 @@ struct NceWS {
   float *St, *Si, *dSt, *dSi, *lse_t, *lse_i, *rl_t, *rl_i, *IallT, *TallT, *dStT, *dSiT, *TlocT, *IlocT, *partial;
   int Np, np;
 };
-int g_nce_tiled = 1;     // ezclip_debug_set(8, 0): the materialising path of round 2 (A/B, cross-check)
 size_t layout_nce(int n, int N, int e, void* base, NceWS* out) {
   Arena a(base);
   NceWS w;
@@ -171,7 +170,6 @@ int ezclip_infonce_from_logits_bwd(const float* logits, int n, const float* grad
 }
 
 size_t ezclip_infonce_workspace_bytes(int n_local, int n_global, int e) {
-  if (infonce_tiled_eligible(e) && g_nce_tiled) return infonce_tiled_workspace_bytes(n_local, n_global, e);
   return layout_nce(n_local, n_global, e, nullptr, nullptr);
 }
 
@@ -197,11 +195,6 @@ int ezclip_infonce_fused(const float* T, const float* I, int n, int N, int off, 
   EZ_REQUIRE(n > 0 && N >= n && off >= 0 && off + n <= N, "ezclip_infonce_fused: bad shard n=%d N=%d offset=%d", n, N, off);
   EZ_REQUIRE(e % 32 == 0, "ezclip_infonce_fused: embed dim %d must be a multiple of 32", e);
   EZ_REQUIRE(((uintptr_t)wsp % 256) == 0, "ezclip_infonce_fused: workspace must be 256-byte aligned");
-  if (infonce_tiled_eligible(e) && g_nce_tiled) {     // tiled kernels, split operands: float32-class results, no [n, N] buffer
-    EZ_REQUIRE((dT == nullptr) == (dI == nullptr) && (dT == nullptr) == (dls == nullptr),
-               "ezclip_infonce_fused: d_text/d_image/d_logit_scale must be all set or all NULL");
-    return infonce_tiled(T, I, n, N, off, e, ls, grad_scale, 1, loss, dT, dI, dls, wsp, ws_bytes, S(stream));
-  }
   NceWS w;
   const size_t need = layout_nce(n, N, e, wsp, &w);
   EZ_REQUIRE(ws_bytes >= need, "ezclip_infonce_fused: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -415,7 +408,6 @@ int ezclip_debug_set(int key, int value) {
   if (key == 5) { set_device_resample_tables(value); return EZ_OK; }
   if (key == 6) { set_gemm_raster(value); return EZ_OK; }
   if (key == 7) { set_fuse_bert_qkv(value); return EZ_OK; }
-  if (key == 8) { g_nce_tiled = value != 0; return EZ_OK; }
   set_error("ezclip_debug_set: unknown key %d", key);
   return EZ_ERR_INVALID;
 }

@@ -232,9 +232,9 @@ int ezclip_infonce_from_logits_bwd(const float* logits_dev, int n, const float* 
  * (three products, float32-class results: loss 1e-5, gradients 1e-5 -- the f32 pipeline); 0 rounds the embeddings to bf16 once
  * (the bf16 pipeline).  Workspace O((n_local + n_global) * e): ezclip_infonce_tiled_workspace_bytes (0 = e not supported).
  *
- * ezclip_infonce_fused: the same contract; runs the tiled kernels with split operands when e allows and otherwise the
- * materialising path of rounds 1-2 (two [n_local, n_global] float32 logit blocks + their gradients in the workspace, f32 MFMA
- * products, row kernels of loss.hip).  workspace: ezclip_infonce_workspace_bytes(n_local, n_global, e). */
+ * ezclip_infonce_fused: the same contract on the materialising path of rounds 1-2 (exact float32: two [n_local, n_global] f32
+ * logit blocks + their gradients in the workspace, f32-MFMA products, row kernels of loss.hip) -- any e % 32 == 0; the f32
+ * pipeline's choice while the blocks are small.  workspace: ezclip_infonce_workspace_bytes(n_local, n_global, e). */
 size_t ezclip_infonce_workspace_bytes(int n_local, int n_global, int e);
 int ezclip_infonce_fused(const float* text_all_dev, const float* image_all_dev, int n_local, int n_global,
                          int rank_offset, int e, const float* logit_scale_dev, float grad_scale,

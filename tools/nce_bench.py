@@ -27,7 +27,6 @@ for n, N, off, e in ((1024, 1024, 0, 512), (1024, 8192, 3072, 512), (512, 4096, 
             L.check(lib.ezclip_infonce_tiled(L.ptr(t), L.ptr(i), n, N, off, e, L.ptr(ls), 1.0, 1 if kind == "split" else 0, L.ptr(loss), *a,
                                              L.ptr(ws), ws.numel(), L.stream_ptr()))
     for kind in ("old", "split", "bf16"):
-        L.check(lib.ezclip_debug_set(8, 0 if kind == "old" else 1))
         nbytes = lib.ezclip_infonce_workspace_bytes(n, N, e) if kind == "old" else lib.ezclip_infonce_tiled_workspace_bytes(n, N, e)
         ws = L.alloc_bytes(nbytes, dev)
         res = []
@@ -43,4 +42,3 @@ for n, N, off, e in ((1024, 1024, 0, 512), (1024, 8192, 3072, 512), (512, 4096, 
             torch.cuda.synchronize()
             res.append(ev0.elapsed_time(ev1) / 20)
         print("n=%5d N=%5d e=%4d  %-5s  fwd %.3f ms  fwd+bwd %.3f ms  workspace %.1f MB  loss %.6f" % (n, N, e, kind, res[0], res[1], nbytes / 2**20, loss.item()), flush=True)
-    L.check(lib.ezclip_debug_set(8, 1))

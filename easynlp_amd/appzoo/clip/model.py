@@ -66,11 +66,15 @@ class _ParamTree(nn.Module):
 
 
 def _cfg_struct(cfg: dict, dtype_code: int) -> L.EzclipConfig:
-    if isinstance(cfg.get("vision_layers"), (list, tuple)):
-        raise L.EzclipError("ModifiedResNet vision towers are not on the HIP path (SURVEY.md 8f)")
     c = L.EzclipConfig()
+    # a tuple of stage depths = ModifiedResNet (modeling_chineseclip.py:279-287): it runs behind its own handle
+    # (rn_tower.RnEngine) and this one is created text-only (vision_layers = 0; the ViT fields are then not read)
+    resnet = isinstance(cfg.get("vision_layers"), (list, tuple))
     for f in _CFG_FIELDS:
-        setattr(c, f, int(cfg[f]))
+        if resnet and f in ("vision_layers", "vision_patch_size"):
+            setattr(c, f, 0)
+        else:
+            setattr(c, f, int(cfg[f]))
     c.compute_dtype = dtype_code
     return c
 
@@ -732,6 +736,20 @@ class CLIPApp(Application):
         else:
             eng = HipClipEngine(cfg, self.compute_dtype)
         tree = _ParamTree()
+        self._rn, self._rn_tensors = None, {}
+        if not open_clip and isinstance(cfg.get("vision_layers"), (list, tuple)):
+            # ModifiedResNet image tower (frozen, eval-mode BatchNorm): reference-named parameters / statistics in the same tree,
+            # in the reference module's order (visual.* first)
+            from .rn_tower import RnEngine
+            self._rn = RnEngine(cfg["vision_layers"], int(cfg["vision_width"]), int(cfg["embed_dim"]), int(cfg["image_resolution"]),
+                                self.compute_dtype)
+            for n in self._rn.names:
+                t = torch.zeros(self._rn.shapes[n], dtype=torch.float32)
+                if n.endswith("running_var") or (n.endswith(".weight") and (".bn" in n or "downsample.1" in n)):
+                    t.fill_(1.0)                                        # nn.BatchNorm2d defaults
+                tree.add(n, t, buffer=RnEngine.is_statistic(n))
+                if n.endswith(".running_var"):                          # the step counter BatchNorm2d keeps in its state_dict
+                    tree.add(n[:-len("running_var")] + "num_batches_tracked", torch.zeros((), dtype=torch.int64), buffer=True)
         for n in eng.names:
             shape = eng.shapes[n]
             t = torch.zeros(shape, dtype=torch.float32)
@@ -750,6 +768,18 @@ class CLIPApp(Application):
             eng.pack_text = str(self._pack_text_opt) not in ("0", "False", "false")
         named = dict(tree.named_parameters())
         self._params = {n: named[n] for n in eng.names}
+        if self._rn is not None:
+            both = dict(named, **dict(tree.named_buffers()))
+            self._rn_tensors = {n: both[n] for n in self._rn.names}
+            for n in self._rn.names:                                    # frozen tower: no backward pass exists for it
+                if n in named:
+                    named[n].requires_grad_(False)
+
+    def _encode_image_resnet(self, pixel_values):
+        """ModifiedResNet tower: eval-mode BatchNorm, no gradient (rn_tower.py)."""
+        self._rn.sync(self._rn_tensors)
+        with torch.no_grad():
+            return self._rn.encode_image(pixel_values)
 
     def _build_hf(self, raw: dict) -> None:
         """huggingface_clip branch (model.py:73-104): reference-named parameters + the name map of hf_branch.py."""
@@ -892,6 +922,9 @@ class CLIPApp(Application):
         import torch.distributed as dist
         eng = self._engine
         lib = eng.lib
+        if getattr(self, "_rn", None) is not None:
+            raise L.EzclipError("contrastive_step drives the ViT image tower; a ModifiedResNet model goes through forward() / "
+                                "compute_loss() (frozen image tower, the text tower trains)")
         hf = getattr(self, "model_type", None) == "huggingface_clip"
         extras, transposed = None, []
         pixel_values = pixel_values.contiguous()
@@ -1053,6 +1086,12 @@ class CLIPApp(Application):
             return (img if pixel_values is not None else None), (txt if input_ids is not None else None)
         plist = self._plist()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
+        if getattr(self, "_rn", None) is not None:
+            img = self._encode_image_resnet(pixel_values) if pixel_values is not None else None
+            txt = None
+            if input_ids is not None:
+                _, txt = _EncodeFn.apply(self, need_grad, pack_hint, None, input_ids, *plist)
+            return img, txt
         img, txt = _EncodeFn.apply(self, need_grad, pack_hint, pixel_values, input_ids, *plist)
         return (img if pixel_values is not None else None), (txt if input_ids is not None else None)
 

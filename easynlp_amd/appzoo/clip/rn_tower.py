@@ -1,0 +1,95 @@
+"""Host side of the ModifiedResNet image tower (include/ezclip.h: ezclip_rn_*; csrc/resnet.hip).
+
+Reference: CHINESE_CLIP builds ``ModifiedResNet(vision_layers, embed_dim, vision_width * 32 // 64, image_resolution, vision_width)``
+when ``vision_layers`` is a tuple (easynlp/modelzoo/models/clip/modeling_chineseclip.py:279-287).  The tower runs in EVAL mode
+(BatchNorm with its running statistics) and has no backward pass here: a FROZEN image tower -- evaluation, prediction, and
+fine-tuning of the text tower against fixed image features.  Parameters and BatchNorm statistics keep the reference checkpoint's
+names (``visual.conv1.weight``, ``visual.bn1.running_mean``, ``visual.layer1.0.downsample.1.weight``, ...) so that
+``state_dict`` / ``load_state_dict`` exchange checkpoints with the reference."""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import torch
+
+from ... import lib as L
+
+
+class RnEngine:
+    """Owns the C handle, the BatchNorm-folded packed weights and the workspace of one ModifiedResNet tower on one device."""
+
+    def __init__(self, layers: Sequence[int], width: int, output_dim: int, resolution: int, dtype_code: int):
+        self.lib = L.load()
+        if len(layers) != 4:
+            raise L.EzclipError("ModifiedResNet: vision_layers must hold 4 stage depths, got %r" % (tuple(layers),))
+        c = L.EzclipRnConfig()
+        for i, n in enumerate(layers):
+            c.layers[i] = int(n)
+        c.width, c.output_dim, c.image_resolution, c.compute_dtype = int(width), int(output_dim), int(resolution), int(dtype_code)
+        self._cstruct = c
+        h = L.C.c_void_p()
+        L.check(self.lib.ezclip_rn_create(L.C.byref(c), L.C.byref(h)), "ezclip_rn_create")
+        self.handle = h
+        self.resolution, self.output_dim, self.dtype_code = int(resolution), int(output_dim), int(dtype_code)
+        self.names: List[str] = []
+        self.shapes: Dict[str, tuple] = {}
+        name, shape, ndim = L.C.c_char_p(), (L.C.c_int64 * 8)(), L.C.c_int()
+        for i in range(self.lib.ezclip_rn_num_params(h)):
+            L.check(self.lib.ezclip_rn_param_info(h, i, L.C.byref(name), shape, L.C.byref(ndim)), "rn_param_info")
+            n = name.value.decode()
+            self.names.append(n)
+            self.shapes[n] = tuple(int(shape[j]) for j in range(ndim.value))
+        self._shadow = None
+        self._ws = {}
+        self._sig = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ezclip_rn_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def is_statistic(name: str) -> bool:
+        """BatchNorm running statistics: buffers of the reference module, not parameters"""
+        return name.endswith(".running_mean") or name.endswith(".running_var")
+
+    def sync(self, tensors: Dict[str, torch.Tensor]) -> None:
+        """Bind the tensors (float32, on the GPU) and re-fold / re-pack when any of them moved or changed."""
+        sig = tuple((tensors[n].data_ptr(), tensors[n]._version) for n in self.names)
+        if sig == self._sig:
+            return
+        dev = tensors[self.names[0]].device
+        if self._shadow is None or self._shadow.device != dev:
+            self._shadow = L.alloc_bytes(self.lib.ezclip_rn_shadow_bytes(self.handle), dev)
+            L.check(self.lib.ezclip_rn_set_shadow(self.handle, L.ptr(self._shadow), self._shadow.numel()), "rn_set_shadow")
+        for n in self.names:
+            t = tensors[n]
+            if t.dtype != torch.float32 or tuple(t.shape) != self.shapes[n]:
+                raise L.EzclipError("ModifiedResNet parameter %s: expected float32 %s, got %s %s" % (n, self.shapes[n], t.dtype, tuple(t.shape)))
+            L.check(self.lib.ezclip_rn_bind_param(self.handle, n.encode(), L.ptr(t)), "rn_bind_param")
+        L.check(self.lib.ezclip_rn_refresh_weights(self.handle, L.stream_ptr()), "rn_refresh_weights")
+        self._sig = sig
+
+    def mark_dirty(self) -> None:
+        self._sig = None
+
+    def encode_image(self, pixels: torch.Tensor, stream=None) -> torch.Tensor:
+        pixels = pixels.contiguous()
+        if pixels.dtype != torch.float32:
+            pixels = pixels.float()
+        B = pixels.shape[0]
+        if tuple(pixels.shape[1:]) != (3, self.resolution, self.resolution):
+            raise L.EzclipError("pixel_values must be [B,3,%d,%d], got %s" % (self.resolution, self.resolution, tuple(pixels.shape)))
+        out = torch.empty((B, self.output_dim), dtype=torch.float32, device=pixels.device)
+        key = (B, str(pixels.device))
+        ws = self._ws.get(key)
+        if ws is None:
+            self._ws.clear()
+            ws = L.alloc_bytes(self.lib.ezclip_rn_workspace_bytes(self.handle, B), pixels.device)
+            self._ws[key] = ws
+        L.check(self.lib.ezclip_rn_encode_image(self.handle, L.ptr(pixels), B, L.ptr(out), L.ptr(ws), ws.numel(),
+                                                L.stream_ptr(stream)), "rn_encode_image")
+        return out

@@ -13,7 +13,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int kWave = 64;  // CDNA wavefront
 
-enum Act { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2, ACT_TANH = 3 };   // TANH: 128x128 kernels only (pooler)
+// TANH: 128x128 kernels only (pooler).  RELU: max(x, 0) in the activation slot; RELU_POST: applied AFTER the residual add
+// (Bottleneck: relu(bn3(conv3(.)) + identity), modeling_chineseclip.py:72-73)
+enum Act { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2, ACT_TANH = 3, ACT_RELU = 4, ACT_RELU_POST = 5 };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
@@ -141,6 +143,7 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
   }
   if (act == ACT_TANH) return tanhf(x);     // BertPooler / RobertaPooler (B rows per step: never hot)
+  if (act == ACT_RELU) return fmaxf(x, 0.f);
   return x;
 }
 

@@ -81,7 +81,40 @@ __device__ __forceinline__ void stage_rows(const char* __restrict__ g, int64_t l
   }
 }
 
-template <typename T, typename TO, int WM, int WN, int TI, int TJ>
+// A tile of an implicit 3x3 convolution (GemmArgs::conv_*): row r of the tile is output pixel m0 + r, the K-tile selects a tap
+// and a 128-byte channel slice; the rows a lane stages are fixed for the whole K loop, so their (y, x) are computed once.
+template <int ROWS, int NWAVES>
+struct ConvRows {
+  static constexpr int kPer = ROWS / 8 / NWAVES;
+  int m[kPer], y[kPer], x[kPer];
+  __device__ __forceinline__ void init(const GemmArgs& p, int m0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int r = (wave * kPer + i) * 8 + (lane >> 3);
+      int mm = m0 + r;
+      mm = mm < p.M ? mm : p.M - 1;
+      const int hw = p.conv_H * p.conv_W, rem = mm % hw;
+      m[i] = mm; y[i] = rem / p.conv_W; x[i] = rem - y[i] * p.conv_W;
+    }
+  }
+  __device__ __forceinline__ void stage(const GemmArgs& p, const char* __restrict__ g, int64_t ld_bytes, int k0_elems, int esz,
+                                        char* lds_tile, int wave, int lane) const {
+    const int tap = k0_elems / p.conv_C, c0 = k0_elems - tap * p.conv_C;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int inst = wave * kPer + i;
+      const int r = inst * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      const bool in = (unsigned)(y[i] + dy) < (unsigned)p.conv_H && (unsigned)(x[i] + dx) < (unsigned)p.conv_W;
+      const char* src = in ? g + (int64_t)(m[i] + dy * p.conv_W + dx) * ld_bytes + (int64_t)c0 * esz + c * 16
+                           : reinterpret_cast<const char*>(p.conv_zero) + c * 16;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lds_tile + inst * 1024), 16, 0, 0);
+    }
+  }
+};
+
+template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool CONV = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void gemm_nt_kernel(GemmArgs p) {
   using SH = Shape<WM, WN, TI, TJ>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -109,7 +142,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / BK;
-  stage_rows<SH::kBM, SH::kWaves>(gA, lda_b, m0, p.M, 0, smem, wave, lane);
+  ConvRows<SH::kBM, SH::kWaves> cr;
+  if constexpr (CONV) {
+    cr.init(p, m0, wave, lane);
+    cr.stage(p, gA, lda_b, 0, (int)sizeof(T), smem, wave, lane);
+  } else {
+    stage_rows<SH::kBM, SH::kWaves>(gA, lda_b, m0, p.M, 0, smem, wave, lane);
+  }
   stage_rows<SH::kBN, SH::kWaves>(gB, ldb_b, n0, p.N, 0, smem + SH::kABytes, wave, lane);
 
   const int arow = wm * TI * 32 + l31, brow = wn * TJ * 32 + l31;
@@ -120,7 +159,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
     __syncthreads();  // tile kt landed everywhere; everyone is done reading `nxt`
     if (kt + 1 < nk) {
       const int64_t kb = (int64_t)(kt + 1) * 128;
-      stage_rows<SH::kBM, SH::kWaves>(gA, lda_b, m0, p.M, kb, nxt, wave, lane);
+      if constexpr (CONV) cr.stage(p, gA, lda_b, (kt + 1) * BK, (int)sizeof(T), nxt, wave, lane);
+      else stage_rows<SH::kBM, SH::kWaves>(gA, lda_b, m0, p.M, kb, nxt, wave, lane);
       stage_rows<SH::kBN, SH::kWaves>(gB, ldb_b, n0, p.N, kb, nxt + SH::kABytes, wave, lane);
     }
     const char* tA = cur;
@@ -189,6 +229,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += rv[e];
           }
+          if (p.act == ACT_RELU_POST) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
           st4(C + (int64_t)m * p.ldc + n, v);
         } else {
 #pragma unroll
@@ -200,6 +244,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
             if (U) x *= act_grad<kFast>(Elem<T>::ld(U + (int64_t)m * p.ldu + n + e), p.act);
             else x = act_apply<kFast>(x, p.act);
             if (R) x += Elem<T>::ld(R + (int64_t)m * p.ldr + n + e);
+            if (p.act == ACT_RELU_POST) x = fmaxf(x, 0.f);
             Elem<TO>::st(C + (int64_t)m * p.ldc + n + e, x);
           }
         }
@@ -208,22 +253,29 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
   });
 }
 
-template <typename T, typename TO, int WM, int WN, int TI, int TJ>
+template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool CONV = false>
 int launch_nt_shape(const GemmArgs& p, hipStream_t stream) {
   using SH = Shape<WM, WN, TI, TJ>;
   const int tiles = ((p.M + SH::kBM - 1) / SH::kBM) * ((p.N + SH::kBN - 1) / SH::kBN);
   static bool attr_set = false;
   if (!attr_set) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, TI, TJ>),
+    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, TI, TJ, CONV>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SH::kLds));
     attr_set = true;
   }
   {
     ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, TI, TJ>), dim3(tiles), dim3(SH::kThreadsS), SH::kLds, stream, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, TI, TJ, CONV>), dim3(tiles), dim3(SH::kThreadsS), SH::kLds, stream, p);
   }
   EZ_LAUNCH_CHECK();
   return EZ_OK;
+}
+
+// implicit 3x3 convolution: 256 x 256 tiles when they fill the chip, else 128 x 128
+template <typename T>
+int launch_nt_conv(const GemmArgs& p, hipStream_t stream) {
+  if (p.N % 256 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 256) >= 192) return launch_nt_shape<T, T, 2, 4, 4, 2, true>(p, stream);
+  return launch_nt_shape<T, T, 2, 2, 2, 2, true>(p, stream);
 }
 
 int g_gemm_variant = -1;   // -1: heuristic; 0: 128x128; 1: 256x256 (2-phase); 2: 256x256 8-phase (gemm8p.hip); 3: 64x64
@@ -276,6 +328,12 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
              (p.R == nullptr || (p.ldr % 4 == 0 && (uintptr_t)p.R % 16 == 0)) &&
              (p.U == nullptr || (p.ldu % 4 == 0 && (uintptr_t)p.U % 16 == 0));
   p.vec_ok = vec ? 1 : 0;
+  if (p.conv_H > 0) {
+    EZ_REQUIRE(p.conv_W > 0 && p.conv_C > 0 && p.conv_zero != nullptr && p.K == 9 * p.conv_C && (p.conv_C * esz) % 128 == 0 &&
+                   p.M % (p.conv_H * p.conv_W) == 0 && p.lda >= p.conv_C && !p.out_f32 && !p.colsum && !p.rowstat_part && !p.ln_stats,
+               "gemm_nt: bad implicit-convolution problem (H %d W %d C %d K %d M %d)", p.conv_H, p.conv_W, p.conv_C, p.K, p.M);
+    return dtype == EZCLIP_F32 ? launch_nt_conv<float>(p, stream) : launch_nt_conv<bf16_t>(p, stream);
+  }
   if (gemm_nt_uses_8p(p, dtype)) return gemm_nt_8p(p, stream);
   if (p.colsum != nullptr) {   // not the 8-phase kernel: separate column-sum pass after the GEMM
     float* cs = p.colsum;

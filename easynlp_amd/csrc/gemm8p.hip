@@ -577,7 +577,9 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* part, int s
 }  // namespace
 
 bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype) {
-  if (dtype != EZCLIP_BF16 || p.out_f32 || p.scale_log != nullptr || p.act > ACT_GELU_ERF) return false;
+  if (dtype != EZCLIP_BF16 || p.out_f32 || p.scale_log != nullptr || p.act == ACT_TANH || p.conv_H > 0) return false;
+  if (p.act == ACT_RELU_POST && !p.R) return false;
+  if ((p.act == ACT_RELU || p.act == ACT_RELU_POST) && p.U) return false;
   if (p.M < 256 || (p.N & 255) || (p.K & 127) || p.K < 256) return false;
   if ((p.lda & 7) || (p.ldb & 7) || (p.ldc & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15) ||
       ((uintptr_t)p.C & 15))

@@ -362,11 +362,21 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
           for (int e = 0; e < 8; ++e) y[e] = act_apply<FAST>(y[e], ACT_GELU_ERF);
         }
       }
+      if constexpr (!HAS_U) {
+        if (act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = fmaxf(y[e], 0.f);
+        }
+      }
       if constexpr (HAS_R) {
         float rf[8];
         unpack8(ld.r[b][it], rf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] += rf[e];
+        if (act == ACT_RELU_POST) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = fmaxf(y[e], 0.f);
+        }
       }
       const u32x4_t o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
                          pack_bf16x2(y[6], y[7])};

@@ -37,6 +37,12 @@ struct GemmArgs {
   // Backward only (with U): colsum[n] += sum_m C[m][n] -- the bias gradient of the Linear whose output gradient C is
   // (8-phase kernel: accumulated in the epilogue, one hardware atomic per column per wave tile; else a separate pass)
   float* colsum = nullptr;
+  // Implicit 3x3 convolution, pad 1, stride 1, over an NHWC image batch (128x128 / 256x256 kernels of gemm.hip; ModifiedResNet's
+  // convs, modeling_chineseclip.py:41-43,115-121): A = x [B * H * W, lda] with conv_C (<= lda) channels per pixel, output row
+  // m = (b, y, x) of the same H x W grid, K = 9 * conv_C ordered k = (ky * 3 + kx) * conv_C + c -- the A tile of a K-tile is the
+  // 128-byte channel slice of the pixel shifted by (ky - 1, kx - 1); taps outside the image read conv_zero (>= 128 zero bytes).
+  int conv_H = 0, conv_W = 0, conv_C = 0;
+  const void* conv_zero = nullptr;
   float alpha = 1.0f;                         // acc *= alpha
   int M = 0, N = 0, K = 0;
   int act = 0;                                // ezclip::Act

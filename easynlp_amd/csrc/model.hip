@@ -85,13 +85,15 @@ int model_create(const ezclip_config* c, ezclip_model** out, int text_arch) {
   EZ_REQUIRE(c->compute_dtype == EZCLIP_F32 || c->compute_dtype == EZCLIP_BF16, "ezclip_create: bad compute_dtype %d", c->compute_dtype);
   const int kmult = 128 / dtype_size(c->compute_dtype);
   const int W = c->vision_width, H = c->text_hidden_size, F = c->text_intermediate_size, E = c->embed_dim;
-  EZ_REQUIRE(W > 0 && W % 64 == 0 && W <= 1024, "vision_width %d must be a multiple of 64 (head_dim 64) and <= 1024", W);
+  // vision_layers == 0: a text-only handle (the image tower is not a ViT: ModifiedResNet runs behind its own handle, ezclip_rn_*)
+  const bool vis = c->vision_layers > 0;
+  EZ_REQUIRE(!vis || (W > 0 && W % 64 == 0 && W <= 1024), "vision_width %d must be a multiple of 64 (head_dim 64) and <= 1024", W);
   EZ_REQUIRE(c->text_num_attention_heads > 0 && H == 64 * c->text_num_attention_heads && H <= 1024,
              "text_hidden_size %d must be 64 * heads (head_dim 64) and <= 1024", H);
   EZ_REQUIRE(F % kmult == 0 && F % 4 == 0, "text_intermediate_size %d must be a multiple of %d", F, kmult);
   EZ_REQUIRE(E % 32 == 0 && E <= 1024, "embed_dim %d must be a multiple of 32 and <= 1024", E);
-  EZ_REQUIRE(c->vision_patch_size > 0 && c->image_resolution >= c->vision_patch_size, "bad patch/resolution");
-  EZ_REQUIRE(c->vision_layers > 0 && c->text_num_hidden_layers > 0, "layer counts must be positive");
+  EZ_REQUIRE(!vis || (c->vision_patch_size > 0 && c->image_resolution >= c->vision_patch_size), "bad patch/resolution");
+  EZ_REQUIRE(c->vision_layers >= 0 && c->text_num_hidden_layers > 0, "layer counts must be positive");
   EZ_REQUIRE(c->vocab_size > 0 && c->text_max_position_embeddings > 0 && (c->text_type_vocab_size > 0 || text_arch == 1),
              "bad text table sizes");
   EZ_REQUIRE(text_arch == 0 || text_arch == 1, "text_arch %d: 0 = BERT / RoBERTa, 1 = CLIP text transformer", text_arch);
@@ -100,14 +102,16 @@ int model_create(const ezclip_config* c, ezclip_model** out, int text_arch) {
   ezclip_model* m = new ezclip_model();
   m->cfg = *c;
   m->dtype = c->compute_dtype;
+  m->theads = c->text_num_attention_heads;
+  m->text_arch = text_arch;
+  m->cls_p = m->pos_p = m->lnpre_w = m->lnpre_b = m->lnpost_w = m->lnpost_b = -1;
+  const int P = vis ? c->vision_patch_size : 1;
+  if (vis) {
   m->G = c->image_resolution / c->vision_patch_size;
   m->Lv = m->G * m->G + 1;
   m->Kpatch = 3 * c->vision_patch_size * c->vision_patch_size;
   m->Kpad = round_up(m->Kpatch, kmult);
   m->vheads = W / 64;
-  m->theads = c->text_num_attention_heads;
-  m->text_arch = text_arch;
-  const int P = c->vision_patch_size;
 
   m->cls_p = add_param(m, "visual.class_embedding", {W});
   m->pos_p = add_param(m, "visual.positional_embedding", {m->Lv, W});
@@ -141,6 +145,7 @@ int model_create(const ezclip_config* c, ezclip_model** out, int text_arch) {
   }
   m->lnpost_w = add_param(m, "visual.ln_post.weight", {W});
   m->lnpost_b = add_param(m, "visual.ln_post.bias", {W});
+  }   // vis
   if (text_arch == 1) {
     // OPEN_CLIP state_dict names (modeling_openclip.py:296-311)
     m->tok_p = add_param(m, "token_embedding.weight", {c->vocab_size, H});
@@ -209,8 +214,8 @@ int model_create(const ezclip_config* c, ezclip_model** out, int text_arch) {
 
 // -------------------------------------------------------- weight shadows ---
 static void for_each_weight(ezclip_model* m, const std::function<void(ezclip_model::Weight&)>& f) {
-  f(m->conv_w);
-  f(m->vproj_w);
+  if (m->conv_w.p >= 0) f(m->conv_w);          // (text-only handles have no image tower)
+  if (m->vproj_w.p >= 0) f(m->vproj_w);
   f(m->tproj_w);
   if (m->text_arch == 0) f(m->pool_w);
   for (auto& L : m->vit) { f(L.in_w); f(L.out_w); f(L.fc_w); f(L.proj_w); }
@@ -605,7 +610,9 @@ size_t layout_text(const ezclip_model* m, int B, int L, bool save, void* base, T
 
 }  // namespace
 
-size_t image_workspace_bytes(const ezclip_model* m, int B, bool save) { return layout_image(m, B, save, nullptr, nullptr); }
+size_t image_workspace_bytes(const ezclip_model* m, int B, bool save) {
+  return m->vit.empty() ? 0 : layout_image(m, B, save, nullptr, nullptr);
+}
 
 
 // One pre-LN residual attention block (ResidualAttentionBlock, modeling_chineseclip.py:184-205 == modeling_openclip.py's
@@ -726,6 +733,7 @@ static int resblock_forward_cls_save(ezclip_model* m, const ezclip_model::VitLay
 int encode_image(ezclip_model* m, const float* pixels, int B, float* out, void* wsp, size_t ws_bytes, bool save,
                  hipStream_t stream) {
   EZ_REQUIRE(B > 0 && pixels && out && wsp, "encode_image: null/empty argument");
+  EZ_REQUIRE(!m->vit.empty(), "encode_image: this handle has no image tower (created with vision_layers = 0)");
   EZ_REQUIRE(m->weights_fresh, "encode_image: call ezclip_refresh_weights after binding/updating parameters");
   EZ_REQUIRE(((uintptr_t)wsp % 256) == 0, "encode_image: workspace must be 256-byte aligned");
   ImgWS ws;
@@ -1194,6 +1202,7 @@ static int resblock_backward_cls(ezclip_model* m, const ezclip_model::VitLayer& 
 int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_emb, void* wsp, size_t ws_bytes,
                    hipStream_t stream) {
   EZ_REQUIRE(B > 0 && d_emb && wsp, "backward_image: null/empty argument");
+  EZ_REQUIRE(!m->vit.empty(), "backward_image: this handle has no image tower (created with vision_layers = 0)");
   EZ_REQUIRE(m->weights_fresh && m->shadow_backward, "backward_image: weights not packed for backward");
   ImgWS ws;
   const size_t need = layout_image(m, B, true, wsp, &ws);

@@ -34,6 +34,12 @@ class EzclipConfig(C.Structure):
         "text_num_attention_heads", "text_num_hidden_layers", "text_type_vocab_size", "compute_dtype")]
 
 
+class EzclipRnConfig(C.Structure):
+    """ezclip_rn_config (include/ezclip.h)"""
+    _fields_ = [("layers", C.c_int32 * 4), ("width", C.c_int32), ("output_dim", C.c_int32), ("image_resolution", C.c_int32),
+                ("compute_dtype", C.c_int32)]
+
+
 class EzclipAttentionOpts(C.Structure):
     """ezclip_attention_opts (include/ezclip.h)"""
     _fields_ = [("causal", C.c_int32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("dropout_site", C.c_uint32),
@@ -93,6 +99,16 @@ SIGNATURES = {
     "ezclip_infonce_workspace_bytes": (_sz, [_i, _i, _i]),
     "ezclip_infonce_fused": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ezclip_infonce_tiled_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ezclip_rn_create": (_i, [_vp, C.POINTER(_vp)]),
+    "ezclip_rn_destroy": (None, [_vp]),
+    "ezclip_rn_num_params": (_i, [_vp]),
+    "ezclip_rn_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(_i)]),
+    "ezclip_rn_bind_param": (_i, [_vp, C.c_char_p, _vp]),
+    "ezclip_rn_shadow_bytes": (_sz, [_vp]),
+    "ezclip_rn_set_shadow": (_i, [_vp, _vp, _sz]),
+    "ezclip_rn_refresh_weights": (_i, [_vp, _vp]),
+    "ezclip_rn_workspace_bytes": (_sz, [_vp, _i]),
+    "ezclip_rn_encode_image": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "ezclip_pack_text_meta": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, C.POINTER(C.c_int), _vp]),
     "ezclip_pack_text_meta_result": (_i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ezclip_infonce_tiled": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

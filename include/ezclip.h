@@ -246,6 +246,36 @@ int ezclip_infonce_tiled(const float* text_all_dev, const float* image_all_dev, 
                          float* loss_dev, float* d_text_all_dev, float* d_image_all_dev,
                          float* d_logit_scale_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ---- ModifiedResNet image tower (csrc/resnet.hip) ------------------------------------------------
+ * CHINESE_CLIP builds `ModifiedResNet(vision_layers, embed_dim, heads, image_resolution, vision_width)` when `vision_layers` is a
+ * tuple (modeling_chineseclip.py:279-287; Bottleneck :27-74, AttentionPool2d :77-108).  It runs behind its own handle, in EVAL
+ * mode (BatchNorm with running statistics): a frozen image tower -- evaluation, prediction, LiT-style fine-tuning of the text
+ * tower (the text side then comes from a handle created with vision_layers = 0).  Convolutions are MFMA GEMMs over NHWC
+ * activations (3x3: read implicitly, no im2col buffer), BatchNorm is folded into the packed weights by
+ * ezclip_rn_refresh_weights, the attention pool runs the one-query attention kernel.
+ * Parameter names = the reference checkpoint's ("visual.conv1.weight", "visual.bn1.running_var", "visual.layer1.0.downsample.1.bias",
+ * "visual.attnpool.k_proj.weight", ...; `num_batches_tracked` counters are not read).  All float32, caller-owned. */
+typedef struct ezclip_rn* ezclip_rn_handle;
+typedef struct ezclip_rn_config {
+  int32_t layers[4];         /* blocks per stage, e.g. {3, 4, 6, 3} for RN50 */
+  int32_t width;             /* 64 for RN50: stem 32/32/64, stages 64/128/256/512 -> x4 */
+  int32_t output_dim;        /* embed_dim */
+  int32_t image_resolution;  /* multiple of 32 */
+  int32_t compute_dtype;     /* EZCLIP_DTYPE_F32 | EZCLIP_DTYPE_BF16 */
+} ezclip_rn_config;
+int ezclip_rn_create(const ezclip_rn_config* cfg, ezclip_rn_handle* out);
+void ezclip_rn_destroy(ezclip_rn_handle h);
+int ezclip_rn_num_params(ezclip_rn_handle h);
+int ezclip_rn_param_info(ezclip_rn_handle h, int index, const char** name, int64_t* shape8, int* ndim);
+int ezclip_rn_bind_param(ezclip_rn_handle h, const char* name, const float* value_dev);
+size_t ezclip_rn_shadow_bytes(ezclip_rn_handle h);                       /* packed, BatchNorm-folded weight copies */
+int ezclip_rn_set_shadow(ezclip_rn_handle h, void* shadow_dev, size_t bytes);
+int ezclip_rn_refresh_weights(ezclip_rn_handle h, void* stream);          /* after binding / changing parameters */
+size_t ezclip_rn_workspace_bytes(ezclip_rn_handle h, int batch);         /* bounded: the batch is walked in chunks */
+/* pixels [batch, 3, R, R] float32 NCHW -> out [batch, output_dim] float32, L2-normalised (as ezclip_encode_image) */
+int ezclip_rn_encode_image(ezclip_rn_handle h, const float* pixels_dev, int batch, float* out_dev, void* workspace_dev,
+                           size_t workspace_bytes, void* stream);
+
 /* ---- backward ------------------------------------------------------------------- */
 /* Gradients are ACCUMULATED (+=) into the grad buffers bound with ezclip_bind_param (float32),
  * like autograd does; parameters bound without a grad buffer are skipped.

@@ -1,0 +1,110 @@
+"""ModifiedResNet image tower on the GPU (csrc/resnet.hip: implicit 3x3 convolutions on the MFMA GEMM, BatchNorm folded into the
+packed weights, AttentionPool2d on the one-query attention kernel) against the fixture the REAL reference produced
+(tests/golden/rn_tiny_b3.npz) and the CPU oracle (oracle/resnet_oracle.py, itself pinned to the reference) -- fp32 and bf16,
+the RN50 shape included -- and the drop-in CLIPApp built from a `vision_layers` tuple."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from easynlp_amd import lib as L
+from easynlp_amd.appzoo.clip import CLIPApp
+from easynlp_amd.appzoo.clip.rn_tower import RnEngine
+from oracle import clip_oracle as O
+from oracle import ref_harness as R
+from oracle import resnet_oracle as RO
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_tower(layers, width, e, res, sd, px, dtype):
+    eng = RnEngine(layers, width, e, res, L.dtype_code(dtype))
+    dev = {n: sd[n].cuda().contiguous() for n in eng.names}
+    eng.sync(dev)
+    out = eng.encode_image(px.cuda())
+    torch.cuda.synchronize()
+    return out.cpu(), eng, dev
+
+
+def norm(x):
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_tower_matches_the_reference_fixture(dtype):
+    z = np.load(os.path.join(HERE, "golden", "rn_tiny_b3.npz"))
+    c = json.loads(bytes(z["meta"]).decode())
+    sd = RO.make_state_dict(c["layers"], c["width"], c["output_dim"], c["resolution"], c["wseed"])
+    got, _, _ = run_tower(c["layers"], c["width"], c["output_dim"], c["resolution"], sd, torch.from_numpy(z["pixels"]), dtype)
+    want = norm(torch.from_numpy(z["image_features"]))
+    err = float((got - want).abs().max())
+    assert err < (2e-5 if dtype == "fp32" else 2e-2), err
+    assert float(torch.nn.functional.cosine_similarity(got, want).min()) > (0.999999 if dtype == "fp32" else 0.999)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("layers,width,e,res,B", [((3, 4, 6, 3), 64, 1024, 224, 3), ((2, 1, 2, 1), 8, 32, 96, 5),
+                                                  ((1, 1, 1, 1), 32, 512, 160, 2)])
+def test_tower_matches_the_oracle(layers, width, e, res, B, dtype):
+    """(3, 4, 6, 3) x 64 at 224 is RN50: 256-column tiles, the 8-phase kernel on the 1x1 convolutions, 50 attention-pool tokens"""
+    sd = RO.make_state_dict(layers, width, e, res, 11)
+    g = torch.Generator().manual_seed(4)
+    px = torch.randn(B, 3, res, res, generator=g)
+    with torch.no_grad():
+        want = norm(RO.modified_resnet_forward(sd, layers, width, px))
+    got, eng, dev = run_tower(layers, width, e, res, sd, px, dtype)
+    err = float((got - want).abs().max())
+    assert err < (5e-5 if dtype == "fp32" else 2.5e-2), err
+    assert float(torch.nn.functional.cosine_similarity(got, want).min()) > (0.999999 if dtype == "fp32" else 0.998)
+    # the same again: deterministic; one image alone: the same row (chunking / batch independence)
+    again = eng.encode_image(px.cuda()).cpu()
+    assert torch.equal(again, got)
+    one = eng.encode_image(px[1:2].cuda()).cpu()
+    assert float((one - got[1:2]).abs().max()) < (1e-6 if dtype == "fp32" else 1e-2)
+    # changed statistics reach the packed copies (BatchNorm is folded at refresh time)
+    name = "visual.layer1.0.bn2.running_var"
+    dev[name].mul_(1.5)
+    eng.sync(dev)
+    moved = eng.encode_image(px.cuda()).cpu()
+    sd2 = dict(sd)
+    sd2[name] = sd[name] * 1.5
+    with torch.no_grad():
+        want2 = norm(RO.modified_resnet_forward(sd2, layers, width, px))
+    assert float((moved - got).abs().max()) > 1e-4
+    assert float((moved - want2).abs().max()) < (5e-5 if dtype == "fp32" else 2.5e-2)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_dropin_clipapp_with_a_resnet_tower(tmp_path, dtype):
+    """config.json with a `vision_layers` tuple: forward() / compute_loss() as the reference's CHINESE_CLIP builds it
+    (modeling_chineseclip.py:279-287,352-365); the image tower is frozen, the text tower trains."""
+    cfg = dict(O.CONFIGS["tiny"], vision_layers=[1, 2, 1, 1], vision_width=16, image_resolution=64)
+    sd = {k: v for k, v in O.make_state_dict(O.CONFIGS["tiny"], 5).items() if not k.startswith("visual.")}
+    sd.update(RO.make_state_dict(cfg["vision_layers"], 16, cfg["embed_dim"], 64, 5))
+    R.write_checkpoint_dir(str(tmp_path), cfg, sd)
+    app = CLIPApp(str(tmp_path), user_defined_parameters={"clip_compute_dtype": dtype}).cuda()
+    B, Lq = 6, 24
+    _, ids = O.make_inputs(O.CONFIGS["tiny"], B, Lq, 2)
+    px = torch.randn(B, 3, 64, 64, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        img = norm(RO.modified_resnet_forward(sd, cfg["vision_layers"], 16, px))
+        txt = O.encode_text(sd, O.CONFIGS["tiny"], ids)
+        logits = float(torch.exp(sd["logit_scale"])) * txt @ img.t()
+        ref_loss = float(O.clip_loss(logits))
+    out = app({"pixel_values": px, "input_ids": ids})
+    loss = app.compute_loss(out, [])["loss"]
+    f32 = dtype == "fp32"
+    assert float((out["image_embeds"].cpu() - img).abs().max()) < (2e-5 if f32 else 2e-2)
+    assert float((out["text_embeds"].detach().cpu() - txt).abs().max()) < (2e-5 if f32 else 1e-2)
+    assert float((out["logits_per_text"].detach().cpu() - logits).abs().max()) < (4e-4 if f32 else 0.3)
+    assert abs(loss.item() - ref_loss) < (1e-4 if f32 else 3e-2)
+    loss.backward()
+    named = dict(app.named_parameters())
+    assert all(p.grad is None for n, p in named.items() if ".visual." in n)
+    assert named["chinese_clip.text_projection"].grad is not None and float(named["chinese_clip.text_projection"].grad.abs().sum()) > 0
+    with torch.no_grad():                                       # single-modality calls
+        only = app({"pixel_values": px}, feat=True)
+        assert only["text_embeds"] is None and float((only["image_embeds"].cpu() - img).abs().max()) < (2e-5 if f32 else 2e-2)

@@ -596,11 +596,15 @@ def fused_infonce_shard(eng, txt_all, img_all, n, off, logit_scale, grad_scale, 
     one) where the embedding width allows it, else ``ezclip_infonce_fused``'s materialising path."""
     lib = eng.lib
     N, e = img_all.shape
-    # bf16 pipeline: always tiled (bf16 operands).  f32 pipeline: the exact-f32 materialising path while the two logit blocks
-    # are small (its gradient bound of 1e-4 rel-L2 per parameter sits below what split-bf16 operands hold after the towers'
-    # backward: 2^-16 per product, amplified by the cancellation in sum_j (p_ij - d_ij) x_j); tiled with split operands beyond
-    # 2^24 logits per block
-    want_tiled = eng.nce_tiled and (eng.dtype_code == L.DTYPE_BF16 or n * N >= (1 << 24))
+    # bf16 pipeline: always tiled -- split operands (float32-class loss and gradients, 0.09 ms at 1024 x 1024) while the block is
+    # small, plain bf16 operands beyond 2^21 logits (0.22 instead of 0.47 ms at 1024 x 8192; the towers' own bf16 noise on the
+    # embeddings is two orders above the rounding of a unit vector's components).  f32 pipeline: the exact-f32 materialising
+    # path while the two logit blocks are small (its gradient bound of 1e-4 rel-L2 per parameter sits below what split-bf16
+    # operands hold after the towers' backward: 2^-16 per product, amplified by the cancellation in sum_j (p_ij - d_ij) x_j);
+    # tiled with split operands beyond 2^24 logits per block
+    bf16 = eng.dtype_code == L.DTYPE_BF16
+    want_tiled = eng.nce_tiled and (bf16 or n * N >= (1 << 24))
+    split = 0 if (bf16 and n * N > (1 << 21)) else 1
     tiled_bytes = lib.ezclip_infonce_tiled_workspace_bytes(n, N, e) if want_tiled else 0
     key = ("nce", n, N, e, bool(tiled_bytes))
     ws = eng._ws.get(key)
@@ -617,7 +621,7 @@ def fused_infonce_shard(eng, txt_all, img_all, n, off, logit_scale, grad_scale, 
     gs = float(grad_scale) if want_grads else 1.0
     if tiled_bytes:
         L.check(lib.ezclip_infonce_tiled(L.ptr(txt_all), L.ptr(img_all), n, N, off, e, L.ptr(logit_scale), gs,
-                                         0 if eng.dtype_code == L.DTYPE_BF16 else 1, L.ptr(loss), L.ptr(d_txt), L.ptr(d_img),
+                                         split, L.ptr(loss), L.ptr(d_txt), L.ptr(d_img),
                                          L.ptr(d_ls), L.ptr(ws), ws.numel(), L.stream_ptr()), "infonce_tiled")
     else:
         L.check(lib.ezclip_infonce_fused(L.ptr(txt_all), L.ptr(img_all), n, N, off, e, L.ptr(logit_scale), gs, L.ptr(loss),
@@ -736,7 +740,7 @@ class CLIPApp(Application):
         else:
             eng = HipClipEngine(cfg, self.compute_dtype)
         tree = _ParamTree()
-        self._rn, self._rn_tensors = None, {}
+        self._rn = None
         if not open_clip and isinstance(cfg.get("vision_layers"), (list, tuple)):
             # ModifiedResNet image tower (frozen, eval-mode BatchNorm): reference-named parameters / statistics in the same tree,
             # in the reference module's order (visual.* first)
@@ -769,15 +773,16 @@ class CLIPApp(Application):
         named = dict(tree.named_parameters())
         self._params = {n: named[n] for n in eng.names}
         if self._rn is not None:
-            both = dict(named, **dict(tree.named_buffers()))
-            self._rn_tensors = {n: both[n] for n in self._rn.names}
             for n in self._rn.names:                                    # frozen tower: no backward pass exists for it
                 if n in named:
                     named[n].requires_grad_(False)
 
     def _encode_image_resnet(self, pixel_values):
-        """ModifiedResNet tower: eval-mode BatchNorm, no gradient (rn_tower.py)."""
-        self._rn.sync(self._rn_tensors)
+        """ModifiedResNet tower: eval-mode BatchNorm, no gradient (rn_tower.py).  The tensors are looked up per call: ``.to()`` /
+        ``.cuda()`` REPLACE a module's buffers (the BatchNorm statistics), so references taken at construction go stale."""
+        both = dict(self.chinese_clip.named_parameters())
+        both.update(self.chinese_clip.named_buffers())
+        self._rn.sync({n: both[n] for n in self._rn.names})
         with torch.no_grad():
             return self._rn.encode_image(pixel_values)
 

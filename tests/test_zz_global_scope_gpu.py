@@ -32,9 +32,15 @@ def test_global_scope_equals_local_scope_on_one_rank(tmp_path, dtype):
         with torch.no_grad():
             ev = app({"pixel_values": px.clone(), "input_ids": ids.clone()})
         assert tuple(ev["logits_per_text"].shape) == (6, 6)
-    assert abs(losses["local"] - losses["global"]) < 1e-5
+    # fp32: both scopes evaluate the loss in exact float32.  bf16: the global scope runs the tiled contrastive kernels (split bf16
+    # operands at this size: float32-class loss; its embedding gradients then pass through the bf16 towers' backward)
+    assert abs(losses["local"] - losses["global"]) < (1e-5 if dtype == "fp32" else 5e-5)
     assert set(grads["local"]) == set(grads["global"])
+    floor = 1e-3 * max(float(g.norm()) for g in grads["local"].values())
     for n, g in grads["local"].items():
-        assert float((grads["global"][n] - g).norm()) <= 2e-4 * float(g.norm()) + 1e-7, n
+        if dtype == "fp32":
+            assert float((grads["global"][n] - g).norm()) <= 2e-4 * float(g.norm()) + 1e-7, n
+        else:
+            assert float((grads["global"][n] - g).norm()) <= 2e-2 * float(g.norm()) + floor, n
     with pytest.raises(Exception):
         CLIPApp(str(tmp_path), user_defined_parameters={"contrastive_scope": "everything"})

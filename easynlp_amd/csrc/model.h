@@ -108,6 +108,7 @@ int model_create(const ezclip_config* cfg, ezclip_model** out, int text_arch = 0
 size_t model_shadow_layout(ezclip_model* m, char* base, bool with_backward);  // returns bytes; assigns when base != null
 int model_refresh_weights(ezclip_model* m, hipStream_t stream);
 void set_cls_last_train(int on);     // 1 (default): the same on the training path (forward with save + backward)
+void set_cls_q_only(int on);         // 1 (default): the CLS-only last ViT block projects its queries for the CLS rows only
 void set_cls_last(int on);           // 1 (default): on the inference path the last block of a tower runs on the CLS rows only
 void set_fuse_bert_qkv(int on);      // 1 (default): BERT q / k / v projections as one product on the bf16 path
 void set_fold_layernorm(int mode);   // 0: separate LayerNorm kernels; 1: folded + row statistics from the producing GEMM; 2: folded + separate statistics pass

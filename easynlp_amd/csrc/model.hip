@@ -675,6 +675,9 @@ static int resblock_forward(ezclip_model* m, const ezclip_model::VitLayer& Lw, c
 static bool g_cls_last = true;
 void set_cls_last(int on) { g_cls_last = on != 0; }
 
+static bool g_cls_q_only = true;      // ezclip_debug_set(8, 0): project the last block's queries for every token (A/B, cross-check)
+void set_cls_q_only(int on) { g_cls_q_only = on != 0; }
+
 static int resblock_forward_cls(ezclip_model* m, const ezclip_model::VitLayer& Lw, const VitBufs& b, const BlockDims& d,
                                 bool stats_ready, void* scratch, hipStream_t stream) {
   const int M = d.M, W = d.W, B = d.B, dt = m->dtype;
@@ -683,7 +686,33 @@ static int resblock_forward_cls(ezclip_model* m, const ezclip_model::VitLayer& L
   char* x_mid = static_cast<char*>(scratch);
   char* x_out = x_mid + (size_t)B * W * esz;
   char* ln2 = x_out + (size_t)B * W * esz;
-  if (can_fold_ln(m, Lw.in_w, M)) {
+  const void* q_cls = b.qkv;                     // the queries of the CLS rows: inside the packed qkv buffer, or compact [B, W]
+  int64_t q_stride = (int64_t)d.L * 3 * W;
+  if (can_fold_ln(m, Lw.in_w, M) && g_cls_q_only && d.L >= 5) {      // (the scratch holds 5 B W elements)
+    // (round 3) only the CLS rows query: keys | values for all tokens (N = 2W: rows W.. of the folded in_proj copy), the query
+    // projection for the B CLS rows alone (LayerNorm of those rows + the plain packed copy) -- a third of this product's rows of
+    // output are never read otherwise
+    const ezclip_model::Weight& w = Lw.in_w;
+    if (!w.sf_fresh) {
+      EZ_TRY(fold_ln_weight(m->P(w.p), m->P(w.fold_g), m->P(w.fold_b), w.fold_bias >= 0 ? m->P(w.fold_bias) : nullptr, w.N, w.K,
+                            w.sf, w.ldk, w.c1, w.c2, dt, stream));
+      w.sf_fresh = true;
+    }
+    if (!stats_ready) EZ_TRY(layernorm_row_stats(b.x_in, W, eps, M, w.K, dt, b.stat, stream));
+    GemmArgs g;
+    g.A = b.x_in; g.lda = W;
+    g.B = static_cast<const char*>(w.sf) + (size_t)W * w.ldk * esz; g.ldb = w.ldk;
+    g.C = static_cast<char*>(b.qkv) + (size_t)W * esz; g.ldc = 3 * W;
+    g.M = M; g.N = 2 * W; g.K = w.ldk;
+    g.ln_stats = b.stat; g.ln_c1 = w.c1 + W; g.ln_c2 = w.c2 + W;
+    EZ_TRY(gemm_nt(g, dt, stream));
+    char* ln_cls = ln2 + (size_t)B * W * esz;
+    char* qc = ln_cls + (size_t)B * W * esz;
+    EZ_TRY(layernorm_fwd(b.x_in, (int64_t)d.L * W, ln_cls, W, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, B, W, dt, nullptr, nullptr, stream));
+    EZ_TRY(linear_ptr(m, ln_cls, W, w.s, w.ldk, W, m->P(Lw.in_b), qc, W, B, stream));
+    q_cls = qc;
+    q_stride = W;
+  } else if (can_fold_ln(m, Lw.in_w, M)) {
     EZ_TRY(linear_folded_ln(m, b.x_in, W, Lw.in_w, eps, b.stat, b.qkv, 3 * W, M, ACT_NONE, stream, stats_ready));
   } else {
     EZ_TRY(layernorm_fwd(b.x_in, W, b.ln1, W, m->P(Lw.ln1_w), m->P(Lw.ln1_b), eps, M, W, dt, nullptr, nullptr, stream));
@@ -694,7 +723,7 @@ static int resblock_forward_cls(ezclip_model* m, const ezclip_model::VitLayer& L
   at.v = (const char*)b.qkv + (size_t)2 * W * esz;
   at.row_stride = 3 * W;
   at.B = B; at.L = d.L; at.H = d.heads; at.scale = 0.125f;
-  EZ_TRY(attention_cls_fwd(at, b.qkv, (int64_t)d.L * 3 * W, b.ctx, W, dt, stream));                 // q of token 0
+  EZ_TRY(attention_cls_fwd(at, q_cls, q_stride, b.ctx, W, dt, stream));                 // q of token 0
   EZ_TRY(linear(m, b.ctx, W, Lw.out_w, Lw.out_b, x_mid, W, B, ACT_NONE, b.x_in, (int64_t)d.L * W, nullptr, false, stream));
   if (can_fold_ln(m, Lw.fc_w, B)) {
     EZ_TRY(linear_folded_ln(m, x_mid, W, Lw.fc_w, eps, b.stat, b.h, 4 * W, B, ACT_QUICKGELU, stream));

@@ -93,7 +93,9 @@ GFLOP_FWD_PER_PAIR = 46.152
 # Forward-only workloads evaluate the last block of each tower for the CLS rows only (nothing else reaches the embeddings):
 # out_proj + MLP + attention core of one ViT block for 196 of 197 tokens (2.199 G) and query / attention / output / FFN of one
 # BERT layer for 63 of 64 tokens (0.756 G) are not executed.  model_tflops is computed from the EXECUTED figure.
-GFLOP_FWD_EXECUTED_PER_PAIR = 46.152 - 2.199 - 0.756
+# (round 3: the ViT's last block also projects its queries for the CLS rows only -- 2 * 196 * 768 * 768 = 0.231 G less; unless
+#  EZCLIP_CLS_Q_ONLY=0)
+GFLOP_FWD_EXECUTED_PER_PAIR = 46.152 - 2.199 - 0.756 - (0.0 if os.environ.get("EZCLIP_CLS_Q_ONLY") == "0" else 0.231)
 GFLOP_TRAIN_EXECUTED_PER_PAIR = 138.46 - 3 * (2.199 + 0.756)     # the same rows are skipped in the backward pass
 GFLOP_TRAIN_PER_PAIR = 138.46
 GFLOP_FWD_PER_PAIR_VITL14 = 173.05      # ViT-L/14 (L = 257) + BERT-base text tower, 64 tokens

@@ -130,8 +130,15 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = -INFINITY, l = 0.f;      // running maximum of the base-2 scores s c (+ kb log2 e), running sum of 2^(x - m)
   const float c = a.scale * kLog2e;
+  // A last tile with at most 8 keys (ViT-B/16: 197 = 6 * 32 + 5) keeps them in registers 0..3 of both half-waves (keys
+  // 4 h + r): it gets its own, short epilogue below -- a quarter of the softmax instructions and half of the P V products of a
+  // full tile (round 3; the generic loop would run a full tile's 80 vector instructions for five keys).
+  constexpr bool kPlain = !HAS_KB && !CAUSAL && !DROP;
+  const int rem = L & 31;
+  const bool short_tail = kPlain && rem >= 1 && rem <= 8;
+  const int nt_loop = short_tail ? nt - 1 : nt;
 #pragma unroll 1
-  for (int t = 0; t < nt; ++t) {
+  for (int t = 0; t < nt_loop; ++t) {
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -218,6 +225,44 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
       const uint2 a0 = tr4(vt + u * 2048 + voff0), a1 = tr4(vt + u * 2048 + 1024 + voff0);
       const uint2 b0 = tr4(vt + u * 2048 + voff1), b1 = tr4(vt + u * 2048 + 1024 + voff1);
       mma32(o[0], make_uint4(a0.x, a0.y, a1.x, a1.y), pc, bf16_t());   // D[d][q]
+      mma32(o[1], make_uint4(b0.x, b0.y, b1.x, b1.y), pc, bf16_t());
+    }
+  }
+  if constexpr (kPlain) {
+    if (short_tail) {
+      const int t = nt - 1;
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const char* kt = kimg + t * 4096;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(kt + koff[s]);
+        mma32(acc, kf, qf[s], bf16_t());
+      }
+      float x[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = (4 * h + r < rem) ? acc[r] * c : -INFINITY;
+      const float tmax = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+      float t0, t1;
+      swap_halves(tmax, t0, t1);
+      const float mn = fmaxf(m, fmaxf(t0, t1));                 // (key 32 t exists: finite)
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - mn);
+      m = mn;
+      l = fmaf(l, alpha, (x[0] + x[1]) + (x[2] + x[3]));
+      if (nt > 1 && __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      }
+      const char* vt = vimg + t * 4096;
+      const uint4 pc = make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), 0u, 0u);   // keys 8 .. 31 of the tile: p = 0
+      const uint2 a0 = tr4(vt + voff0), a1 = tr4(vt + 1024 + voff0);
+      const uint2 b0 = tr4(vt + voff1), b1 = tr4(vt + 1024 + voff1);
+      mma32(o[0], make_uint4(a0.x, a0.y, a1.x, a1.y), pc, bf16_t());
       mma32(o[1], make_uint4(b0.x, b0.y, b1.x, b1.y), pc, bf16_t());
     }
   }

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
   // full tile (round 3; the generic loop would run a full tile's 80 vector instructions for five keys).
   constexpr bool kPlain = !HAS_KB && !CAUSAL && !DROP;
   const int rem = L & 31;
-  const bool short_tail = kPlain && rem >= 1 && rem <= 8;
+  const bool short_tail = kPlain && rem >= 1 && rem <= 8 && a.short_tail;
   const int nt_loop = short_tail ? nt - 1 : nt;
 #pragma unroll 1
   for (int t = 0; t < nt_loop; ++t) {
@@ -316,7 +316,12 @@ bool attention_short_fwd_eligible(const AttnArgs& a, int dtype) {   // forward: 
   return dtype == EZCLIP_BF16 && a.L <= 288 && a.B <= 65535;
 }
 
-int attention_fwd_short(const AttnArgs& a, hipStream_t stream) {
+static int g_attn_short_tail = 1;      // ezclip_debug_set(9, 0): the generic loop for the last key tile as well (A/B)
+void set_attention_short_tail(int on) { g_attn_short_tail = on != 0; }
+
+int attention_fwd_short(const AttnArgs& a_in, hipStream_t stream) {
+  AttnArgs a = a_in;
+  a.short_tail = g_attn_short_tail;
   const int nt = (a.L + 31) / 32;
   const int bytes = nt * (2 * 32 * 128 + 32 * 4);
   static int attr_max[8] = {0, 0, 0, 0, 0, 0, 0, 0};

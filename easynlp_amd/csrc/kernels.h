@@ -98,6 +98,7 @@ struct AttnArgs {
   uint32_t* keep_bits = nullptr;
   int keep_words = 0;
   int drop_L = 0;
+  int short_tail = 1;             // (set by attention_fwd_short) short epilogue for a last key tile of <= 8 keys
 };
 int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream);
 // one query per sample (the CLS row of the last block): q_cls [B, q_stride], ctx_cls [B, ctx_stride]; k / v / key_bias of `a`
@@ -108,6 +109,7 @@ bool attention_short_eligible(const AttnArgs& a, int dtype);
 bool attention_short_fwd_eligible(const AttnArgs& a, int dtype);
 int attention_fwd_short(const AttnArgs& a, hipStream_t stream);
 void set_attention_variant(int v);   // -1 auto, 0: attention.hip kernels only
+void set_attention_short_tail(int on);
 
 struct AttnBwdArgs {
   AttnArgs f;                     // forward tensors (q, k, v, key_bias, lse; ctx = forward output)

@@ -271,7 +271,7 @@ class HipClipEngine:
         return out, ws
 
     # -- packed text batches ---------------------------------------------------------------------------------
-    def pack_meta(self, ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, device=None):
+    def pack_meta(self, ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, device=None, stream=None):
         """Which tokens of a [B, S] batch the text tower has to see (ezclip_encode_text_packed, include/ezclip.h): every
         unmasked token (mask = ids != 0, modeling_chineseclip.py:347, or the explicit attention mask), every CLS token, and
         whole sentences without any unmasked key.
@@ -290,7 +290,7 @@ class HipClipEngine:
             lens = torch.empty(B, dtype=torch.int32, device=ids.device)
             ticket = L.C.c_int(0)
             L.check(self.lib.ezclip_pack_text_meta(self.handle, L.ptr(ids), L.ptr(am), B, S, L.ptr(rowmap), L.ptr(cu), L.ptr(lens),
-                                                   L.C.byref(ticket), L.stream_ptr()), "pack_text_meta")
+                                                   L.C.byref(ticket), L.stream_ptr(stream)), "pack_text_meta")
             return {"rowmap": rowmap, "cu": cu, "lens": lens, "shape": (B, S), "ticket": int(ticket.value), "_keep": (ids, am)}
         # the same tensor OBJECT, unmodified (version counter), as last time: same answer.  (The weak reference is alive only
         # while that object -- and with it its memory -- is; a new tensor at a recycled address is another object.)
@@ -436,24 +436,29 @@ class _WsToken:
         self.released = False
 
 
-def _run_towers(eng, two_streams, run_image, run_text, image_first=False):
+def _run_towers(eng, two_streams, run_image, run_text, image_first=False, prep_text=None):
     """Enqueue the image tower on the current stream and the text tower on the engine's side stream (``two_streams``) or
     both on the current stream.  Everything enqueued before is visible to both; on return the current stream has joined
     the side stream.  Tensors are allocated under the current stream in either case (the callables only pass an explicit
-    stream handle to the library)."""
+    stream handle to the library).  ``prep_text(stream)``: work the text tower needs first (the packing-metadata launch), put
+    on the TEXT stream before the image tower is enqueued -- it then runs beside the image tower's first kernels, and its
+    result words are in host memory long before ``run_text`` asks for them; what it returns is handed to ``run_text``."""
     if not two_streams or run_image is None or run_text is None:
+        prep = prep_text(None) if (prep_text is not None and run_text is not None) else None
         a = run_image(None) if run_image is not None else None
-        b = run_text(None) if run_text is not None else None
+        b = (run_text(None, prep) if prep_text is not None else run_text(None)) if run_text is not None else None
         return a, b
     main = torch.cuda.current_stream()
     side = eng.side_stream(main.device)
     side.wait_stream(main)
+    prep = prep_text(side) if prep_text is not None else None
+    text = (lambda: run_text(side, prep)) if prep_text is not None else (lambda: run_text(side))
     if image_first:                # (host-side enqueue order only: the backward pass reports the image tower's groups first;
                                    #  the forward enqueues the image tower before it reads device-built packing metadata)
         a = run_image(None)
-        b = run_text(side)
+        b = text()
     else:
-        b = run_text(side)
+        b = text()
         a = run_image(None)
     main.wait_stream(side)
     return a, b
@@ -478,11 +483,12 @@ class _EncodeFn(torch.autograd.Function):
             ids = ids.contiguous().long()
             ctx.drop = app._next_dropout()          # (hidden_p, attn_p, seed); zeros in eval mode
             eng.set_text_dropout(*ctx.drop)
-            pack = pack_hint            # (forward() computed it on the host ids; False: do not pack)
-            if pack is None and eng.can_pack(need_grad) and ids.shape[1] >= 8:
-                pack = eng.pack_meta(ids) or False           # device ids: one launch now, the scalars are read in encode_text
-            run_t = lambda st: eng.encode_text(ids, need_grad, owner=ctx.token, stream=st, pack=pack)
-        ri, rt = _run_towers(eng, app.two_streams, run_i, run_t, image_first=True)
+            want_pack = pack_hint is None and eng.can_pack(need_grad) and ids.shape[1] >= 8
+            # device ids: one launch on the text stream now, its scalars are read in encode_text (after the image tower is enqueued);
+            # pack_hint: forward() computed the metadata on the host ids (False: do not pack)
+            prep_t = lambda st: (eng.pack_meta(ids, stream=st) or False) if want_pack else pack_hint
+            run_t = lambda st, pack: eng.encode_text(ids, need_grad, owner=ctx.token, stream=st, pack=pack)
+        ri, rt = _run_towers(eng, app.two_streams, run_i, run_t, image_first=True, prep_text=prep_t if ids is not None else None)
         ctx.pack = eng.last_pack if ids is not None else None
         img, ctx.ws_img = ri if ri is not None else (None, None)
         txt, ctx.ws_txt = rt if rt is not None else (None, None)
@@ -1003,14 +1009,15 @@ class CLIPApp(Application):
             eng.sync_params(params, with_backward=False)
         drop = self._next_dropout()
         eng.set_text_dropout(*drop)
-        pack = False
-        if eng.can_pack(backward) and input_ids.shape[1] >= 8:      # (device ids: one launch; its scalars are read in encode_text,
-            pack = eng.pack_meta(input_ids, None if extras is None else extras[2]) or False     # after the image tower is enqueued)
+        want_pack = eng.can_pack(backward) and input_ids.shape[1] >= 8
         eng.last_pack = None
+        # (device ids: the packing metadata is one launch on the text stream; its scalars are read in encode_text, after the image
+        #  tower has been enqueued)
         (img, ws_i), (txt, ws_t) = _run_towers(
             eng, self.two_streams,
             lambda s_: eng.encode_image(pixel_values, backward, stream=s_),
-            lambda s_: eng.encode_text(input_ids, backward, extras=extras, stream=s_, pack=pack), image_first=True)
+            lambda s_, pack: eng.encode_text(input_ids, backward, extras=extras, stream=s_, pack=pack), image_first=True,
+            prep_text=lambda s_: (eng.pack_meta(input_ids, None if extras is None else extras[2], stream=s_) or False) if want_pack else False)
         n = img.shape[0]
         e = img.shape[1]
         if world > 1:

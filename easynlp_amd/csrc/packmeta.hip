@@ -53,6 +53,15 @@ __device__ __forceinline__ int sentence_masks(const int64_t* __restrict__ src, i
   return cnt;
 }
 
+// S <= 64: one 64-token chunk per sentence.  A wave keeps EIGHT sentences' loads in flight (the loop is latency-bound: one
+// dependent global load per sentence and wave measured 114 us for 1024 sentences; this form ~15 us)
+constexpr int kPmUnroll = 8;
+__device__ __forceinline__ uint64_t keep_mask64(uint64_t m, int S) {
+  const uint64_t full = S == 64 ? ~0ull : ((1ull << S) - 1ull);
+  if (m == 0) m = full;                      // no unmasked key: the whole sentence is kept
+  return m | 1ull;                           // the CLS query
+}
+
 __global__ __launch_bounds__(kPmThreads) void pack_meta_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int B,
                                                                int S, int* __restrict__ rowmap, int* __restrict__ cu,
                                                                int* __restrict__ lens, volatile int* host_out, int ticket) {
@@ -64,13 +73,36 @@ __global__ __launch_bounds__(kPmThreads) void pack_meta_kernel(const int64_t* __
   const int64_t* src = mask ? mask : ids;
   int longest = 0;
   bool prefix = true;
-  for (int b = wave; b < B; b += kPmWaves) {
-    uint64_t m[kPmMaxChunks];
-    bool pre;
-    const int n = sentence_masks(src, b, S, lane, m, pre);
-    if (lane == 0) s_len[b] = n;
-    longest = max(longest, n);
-    prefix &= pre;
+  const bool one_chunk = S <= 64;
+  if (one_chunk) {
+    for (int b0 = wave; b0 < B; b0 += kPmWaves * kPmUnroll) {
+      int64_t v[kPmUnroll];
+#pragma unroll
+      for (int u = 0; u < kPmUnroll; ++u) {
+        const int b = b0 + u * kPmWaves;
+        v[u] = (b < B && lane < S) ? src[(int64_t)b * S + lane] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kPmUnroll; ++u) {
+        const int b = b0 + u * kPmWaves;
+        const uint64_t m = keep_mask64(__ballot(v[u] != 0), S);
+        if (b < B) {
+          const int n = __popcll(m);
+          if (lane == 0) s_len[b] = n;
+          longest = max(longest, n);
+          prefix &= (m & (m + 1ull)) == 0;
+        }
+      }
+    }
+  } else {
+    for (int b = wave; b < B; b += kPmWaves) {
+      uint64_t m[kPmMaxChunks];
+      bool pre;
+      const int n = sentence_masks(src, b, S, lane, m, pre);
+      if (lane == 0) s_len[b] = n;
+      longest = max(longest, n);
+      prefix &= pre;
+    }
   }
   __syncthreads();
   // exclusive scan of s_len: thread i owns a contiguous segment
@@ -101,7 +133,23 @@ __global__ __launch_bounds__(kPmThreads) void pack_meta_kernel(const int64_t* __
     }
   }
   __syncthreads();
-  for (int b = wave; b < B; b += kPmWaves) {
+  if (one_chunk) {
+    for (int b0 = wave; b0 < B; b0 += kPmWaves * kPmUnroll) {
+      int64_t v[kPmUnroll];
+#pragma unroll
+      for (int u = 0; u < kPmUnroll; ++u) {
+        const int b = b0 + u * kPmWaves;
+        v[u] = (b < B && lane < S) ? src[(int64_t)b * S + lane] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kPmUnroll; ++u) {
+        const int b = b0 + u * kPmWaves;
+        const uint64_t m = keep_mask64(__ballot(v[u] != 0), S);
+        if (b < B && ((m >> lane) & 1ull)) rowmap[s_len[b] + __popcll(m & ((1ull << lane) - 1ull))] = b * S + lane;
+      }
+    }
+  }
+  for (int b = wave; b < B && !one_chunk; b += kPmWaves) {
     uint64_t m[kPmMaxChunks];
     bool pre;
     sentence_masks(src, b, S, lane, m, pre);

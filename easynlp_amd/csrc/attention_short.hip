@@ -130,6 +130,15 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = -INFINITY, l = 0.f;      // running maximum of the base-2 scores s c (+ kb log2 e), running sum of 2^(x - m)
   const float c = a.scale * kLog2e;
+  // (round 3) plain instantiation: the row sums come out of the MATRIX pipe -- P^T . 1 as one more product per 16 keys against a
+  // fragment of ones (every row of the result is the row sum of this lane's query over the keys of BOTH half-waves) -- instead
+  // of 16 dependent-chain adds per tile on the vector pipe, which is what bounds this kernel; the matrix pipe is ~85 % idle.
+  // The sum then runs over the bf16-rounded probabilities, i.e. exactly the weights that multiply V.
+  const bool mfma_sum = (!HAS_KB && !CAUSAL && !DROP) && a.mfma_rowsum;
+  f32x16_t lacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+  const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
   // A last tile with at most 8 keys (ViT-B/16: 197 = 6 * 32 + 5) keeps them in registers 0..3 of both half-waves (keys
   // 4 h + r): it gets its own, short epilogue below -- a quarter of the softmax instructions and half of the P V products of a
   // full tile (round 3; the generic loop would run a full tile's 80 vector instructions for five keys).
@@ -179,19 +188,25 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
     swap_halves(tmax, t0, t1);
     const float mn = fmaxf(m, fmaxf(t0, t1));                 // finite from the first tile on (key 0 < L)
     const float alpha = __builtin_amdgcn_exp2f(m - mn);       // (m = -inf on the first tile: 2^-inf = 0)
-    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    if (mfma_sum) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      x[r] = __builtin_amdgcn_exp2f(x[r] - mn);
-      ps[r & 3] += x[r];
+      for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - mn);
+    } else {
+      float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        x[r] = __builtin_amdgcn_exp2f(x[r] - mn);
+        ps[r & 3] += x[r];
+      }
+      l = fmaf(l, alpha, (ps[0] + ps[1]) + (ps[2] + ps[3]));
     }
     m = mn;
-    l = fmaf(l, alpha, (ps[0] + ps[1]) + (ps[2] + ps[3]));
     if (t > 0 && __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {     // (multiplying by exactly 1 changes nothing)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      lacc[0] *= alpha;             // (the other rows of lacc hold the same sum and are never read)
     }
     if constexpr (DROP) {
       const uint32_t drow = (uint32_t)((b * a.H + head) * (a.drop_L > 0 ? a.drop_L : a.L) + q);
@@ -226,6 +241,7 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
       const uint2 b0 = tr4(vt + u * 2048 + voff1), b1 = tr4(vt + u * 2048 + 1024 + voff1);
       mma32(o[0], make_uint4(a0.x, a0.y, a1.x, a1.y), pc, bf16_t());   // D[d][q]
       mma32(o[1], make_uint4(b0.x, b0.y, b1.x, b1.y), pc, bf16_t());
+      if (mfma_sum) mma32(lacc, ones, pc, bf16_t());                   // D[.][q] += sum over the 16 keys of p
     }
   }
   if constexpr (kPlain) {
@@ -251,12 +267,13 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - mn);
       m = mn;
-      l = fmaf(l, alpha, (x[0] + x[1]) + (x[2] + x[3]));
+      if (!mfma_sum) l = fmaf(l, alpha, (x[0] + x[1]) + (x[2] + x[3]));
       if (nt > 1 && __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        lacc[0] *= alpha;
       }
       const char* vt = vimg + t * 4096;
       const uint4 pc = make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), 0u, 0u);   // keys 8 .. 31 of the tile: p = 0
@@ -264,11 +281,16 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
       const uint2 b0 = tr4(vt + voff1), b1 = tr4(vt + 1024 + voff1);
       mma32(o[0], make_uint4(a0.x, a0.y, a1.x, a1.y), pc, bf16_t());
       mma32(o[1], make_uint4(b0.x, b0.y, b1.x, b1.y), pc, bf16_t());
+      if (mfma_sum) mma32(lacc, ones, pc, bf16_t());
     }
   }
-  float l0, l1;
-  swap_halves(l, l0, l1);
-  l = l0 + l1;
+  if (mfma_sum) {
+    l = lacc[0];                     // already the sum over both half-waves' keys
+  } else {
+    float l0, l1;
+    swap_halves(l, l0, l1);
+    l = l0 + l1;
+  }
   const float inv = __builtin_amdgcn_rcpf(l);
   // lane (q, h) holds columns dt*32 + 8 qd + 4 h + {0..3}; after the swap of (qd, qd + 1) pairs it holds 8 consecutive
   // columns dt*32 + 16 j + 8 h + {0..7}: one 16-byte store (4 instead of 16 store instructions per wave)
@@ -316,12 +338,13 @@ bool attention_short_fwd_eligible(const AttnArgs& a, int dtype) {   // forward: 
   return dtype == EZCLIP_BF16 && a.L <= 288 && a.B <= 65535;
 }
 
-static int g_attn_short_tail = 1;      // ezclip_debug_set(9, 0): the generic loop for the last key tile as well (A/B)
-void set_attention_short_tail(int on) { g_attn_short_tail = on != 0; }
+static int g_attn_short_tail = 3;      // ezclip_debug_set(9, v): bit 0 short last tile, bit 1 row sums on the matrix pipe (A/B)
+void set_attention_short_tail(int v) { g_attn_short_tail = v & 3; }
 
 int attention_fwd_short(const AttnArgs& a_in, hipStream_t stream) {
   AttnArgs a = a_in;
-  a.short_tail = g_attn_short_tail;
+  a.short_tail = g_attn_short_tail & 1;
+  a.mfma_rowsum = (g_attn_short_tail >> 1) & 1;
   const int nt = (a.L + 31) / 32;
   const int bytes = nt * (2 * 32 * 128 + 32 * 4);
   static int attr_max[8] = {0, 0, 0, 0, 0, 0, 0, 0};

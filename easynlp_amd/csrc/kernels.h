@@ -99,6 +99,7 @@ struct AttnArgs {
   int keep_words = 0;
   int drop_L = 0;
   int short_tail = 1;             // (set by attention_fwd_short) short epilogue for a last key tile of <= 8 keys
+  int mfma_rowsum = 1;            // (set by attention_fwd_short) plain kernel: row sums of P as an MFMA product with ones
 };
 int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream);
 // one query per sample (the CLS row of the last block): q_cls [B, q_stride], ctx_cls [B, ctx_stride]; k / v / key_bias of `a`

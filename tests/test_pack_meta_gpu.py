@@ -85,11 +85,14 @@ def test_no_stream_synchronisation_is_needed_to_read_the_result(engine):
     torch.cuda.synchronize()
     pack = engine.pack_meta(ids)
     done = torch.cuda.Event()
-    for _ in range(20):
-        a = a @ a * 1e-4                                # ~20 x 1.1 TFLOP behind the launch
+    for _ in range(40):
+        a = a @ a * 1e-4                                # ~40 x 1.1 TFLOP behind the launch
     done.record()
     res = engine.resolve_pack(pack)
     still_running = not done.query()
     torch.cuda.synchronize()
-    assert res["rows"] == int(ids.ne(0).sum().item()) or res["rows"] > 0
-    assert still_running, "the queued GEMMs finished before the metadata was read: the check is inconclusive on this box"
+    keep = ids.ne(0)
+    keep[:, 0] = True
+    assert res["rows"] == int(keep.sum().item())
+    if not still_running:       # (never seen; a box that drains 44 TFLOP in under a millisecond proves nothing either way)
+        pytest.skip("the queued GEMMs finished before the metadata was read: inconclusive on this box")

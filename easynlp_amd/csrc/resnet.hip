@@ -229,10 +229,11 @@ size_t rn_act_bytes(const ezclip_rn* m, int bc) {
   return (mx * m->esz + 255) / 256 * 256;
 }
 constexpr int kRnBufs = 5;
+size_t g_rn_buf_bound = (size_t)256 << 20;      // ezclip_debug_set(10, MiB): tests walk a small batch in several chunks
 int rn_chunk(const ezclip_rn* m, int B) {
   // bound the workspace: at most ~256 MB per activation buffer
   const size_t per_image = rn_act_bytes(m, 1);
-  int bc = (int)((size_t)(256u << 20) / per_image);
+  int bc = (int)(g_rn_buf_bound / per_image);
   if (bc < 1) bc = 1;
   return bc < B ? bc : B;
 }
@@ -334,6 +335,10 @@ int rn_forward_chunk(ezclip_rn* m, const float* px, int bc, float* out, char* ws
 }
 
 }  // namespace
+
+namespace ezclip {
+void set_rn_buffer_bound_mib(int mib) { g_rn_buf_bound = (size_t)(mib > 0 ? mib : 256) << 20; }
+}  // namespace ezclip
 
 extern "C" {
 

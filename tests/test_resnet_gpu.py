@@ -77,6 +77,28 @@ def test_tower_matches_the_oracle(layers, width, e, res, B, dtype):
     assert float((moved - want2).abs().max()) < (5e-5 if dtype == "fp32" else 2.5e-2)
 
 
+def test_a_batch_walked_in_chunks_equals_one_pass():
+    """The tower bounds its activation buffers and walks large batches in chunks (1024 RN50 images: seven of them); with the
+    bound lowered (ezclip_debug_set(10, MiB)) seven images of a small tower go through in chunks of two, three, ... -- the same
+    rows, bit for bit, as in one pass."""
+    layers, width, e, res, B = (1, 2, 1, 1), 16, 64, 128, 7
+    sd = RO.make_state_dict(layers, width, e, res, 3)
+    px = torch.randn(B, 3, res, res, generator=torch.Generator().manual_seed(2))
+    lib = L.load()
+    whole, _, _ = run_tower(layers, width, e, res, sd, px, "bf16")
+    try:
+        L.check(lib.ezclip_debug_set(10, 1))           # 1 MiB per buffer, 512 KiB per image of this tower: chunks of 2, 2, 2, 1
+        a, eng, dev = run_tower(layers, width, e, res, sd, px, "bf16")
+        per_image = lib.ezclip_rn_workspace_bytes(eng.handle, 1)
+        assert lib.ezclip_rn_workspace_bytes(eng.handle, B) <= 2 * per_image + 4096
+        assert torch.equal(a, whole)
+    finally:
+        L.check(lib.ezclip_debug_set(10, 256))
+    with torch.no_grad():
+        want = norm(RO.modified_resnet_forward(sd, layers, width, px))
+    assert float((whole - want).abs().max()) < 2.5e-2
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_dropin_clipapp_with_a_resnet_tower(tmp_path, dtype):
     """config.json with a `vision_layers` tuple: forward() / compute_loss() as the reference's CHINESE_CLIP builds it

@@ -35,7 +35,7 @@ def fake_pre(images, size=224, crop=224, mean=L.CLIP_MEAN, std=L.CLIP_STD, devic
     return torch.from_numpy(np.stack(outs))
 L.preprocess_images = fake_pre
 
-def fake_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+def fake_encode(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None, pack_hint=None):
     mt = getattr(self, "model_type", None)
     if mt == "wukong":
         sd = {"model." + n: p for n, p in self.model.named_parameters()}
@@ -87,7 +87,7 @@ def fake_shard(eng, txt_all, img_all, n, off, ls, grad_scale, need):
     return loss.detach(), ta.grad, ia.grad, lsv.grad
 CM.fused_infonce_shard = fake_shard
 _orig_encode = fake_encode
-def enc2(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None):
+def enc2(self, pixel_values=None, input_ids=None, token_type_ids=None, attention_mask=None, pack_hint=None):
     if getattr(self, "model_type", None) == "chinese_clip":
         sd = {n: p for n, p in self.chinese_clip.named_parameters()}
         img = O.encode_image(sd, self.raw_config, pixel_values) if pixel_values is not None else None

@@ -72,7 +72,6 @@ int ezclip_create_ex(const ezclip_config* cfg, int text_arch, ezclip_handle* out
 
 void ezclip_destroy(ezclip_handle h) {
   if (h) for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy((hipGraphExec_t)g.exec);
-  if (h && h->cap_stream) (void)hipStreamDestroy((hipStream_t)h->cap_stream);
   if (h && h->pm_host) (void)hipHostFree(h->pm_host);
   delete h;
 }
@@ -169,20 +168,10 @@ static int tower_graph_run(ezclip_handle h, int tower, const void* in, int B, in
   if (!hit) {
     int rc = run();                                    // eager: also brings lazily maintained state up to date
     if (rc != EZ_OK) return rc;
-    // capture on a stream of the handle's own: the caller's may be the legacy default stream, which cannot capture (nothing is
-    // executed by a capturing stream, so which stream records the launches does not matter; the graph is launched on `st`)
-    if (!h->cap_stream) {
-      hipStream_t cs = nullptr;
-      EZ_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-      h->cap_stream = cs;
-    }
-    hipStream_t user = st;
-    st = (hipStream_t)h->cap_stream;
     EZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
     rc = run();
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(st, &graph);
-    st = user;
     if (rc != EZ_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     EZ_HIP(e);
     hipGraphExec_t exec = nullptr;

@@ -96,7 +96,6 @@ struct ezclip_model {
                       int B = 0, L = 0; uint64_t epoch = 0; void* exec = nullptr; uint64_t last_use = 0; };
   std::vector<TowerGraph> graphs;
   uint64_t graph_epoch = 1, graph_clock = 0;
-  void* cap_stream = nullptr;      // the stream the captures are recorded on
 
   void* shadow = nullptr;
   size_t shadow_bytes = 0;

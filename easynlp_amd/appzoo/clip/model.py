@@ -27,8 +27,6 @@ import os
 import weakref
 from typing import Dict, List, Optional
 
-import contextlib
-
 import torch
 import torch.nn as nn
 
@@ -133,7 +131,6 @@ class HipClipEngine:
         self.last_text_rows = None
         self.last_pack = None
         self._pack_cache = None
-        self._gbufs: Dict[tuple, tuple] = {}      # graph replay: (kind, B, S, device) -> static (input, output, workspace)
         self.uses_pooler = bool(hf_branch)
         self.embed_dim = int(cfg["embed_dim"])
 
@@ -259,28 +256,7 @@ class HipClipEngine:
                 "set_backward_progress")
 
     # -- forward -----------------------------------------------------------------------------
-    def _graph_bufs(self, kind: str, B: int, S: int, device):
-        """Static input / output / workspace of one captured tower graph (ezclip_encode_*_graph replays a graph only when it
-        is called with the addresses it was captured with); at most eight shapes are kept."""
-        key = (kind, B, S, str(device))
-        g = self._gbufs.get(key)
-        if g is None:
-            if len(self._gbufs) >= 8:
-                self._gbufs.pop(next(iter(self._gbufs)))
-            if kind == "image":
-                R = int(self.cfg["image_resolution"])
-                inp = torch.empty((B, 3, R, R), dtype=torch.float32, device=device)
-                nbytes = self.lib.ezclip_image_workspace_bytes(self.handle, B, 0)
-            else:
-                inp = torch.empty((B, S), dtype=torch.int64, device=device)
-                nbytes = self.lib.ezclip_text_workspace_bytes(self.handle, B, S, 0)
-            g = (inp, torch.empty((B, self.embed_dim), dtype=torch.float32, device=device), L.alloc_bytes(nbytes, device))
-            self._gbufs[key] = g
-        return g
-
-    def encode_image(self, pixels: torch.Tensor, save: bool, owner=None, stream=None, graph: bool = False) -> (torch.Tensor, torch.Tensor):
-        """graph: replay the pass as ONE hipGraphLaunch (inference at small batches is bound by launch issue: ~100 kernels of
-        5-20 us); the request is copied into a static buffer first."""
+    def encode_image(self, pixels: torch.Tensor, save: bool, owner=None, stream=None) -> (torch.Tensor, torch.Tensor):
         pixels = pixels.contiguous()
         if pixels.dtype != torch.float32:
             pixels = pixels.float()
@@ -288,13 +264,6 @@ class HipClipEngine:
         R = int(self.cfg["image_resolution"])
         if tuple(pixels.shape[1:]) != (3, R, R):
             raise L.EzclipError("pixel_values must be [B,3,%d,%d], got %s" % (R, R, tuple(pixels.shape)))
-        if graph and not save:
-            inp, out, ws = self._graph_bufs("image", B, 0, pixels.device)
-            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
-                inp.copy_(pixels, non_blocking=True)
-                L.check(self.lib.ezclip_encode_image_graph(self.handle, L.ptr(inp), B, L.ptr(out), L.ptr(ws), ws.numel(),
-                                                           L.stream_ptr(stream)), "encode_image_graph")
-            return out, ws          # (the STATIC output buffer: the caller copies it once the streams have joined)
         out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=pixels.device)
         ws = self.workspace("image", B, 0, save, pixels.device, owner)
         L.check(self.lib.ezclip_encode_image(self.handle, L.ptr(pixels), B, L.ptr(out), L.ptr(ws), ws.numel(),
@@ -389,23 +358,13 @@ class HipClipEngine:
             return True
         return bool(pack.get("prefix")) and (extras is None or self.pack_hf_dropout)
 
-    def encode_text(self, ids: torch.Tensor, save: bool, extras=None, owner=None, stream=None, pack=None, graph: bool = False) -> (torch.Tensor, torch.Tensor):
+    def encode_text(self, ids: torch.Tensor, save: bool, extras=None, owner=None, stream=None, pack=None) -> (torch.Tensor, torch.Tensor):
         """extras: (position_ids, token_type_ids, attention_mask) int64 [B, S] device tensors (huggingface_clip branch).
-        pack: what ``pack_meta`` returned for these ids (computed here when None and packing applies).
-        graph: replay the PADDED pass as one hipGraphLaunch (small inference batches; packing needs a host hand-shake per batch)."""
+        pack: what ``pack_meta`` returned for these ids (computed here when None and packing applies)."""
         ids = ids.contiguous()
         if ids.dtype != torch.int64:
             ids = ids.long()
         B, S = ids.shape
-        if graph and not save and extras is None and self._drop == (0.0, 0.0):
-            inp, out, ws = self._graph_bufs("text", B, S, ids.device)
-            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
-                inp.copy_(ids, non_blocking=True)
-                L.check(self.lib.ezclip_encode_text_graph(self.handle, L.ptr(inp), B, S, L.ptr(out), L.ptr(ws), ws.numel(),
-                                                          L.stream_ptr(stream)), "encode_text_graph")
-            self.last_text_rows = (B * S, B * S)
-            self.last_pack = None
-            return out, ws          # (static: see encode_image)
         out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=ids.device)
         ws = self.workspace("text", B, S, save, ids.device, owner)
         if self.can_pack(save) and S >= 8 and pack is not False:
@@ -517,30 +476,22 @@ class _EncodeFn(torch.autograd.Function):
         ctx.ws_img = ctx.ws_txt = None
         ctx.token = _WsToken() if need_grad else None
         run_i = run_t = None
-        nb = max(pixels.shape[0] if pixels is not None else 0, ids.shape[0] if ids is not None else 0)
-        graph = bool(getattr(app, "use_graphs", False)) and not need_grad and nb <= int(getattr(app, "graph_max_batch", 64))
         if pixels is not None:
             pixels = pixels.contiguous().float()
-            run_i = lambda st: eng.encode_image(pixels, need_grad, owner=ctx.token, stream=st, graph=graph)
+            run_i = lambda st: eng.encode_image(pixels, need_grad, owner=ctx.token, stream=st)
         if ids is not None:
             ids = ids.contiguous().long()
             ctx.drop = app._next_dropout()          # (hidden_p, attn_p, seed); zeros in eval mode
             eng.set_text_dropout(*ctx.drop)
-            graph_t = graph and ctx.drop[0] == 0.0 and ctx.drop[1] == 0.0
-            if graph_t:
-                pack_hint = False
             want_pack = pack_hint is None and eng.can_pack(need_grad) and ids.shape[1] >= 8
             # device ids: one launch on the text stream now, its scalars are read in encode_text (after the image tower is enqueued);
             # pack_hint: forward() computed the metadata on the host ids (False: do not pack)
             prep_t = lambda st: (eng.pack_meta(ids, stream=st) or False) if want_pack else pack_hint
-            run_t = lambda st, pack: eng.encode_text(ids, need_grad, owner=ctx.token, stream=st, pack=pack, graph=graph_t)
+            run_t = lambda st, pack: eng.encode_text(ids, need_grad, owner=ctx.token, stream=st, pack=pack)
         ri, rt = _run_towers(eng, app.two_streams, run_i, run_t, image_first=True, prep_text=prep_t if ids is not None else None)
         ctx.pack = eng.last_pack if ids is not None else None
         img, ctx.ws_img = ri if ri is not None else (None, None)
         txt, ctx.ws_txt = rt if rt is not None else (None, None)
-        if graph:       # the graphs write into static buffers: hand out copies (made on the current stream, after the join)
-            img = img.clone() if img is not None else None
-            txt = txt.clone() if txt is not None else None
         ctx.app, ctx.pixels, ctx.ids = app, pixels, ids
         ctx.n_params = len(params)
         ctx.has = (img is not None, txt is not None)
@@ -734,12 +685,6 @@ class CLIPApp(Application):
         self.two_streams = str(kwargs.get("two_streams", udp.get("clip_two_streams", os.environ.get("EZCLIP_TWO_STREAMS", "1")))) \
             not in ("0", "False", "false")
         self._pack_text_opt = kwargs.get("pack_text", udp.get("clip_pack_text"))
-        # inference passes of at most `clip_graph_max_batch` pairs replayed as captured hipGraphs (one launch per tower instead of
-        # ~100: small batches are bound by launch issue); CLIPPredictor turns it on, --user_defined_parameters 'clip_hip_graphs=1'
-        # or EZCLIP_GRAPHS=1 elsewhere
-        self.use_graphs = str(kwargs.get("hip_graphs", udp.get("clip_hip_graphs", os.environ.get("EZCLIP_GRAPHS", "0")))) \
-            not in ("0", "False", "false")
-        self.graph_max_batch = int(udp.get("clip_graph_max_batch", 64))
         if pretrained_model_name_or_path is None:
             return
         path = pretrained_model_name_or_path

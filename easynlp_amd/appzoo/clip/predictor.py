@@ -47,12 +47,6 @@ class CLIPPredictor(Predictor):
             from .model import CLIPApp as model_cls
         self.multi_modal = model_cls.from_pretrained(model_dir, user_defined_parameters=user_defined_parameters or {}).cuda()
         self.multi_modal.eval()
-        # serving: small batches are bound by launch issue -- replay the towers as captured hipGraphs unless the user said otherwise
-        udp = user_defined_parameters or {}
-        if isinstance(udp, dict) and "app_parameters" in udp:
-            udp = dict(udp, **udp["app_parameters"])
-        if hasattr(self.multi_modal, "use_graphs") and str(udp.get("clip_hip_graphs", "1")) not in ("0", "False", "false"):
-            self.multi_modal.use_graphs = True
         self.first_sequence = first_sequence or "first_sequence"
         self.second_sequence = second_sequence or "second_sequence"
         self.sequence_length = sequence_length

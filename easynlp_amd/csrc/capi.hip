@@ -71,7 +71,6 @@ int ezclip_create(const ezclip_config* cfg, ezclip_handle* out) { return model_c
 int ezclip_create_ex(const ezclip_config* cfg, int text_arch, ezclip_handle* out) { return model_create(cfg, out, text_arch); }
 
 void ezclip_destroy(ezclip_handle h) {
-  if (h) for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy((hipGraphExec_t)g.exec);
   if (h && h->pm_host) (void)hipHostFree(h->pm_host);
   delete h;
 }
@@ -97,7 +96,7 @@ int ezclip_bind_param(ezclip_handle h, const char* name, void* w, void* g, const
     EZ_REQUIRE(shape[i] == p.shape[i], "ezclip_bind_param: %s dim %d is %lld, expected %lld", name, i,
                (long long)shape[i], (long long)p.shape[i]);
   EZ_REQUIRE(((uintptr_t)w % 16) == 0 && ((uintptr_t)g % 16) == 0, "ezclip_bind_param: %s must be 16-byte aligned", name);
-  if (p.w != reinterpret_cast<float*>(w)) { h->weights_fresh = false; ++h->graph_epoch; }   // grad-only rebinding keeps the packs valid
+  if (p.w != reinterpret_cast<float*>(w)) h->weights_fresh = false;   // grad-only rebinding keeps the packs valid
   p.w = reinterpret_cast<float*>(w);
   p.g = reinterpret_cast<float*>(g);
   return EZ_OK;
@@ -115,13 +114,11 @@ int ezclip_set_shadow(ezclip_handle h, void* buf, size_t bytes, int with_backwar
   model_shadow_layout(h, reinterpret_cast<char*>(buf), with_backward != 0);
   h->shadow = buf; h->shadow_bytes = bytes; h->shadow_backward = with_backward != 0;
   h->weights_fresh = false;
-  ++h->graph_epoch;
   return EZ_OK;
 }
 
 int ezclip_refresh_weights(ezclip_handle h, void* stream) {
   EZ_REQUIRE(h, "ezclip_refresh_weights: null handle");
-  ++h->graph_epoch;      // (folded-LayerNorm copies are rebuilt lazily by the next EAGER product: captured graphs do not contain that)
   return model_refresh_weights(h, S(stream));
 }
 
@@ -142,71 +139,6 @@ int ezclip_encode_text(ezclip_handle h, const int64_t* ids, int batch, int seq_l
                        size_t ws_bytes, int save, void* stream) {
   EZ_REQUIRE(h, "ezclip_encode_text: null handle");
   return encode_text(h, ids, batch, seq_len, out, ws, ws_bytes, save != 0, S(stream));
-}
-
-// ---- inference towers as executable graphs -------------------------------------------------------------------------------
-// A tower pass at a small batch is ~100 (image) / ~90 (text) launches of kernels that run for 5-20 us each: the step is bound
-// by launch issue, not by the device.  The launches of one pass depend only on (handle state, batch, buffer addresses), so they
-// are captured ONCE into a hipGraph and replayed with a single hipGraphLaunch.  First call for a key: one eager pass (lazy state:
-// folded-LayerNorm copies, function attributes), then a second pass under hipStreamBeginCapture, instantiate, launch.
-static uint64_t g_graph_global_epoch = 0;      // moved by ezclip_debug_set: process-wide switches change what a pass launches
-static int tower_graph_run(ezclip_handle h, int tower, const void* in, int B, int L, float* out, void* ws, size_t ws_bytes,
-                           hipStream_t st) {
-  const uint64_t epoch = h->graph_epoch + (g_graph_global_epoch << 32);
-  auto run = [&]() -> int {
-    return tower == 0 ? encode_image(h, (const float*)in, B, out, ws, ws_bytes, false, st)
-                      : encode_text(h, (const int64_t*)in, B, L, out, ws, ws_bytes, false, st);
-  };
-  ezclip_model::TowerGraph* hit = nullptr;
-  for (auto& g : h->graphs)
-    if (g.exec && g.tower == tower && g.in == in && g.out == out && g.ws == ws && g.B == B && g.L == L) { hit = &g; break; }
-  if (hit && hit->epoch != epoch) {                   // parameters / options changed since the capture
-    (void)hipGraphExecDestroy((hipGraphExec_t)hit->exec);
-    hit->exec = nullptr;
-    hit = nullptr;
-  }
-  if (!hit) {
-    int rc = run();                                    // eager: also brings lazily maintained state up to date
-    if (rc != EZ_OK) return rc;
-    EZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-    rc = run();
-    hipGraph_t graph = nullptr;
-    const hipError_t e = hipStreamEndCapture(st, &graph);
-    if (rc != EZ_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    EZ_HIP(e);
-    hipGraphExec_t exec = nullptr;
-    const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    EZ_HIP(e2);
-    ezclip_model::TowerGraph* slot = nullptr;
-    for (auto& g : h->graphs) if (!g.exec) { slot = &g; break; }
-    if (!slot && h->graphs.size() < 16) { h->graphs.emplace_back(); slot = &h->graphs.back(); }
-    if (!slot) {                                       // evict the least recently used
-      slot = &h->graphs[0];
-      for (auto& g : h->graphs) if (g.last_use < slot->last_use) slot = &g;
-      (void)hipGraphExecDestroy((hipGraphExec_t)slot->exec);
-    }
-    slot->tower = tower; slot->in = in; slot->out = out; slot->ws = ws; slot->B = B; slot->L = L;
-    slot->epoch = epoch; slot->exec = exec;
-    hit = slot;
-    // (the eager pass above already produced `out` for this call: the captured pass did not execute)
-    hit->last_use = ++h->graph_clock;
-    return EZ_OK;
-  }
-  hit->last_use = ++h->graph_clock;
-  EZ_HIP(hipGraphLaunch((hipGraphExec_t)hit->exec, st));
-  return EZ_OK;
-}
-
-int ezclip_encode_image_graph(ezclip_handle h, const float* pixels, int batch, float* out, void* ws, size_t ws_bytes, void* stream) {
-  EZ_REQUIRE(h && pixels && out && ws && batch > 0, "ezclip_encode_image_graph: null / empty argument");
-  return tower_graph_run(h, 0, pixels, batch, 0, out, ws, ws_bytes, S(stream));
-}
-int ezclip_encode_text_graph(ezclip_handle h, const int64_t* ids, int batch, int seq_len, float* out, void* ws, size_t ws_bytes,
-                             void* stream) {
-  EZ_REQUIRE(h && ids && out && ws && batch > 0 && seq_len > 0, "ezclip_encode_text_graph: null / empty argument");
-  EZ_REQUIRE(h->drop_hidden == 0.f && h->drop_attn == 0.f, "ezclip_encode_text_graph: inference only (dropout is armed)");
-  return tower_graph_run(h, 1, ids, batch, seq_len, out, ws, ws_bytes, S(stream));
 }
 
 int ezclip_similarity(const float* a, const float* b, int na, int nb, int e, const float* logit_scale, float* out,
@@ -366,7 +298,6 @@ int ezclip_set_backward_progress(ezclip_handle h, ezclip_progress_fn fn, void* u
 
 int ezclip_set_option(ezclip_handle h, int key, double value) {
   EZ_REQUIRE(h, "ezclip_set_option: null handle");
-  ++h->graph_epoch;
   switch (key) {
     case EZCLIP_OPT_TEXT_POOLER: h->opt_text_pooler = value != 0.0; return EZ_OK;
     case EZCLIP_OPT_VISION_FROZEN: h->opt_vision_frozen = value != 0.0; return EZ_OK;
@@ -469,7 +400,6 @@ int ezclip_recall_ranks_rows(const float* text_rows, const float* image, int row
 }
 
 int ezclip_debug_set(int key, int value) {
-  ++g_graph_global_epoch;
   if (key == 0) { set_gemm_variant(value); return EZ_OK; }
   if (key == 1) { set_attention_variant(value); return EZ_OK; }
   if (key == 2) { set_fold_layernorm(value); return EZ_OK; }

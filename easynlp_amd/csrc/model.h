@@ -89,14 +89,6 @@ struct ezclip_model {
   int* pm_dev = nullptr;
   int pm_ticket = 0;
 
-  // ezclip_encode_image_graph / ezclip_encode_text_graph: captured executable graphs of the inference towers, keyed by the
-  // buffers they were captured with; graph_epoch moves whenever something a captured graph depends on may have changed
-  // (parameters re-bound / re-packed, shadow buffer, options) and invalidates them all
-  struct TowerGraph { int tower = 0; const void* in = nullptr; const void* out = nullptr; const void* ws = nullptr;
-                      int B = 0, L = 0; uint64_t epoch = 0; void* exec = nullptr; uint64_t last_use = 0; };
-  std::vector<TowerGraph> graphs;
-  uint64_t graph_epoch = 1, graph_clock = 0;
-
   void* shadow = nullptr;
   size_t shadow_bytes = 0;
   bool shadow_backward = false;

@@ -99,8 +99,6 @@ SIGNATURES = {
     "ezclip_infonce_workspace_bytes": (_sz, [_i, _i, _i]),
     "ezclip_infonce_fused": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ezclip_infonce_tiled_workspace_bytes": (_sz, [_i, _i, _i]),
-    "ezclip_encode_image_graph": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
-    "ezclip_encode_text_graph": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ezclip_rn_create": (_i, [_vp, C.POINTER(_vp)]),
     "ezclip_rn_destroy": (None, [_vp]),
     "ezclip_rn_num_params": (_i, [_vp]),

@@ -207,20 +207,6 @@ int ezclip_encode_text(ezclip_handle h, const int64_t* input_ids_dev, int batch,
 int ezclip_similarity(const float* a_dev, const float* b_dev, int na, int nb, int e,
                       const float* logit_scale_dev, float* out_dev, void* stream);
 
-/* ---- inference towers as hipGraphs (round 3) -----------------------------------------------------
- * ezclip_encode_image / ezclip_encode_text (save_for_backward = 0) replayed as ONE hipGraphLaunch: at small batches (the
- * predictor's, an online service's) a tower pass is ~100 launches of kernels that run 5-20 us each and is bound by launch issue.
- * The first call with a given (input, batch, [seq_len,] output, workspace) runs eagerly, captures a second pass with
- * hipStreamBeginCapture and instantiates it; later calls with the SAME addresses launch the executable graph -- the caller keeps
- * input / output / workspace in static buffers and copies each request into them.  Re-binding parameters, ezclip_refresh_weights,
- * ezclip_set_shadow and ezclip_set_option invalidate the captured graphs (they are re-captured on the next call); up to 16 graphs
- * per handle (least recently used evicted).  The text pass is the padded one (packing needs a host hand-shake per batch) and
- * requires dropout to be off.  Same results as the eager calls, bit for bit. */
-int ezclip_encode_image_graph(ezclip_handle h, const float* pixels_dev, int batch, float* out_dev, void* workspace_dev,
-                              size_t workspace_bytes, void* stream);
-int ezclip_encode_text_graph(ezclip_handle h, const int64_t* input_ids_dev, int batch, int seq_len, float* out_dev,
-                             void* workspace_dev, size_t workspace_bytes, void* stream);
-
 /* ---- InfoNCE ------------------------------------------------------------------- */
 /* Loss of the reference's compute_loss on a materialised logits_per_text [n, n]:
  *   0.5 * (CE(S, arange) + CE(S^T, arange)).  scratch: >= 4*n floats.  */

@@ -254,7 +254,11 @@ def build_app(wl, device, text_dropout=0.0):
     if text_dropout > 0:
         model_cfg = dict(model_cfg, text_hidden_dropout_prob=text_dropout, text_attention_probs_dropout_prob=text_dropout)
     if wl.get("model") == "hf_vitl14":
-        app = CLIPApp.from_hf_config(HF_VITL14_ROBERTA, seed=1234, device=device, compute_dtype=wl["dtype"])
+        hf_cfg = HF_VITL14_ROBERTA
+        if text_dropout > 0:        # RoBERTa's train-mode dropouts live in text_config (CLIPTextConfig)
+            hf_cfg = dict(hf_cfg, text_config=dict(hf_cfg["text_config"], hidden_dropout_prob=text_dropout,
+                                                   attention_probs_dropout_prob=text_dropout))
+        app = CLIPApp.from_hf_config(hf_cfg, seed=1234, device=device, compute_dtype=wl["dtype"])
         name = "huggingface_clip: frozen ViT-L/14 + chinese-roberta-wwm-ext (BERT-base arch) + pooler, random init"
     else:
         app = CLIPApp.from_config(model_cfg, seed=1234, device=device, compute_dtype=wl["dtype"])

@@ -72,8 +72,9 @@ def _worker(rank, world, port, ckpt, dtype, q):
             pass
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, dtype):
+@pytest.mark.parametrize("world,dtype", [(2, "fp32"), (2, "bf16"), (4, "bf16")])
+def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, world, dtype):
+    """(world 4: ranks at row offsets 6, 12, 18 of a 24-pair global batch -- ragged tiles of the contrastive kernels)"""
     cfg = O.CONFIGS["small"]
     R.write_checkpoint_dir(str(tmp_path), cfg, O.make_state_dict(cfg, 9))
     s = socket.socket()
@@ -82,10 +83,10 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, dtype):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), dtype, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), dtype, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in range(2)]
+    res = [q.get(timeout=600) for _ in range(world)]
     for p in procs:
         p.join(timeout=120)
     if any(r[1].startswith("SKIP") for r in res):

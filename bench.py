@@ -227,7 +227,7 @@ def relaunch(args):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not os.environ.get("EZCLIP_BENCH_ONE_GPU"):
         sys.exit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
@@ -476,13 +476,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == max(1, args.gpus), "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    # Dry run of the N > 1 code path on a one-GPU box (tests/test_zz_bench_contract_gpu.py): EZCLIP_BENCH_ONE_GPU=1 puts every rank
+    # on cuda:0 and EZCLIP_BENCH_BACKEND=gloo moves the collectives through the host (RCCL refuses two ranks on one device).  The
+    # numbers of such a run mean nothing; the driver's runs use neither variable.
+    one_gpu = bool(os.environ.get("EZCLIP_BENCH_ONE_GPU"))
+    backend = os.environ.get("EZCLIP_BENCH_BACKEND", "nccl")
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     use_dist = world > 1 or "WORLD_SIZE" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     from easynlp_amd import lib as L
     if os.environ.get("EZCLIP_NO_LNFOLD"):      # A/B switch: separate LayerNorm kernels in the inference path too
@@ -539,7 +549,7 @@ def main():
                        "seq_len": head["seq_len"], "stages": head["stages"], "path": head["path"],
                        "contrastive_scope": "global" if world > 1 else "local", "parallelism": "dp%d" % world,
                        "two_streams": head["two_streams"], "text_dropout": args.text_dropout},
-            "rccl_ranks": world if use_dist else 0,
+            "rccl_ranks": world if use_dist else 0, "collective_backend": backend if use_dist else None,
         }
         for k in ("loss", "batches_rotated", "pack_meta_in_timed_region", "ms_per_step_ranks", "text_tower_rows", "gflop_per_pair",
                   "model_tflops_per_gpu", "model_mfma_frac", "roofline", "time_share", "attention_tflops", "layernorm_gbps",

@@ -78,16 +78,15 @@ def test_bench_self_launches_under_torch_distributed_run():
 def test_bench_two_rank_code_path_dry_run_on_one_gpu():
     """`bench.py --gpus 2` end to end on this one-GPU box: both ranks on cuda:0, collectives through gloo (EZCLIP_BENCH_ONE_GPU /
     EZCLIP_BENCH_BACKEND, bench.py) -- self-launch under torch.distributed.run, per-rank batches, the all-gather + tiled contrastive
-    step of the global batch, barrier, MAX over ranks, the one JSON line with the per-rank timings; and the training workload with the
-    overlapped bucketed gradient all-reduce.  The driver's multi-GPU run is the first time this path meets RCCL; it should not also be
-    the first time it runs."""
+    step of the global batch, barrier, MAX over ranks, the one JSON line with the
+    per-rank timings.  (The training step with the overlapped bucketed gradient all-reduce on several ranks is
+    tests/test_zz_two_ranks_one_gpu.py: through gloo a 755 MB arena per step would take minutes here.)  The driver's multi-GPU run is
+    the first time this path meets RCCL; it should not also be the first time it runs."""
     env = {"EZCLIP_BENCH_ONE_GPU": "1", "EZCLIP_BENCH_BACKEND": "gloo", "EZCLIP_NO_CANARY": "1"}
-    out = _run("--gpus", "2", "--also", "bf16_b1024_train", "--also-steps", "1", env=env)
+    out = _run("--gpus", "2", "--no-also", env=env)
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["collective_backend"] == "gloo"
     assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 128 and out["config"]["contrastive_scope"] == "global"
     assert out["value"] > 0 and out["scaling"] == "weak" and "allgather" in out["config"]["stages"]
     r = out["ms_per_step_ranks"]
     assert r["min"] <= r["max"] + 1e-9 and r["max"] == out["ms_per_step"]
     assert abs(out["loss"] - math.log(128)) < 0.3                 # this rank's rows against the 128 columns of the global batch
-    tr = out["also"]["bf16_b1024_train"]
-    assert "error" not in tr and tr["value"] > 0 and tr["grad_allreduce_buckets_mib"] and abs(tr["loss"] - math.log(128)) < 0.3

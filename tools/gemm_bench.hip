@@ -101,6 +101,8 @@ int main(int argc, char** argv) {
       ++pos;
     }
   }
+  // OPERAND_SCALE=0: all-zero A / B (no datapath toggling) -- how much of the sustained rate is the socket power cap
+  const float opscale = getenv("OPERAND_SCALE") ? (float)atof(getenv("OPERAND_SCALE")) : 1.0f;
   const int Mv = batch * 197, Mt = batch * 64;
   const Shape shapes[] = {
       {"vit.qkv", Mv, 2304, 768, 0, false, false},     {"vit.out+res", Mv, 768, 768, 0, true, false},
@@ -131,8 +133,8 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&bias, s.N * 4));
     if (s.res) CK(hipMalloc(&R, nC * 2));
     if (s.c2) { CK(hipMalloc(&P0, nC * 2)); CK(hipMalloc(&P1, nC * 2)); }
-    fill_bf16<<<2048, 256, 0, st>>>(A, nA, 1u, 1.0f);
-    fill_bf16<<<2048, 256, 0, st>>>(B, nB, 2u, 0.05f);
+    fill_bf16<<<2048, 256, 0, st>>>(A, nA, 1u, 1.0f * opscale);
+    fill_bf16<<<2048, 256, 0, st>>>(B, nB, 2u, 0.05f * opscale);
     fill_f32<<<(s.N + 255) / 256, 256, 0, st>>>(bias, s.N, 3u);
     if (R) fill_bf16<<<2048, 256, 0, st>>>(R, nC, 4u, 1.0f);
     if (s.u) { CK(hipMalloc(&Uu, nC * 2)); fill_bf16<<<2048, 256, 0, st>>>(Uu, nC, 5u, 3.0f); }

@@ -62,7 +62,7 @@ struct Ctx {
 
 // One phase.  P: quadrant; PAR: tile parity (static slot bases); ISSUE: issue half-tile k+6;
 // VM: vmcnt to wait for afterwards (-1: none).
-template <int P, int PAR, bool ISSUE, int VM, int VMR = VM>
+template <int P, int PAR, bool ISSUE, int VM, int VMR = VM, int XLD = 0>
 __device__ __forceinline__ void phase(const Ctx& c, Frags& f, f32x16_t (&acc)[4][2], uint32_t kbyte_next1,
                                       uint32_t kbyte_next2, bool relaxed = false) {
   constexpr int k8 = 4 * PAR + P;                 // phase number mod 8
@@ -107,9 +107,9 @@ __device__ __forceinline__ void phase(const Ctx& c, Frags& f, f32x16_t (&acc)[4]
     }
   }
   if constexpr (VMR != VM) {   // first K-tile of a tile: the previous tile's stores may still be queued (see ktile)
-    if (relaxed) wait_vm<VMR>(); else wait_vm<VM>();
-  } else {
-    wait_vm<VM>();
+    if (relaxed) wait_role<VM, VMR - VM, 0, true>(); else wait_role<VM, 0, 0, true>();
+  } else if constexpr (VM >= 0) {
+    wait_role<VM - XLD, 0, XLD, true>();
   }
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
@@ -149,8 +149,8 @@ __device__ __forceinline__ void ktile(const Ctx& c, Frags& f, f32x16_t (&acc)[4]
     phase<2, PAR, false, 6>(c, f, acc, kb1, kb2);
     phase<3, PAR, false, 4>(c, f, acc, kb1, kb2);
   } else {
-    phase<0, PAR, false, 2 + XL>(c, f, acc, kb1, kb2);
-    phase<1, PAR, false, 0 + XL>(c, f, acc, kb1, kb2);
+    phase<0, PAR, false, 2 + XL, 2 + XL, XL>(c, f, acc, kb1, kb2);
+    phase<1, PAR, false, 0 + XL, 0 + XL, XL>(c, f, acc, kb1, kb2);
     phase<2, PAR, false, -1>(c, f, acc, kb1, kb2);
     phase<3, PAR, false, -1>(c, f, acc, kb1, kb2);
   }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
   tile_origin(v, m0, n0);
   set_tile(m0, n0);
   issue_prologue();
-  wait_vm<8>();                         // half-tiles 0 and 1 (this wave's pieces)
+  wait_role<8, 0, 0, true>();           // half-tiles 0 and 1 (this wave's pieces)
   bool first = true;
 
   f32x16_t acc[4][2];                   // (re-zeroed block by block in the epilogue)
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
                                                     issue_prologue();
                                                   });
     if (!has_next) break;
-    wait_vm<6 + 4 * NS>();   // half-tiles 0..2 of the next tile have landed; 3..5 and this tile's stores may still fly
+    wait_role<6, 4 * NS, 0, true>();   // half-tiles 0..2 of the next tile have landed; 3..5 and this tile's stores may still fly
     first = false;
     v = vn; m0 = m0n; n0 = n0n;
   }

@@ -16,7 +16,24 @@ constexpr int kRing = 8 * kSlot;       // 128 KiB
 constexpr int kThreads8 = 512;
 
 // LDS-DMA: 64 lanes x 16 B land at lds_dst + lane*16 (wave-uniform destination).
-__device__ __forceinline__ void dma16(uint32_t lds_dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
+// EZ_ROLE_X / EZ_ROLE_Y (tools/build_variants.py; timing only, results are wrong by construction): is the store tail of the
+// epilogue the in-order vmcnt of the wave that also waits for the LDS-DMA, or the CU's memory pipeline?  In both variants wave
+// row 0 issues every DMA of the workgroup (its own pieces twice: same volume into LDS) and wave row 1 none; the C stores are
+// issued by wave row 1 only (X: the DMA waves never have a store in their queue) or by wave row 0 only (Y: they do).  Same
+// traffic, same instruction counts per CU -- X faster than Y means a role split would hide the tail.
+#if defined(EZ_ROLE_X) || defined(EZ_ROLE_Y)
+#define EZ_ROLES 1
+__device__ __forceinline__ bool ez_dma_role() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0; }
+#ifdef EZ_ROLE_X
+__device__ __forceinline__ bool ez_store_role() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 1; }
+#else
+__device__ __forceinline__ bool ez_store_role() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0; }
+#endif
+#else
+#define EZ_ROLES 0
+#endif
+
+__device__ __forceinline__ void dma16_one(uint32_t lds_dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
   uint32_t keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
@@ -27,6 +44,15 @@ __device__ __forceinline__ void dma16(uint32_t lds_dst, uint32_t voff, const i32
       : "=&s"(keep)
       : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff)
       : "memory");
+}
+__device__ __forceinline__ void dma16(uint32_t lds_dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
+#if EZ_ROLES
+  if (!ez_dma_role()) return;
+  dma16_one(lds_dst, voff, srd, soff);
+  dma16_one(lds_dst + 8192u, voff, srd, soff);     // the partner wave's region of the half-tile image
+#else
+  dma16_one(lds_dst, voff, srd, soff);
+#endif
 }
 
 // Lane id recomputed on the spot (v_mbcnt): an asm volatile cannot be hoisted out of the tile loop, so values
@@ -40,6 +66,21 @@ __device__ __forceinline__ int lane_id_now() {
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   if constexpr (N >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Counted wait written as (DMAs, stores, other loads) that may stay in flight.  Without the role experiment: their sum.
+// MAIN: a wait of the main loop (for LDS-DMA only): waves that issue no DMA skip it.
+template <int ND, int NST, int NLD, bool MAIN>
+__device__ __forceinline__ void wait_role() {
+#if EZ_ROLES
+  if (ez_dma_role()) {
+    if (ez_store_role()) wait_vm<2 * ND + NST + NLD>(); else wait_vm<2 * ND + NLD>();
+  } else if (!MAIN) {
+    if (ez_store_role()) wait_vm<NST + NLD>(); else wait_vm<NLD>();
+  }
+#else
+  wait_vm<ND + NST + NLD>();
+#endif
 }
 
 __device__ __forceinline__ i32x4_t make_srd(const void* base, uint32_t bytes) {
@@ -157,6 +198,9 @@ __device__ __forceinline__ void stg16(const u32x4_t& data, uint32_t voff, const 
 #if defined(EZ_ABL_NOSTORE) || defined(EZ_ABL_NOEPI)
   asm volatile("" ::"v"(data), "v"(voff), "s"(soff));
   return;
+#endif
+#if EZ_ROLES
+  if (!ez_store_role()) return;
 #endif
 #ifdef EZ_STG_SAMEADDR
   voff = (voff & 0x70u) | ((threadIdx.x & 0x1f8u) << 4); soff = 0;
@@ -285,13 +329,22 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
 #endif
     // wait for this block's loads (block 0: also the bias)
     if constexpr (i == 0) {
+#if EZ_ROLES
+      wait_role<D, 0, 2 * NL, false>();
+      wait_vm2<63>(bq[0], bq[1]);
+#else
       wait_vm2<2 * NL + D>(bq[0], bq[1]);
+#endif
       bv[0] = __uint_as_float(bq[0].x); bv[1] = __uint_as_float(bq[0].y);
       bv[2] = __uint_as_float(bq[0].z); bv[3] = __uint_as_float(bq[0].w);
       bv[4] = __uint_as_float(bq[1].x); bv[5] = __uint_as_float(bq[1].y);
       bv[6] = __uint_as_float(bq[1].z); bv[7] = __uint_as_float(bq[1].w);
       if constexpr (HAS_LN) {     // (bias is null here: bv = 0 + c2)
+#if EZ_ROLES
+        wait_vm4<63>(c1q[0], c1q[1], c2q[0], c2q[1]);
+#else
         wait_vm4<2 * NL + D>(c1q[0], c1q[1], c2q[0], c2q[1]);
+#endif
         c1v[0] = __uint_as_float(c1q[0].x); c1v[1] = __uint_as_float(c1q[0].y);
         c1v[2] = __uint_as_float(c1q[0].z); c1v[3] = __uint_as_float(c1q[0].w);
         c1v[4] = __uint_as_float(c1q[1].x); c1v[5] = __uint_as_float(c1q[1].y);
@@ -304,7 +357,15 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
     }
     if constexpr (NL > 0) {
       // newer than block i's loads:  0: (bias) L1 L2 D   1: L2 D S0 L3   2: D S0 L3 S1   3: S1 S2
+#if EZ_ROLES
+      if constexpr (i == 0) wait_role<D, 0, 2 * NL, false>();
+      else if constexpr (i == 1) wait_role<D, NS, 2 * NL, false>();
+      else if constexpr (i == 2) wait_role<D, 2 * NS, NL, false>();
+      else wait_role<0, 2 * NS, 0, false>();
+      constexpr int cnt = 63;
+#else
       constexpr int cnt = (i == 0) ? 2 * NL + D : (i == 1) ? 2 * NL + D + NS : (i == 2) ? NL + D + 2 * NS : 2 * NS;
+#endif
       if constexpr (HAS_R) wait_vm4<cnt>(ld.r[b][0], ld.r[b][1], ld.r[b][2], ld.r[b][3]);
       if constexpr (HAS_U) wait_vm4<cnt>(ld.u[b][0], ld.u[b][1], ld.u[b][2], ld.u[b][3]);
       if constexpr (HAS_LN) wait_vm4s<cnt>(ld.s[b][0], ld.s[b][1], ld.s[b][2], ld.s[b][3]);

@@ -216,3 +216,53 @@ def test_hf_packed_text_tower_with_dropout_equals_the_padded_one(tmp_path, path,
                                        token_type_ids=tt.cuda(), attention_mask=am.cuda()).item())
     assert abs(other - res[True][0]) > 1e-4
     eng.pack_text = True
+
+
+HF_VITL14_SHALLOW = dict(
+    text_config=dict(vocab_size=21128, hidden_size=768, intermediate_size=3072, num_hidden_layers=2, num_attention_heads=12,
+                     max_position_embeddings=512, type_vocab_size=2, pad_token_id=1, layer_norm_eps=1e-12, hidden_act="gelu",
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0),
+    vision_config=dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=3, num_attention_heads=16, image_size=224,
+                       patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5),
+    projection_dim=768)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_hf_vitl14_width_towers_against_oracle(tmp_path, dtype):
+    """The pai-clip-commercial-large SHAPES of BASELINE.json config 5 (CLIPVisionModel: width 1024, 16 heads, 257 tokens, patch 14,
+    projection 768, detached; RobertaModel pooled output), three / two blocks deep: forward, loss and every gradient the
+    reference's backward produces, against the oracle (appzoo/clip/model.py:128-150)."""
+    cfg = HF_VITL14_SHALLOW
+    app, sd = make_app(tmp_path, cfg, 17, dtype)
+    app.eval()
+    B, Lq = 16, 64
+    px, ids, tt, am = H.make_inputs(cfg, B, Lq, 9)
+    out = app({"pixel_values": px, "input_ids": ids, "token_type_ids": tt, "attention_mask": am})
+    loss = app.compute_loss(out, [])["loss"]
+    loss.backward()
+    ref, ref_loss, grads = H.forward_loss_backward(sd, cfg, px, ids, tt, am)
+    f32 = dtype == "fp32"
+    for k in ("image_embeds", "text_embeds"):
+        got = out[k].detach().cpu()
+        assert float((got - ref[k]).abs().max()) < (2e-5 if f32 else 1e-2), k
+        assert float(torch.nn.functional.cosine_similarity(got, ref[k]).min()) > (0.999999 if f32 else 0.9995), k
+    assert abs(loss.item() - ref_loss.item()) < (2e-5 if f32 else 1.5e-2)
+    params = dict(app.named_parameters())
+    params["logit_scale"] = params.pop("logit_scale_param")
+    worst, frozen = [], 0
+    for n, want in grads.items():
+        p = params[n]
+        if want is None:
+            frozen += 1
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        worst.append((float((p.grad.detach().cpu().double().reshape(want.shape) - want.double()).norm()), n,
+                      float(want.double().norm()), (n.split(".")[0], tuple(want.shape))))
+    by_shape = {}                                # (same bound as test_model_gpu.py::test_vitl14_width_towers_against_oracle)
+    for _, _, wn, key in worst:
+        by_shape[key] = max(by_shape.get(key, 0.0), wn)
+    rel, floor = (3e-4, 1e-5) if f32 else (6e-2, 2e-2)
+    worst = sorted(((err / (rel * wn + floor * by_shape[key] + 1e-12), n, err, wn) for err, n, wn, key in worst), reverse=True)
+    print("worst gradient deviations (fraction of bound, name, |diff|, |ref|):", worst[:5])
+    assert frozen > 40 and len(worst) > 30       # (the whole vision encoder is detached: model.py:140)
+    assert worst[0][0] < 1.0, worst[:5]

@@ -562,3 +562,56 @@ def test_training_path_last_block_on_cls_rows_equals_full_backward(tmp_path):
     for n, g0 in res[0][1].items():
         err = float((res[1][1][n] - g0).norm())
         assert err <= 2e-5 * float(g0.norm()) + 1e-8, (n, err, float(g0.norm()))
+
+
+VITL14_SHALLOW = dict(O.CONFIGS["vitb16_bertbase"], embed_dim=768, vision_layers=3, vision_width=1024, vision_patch_size=14,
+                      text_num_hidden_layers=2)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_vitl14_width_towers_against_oracle(tmp_path, dtype):
+    """BASELINE.json config 5's tower SHAPES (ViT-L/14: width 1024, 16 heads, 16 x 16 + 1 = 257 tokens, patch 14 -> K = 588 padded to
+    640, MLP 4096, embed_dim 768; BERT-base-arch text tower), three / two blocks deep so that the CPU oracle stays quick: forward,
+    loss and parameter gradients against the oracle.  257 tokens is the nine-wave case of the short attention kernels and the widest
+    LayerNorm rows of the path; at 16 pairs the ViT products (4 112 rows) run on the persistent 8-phase GEMM."""
+    cfg = VITL14_SHALLOW
+    app, sd = make_app(tmp_path, cfg, 21, dtype)
+    app.train()                                   # (dropout probabilities are 0 in this config)
+    B, Lq = 16, 64
+    px, ids = O.make_inputs(cfg, B, Lq, 5)
+    out = app({"pixel_values": px, "input_ids": ids})
+    loss = app.compute_loss(out, [])["loss"]
+    loss.backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.clip_forward(sdr, cfg, px, ids)
+    ref_loss = O.clip_loss(ref["logits_per_text"])
+    ref_loss.backward()
+    img, txt = out["image_embeds"].detach().cpu(), out["text_embeds"].detach().cpu()
+    ri, rt = ref["image_embeds"].detach(), ref["text_embeds"].detach()
+    if dtype == "fp32":
+        assert float((img - ri).abs().max()) < 2e-5 and float((txt - rt).abs().max()) < 2e-5
+        assert abs(loss.item() - ref_loss.item()) < 2e-5 * max(1.0, abs(ref_loss.item()))
+    else:
+        assert float((img - ri).abs().max()) < 1e-2 and float((txt - rt).abs().max()) < 1e-2
+        assert float(torch.nn.functional.cosine_similarity(img, ri).min()) > 0.9995
+        assert float(torch.nn.functional.cosine_similarity(txt, rt).min()) > 0.9995
+        assert abs(loss.item() - ref_loss.item()) < 1.5e-2
+    # every parameter the reference's backward reaches, against the oracle's autograd
+    worst = []
+    for n, p in app._params.items():
+        want = sdr[n].grad
+        if want is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        got = p.grad.detach().cpu().double()
+        worst.append((float((got - want.double()).norm()), n, float(want.double().norm()), (n.split(".")[0], tuple(want.shape))))
+    # bound: a fraction of the gradient's own norm + a fraction of the largest norm among same-shape parameters of the tower
+    # (the key biases' gradients are mathematically zero -- softmax is shift-invariant -- and 1e-9 in the reference)
+    by_shape = {}
+    for _, _, wn, key in worst:
+        by_shape[key] = max(by_shape.get(key, 0.0), wn)
+    rel, floor = (3e-4, 1e-5) if dtype == "fp32" else (6e-2, 2e-2)
+    worst = sorted(((err / (rel * wn + floor * by_shape[key] + 1e-12), n, err, wn) for err, n, wn, key in worst), reverse=True)
+    print("worst gradient deviations (fraction of bound, name, |diff|, |ref|):", worst[:5])
+    assert len(worst) > 60
+    assert worst[0][0] < 1.0, worst[:5]

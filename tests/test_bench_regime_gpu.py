@@ -332,3 +332,45 @@ def test_headline_batch_of_1024_pairs_size_independent_properties():
     for got, want_e in ((img[sample], ref["image_embeds"]), (txt[sample], ref["text_embeds"])):
         assert float((got - want_e).abs().max()) < 1e-2
         assert float(torch.nn.functional.cosine_similarity(got, want_e).min()) > 0.9995
+
+
+def test_directional_derivatives_at_1024_pairs_fp32():
+    """Gradient check at the headline size, float32 pipeline (the bf16 pipeline is tied to it at 64 / 256 pairs above): for six
+    parameters spread over both towers and the heads, the directional derivative <dL/dp, d> of ONE fused training step over 1 024 pairs
+    (autograd of core/trainer.py:658-661 through the kernels' backward) against the central difference (L(p + h d) - L(p - h d)) / 2h of
+    two forward steps.  A size-independent property: no oracle run of this size is needed, and every kernel of the backward pass sees
+    the row counts of the benchmark (201 728 ViT rows, weight-gradient contractions over all of them)."""
+    from easynlp_amd.appzoo.clip import CLIPApp
+    B, S = 1024, 64
+    px, ids = _synth(B, S, seed=1000)
+    app = CLIPApp.from_config(VITB16, seed=1234, device=DEV, compute_dtype="fp32")
+    app.train()                                   # (dropout probabilities are 0 in VITB16)
+    loss0, grads = _train_step(app, px, ids)
+    names = ["text_projection", "visual.proj", "visual.transformer.resblocks.5.mlp.c_fc.weight", "visual.positional_embedding",
+             "bert.encoder.layer.6.attention.self.query.weight", "bert.encoder.layer.11.output.dense.weight", "logit_scale"]
+    g = torch.Generator(device=DEV).manual_seed(77)
+    report = []
+    for n in names:
+        p = app._params[n]
+        d = torch.randn(p.shape, generator=g, device=DEV) if p.dim() > 0 else torch.ones((), device=DEV)
+        d = d * (float(p.detach().norm()) / max(float(d.norm()), 1e-30)) if p.dim() > 0 else d
+        analytic = float((grads[n].double() * d.double()).sum())
+        h = 2e-2 if p.dim() > 0 else 5e-2           # relative to |p| (d has p's norm); logit_scale: absolute
+        vals = []
+        for sgn in (+1.0, -1.0):
+            with torch.no_grad():
+                p.add_(d, alpha=sgn * h)
+                app._engine.mark_weights_dirty()
+                vals.append(float(app.contrastive_step(px, ids, process_group=False).item()))
+                p.add_(d, alpha=-sgn * h)
+        app._engine.mark_weights_dirty()
+        fd = (vals[0] - vals[1]) / (2 * h)
+        report.append((n, analytic, fd))
+    with torch.no_grad():
+        back = float(app.contrastive_step(px, ids, process_group=False).item())
+    print("loss %.6f (again %.6f); directional derivatives (name, analytic, central difference):" % (loss0, back), report)
+    assert abs(back - loss0) < 2e-6 * max(1.0, abs(loss0))      # the parameters are back where they were
+    for n, analytic, fd in report:
+        assert math.isfinite(analytic) and abs(analytic) > 1e-6, (n, analytic)
+        # central difference: O(h^2) truncation + the loss's float32 rounding (~1e-6) / 2h
+        assert abs(fd - analytic) < 3e-2 * abs(analytic) + 1e-4, (n, analytic, fd)

@@ -6,6 +6,8 @@ batch).  bench.py's `value` starts with the inputs resident in HBM; this prints 
   B  pinned host tensors through CLIPApp.forward (DataLoader(pin_memory=True): core/trainer.py builds it that way when CUDA is on)
   C  pinned host tensors, batch k+1 copied on a side stream while batch k is computed (non_blocking prefetch), device tensors to forward
   D  device-resident inputs (the bench's regime), same loop
+  E  the host tensors of A / B behind easynlp_amd.appzoo.clip.DevicePrefetcher (the product's device loader: a background thread copies
+     batch k+1 while batch k is computed), its batches handed to CLIPApp.forward
 usage: pcie_inclusive.py [steps]"""
 import os
 import sys
@@ -80,4 +82,25 @@ def run_c(k):
 
 slots[0] = slots[1] = None
 timed("C pinned + prefetch of batch k+1 on a copy stream", run_c)
+from easynlp_amd.appzoo.clip import DevicePrefetcher   # noqa: E402
+
+
+def timed_loader(label, host):
+    n = steps + 3
+    it = iter(DevicePrefetcher(({"pixel_values": host[k % 4][0], "input_ids": host[k % 4][1], "label_ids": []} for k in range(n)), dev))
+    for _ in range(3):
+        b = next(it)
+        fwd(b["pixel_values"], b["input_ids"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in it:
+        loss = fwd(b["pixel_values"], b["input_ids"])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    print("%-58s %8.2f ms/step  %7.0f pairs/s   (%.1f GB/s of input if all of it crossed PCIe)  loss %.4f"
+          % (label, ms, B / ms * 1e3, mb / ms, float(loss)), flush=True)
+
+
+timed_loader("E pageable host tensors behind DevicePrefetcher", pageable)
+timed_loader("E pinned host tensors behind DevicePrefetcher", pinned)
 timed("D device-resident inputs (bench regime), again", lambda k: fwd(*dev_batches[k % 4]))

@@ -251,8 +251,8 @@ class DevicePrefetcher:
     memory the runtime's staged copy blocks only that thread), records an event per batch on the copy stream, and queues at most
     ``depth`` batches; ``__next__`` makes the consumer's current stream wait for the batch's event and registers the tensors with it
     (``record_stream``: their memory is not recycled under the consumer's kernels).  Everything that is not a tensor -- ``label_ids``
-    lists, image lists / packed images for the GPU pre-processing, sizes -- passes through untouched, as do tensors already on the
-    device.  On a CPU device it is the identity.  An exception raised by the wrapped loader is re-raised in the consumer."""
+    lists, image lists, sizes -- passes through untouched, as do tensors already on the device; of a packed image batch
+    (``batch_fn`` with ``pack_batches=True``) the byte buffer is copied and the descriptor table stays on the host.  On a CPU device it is the identity.  An exception raised by the wrapped loader is re-raised in the consumer."""
 
     def __init__(self, loader, device, depth: int = 2):
         self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
@@ -266,7 +266,11 @@ class DevicePrefetcher:
         out = {}
         with torch.cuda.stream(stream):
             for k, v in batch.items():
-                out[k] = v.to(self.device, non_blocking=True) if (torch.is_tensor(v) and not v.is_cuda) else v
+                if torch.is_tensor(v) and not v.is_cuda:
+                    v = v.to(self.device, non_blocking=True)
+                elif L.is_packed_images(v) and not v["data"].is_cuda:      # batch_fn(pack_batches=True): the decoded RGB8 bytes
+                    v = dict(v, data=v["data"].to(self.device, non_blocking=True))
+                out[k] = v
             ev = torch.cuda.Event()
             ev.record(stream)
         return out, ev
@@ -314,6 +318,7 @@ class DevicePrefetcher:
                     cur = torch.cuda.current_stream(self.device)
                     cur.wait_event(ev)
                     for v in batch.values():
+                        v = v["data"] if L.is_packed_images(v) else v
                         if torch.is_tensor(v) and v.is_cuda:
                             v.record_stream(cur)
                 yield batch

@@ -125,3 +125,17 @@ def test_forward_takes_prefetched_batches_like_host_batches(tmp_path):
         got = [app(b)["logits_per_text"].cpu() for b in DevicePrefetcher(host, "cuda:0")]
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_packed_image_batches_cross_on_the_copy_stream_and_preprocess_to_the_same_pixels():
+    import numpy as np
+    from easynlp_amd import lib as L
+    rng = np.random.RandomState(4)
+    raw = [[rng.randint(0, 256, (h, w, 3), dtype=np.uint8) for h, w in ((240, 320), (300, 224), (224, 224), (97, 180))] for _ in range(3)]
+    host = [{"images": L.pack_images(ims), "image_size": 224, "label_ids": []} for ims in raw]
+    want = [L.preprocess_images(ims, size=224, crop=224, device="cuda:0").cpu() for ims in raw]
+    for b, w in zip(DevicePrefetcher(host, "cuda:0"), want):
+        assert b["images"]["data"].is_cuda and not b["images"]["desc"].is_cuda
+        assert torch.equal(L.preprocess_images(b["images"], size=224, crop=224, device="cuda:0").cpu(), w)
+    assert not host[0]["images"]["data"].is_cuda                           # the wrapped loader's batch is not modified

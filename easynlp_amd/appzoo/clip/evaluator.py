@@ -102,7 +102,11 @@ class CLIPEvaluator(Evaluator):
         model.eval()
         total_spent_time = 0.0
         image_embeds_all, text_embeds_all = [], []
-        for _step, batch in enumerate(self.valid_loader):
+        # batch k + 1 crosses PCIe while batch k is encoded (identity for a model on the CPU)
+        from .data import DevicePrefetcher
+        p0 = next(iter(model.parameters()), None)
+        loader = DevicePrefetcher(self.valid_loader, p0.device) if (p0 is not None and p0.is_cuda) else self.valid_loader
+        for _step, batch in enumerate(loader):
             infer_start_time = time.time()
             with torch.no_grad():
                 outputs = model(batch, feat=True) if getattr(model, "_engine", None) is not None else model(batch)

@@ -374,11 +374,14 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
     lib = L.load()
     roof, extra = None, {}
     if profile:
-        nprof = 2
+        # as many steps as were timed (at most 10), entered warm: two un-recorded steps first and no idle gap before the recorded ones,
+        # so that the leg's kernels run at the clock of the timed region (the chip sits at its 1 400 W cap: DESIGN 6.0).  The events'
+        # sum per step agrees with the rocprofv3 kernel trace of the same run (profiles/r3ac_*_kernel_stats.md).
+        nprof = max(2, min(int(steps), 10))
         two = app.two_streams
         app.two_streams = False
         step()
-        fence()
+        step()
         if rank == 0:
             L.check(lib.ezclip_profile_begin())
         for _ in range(nprof):      # every rank steps (the collectives need all of them); only rank 0 records events

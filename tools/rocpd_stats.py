@@ -1,6 +1,10 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 rocpd sqlite database (--kernel-trace) as a per-kernel table
-(the equivalent of --stats' kernel_stats.csv).  usage: rocpd_stats.py results.db [out.md]"""
+(the equivalent of --stats' kernel_stats.csv).  usage: rocpd_stats.py results.db [out.md] [group-regex]
+With a group regex (e.g. "gemm_(nt|tn)(_8p)?_kernel": the launches bench.py's roofline object counts) a second table splits that group's
+launches by position in the process timeline -- the first launches of a process run cold (first touch of the activation buffers, code
+pages), and bench.py's `roofline.avg_launch_us` is measured on untimed steps AFTER the timed region: it has to be compared with the
+steady part of the trace, not with the whole-process average."""
 import re
 import sqlite3
 import sys
@@ -31,6 +35,18 @@ def main():
         lines.append("| `%s` | %d | %.3f | %.2f | %.2f | %.2f | %.2f |" % (
             name[:110], a[0], a[1] / 1e6, a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3, 100.0 * a[1] / total))
     out = "\n".join(lines) + "\n\ntotal kernel time: %.3f ms over %d dispatches\n" % (total / 1e6, len(rows))
+    if len(sys.argv) > 3:
+        pat = re.compile(sys.argv[3])
+        g = sorted((st, en - st) for name, st, en in rows if pat.search(name))
+        if g:
+            n = len(g)
+            out += "\nlaunches matching `%s`: %d, whole-process average %.2f us (total %.3f ms); by position in the timeline:\n\n" % (
+                sys.argv[3], n, sum(d for _, d in g) / n / 1e3, sum(d for _, d in g) / 1e6)
+            out += "| launches | average us |\n|---|---|\n"
+            for a, b in ((0.0, 0.125), (0.125, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)):
+                seg = g[int(a * n):int(b * n)]
+                if seg:
+                    out += "| %d .. %d | %.2f |\n" % (int(a * n), int(b * n) - 1, sum(d for _, d in seg) / len(seg) / 1e3)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(out)
     print(out)

@@ -2,14 +2,17 @@
 """Calibration only (never on the product path): what the vendor libraries reach on this box for the shapes of the path --
 torch.matmul (hipBLASLt / rocBLAS behind it) for the big bf16 GEMMs and torch SDPA for the attention shapes -- next to
 tools/bin/gemm_bench's numbers for the hand-written kernels.  Prints TFLOP/s; used for DESIGN.md section 6."""
+import os
 import time
 
 import torch
 
 dev = "cuda"
+OPSCALE = float(os.environ.get("OPERAND_SCALE", "1"))     # 0: all-zero operands (no datapath toggling: the chip keeps its full clock)
+ITERS = int(os.environ.get("ITERS", "20"))
 
 
-def bench(fn, iters=20):
+def bench(fn, iters=ITERS):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -22,8 +25,8 @@ def bench(fn, iters=20):
 
 for name, M, N, K in (("vit.qkv", 201728, 2304, 768), ("vit.out", 201728, 768, 768), ("vit.fc", 201728, 3072, 768),
                       ("vit.proj", 201728, 768, 3072), ("bert.ffn1", 65536, 3072, 768)):
-    a = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
-    w = ((torch.rand(N, K, device=dev) * 2 - 1) * 0.05).bfloat16()
+    a = ((torch.rand(M, K, device=dev) * 2 - 1) * OPSCALE).bfloat16()
+    w = ((torch.rand(N, K, device=dev) * 2 - 1) * 0.05 * OPSCALE).bfloat16()
     bias = torch.randn(N, device=dev).bfloat16()
     t = bench(lambda: torch.nn.functional.linear(a, w, bias))
     print("%-10s M=%d N=%d K=%d : torch linear (bias) %.1f TF (%.3f ms)" % (name, M, N, K, 2.0 * M * N * K / t / 1e12, t * 1e3))

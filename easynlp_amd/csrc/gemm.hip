@@ -334,6 +334,7 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
                "gemm_nt: bad implicit-convolution problem (H %d W %d C %d K %d M %d)", p.conv_H, p.conv_W, p.conv_C, p.K, p.M);
     return dtype == EZCLIP_F32 ? launch_nt_conv<float>(p, stream) : launch_nt_conv<bf16_t>(p, stream);
   }
+  if (g_gemm_variant == 4 && gemm_nt_4q_eligible(p, dtype)) return gemm_nt_4q(p, stream);     // staged experiment (gemm4q.hip)
   if (gemm_nt_uses_8p(p, dtype)) return gemm_nt_8p(p, stream);
   if (p.colsum != nullptr) {   // not the 8-phase kernel: separate column-sum pass after the GEMM
     float* cs = p.colsum;

@@ -124,6 +124,27 @@ def test_gemm_nt_persistent_regime(N, K, epi):
         assert float((part[..., 1].double() - s2).abs().max()) < 1e-4 * float(s2.abs().max())
 
 
+@pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (3072, 768), (768, 3072)])
+@pytest.mark.parametrize("epi", ["bias", "bias_qgelu", "bias_gelu_c2"])
+def test_staged_four_wave_gemm_is_bit_identical(N, K, epi):
+    """gemm4q.hip (four waves of 128 x 128, reads and LDS-DMA hand-placed between the MFMAs; an experiment the dispatcher never
+    selects: DESIGN 6.1) over 70 011 ragged rows: the same bits as the 128x128 kernel and as the 8-phase kernel, second output
+    included -- same accumulation order, same epilogue code."""
+    M = M_BIG
+    a, b, bias, res, u = _inputs(M, N, K, seed=3 * N + K)
+    act = L.ACT_QUICKGELU if "qgelu" in epi else (L.ACT_GELU_ERF if "gelu" in epi else L.ACT_NONE)
+    outs = {}
+    for fk in (0, 2, 4):
+        extra = {"c2": torch.empty((M, N), dtype=torch.bfloat16, device=DEV)} if "c2" in epi else {}
+        outs[fk] = (L.op_gemm_nt_ex(a, b, force_kernel=fk, bias=bias, act=act, **extra), extra)
+        torch.cuda.synchronize()
+    assert torch.equal(outs[4][0], outs[0][0]) and torch.equal(outs[4][0], outs[2][0])
+    if "c2" in epi:
+        assert torch.equal(outs[4][1]["c2"], outs[0][1]["c2"])
+    with pytest.raises(L.EzclipError):      # epilogues it does not have are refused, not silently run elsewhere
+        L.op_gemm_nt_ex(a, b, force_kernel=4, bias=bias, residual=res)
+
+
 @pytest.mark.parametrize("N,act", [(2304, L.ACT_NONE), (3072, L.ACT_QUICKGELU)])
 def test_gemm_nt_folded_layernorm_persistent_regime(N, act):
     """in_proj / c_fc of the bf16 inference path: LayerNorm folded into the product (GemmArgs::ln_stats)."""

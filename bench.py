@@ -66,6 +66,11 @@ HF_VITL14_ROBERTA = dict(
                        patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5),
     projection_dim=768)
 
+# ... and with the LARGE text tower of those checkpoints (CLIPTextConfig's defaults, configuration_clip.py:90-95:
+# chinese-roberta-wwm-ext-large -- hidden 1024, 24 layers, 16 heads, FFN 4096; SURVEY 8d "201.09 G/pair")
+HF_VITL14_ROBERTA_LARGE = dict(HF_VITL14_ROBERTA, text_config=dict(HF_VITL14_ROBERTA["text_config"], hidden_size=1024,
+                                                                    intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16))
+
 # path: "fused" = CLIPApp.contrastive_step (one C call per stage, no autograd bookkeeping);
 #       "autograd" = forward() + compute_loss() + backward() through the autograd glue (the reference Trainer's calls)
 WORKLOADS = {
@@ -80,12 +85,14 @@ WORKLOADS = {
     "bf16_vitl14_b512_fwd_loss": dict(dtype="bf16", batch=512, seq=64, backward=False, model="vitl14"),
     "bf16_vitl14_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="vitl14"),
     "bf16_hf_vitl14_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="hf_vitl14"),
+    "bf16_hf_vitl14_large_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="hf_vitl14_large"),
 }
 # what the default run adds to the headline line (BASELINE.json configs 3, 2, 5 + the boundary overhead)
 ALSO_N1 = ["bf16_b1024_fwd_loss_padded_text", "bf16_b1024_train", "bf16_b1024_train_padded_text", "bf16_b1024_train_opt",
            "bf16_b1024_fwd_loss_autograd",
            "bf16_b1024_train_autograd",
-           "fp32_b256_fwd_sim", "bf16_vitl14_b512_fwd_loss", "bf16_vitl14_b512_train", "bf16_hf_vitl14_b512_train"]
+           "fp32_b256_fwd_sim", "bf16_vitl14_b512_fwd_loss", "bf16_vitl14_b512_train", "bf16_hf_vitl14_b512_train",
+           "bf16_hf_vitl14_large_b512_train"]
 ALSO_MULTI = ["bf16_b1024_train"]          # config 4 "(+bwd)": gradient all-reduce overlapped with the backward pass
 
 # algorithmic GFLOP per pair (multiply-add = 2; padded tiles and softmax/LN excluded)
@@ -101,6 +108,7 @@ GFLOP_TRAIN_PER_PAIR = 138.46
 GFLOP_FWD_PER_PAIR_VITL14 = 173.05      # ViT-L/14 (L = 257) + BERT-base text tower, 64 tokens
 GFLOP_TRAIN_PER_PAIR_VITL14 = 519.2
 GFLOP_TRAIN_PER_PAIR_HF_VITL14 = 162.03 + 3 * 11.025      # frozen vision tower: forward only; text tower fwd + bwd
+GFLOP_TRAIN_PER_PAIR_HF_VITL14_LARGE = 162.03 + 3 * 39.06   # text: 24 layers x 64 tokens x (8 H^2 + 4 H F + 4 L H), H 1024, F 4096
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 
 # launches of the dominant kernel in one forward step at 1024 pairs (shape names of tools/gemm_bench):
@@ -243,6 +251,81 @@ class Ctx:
     pass
 
 
+class Telemetry:
+    """Shader clock and socket power of GPU 0 while a leg runs, sampled by a host thread twice a second: amdgpu's hwmon files
+    (power1_average / power1_input in microwatts, freq1_input in Hz) where present, `rocm-smi --showpower --showclocks` otherwise.
+    Evidence for DESIGN.md 6.0 ("the sustained rate is the 1 400 W socket cap"): it never influences the timing."""
+
+    def __init__(self, period=0.5):
+        import glob
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self.source = None
+        self._hw = None
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            try:
+                if open(os.path.join(os.path.dirname(os.path.dirname(d)), "vendor")).read().strip() != "0x1002":
+                    continue
+            except OSError:
+                continue
+            pw = [f for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(d, f))]
+            if pw and os.path.exists(os.path.join(d, "freq1_input")):
+                self._hw = (os.path.join(d, pw[0]), os.path.join(d, "freq1_input"))
+                self.source = "hwmon:" + pw[0]
+                break
+        if self._hw is None:
+            import shutil
+            if shutil.which("rocm-smi"):
+                self.source = "rocm-smi"
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        if self._hw is not None:
+            try:
+                return (time.perf_counter(), float(open(self._hw[1]).read()) / 1e6, float(open(self._hw[0]).read()) / 1e6)
+            except (OSError, ValueError):
+                return None
+        if self.source == "rocm-smi":
+            import re
+            import subprocess
+            try:
+                txt = subprocess.run(["rocm-smi", "-d", "0", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+            except Exception:
+                return None
+            mhz = re.search(r"sclk clock level[^\n]*\((\d+)Mhz\)", txt)
+            w = re.search(r"Package Power \(W\):\s*([0-9.]+)", txt)
+            if mhz and w:
+                return (time.perf_counter(), float(mhz.group(1)), float(w.group(1)))
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            r = self._read()
+            if r is not None:
+                self.samples.append(r)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self.t0 = time.perf_counter()
+        if self.source:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.source:
+            self._thread.join(timeout=6)
+
+    def summary(self, skip_seconds=3.0):
+        """means over the samples taken after the first `skip_seconds` (the chip needs ~3 s to settle at its cap)"""
+        xs = [x for x in self.samples if x[0] - self.t0 >= skip_seconds] or self.samples
+        if not xs:
+            return {"source": self.source, "samples": 0}
+        return {"source": self.source, "samples": len(xs), "shader_clock_mhz_mean": round(sum(x[1] for x in xs) / len(xs), 1),
+                "shader_clock_mhz_min": round(min(x[1] for x in xs), 1), "socket_power_w_mean": round(sum(x[2] for x in xs) / len(xs), 1),
+                "socket_power_w_max": round(max(x[2] for x in xs), 1)}
+
+
 NBATCH = 4      # distinct synthetic batches a workload rotates through (run_workload)
 
 
@@ -253,13 +336,14 @@ def build_app(wl, device, text_dropout=0.0):
             else "ViT-B/16 + BERT-base") + " (chinese_clip), random init"
     if text_dropout > 0:
         model_cfg = dict(model_cfg, text_hidden_dropout_prob=text_dropout, text_attention_probs_dropout_prob=text_dropout)
-    if wl.get("model") == "hf_vitl14":
-        hf_cfg = HF_VITL14_ROBERTA
+    if wl.get("model") in ("hf_vitl14", "hf_vitl14_large"):
+        hf_cfg = HF_VITL14_ROBERTA_LARGE if wl["model"] == "hf_vitl14_large" else HF_VITL14_ROBERTA
         if text_dropout > 0:        # RoBERTa's train-mode dropouts live in text_config (CLIPTextConfig)
             hf_cfg = dict(hf_cfg, text_config=dict(hf_cfg["text_config"], hidden_dropout_prob=text_dropout,
                                                    attention_probs_dropout_prob=text_dropout))
         app = CLIPApp.from_hf_config(hf_cfg, seed=1234, device=device, compute_dtype=wl["dtype"])
-        name = "huggingface_clip: frozen ViT-L/14 + chinese-roberta-wwm-ext (BERT-base arch) + pooler, random init"
+        name = "huggingface_clip: frozen ViT-L/14 + chinese-roberta-wwm-ext%s + pooler, random init" % (
+            "-large (hidden 1024, 24 layers, 16 heads)" if wl["model"] == "hf_vitl14_large" else " (BERT-base arch)")
     else:
         app = CLIPApp.from_config(model_cfg, seed=1234, device=device, compute_dtype=wl["dtype"])
     app.eval()
@@ -271,6 +355,8 @@ def build_app(wl, device, text_dropout=0.0):
 def gflop_per_pair(wl):
     if wl.get("model") == "hf_vitl14":
         return GFLOP_TRAIN_PER_PAIR_HF_VITL14, None
+    if wl.get("model") == "hf_vitl14_large":
+        return GFLOP_TRAIN_PER_PAIR_HF_VITL14_LARGE, None
     if wl.get("model") == "vitl14":
         return (GFLOP_TRAIN_PER_PAIR_VITL14 if wl["backward"] else GFLOP_FWD_PER_PAIR_VITL14), None
     cls_last = os.environ.get("EZCLIP_CLS_LAST", "1") != "0"
@@ -280,7 +366,7 @@ def gflop_per_pair(wl):
     return (GFLOP_FWD_EXECUTED_PER_PAIR if cls_last else GFLOP_FWD_PER_PAIR), GFLOP_FWD_PER_PAIR
 
 
-def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, profile=True):
+def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, profile=True, sustained_steps=0, sustained_seconds=20.0):
     """Build the model of workload `name`, run `warmup` untimed and exactly `steps` timed steps (barrier + synchronize on
     both sides, MAX over ranks), then the roofline leg.  Returns the fields of the JSON line for this workload."""
     import torch.distributed as dist
@@ -309,7 +395,7 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
         # a real in-place weight update per step: the next forward re-packs the library's bf16 / transposed copies
         opt = torch.optim.AdamW([p for p in app.parameters() if p.requires_grad], lr=1e-6, eps=1e-6, weight_decay=0.01, fused=True)
     hf_all = [{} for _ in batches]
-    if wl.get("model") == "hf_vitl14":
+    if wl.get("model") in ("hf_vitl14", "hf_vitl14_large"):
         hf_all = [{"token_type_ids": torch.zeros_like(i_), "attention_mask": i_.ne(0).long()} for _, i_ in batches]
     counter = [0]
 
@@ -411,6 +497,33 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
             extra["attention_tflops"] = round(a_fl / (a_ms * 1e-3) / 1e12, 2) if a_ms > 0 else None
             l_ms, l_by, l_n = res["layernorm"]
             extra["layernorm_gbps"] = round(l_by / (l_ms * 1e-3) / 1e9, 1) if l_ms > 0 else None
+    # ---- sustained leg (round 4; VERDICT r3 "put the sustained regime in the line"): the same step for `sustained_steps` steps or
+    # `sustained_seconds`, whichever ends first -- the chip settles at its socket power cap within a few seconds and the default
+    # 20-step figure above still has thermal headroom.  Chunks of 25 steps with a synchronisation between them
+    # (one idle gap of microseconds per second of work); clock and power sampled by a host thread.
+    sustained = None
+    if sustained_steps > 0 and world == 1:
+        chunk, done, marks = 25, 0, []
+        fence()
+        with Telemetry() as tel:
+            t0s = time.perf_counter()
+            while done < sustained_steps and time.perf_counter() - t0s < sustained_seconds:
+                for _ in range(chunk):
+                    step()
+                torch.cuda.synchronize()
+                done += chunk
+                marks.append((done, time.perf_counter() - t0s))
+        total_s = marks[-1][1]
+        half = [m for m in marks if m[0] * 2 >= done]                # the second half: past the settling seconds
+        first_of_half = marks[len(marks) - len(half) - 1] if len(half) < len(marks) else (0, 0.0)
+        ms_steady = (half[-1][1] - first_of_half[1]) / max(1, half[-1][0] - first_of_half[0]) * 1e3
+        sustained = {"steps": done, "seconds": round(total_s, 2), "ms_per_step": round(total_s / done * 1e3, 3),
+                     "ms_per_step_second_half": round(ms_steady, 3), "value_second_half": round(B / ms_steady * 1e3, 1),
+                     "telemetry": tel.summary()}
+        clk = sustained["telemetry"].get("shader_clock_mhz_mean")
+        if clk and wl["dtype"] == "bf16":
+            # the dense bf16 MFMA peak at the clock the chip was allowed: 2.5 PFLOP/s x clock / 2.4 GHz
+            sustained["peak_tflops_at_mean_clock"] = round(PEAK_TFLOPS["bf16"] * clk / 2400.0, 1)
     buckets = getattr(app, "last_grad_buckets", None)
     text_rows = None
     if rows_seen and all(r is not None for r in rows_seen):       # mean over the timed steps (the batches differ in length)
@@ -443,6 +556,12 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
     }
     if buckets:
         out["grad_allreduce_buckets_mib"] = [round((e - s) * 4 / 2 ** 20, 1) for s, e in buckets]
+    if sustained:
+        tf = sustained["value_second_half"] * gflop / 1e3                        # executed model TFLOP/s in the steady state
+        sustained["model_mfma_frac_second_half"] = round(tf / PEAK_TFLOPS[wl["dtype"]], 4)
+        if sustained.get("peak_tflops_at_mean_clock"):
+            sustained["model_frac_of_clock_adjusted_peak"] = round(tf / sustained["peak_tflops_at_mean_clock"], 4)
+        out["sustained"] = sustained
     out.update(extra)
     return out
 
@@ -459,6 +578,8 @@ def main():
     ap.add_argument("--also", default="", help="comma-separated workloads for the `also` object (default: every BASELINE config)")
     ap.add_argument("--also-steps", type=int, default=5)
     ap.add_argument("--launcher", action="store_true", help="self-launch under torch.distributed.run even for --gpus 1")
+    ap.add_argument("--sustained-steps", type=int, default=300,
+                    help="steps of the `sustained` leg of the headline and padded-text workloads (0: off; also capped at 20 s each)")
     ap.add_argument("--text-dropout", type=float, default=0.0,
                     help="BERT hidden / attention dropout probability and train() mode (reference default 0.1; BASELINE runs 0)")
     args = ap.parse_args()
@@ -516,7 +637,8 @@ def main():
 
     c = Ctx()
     c.world, c.rank, c.device = world, rank, device
-    head = run_workload(args.workload, c, args.steps, args.warmup, args.batch, args.text_dropout)
+    sus = args.sustained_steps if world == 1 else 0
+    head = run_workload(args.workload, c, args.steps, args.warmup, args.batch, args.text_dropout, sustained_steps=sus)
     also = {}
     if not args.no_also:
         names = [n for n in args.also.split(",") if n] or (ALSO_N1 if world == 1 else ALSO_MULTI)
@@ -524,7 +646,8 @@ def main():
             if n == args.workload:
                 continue
             try:
-                r = run_workload(n, c, args.also_steps, 2, args.batch, args.text_dropout)
+                r = run_workload(n, c, args.also_steps, 2, args.batch, args.text_dropout,
+                                 sustained_steps=sus if n == "bf16_b1024_fwd_loss_padded_text" else 0)
             except Exception as e:          # one configuration failing (e.g. out of memory) must not lose the headline
                 torch.cuda.empty_cache()
                 r = {"workload": n, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
@@ -532,7 +655,7 @@ def main():
                     raise
             if rank == 0:
                 keep = ("value", "ms_per_step", "dtype", "path", "stages", "pairs_per_gpu", "loss", "text_tower_rows", "model_tflops_per_gpu",
-                        "model_mfma_frac", "time_share", "grad_allreduce_buckets_mib", "error")
+                        "model_mfma_frac", "time_share", "grad_allreduce_buckets_mib", "sustained", "error")
                 also[n] = {k: r[k] for k in keep if k in r}
                 if r.get("roofline"):
                     also[n]["roofline_frac"] = r["roofline"]["frac"]
@@ -541,7 +664,7 @@ def main():
     if rank == 0:
         wl = WORKLOADS[args.workload]
         out = {
-            "metric": "image-text pairs/sec (fwd+loss) " + ("ViT-L/14+roberta-wwm-ext" if wl.get("model") in ("vitl14", "hf_vitl14")
+            "metric": "image-text pairs/sec (fwd+loss) " + ("ViT-L/14+roberta-wwm-ext" if wl.get("model") in ("vitl14", "hf_vitl14", "hf_vitl14_large")
                                                             else "ViT-B/16+BERT-base"),
             "value": head["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
@@ -556,7 +679,7 @@ def main():
         }
         for k in ("loss", "batches_rotated", "pack_meta_in_timed_region", "ms_per_step_ranks", "text_tower_rows", "gflop_per_pair",
                   "model_tflops_per_gpu", "model_mfma_frac", "roofline", "time_share", "attention_tflops", "layernorm_gbps",
-                  "grad_allreduce_buckets_mib"):
+                  "grad_allreduce_buckets_mib", "sustained"):
             if k in head:
                 out[k] = head[k]
         if also:

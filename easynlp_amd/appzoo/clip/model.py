@@ -50,6 +50,16 @@ class Config_Wrapper:
         return json.dumps(self.json_data, ensure_ascii=False)
 
 
+class RnEngineNames:
+    """name predicates of the ModifiedResNet parameter tree (reference names, modeling_chineseclip.py:27-167)"""
+
+    @staticmethod
+    def is_norm(name: str) -> bool:
+        """BatchNorm2d gains / biases (``bn1..3``, the ``downsample.1`` of a stage's first block)"""
+        stem = name.rsplit(".", 1)[0]
+        return stem.rsplit(".", 1)[-1].startswith("bn") or stem.endswith("downsample.1")
+
+
 class _ParamTree(nn.Module):
     """A bare module tree that only holds parameters under dotted reference names."""
 
@@ -308,7 +318,11 @@ class HipClipEngine:
     def resolve_pack(self, pack):
         """Finish a packing started on the device: read (rows, longest, prefix) of its launch from the pinned result words
         (a polled flag, no stream synchronisation).  Returns the usable dict, or False when packing would not pay."""
-        if not pack or "ticket" not in pack:
+        if not pack:
+            return pack
+        if pack.get("unusable"):                 # (resolved before, and found not worth packing)
+            return False
+        if "ticket" not in pack:
             return pack
         rows, longest, prefix = L.C.c_int(0), L.C.c_int(0), L.C.c_int(0)
         L.check(self.lib.ezclip_pack_text_meta_result(self.handle, pack.pop("ticket"), L.C.byref(rows), L.C.byref(longest),
@@ -352,7 +366,7 @@ class HipClipEngine:
         """May this packing (pack_meta) be used under the dropout state armed for the next call?  With dropout: kept tokens must
         be prefixes, and only the chinese_clip text branch (no explicit position / type / mask tensors): that combination is the
         one verified on hardware against the padded run; the huggingface_clip branch stays on padded rows while dropout is armed."""
-        if not pack:
+        if not pack or pack.get("unusable"):
             return False
         if self._drop == (0.0, 0.0):
             return True
@@ -369,7 +383,7 @@ class HipClipEngine:
         ws = self.workspace("text", B, S, save, ids.device, owner)
         if self.can_pack(save) and S >= 8 and pack is not False:
             if pack is None:
-                pack = self.pack_meta(ids, None if extras is None else extras[2])
+                pack = self.pack_meta(ids, None if extras is None else extras[2], stream=stream)   # same stream as the tower that reads it
             elif pack.get("shape") != (B, S):
                 raise L.EzclipError("packing metadata of another batch")
             pack = self.resolve_pack(pack)       # (device-built metadata: the scalars are read here, after the image tower was enqueued)
@@ -593,6 +607,40 @@ class _InfoNCEFn(torch.autograd.Function):
         L.check(lib.ezclip_infonce_from_logits_bwd(L.ptr(logits), n, L.ptr(g), L.ptr(d), L.ptr(scratch),
                                                    L.stream_ptr()), "infonce_from_logits_bwd")
         return d
+
+
+class _CrossEntropyDiagFn(torch.autograd.Function):
+    """F.cross_entropy(logits, arange(len(logits)))  (CLIPApp.contrastive_loss, appzoo/clip/model.py:154-155): one direction."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        lib = L.load()
+        if logits.dim() != 2 or logits.shape[0] > logits.shape[1]:
+            raise L.EzclipError("contrastive_loss expects [rows, cols >= rows] logits (labels arange(rows)), got %s" % (tuple(logits.shape),))
+        if not logits.is_cuda:
+            raise L.EzclipError("contrastive_loss: logits must be on the GPU (no CPU fallback)")
+        x = logits.float()
+        if x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+            x = x.contiguous()                       # (e.g. similarity.T: clip_loss itself never takes this route)
+        rows, cols = x.shape
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(2 * rows, dtype=torch.float32, device=x.device)
+        L.check(lib.ezclip_cross_entropy_diag(L.ptr(x), rows, cols, x.stride(0), L.ptr(loss), L.ptr(scratch), L.stream_ptr()),
+                "cross_entropy_diag")
+        ctx.save_for_backward(x, scratch)
+        ctx.in_dtype = logits.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        x, scratch = ctx.saved_tensors
+        rows, cols = x.shape
+        d = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+        g = g.contiguous().float()
+        L.check(lib.ezclip_cross_entropy_diag_bwd(L.ptr(x), rows, cols, x.stride(0), L.ptr(g), L.ptr(scratch), L.ptr(d), L.stream_ptr()),
+                "cross_entropy_diag_bwd")
+        return d.to(ctx.in_dtype)
 
 
 def fused_infonce_shard(eng, txt_all, img_all, n, off, logit_scale, grad_scale, want_grads):
@@ -884,6 +932,32 @@ class CLIPApp(Application):
                     else:
                         std = float(config.get("text_initializer_range", 0.02))
                     p.copy_(torch.randn(p.shape, generator=g, device=device) * std)
+            if app._rn is not None:
+                # ModifiedResNet tower (CHINESE_CLIP.initialize_parameters, modeling_chineseclip.py:323-334): attnpool projections
+                # N(0, in_features^-0.5), every bn3 gain zero; convolutions at fan-in scale (nn.Conv2d's default has that variance),
+                # attnpool.positional_embedding randn / sqrt(embed) (:62), BatchNorm gains / statistics at their defaults (_build).
+                both = dict(app.chinese_clip.named_parameters())
+                attn_std = None
+                for n in app._rn.names:
+                    if n == "visual.attnpool.c_proj.weight":
+                        attn_std = app._rn.shapes[n][1] ** -0.5
+                for n in app._rn.names:
+                    if n not in both or RnEngineNames.is_norm(n):
+                        if n in both and n.endswith("bn3.weight") and ".layer" in n:
+                            both[n].zero_()
+                        continue
+                    p = both[n]
+                    if n.endswith(".bias"):
+                        p.zero_()
+                    elif n.startswith("visual.attnpool.") and n.endswith("_proj.weight"):
+                        p.copy_(torch.randn(p.shape, generator=g, device=device) * attn_std)
+                    elif n == "visual.attnpool.positional_embedding":
+                        p.copy_(torch.randn(p.shape, generator=g, device=device) * (p.shape[1] ** -0.5))
+                    elif p.dim() == 4:
+                        p.copy_(torch.randn(p.shape, generator=g, device=device) * ((p.shape[1] * p.shape[2] * p.shape[3]) ** -0.5))
+                    else:
+                        p.copy_(torch.randn(p.shape, generator=g, device=device) * (p.shape[-1] ** -0.5))
+                app._rn.mark_dirty()
         return app
 
     @classmethod
@@ -1153,7 +1227,9 @@ class CLIPApp(Application):
                 "image_embeds": image_embeds, "text_embeds": text_embeds}
 
     def contrastive_loss(self, logits: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("use clip_loss: both directions are fused in one HIP call")
+        """One direction: ``F.cross_entropy(logits, arange(len(logits)))`` (reference model.py:154-155), autograd-capable.
+        ``clip_loss`` does not call it twice: both directions of a square block are one fused HIP call there."""
+        return _CrossEntropyDiagFn.apply(logits)
 
     def clip_loss(self, similarity: torch.Tensor) -> torch.Tensor:
         return _InfoNCEFn.apply(similarity)

@@ -416,12 +416,8 @@ __global__ __launch_bounds__(512) void attn_fwd_chunked_kernel(AttnArgs a, int n
 template <typename T, int QBW>
 int launch_fwd_chunked(const AttnArgs& a, int nt, int ch, hipStream_t stream) {
   const Smem<T> S(ch);
-  static int attr_max = 0;
-  if (S.bytes > attr_max) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_chunked_kernel<T, QBW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, S.bytes));
-    attr_max = S.bytes;
-  }
+  static LdsOptIn lds_opt;
+  EZ_ENSURE_LDS((&attn_fwd_chunked_kernel<T, QBW>), lds_opt, S.bytes);
   {
     ProfScope ps(PROF_ATTN, 4.0 * a.B * a.H * (double)a.L * a.L * 64, stream);
     hipLaunchKernelGGL((attn_fwd_chunked_kernel<T, QBW>), dim3(a.H, a.B), dim3(512), S.bytes, stream, a, nt, ch);
@@ -442,12 +438,8 @@ int launch_fwd(const AttnArgs& a, hipStream_t stream) {
     set_error("attention_fwd: sequence length %d > 512 is not supported by the general kernels", a.L);
     return EZ_ERR_UNSUPPORTED;
   }
-  static int attr_max = 0;
-  if (S.bytes > attr_max) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, S.bytes));
-    attr_max = S.bytes;
-  }
+  static LdsOptIn lds_opt;
+  EZ_ENSURE_LDS((&attn_fwd_kernel<T>), lds_opt, S.bytes);
   const int nw = nt < 8 ? nt : 8;
   {
     ProfScope ps(PROF_ATTN, 4.0 * a.B * a.H * (double)a.L * a.L * 64, stream);   // QK^T + PV, unpadded
@@ -1092,15 +1084,9 @@ int launch_bwd(const AttnBwdArgs& a, hipStream_t stream) {
   while (chA > 1 && BwdSmemA<T>(chA).bytes > budget) --chA;
   while (chB > 1 && BwdSmemB<T>(chB).bytes > budget) --chB;
   const int ldsA = BwdSmemA<T>(chA).bytes, ldsB = BwdSmemB<T>(chB).bytes;
-  static int maxA = 0, maxB = 0;
-  if (ldsA > maxA) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsA));
-    maxA = ldsA;
-  }
-  if (ldsB > maxB) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsB));
-    maxB = ldsB;
-  }
+  static LdsOptIn optA, optB;
+  EZ_ENSURE_LDS((&attn_bwd_dq_kernel<T>), optA, ldsA);
+  EZ_ENSURE_LDS((&attn_bwd_dkv_kernel<T>), optB, ldsB);
   const int nw = nt < 8 ? nt : 8;
   const int gz = (nt + nw - 1) / nw;
   ProfScope ps(PROF_ATTN, 10.0 * a.f.B * a.f.H * (double)a.f.L * a.f.L * 64, stream);   // 5 L x L x 64 products

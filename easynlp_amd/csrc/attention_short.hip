@@ -347,7 +347,7 @@ int attention_fwd_short(const AttnArgs& a_in, hipStream_t stream) {
   a.mfma_rowsum = (g_attn_short_tail >> 1) & 1;
   const int nt = (a.L + 31) / 32;
   const int bytes = nt * (2 * 32 * 128 + 32 * 4);
-  static int attr_max[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static LdsOptIn lds_opt[8];
   const int kbi = (a.key_bias != nullptr ? 1 : 0) + (a.causal ? 2 : 0) + (a.drop.thr != 0 ? 4 : 0);
   EZ_REQUIRE(a.drop.thr == 0 || a.keep_bits == nullptr || a.keep_words == nt, "attention_fwd_short: keep_words must be ceil(L / 32)");
   using K = void (*)(AttnArgs, int);
@@ -356,10 +356,7 @@ int attention_fwd_short(const AttnArgs& a_in, hipStream_t stream) {
                              &attn_fwd_short_kernel<false, false, true>,  &attn_fwd_short_kernel<true, false, true>,
                              &attn_fwd_short_kernel<false, true, true>,   &attn_fwd_short_kernel<true, true, true>};
   const K kern = kerns[kbi];
-  if (bytes > attr_max[kbi]) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    attr_max[kbi] = bytes;
-  }
+  EZ_ENSURE_LDS(kern, lds_opt[kbi], bytes);
   {
     ProfScope ps(PROF_ATTN, 4.0 * a.B * a.H * (double)a.L * a.L * 64, stream);   // QK^T + PV, unpadded
     hipLaunchKernelGGL(kern, dim3(a.H, a.B), dim3(64 * nt), bytes, stream, a, nt);

@@ -443,7 +443,7 @@ bool attention_short_eligible(const AttnArgs& a, int dtype) {       // fused bac
 int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
   const int nt = (a.f.L + 31) / 32, ra = (a.f.L + 7) / 8 * 8;
   const int bytes = bwd_short_lds_bytes(a.f.L);
-  static int attr_max[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static LdsOptIn lds_opt[8];
   const int vi = (a.f.key_bias != nullptr ? 1 : 0) + (a.f.causal ? 2 : 0) + (a.f.drop.thr != 0 ? 4 : 0);
   EZ_REQUIRE(a.f.drop.thr == 0 || (a.f.keep_bits != nullptr && a.f.keep_words == nt && nt <= 8),
              "attention_bwd_short: dropout needs the keep bits of the forward (keep_words = ceil(L / 32)) and L <= 256");
@@ -453,10 +453,7 @@ int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
                              &attn_bwd_short_kernel<false, false, true>,  &attn_bwd_short_kernel<true, false, true>,
                              &attn_bwd_short_kernel<false, true, true>,   &attn_bwd_short_kernel<true, true, true>};
   const K kern = kerns[vi];
-  if (bytes > attr_max[vi]) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    attr_max[vi] = bytes;
-  }
+  EZ_ENSURE_LDS(kern, lds_opt[vi], bytes);
   {
     ProfScope ps(PROF_ATTN, 10.0 * a.f.B * a.f.H * (double)a.f.L * a.f.L * 64, stream);   // 5 L x L x 64 products
     hipLaunchKernelGGL(kern, dim3(a.f.H, a.f.B), dim3(64 * nt), bytes, stream, a, nt, ra);

@@ -169,6 +169,24 @@ int ezclip_infonce_from_logits_bwd(const float* logits, int n, const float* grad
   return EZ_OK;
 }
 
+int ezclip_cross_entropy_diag(const float* logits, int rows, int cols, int64_t ld, float* loss, float* scratch, void* stream) {
+  EZ_REQUIRE(logits && loss && scratch, "ezclip_cross_entropy_diag: null argument");
+  EZ_REQUIRE(rows > 0 && cols >= rows && ld >= cols, "ezclip_cross_entropy_diag: bad shape rows=%d cols=%d ld=%lld (the labels are arange(rows))",
+             rows, cols, (long long)ld);
+  hipStream_t st = S(stream);
+  API_TRY(ce_rows_fwd(logits, ld, rows, cols, 0, scratch, scratch + rows, st));
+  API_TRY(sum_scaled(scratch + rows, rows, 1.0f / rows, loss, 0, st));
+  return EZ_OK;
+}
+
+int ezclip_cross_entropy_diag_bwd(const float* logits, int rows, int cols, int64_t ld, const float* grad_out, const float* scratch,
+                                  float* dlogits, void* stream) {
+  EZ_REQUIRE(logits && scratch && dlogits, "ezclip_cross_entropy_diag_bwd: null argument");
+  EZ_REQUIRE(rows > 0 && cols >= rows && ld >= cols, "ezclip_cross_entropy_diag_bwd: bad shape rows=%d cols=%d ld=%lld", rows, cols, (long long)ld);
+  API_TRY(ce_rows_bwd(logits, ld, rows, cols, 0, scratch, grad_out, 1.0f / rows, dlogits, cols, 0, S(stream)));
+  return EZ_OK;
+}
+
 size_t ezclip_infonce_workspace_bytes(int n_local, int n_global, int e) {
   return layout_nce(n_local, n_global, e, nullptr, nullptr);
 }

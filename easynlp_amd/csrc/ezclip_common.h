@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace ezclip {
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
@@ -93,16 +95,19 @@ __device__ __forceinline__ float erf_fast(float x) {
 //   Phi(x)   ~ 0.5 + xc R(t),   xc = clamp(x, -c, c),  t = 2 xc^2 / c^2 - 1        (Phi - 1/2 is odd: one polynomial)
 //   gelu'(x) = Phi(x) + x phi(x) ~ 0.5 + xc Q(t)                                   (gelu' - 1/2 is odd as well)
 // with minimax fits (Lawson iterations on Chebyshev nodes; evaluated by Horner in t in [-1, 1], which keeps float32 rounding
-// at the 1e-7 level): |Phi error| <= 7.5e-6 for all x (c = 4.2, degree 8), |gelu' error| <= 1.2e-5 (c = 4.8, degree 11) --
-// two orders below a bf16 ulp of the result.  13 / 16 plain multiply-adds per element, written on float pairs so that they
+// at the 1e-7 level).  Phi (c = 4.2, degree 8; tools/fit_gelu_poly.py) is fitted UNDER THE CONSTRAINT R(1) = 0.5 / c, i.e. the
+// polynomial is exactly 0 / 1 at the clamp (round 4; the unconstrained fit of round 3 left Phi(-c) +- 7.5e-6 there and
+// gelu(x) = x Phi(x) off by |x| * 2e-5 for ANY x below -c: -7.2e-5 at x = -12): |Phi error| <= 1.36e-5 (at the end points, where
+// 1 - Phi(4.2) = 1.33e-5), |gelu error| <= 5.7e-5 ABSOLUTE for all x -- outside the clamp x * (1 +- 1e-7) or x * (0 +- 1e-7)
+// (tests/test_ops_gpu.py::test_gelu_polynomial_tails).  |gelu' error| <= 1.2e-5 (c = 4.8, degree 11).  13 / 16 plain multiply-adds per element, written on float pairs so that they
 // issue as v_pk_fma_f32 / v_pk_mul_f32 (two elements per instruction); the scalar forms run the SAME operation sequence
 // (every step one IEEE fma / mul), so the packed epilogue of the 8-phase GEMM and the scalar one of the 128x128 kernel stay
 // bit-identical (tests/test_bench_regime_gpu.py).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr float kPhiC = 4.2f, kPhiTs = 2.0f / (4.2f * 4.2f);
-constexpr float kPhiK[9] = {0.1678561419248581f, -0.08148203790187836f, 0.05581444501876831f, -0.03895563259720802f,
-                            0.02500496804714203f, -0.013675360009074211f, 0.008104611188173294f, -0.005817593075335026f,
-                            0.0021966451313346624f};
+constexpr float kPhiK[9] = {0.16785699129104614f, -0.081463746726512909f, 0.055767588317394257f, -0.039157509803771973f,
+                            0.025356100872159004f, -0.013150581158697605f, 0.0073324446566402912f, -0.0061912033706903458f,
+                            0.0026975346263498068f};
 constexpr float kGpC = 4.8f, kGpTs = 2.0f / (4.8f * 4.8f);
 constexpr float kGpK[12] = {0.1484677493572235f, -0.08022641390562057f, 0.07392347604036331f, -0.08052316308021545f,
                             0.0863509252667427f, -0.08870752155780792f, 0.08652839064598083f, -0.06128013879060745f,
@@ -243,6 +248,37 @@ int check_hip(hipError_t e, const char* what);
   } while (0)
 
 #define EZ_LAUNCH_CHECK() EZ_HIP(hipGetLastError())
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE).  Every launcher that needs more than the default
+// 64 KiB keeps one LdsOptIn per kernel instantiation: the largest size already granted per device, read and written atomically
+// (two host threads racing set the attribute twice -- harmless; a process driving a second GPU sets it there as well.  Round 3
+// kept one `static bool` per instantiation: ADVICE r3).
+namespace ezclip {
+struct LdsOptIn {
+  static constexpr int kMaxDev = 32;
+  std::atomic<int> granted[kMaxDev];
+  LdsOptIn() { for (auto& g : granted) g.store(0, std::memory_order_relaxed); }
+};
+inline int ensure_lds(const void* kern, LdsOptIn& st, int bytes) {
+  int dev = 0;
+  int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+  if (rc != EZ_OK) return rc;
+  const bool tracked = dev >= 0 && dev < LdsOptIn::kMaxDev;
+  if (tracked && st.granted[dev].load(std::memory_order_acquire) >= bytes) return EZ_OK;
+  rc = check_hip(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  if (rc != EZ_OK) return rc;
+  if (tracked) {
+    int cur = st.granted[dev].load(std::memory_order_relaxed);
+    while (cur < bytes && !st.granted[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+  }
+  return EZ_OK;
+}
+}  // namespace ezclip
+#define EZ_ENSURE_LDS(kern, state, bytes)                                                            \
+  do {                                                                                               \
+    int _rc = ::ezclip::ensure_lds(reinterpret_cast<const void*>(kern), (state), (int)(bytes));      \
+    if (_rc != EZ_OK) return _rc;                                                                    \
+  } while (0)
 
 #define EZ_REQUIRE(cond, ...)                                          \
   do {                                                                 \

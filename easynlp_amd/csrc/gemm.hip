@@ -257,12 +257,8 @@ template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool CONV = f
 int launch_nt_shape(const GemmArgs& p, hipStream_t stream) {
   using SH = Shape<WM, WN, TI, TJ>;
   const int tiles = ((p.M + SH::kBM - 1) / SH::kBM) * ((p.N + SH::kBN - 1) / SH::kBN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, TI, TJ, CONV>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SH::kLds));
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt;
+  EZ_ENSURE_LDS((&gemm_nt_kernel<T, TO, WM, WN, TI, TJ, CONV>), lds_opt, SH::kLds);
   {
     ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);
     hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, TI, TJ, CONV>), dim3(tiles), dim3(SH::kThreadsS), SH::kLds, stream, p);
@@ -543,12 +539,8 @@ int launch_tn(const GemmTNArgs& p, hipStream_t stream) {
   rows = (rows + BMc - 1) / BMc * BMc;
   splits = (p.M + rows - 1) / rows;
   const size_t lds = 4 * kTileBytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt;
+  EZ_ENSURE_LDS((&gemm_tn_kernel<T>), lds_opt, lds);
   if (splits > 1 && !p.accumulate) EZ_HIP(hipMemset2DAsync(p.C, p.ldc * 4, 0, (size_t)p.K * 4, p.N, stream));
   {
     ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);

@@ -312,21 +312,15 @@ int gemm_nt_4q(const GemmArgs& p_in, hipStream_t stream) {
   const int tiles = ((p.M + 255) >> 8) * (p.N >> 8);
   int grid = tiles;
   if (tiles > num_cus) grid = num_cus >= 8 ? (num_cus & ~7) : num_cus;
-  static bool attr_set[2] = {false, false};
+  static LdsOptIn lds_opt[2];
   ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);
   if (p.C2) {
     auto* kern = &gemm_nt_4q_kernel<true>;
-    if (!attr_set[1]) {
-      EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsQ));
-      attr_set[1] = true;
-    }
+    EZ_ENSURE_LDS(kern, lds_opt[1], kLdsQ);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreadsQ), kLdsQ, stream, p, tiles);
   } else {
     auto* kern = &gemm_nt_4q_kernel<false>;
-    if (!attr_set[0]) {
-      EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsQ));
-      attr_set[0] = true;
-    }
+    EZ_ENSURE_LDS(kern, lds_opt[0], kLdsQ);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreadsQ), kLdsQ, stream, p, tiles);
   }
   EZ_LAUNCH_CHECK();

@@ -620,12 +620,9 @@ int g_num_cus = 0;
 
 template <bool R, bool U, bool C2, bool LN = false, bool PS = false>
 int launch_8p(const GemmArgs& p, int tiles, int grid, hipStream_t stream) {
-  static bool attr_set = false;
+  static LdsOptIn lds_opt;
   auto* kern = &gemm_nt_8p_kernel<true, R, U, C2, LN, PS>;
-  if (!attr_set) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    attr_set = true;
-  }
+  EZ_ENSURE_LDS(kern, lds_opt, kLds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads8), kLds, stream, p, tiles);
   return EZ_OK;
 }
@@ -708,12 +705,8 @@ int gemm_tn_8p(const GemmTNArgs& p, hipStream_t stream) {
     }
     scratch = sc.ptr;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_8p_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kRing));
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt;
+  EZ_ENSURE_LDS(&gemm_tn_8p_kernel, lds_opt, kRing);
   {
     ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);
     hipLaunchKernelGGL(gemm_tn_8p_kernel, dim3(ntiles * splits), dim3(kThreads8), kRing, stream, p, scratch, ntiles,

@@ -432,24 +432,16 @@ size_t nce_tiled_layout(int n, int N, int off_unused, int e, void* base, NceTile
 
 template <int SEGS, int CB>
 int nce_launch_bwd(const NceArgs& a, int items, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nce_tile_kernel<SEGS, false, CB>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kNceLds));
-    attr = true;
-  }
+  static LdsOptIn lds_opt;
+  EZ_ENSURE_LDS((&nce_tile_kernel<SEGS, false, CB>), lds_opt, kNceLds);
   hipLaunchKernelGGL((nce_tile_kernel<SEGS, false, CB>), dim3(items, 2), dim3(kNceThreads), kNceLds, st, a);
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }
 template <int SEGS>
 int nce_launch_fwd(const NceArgs& a, int items, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    EZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nce_tile_kernel<SEGS, true, 0>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kNceLds));
-    attr = true;
-  }
+  static LdsOptIn lds_opt;
+  EZ_ENSURE_LDS((&nce_tile_kernel<SEGS, true, 0>), lds_opt, kNceLds);
   hipLaunchKernelGGL((nce_tile_kernel<SEGS, true, 0>), dim3(items, 2), dim3(kNceThreads), kNceLds, st, a);
   EZ_LAUNCH_CHECK();
   return EZ_OK;

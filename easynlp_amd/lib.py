@@ -96,6 +96,8 @@ SIGNATURES = {
     "ezclip_similarity": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ezclip_infonce_from_logits": (_i, [_vp, _i, _vp, _vp, _vp]),
     "ezclip_infonce_from_logits_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "ezclip_cross_entropy_diag": (_i, [_vp, _i, _i, C.c_int64, _vp, _vp, _vp]),
+    "ezclip_cross_entropy_diag_bwd": (_i, [_vp, _i, _i, C.c_int64, _vp, _vp, _vp, _vp]),
     "ezclip_infonce_workspace_bytes": (_sz, [_i, _i, _i]),
     "ezclip_infonce_fused": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ezclip_infonce_tiled_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -175,7 +175,9 @@ int ezclip_backward_text_packed(ezclip_handle h, const int64_t* input_ids_dev, c
  * identifies it.  ezclip_pack_text_meta_result blocks the HOST until that one launch has written its result words into pinned
  * host memory owned by the handle (a polled flag -- no hipStreamSynchronize, no hipMemcpy; work queued behind the launch keeps
  * the device busy) and returns rows (= packed_rows), longest (= max_len) and prefix (1: the kept tokens of every sentence are a
- * prefix -- the condition for packing under dropout).  At most 8 tickets may be outstanding.  seq_len <= 512. */
+ * prefix -- the condition for packing under dropout).  At most 8 tickets may be outstanding.  seq_len <= 512.
+ * NOT usable while `stream` is being captured into a hipGraph: a captured launch does not execute, so the poll would only return
+ * after its 120 s timeout (EZ_ERR_HIP).  Under capture pass host-computed metadata to ezclip_encode_text_packed instead. */
 int ezclip_pack_text_meta(ezclip_handle h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev, int batch,
                           int seq_len, int32_t* rowmap_dev, int32_t* cu_dev, int32_t* lens_dev, int* ticket, void* stream);
 int ezclip_pack_text_meta_result(ezclip_handle h, int ticket, int* rows, int* longest, int* prefix);
@@ -215,6 +217,15 @@ int ezclip_infonce_from_logits(const float* logits_dev, int n, float* loss_dev, 
 /* d loss / d logits for the above, scaled by *grad_out_dev (scalar, device). */
 int ezclip_infonce_from_logits_bwd(const float* logits_dev, int n, const float* grad_out_dev,
                                    float* dlogits_dev, float* scratch_dev, void* stream);
+/* One direction only -- CLIPApp.contrastive_loss(logits) = F.cross_entropy(logits, arange(len(logits)))
+ * (appzoo/clip/model.py:154-155): mean over the rows of (logsumexp(logits[i, :]) - logits[i, i]).  logits [rows, cols] float32,
+ * row-major with leading dimension ld >= cols, rows <= cols.  scratch: >= 2*rows floats (holds the row log-sum-exps for the
+ * backward call: pass the same buffer).  The backward writes d loss / d logits * (*grad_out_dev) into dlogits [rows, cols]
+ * (leading dimension cols). */
+int ezclip_cross_entropy_diag(const float* logits_dev, int rows, int cols, int64_t ld, float* loss_dev, float* scratch_dev,
+                              void* stream);
+int ezclip_cross_entropy_diag_bwd(const float* logits_dev, int rows, int cols, int64_t ld, const float* grad_out_dev,
+                                  const float* scratch_dev, float* dlogits_dev, void* stream);
 /* Contrastive step on embeddings (local or all-gathered global batch): loss, d embeddings and d logit_scale of THIS rank's
  * n_local rows of both directions against all n_global columns.
  *   text_all/image_all: float32 [n_global, e] (rows rank_offset..rank_offset+n_local are this rank's)

@@ -86,6 +86,18 @@ CONFIGS: Dict[str, dict] = {
         text_intermediate_size=3072, text_max_position_embeddings=512,
         text_num_attention_heads=12, text_num_hidden_layers=12,
         text_type_vocab_size=2),
+    # the LARGE text tower (chinese-roberta-wwm-ext-large / CLIPTextConfig's defaults, configuration_clip.py:90-95: hidden 1024,
+    # 16 heads, FFN 4096), two layers deep over a tiny image tower: post-LN LayerNorm at D = 1024, 16-head attention, K = 1024 /
+    # 4096 BERT products; 24 rows x 40 tokens reach the 8-phase GEMM kernels
+    "large_text": dict(
+        model_type="chinese_clip", embed_dim=256, image_resolution=64,
+        vision_layers=2, vision_width=128, vision_patch_size=16,
+        vocab_size=523, text_attention_probs_dropout_prob=0.0,
+        text_hidden_act="gelu", text_hidden_dropout_prob=0.0,
+        text_hidden_size=1024, text_initializer_range=0.02,
+        text_intermediate_size=4096, text_max_position_embeddings=64,
+        text_num_attention_heads=16, text_num_hidden_layers=2,
+        text_type_vocab_size=2),
 }
 
 VIT_LN_EPS = 1e-5    # nn.LayerNorm default, modeling_chineseclip.py:170

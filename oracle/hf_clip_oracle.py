@@ -39,6 +39,16 @@ HF_CONFIGS: Dict[str, dict] = {
         vision_config=dict(hidden_size=192, intermediate_size=768, num_hidden_layers=3, num_attention_heads=3,
                            image_size=80, patch_size=16, hidden_act="quick_gelu", layer_norm_eps=1e-5),
         projection_dim=128),
+    # the LARGE text tower of the pai-clip-commercial-large checkpoints (CLIPTextConfig defaults, configuration_clip.py:90-95:
+    # hidden 1024, 16 heads, FFN 4096; RoBERTa pad id 1, eps 1e-5), two layers deep over a small patch-14 vision tower
+    "hf_large_text": dict(
+        text_config=dict(vocab_size=523, hidden_size=1024, intermediate_size=4096, num_hidden_layers=2,
+                         num_attention_heads=16, max_position_embeddings=128, type_vocab_size=2, pad_token_id=1,
+                         layer_norm_eps=1e-5, hidden_act="gelu", hidden_dropout_prob=0.0,
+                         attention_probs_dropout_prob=0.0),
+        vision_config=dict(hidden_size=256, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
+                           image_size=56, patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5),
+        projection_dim=256),
 }
 
 

@@ -344,6 +344,14 @@ def test_headline_batch_of_1024_pairs_size_independent_properties():
     order = torch.sort(sim, dim=1, descending=True, stable=True).indices
     want = (order == torch.arange(B)[:, None]).long().argmax(dim=1)
     assert torch.equal(rank, want)
+    # (round 4) the bf16 rows of the 1 024-pair batch against the CPU ORACLE itself on the 16 sampled pairs --
+    # not only against the float32 HIP pipeline below (which the 64 / 256-pair test ties to the oracle)
+    sd = {k: v.detach().cpu() for k, v in app._params.items()}
+    with torch.no_grad():
+        oref = O.clip_forward(sd, O.CONFIGS["vitb16_bertbase"], px[sample].cpu(), ids[sample].cpu())
+    for got, want_e in ((img[sample].cpu(), oref["image_embeds"]), (txt[sample].cpu(), oref["text_embeds"])):
+        assert float((got - want_e).abs().max()) < 1e-2
+        assert float(torch.nn.functional.cosine_similarity(got, want_e).min()) > 0.9995
     del app, out, again, sub, quarter
     torch.cuda.empty_cache()
     f32 = CLIPApp.from_config(VITB16, seed=1234, device=DEV, compute_dtype="fp32")
@@ -353,6 +361,78 @@ def test_headline_batch_of_1024_pairs_size_independent_properties():
     for got, want_e in ((img[sample], ref["image_embeds"]), (txt[sample], ref["text_embeds"])):
         assert float((got - want_e).abs().max()) < 1e-2
         assert float(torch.nn.functional.cosine_similarity(got, want_e).min()) > 0.9995
+
+
+@pytest.mark.parametrize("flavour", ["chinese_clip_vitl14", "huggingface_clip_vitl14_large_text"])
+def test_config5_batch_of_512_pairs_size_independent_properties(flavour):
+    """BASELINE.json config 5 at the bench's own depth and batch (round 4): ViT-L/14 with all 24 blocks
+    (257 tokens, width 1024, patch 14) at 512 pairs in bf16 -- as a chinese_clip model over the BERT-base-arch text tower
+    (`bf16_vitl14_b512_*`) and as the huggingface_clip flavour over the LARGE RoBERTa text tower (hidden 1024, 24 layers, 16 heads,
+    FFN 4096: configuration_clip.py:90-95; `bf16_hf_vitl14_large_b512_train`).  No oracle run of that size is needed:
+      * a second evaluation gives the same bits; pairs 128..255 encoded alone give the same BITS as inside the 512-pair batch (the towers
+        are per-sample: modeling_chineseclip.py:343-365 / model.py:128-144) -- other tile counts, another packing of the text rows;
+      * 8 scattered pairs against the CPU ORACLE evaluated on exactly those pairs with the same weights (bf16 bound of the golden tests);
+      * the loss of the fused step equals the reference's formula (model.py:154-164) in float64 on the embeddings the step produced;
+      * the evaluator's ranks equal a host sort of the same scores."""
+    import bench
+    from easynlp_amd.appzoo.clip import CLIPApp
+    from easynlp_amd.appzoo.clip.evaluator import recall_ranks
+    from oracle import hf_clip_oracle as H
+    B, S = 512, 64
+    px, ids = _synth(B, S, seed=2000)
+    hf = flavour.startswith("huggingface")
+    if hf:
+        cfg = bench.HF_VITL14_ROBERTA_LARGE
+        app = CLIPApp.from_hf_config(cfg, seed=4321, device=DEV, compute_dtype="bf16")
+        extra = lambda i: {"token_type_ids": torch.zeros_like(i), "attention_mask": i.ne(0).long()}     # noqa: E731
+    else:
+        cfg = O.CONFIGS["vitl14_robertabase"]
+        assert cfg == bench.VITL14_ROBERTA
+        app = CLIPApp.from_config(cfg, seed=4321, device=DEV, compute_dtype="bf16")
+        extra = lambda i: {}                                                                            # noqa: E731
+    app.eval()
+    sample = torch.arange(3, B, B // 8)[:8].to(DEV)
+
+    def run(p, i):
+        return app(dict({"pixel_values": p.contiguous(), "input_ids": i.contiguous()}, **extra(i.contiguous())))
+
+    with torch.no_grad():
+        out = run(px, ids)
+        img, txt = out["image_embeds"].float(), out["text_embeds"].float()
+        loss_ag = float(app.compute_loss(out, [])["loss"].item())
+        e = extra(ids)
+        loss_fused = float(app.contrastive_step(px, ids, process_group=False, **e).item())
+        again = run(px, ids)
+        quarter = run(px[128:256], ids[128:256])
+    assert torch.equal(again["image_embeds"], out["image_embeds"]) and torch.equal(again["text_embeds"], out["text_embeds"])
+    assert float((img.norm(dim=-1) - 1).abs().max()) < 1e-3 and float((txt.norm(dim=-1) - 1).abs().max()) < 1e-3
+    q_img = float((quarter["image_embeds"].float() - img[128:256]).abs().max())
+    q_txt = float((quarter["text_embeds"].float() - txt[128:256]).abs().max())
+    print("%s: 512-pair batch vs pairs 128..255 alone: max |d image_embeds| %.3e  |d text_embeds| %.3e" % (flavour, q_img, q_txt))
+    assert q_img == 0.0 and q_txt == 0.0
+    scale = math.exp(float((app._hf_params if hf else app._params)["logit_scale"].detach()))
+    logits = scale * txt.double().cpu() @ img.double().cpu().t()
+    ref_loss = float(O.clip_loss(logits))
+    assert abs(loss_fused - ref_loss) < 5e-3 and abs(loss_ag - ref_loss) < 5e-3, (loss_fused, loss_ag, ref_loss)
+    rank = recall_ranks(txt, img).cpu().long()
+    order = torch.sort((txt.double().cpu() @ img.double().cpu().t()).float(), dim=1, descending=True, stable=True).indices
+    assert torch.equal(rank, (order == torch.arange(B)[:, None]).long().argmax(dim=1))
+    # the oracle on the 8 sampled pairs, same weights (24 + 12 / 24 + 24 blocks in float32 on the host: seconds)
+    spx, sids = px[sample].cpu(), ids[sample].cpu()
+    with torch.no_grad():
+        if hf:
+            sd = {n: p.detach().cpu() for n, p in app._hf_params.items()}
+            ref = H.hf_clip_forward(sd, cfg, spx, sids, torch.zeros_like(sids), sids.ne(0).long())
+        else:
+            sd = {k: v.detach().cpu() for k, v in app._params.items()}
+            ref = O.clip_forward(sd, cfg, spx, sids)
+    for got, want in ((img[sample].cpu(), ref["image_embeds"]), (txt[sample].cpu(), ref["text_embeds"])):
+        d = float((got - want).abs().max())
+        c = float(torch.nn.functional.cosine_similarity(got, want).min())
+        print("  vs oracle on 8 pairs: max |d| %.3e  min cosine %.6f" % (d, c))
+        assert d < 1e-2 and c > 0.9995
+    del app, out, again, quarter
+    torch.cuda.empty_cache()
 
 
 def test_directional_derivatives_at_1024_pairs_fp32():

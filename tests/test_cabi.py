@@ -41,7 +41,7 @@ def make_handle(cfg_name, dtype):
     return lib, h, rc
 
 
-@pytest.mark.parametrize("cfg_name", ["tiny", "small", "vitb16_bertbase", "vitl14_robertabase"])
+@pytest.mark.parametrize("cfg_name", ["tiny", "small", "vitb16_bertbase", "vitl14_robertabase", "large_text"])
 @pytest.mark.parametrize("dtype", [L.DTYPE_F32, L.DTYPE_BF16])
 def test_param_table_matches_reference_state_dict(cfg_name, dtype):
     lib, h, rc = make_handle(cfg_name, dtype)

@@ -29,7 +29,7 @@ def make_app(tmp_path, cfg, seed, dtype):
     return app, sd
 
 
-@pytest.mark.parametrize("name", ["hf_tiny_b6_l24", "hf_small_b5_l40"])
+@pytest.mark.parametrize("name", ["hf_tiny_b6_l24", "hf_small_b5_l40", "hf_large_text_b24_l40"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_hf_forward_and_backward_match_reference_golden(tmp_path, name, dtype):
     z, cfg, B, Lq, wseed, iseed = load(name)

@@ -19,7 +19,7 @@ def load(name):
     return z, H.HF_CONFIGS[cfg_name], int(B), int(L), int(wseed), int(iseed)
 
 
-@pytest.mark.parametrize("name", ["hf_tiny_b6_l24", "hf_small_b5_l40"])
+@pytest.mark.parametrize("name", ["hf_tiny_b6_l24", "hf_small_b5_l40", "hf_large_text_b24_l40"])
 def test_hf_oracle_matches_reference_golden(name):
     z, cfg, B, L, wseed, iseed = load(name)
     sd = H.make_state_dict(cfg, wseed)

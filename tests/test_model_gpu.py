@@ -34,7 +34,7 @@ def make_app(tmp_path, cfg, seed, dtype):
     return app, sd
 
 
-@pytest.mark.parametrize("name", ["tiny_b6_l24", "small_b5_l40", "p14_w256_b16_l32", "vitb16_bertbase_b4_l64"])
+@pytest.mark.parametrize("name", ["tiny_b6_l24", "small_b5_l40", "p14_w256_b16_l32", "vitb16_bertbase_b4_l64", "large_text_b24_l40"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_forward_matches_reference_golden(tmp_path, name, dtype):
     z, cfg, B, Lq, wseed, iseed = load_gold(name)
@@ -427,7 +427,7 @@ def _grad_check(app, z, tol_rel, tol_norm, skip_tiny=1e-7, noise_factor=0.0, sca
     assert not bad, bad[:12]
 
 
-@pytest.mark.parametrize("name", ["tiny_b6_l24", "small_b5_l40", "p14_w256_b16_l32", "vitb16_bertbase_b4_l64"])
+@pytest.mark.parametrize("name", ["tiny_b6_l24", "small_b5_l40", "p14_w256_b16_l32", "vitb16_bertbase_b4_l64", "large_text_b24_l40"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("path", ["autograd", "fused"])
 def test_backward_matches_reference_golden(tmp_path, name, dtype, path):

@@ -675,3 +675,69 @@ def test_attention_cls_query_forward_and_backward(Lq, dtype, compact_dq):
         assert torch.isnan(got[:, :D]).all()          # untouched
     else:
         assert rel_err(got[:, :D], gq) < (1e-5 if dtype == "f32" else 2e-2)      # (zeros outside row 0 on both sides)
+
+
+# ----------------------------------------------------------------------------- round 4: polynomial erf-GELU outside its clamp
+
+@pytest.mark.parametrize("variant", [0, 2])
+def test_gelu_polynomial_tails(variant):
+    """F.gelu of the bf16 pipeline (ezclip_common.h: Phi(x) ~ 0.5 + xc R(t), xc = clamp(x, +-4.2)) for |x| up to 50 through the
+    epilogue of both bf16 GEMM kernels (x = A I^T exactly: identity weights).  The round-3 fit left Phi(-4.2) +- 7.5e-6 at the clamp,
+    so gelu(x) = x Phi(x) was off by |x| * 2e-5 for EVERY x below it (-7.2e-5 at -12, -3.6e-4 at -50); the round-4 fit is
+    exactly 0 / 1 there (tools/fit_gelu_poly.py): |error| <= 5.7e-5 absolute everywhere, x (0 +- 1e-7) below the clamp."""
+    lib = L.load()
+    M, K = 512, 256
+    xs = torch.cat([torch.linspace(-50, -4.2, 120), torch.linspace(-4.2, 4.2, 272), torch.linspace(4.2, 50, 120)])
+    a = xs.bfloat16().float()[:, None].repeat(1, K)                   # row i holds x_i in every column; B = I picks it up unchanged
+    b = torch.eye(K)
+    ad, bd_ = a.bfloat16().to(DEV), b.bfloat16().to(DEV)
+    c = torch.empty((M, K), dtype=torch.bfloat16, device=DEV)
+    L.check(lib.ezclip_debug_set(0, variant))
+    try:
+        L.check(lib.ezclip_op_gemm_nt(ad.data_ptr(), K, bd_.data_ptr(), K, c.data_ptr(), K, None, None, 0, M, K, K, L.ACT_GELU_ERF,
+                                      L.DTYPE_BF16, 0, L.stream_ptr()))
+        torch.cuda.synchronize()
+    finally:
+        L.check(lib.ezclip_debug_set(0, -1))
+    x = a.bfloat16().double()[:, 0]
+    got = c.double().cpu()
+    assert float((got - got[:, :1]).abs().max()) == 0.0               # every column of a row saw the same x
+    exact = O.gelu_erf(x)
+    err = (got[:, 0] - exact).abs()
+    bound = 5.7e-5 + 2.0 ** -8 * exact.abs()                          # the fit + bf16 rounding of the stored result
+    worst = int(torch.argmax(err / bound))
+    assert bool((err <= bound).all()), (float(x[worst]), float(got[worst, 0]), float(exact[worst]))
+    far = x < -6.0
+    assert float(got[far, 0].abs().max()) < 1e-5                      # round 3: -7e-5 ... -3.6e-4 here
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (7, 7), (64, 64), (300, 300), (37, 90)])
+def test_contrastive_loss_one_direction(rows, cols):
+    """CLIPApp.contrastive_loss(logits) = F.cross_entropy(logits, arange(len(logits))) (appzoo/clip/model.py:154-155), value and
+    gradient against torch's float64 evaluation; the transposed view of a square block (what clip_loss feeds it in the reference)
+    and the sum of both directions = 2 x clip_loss."""
+    from easynlp_amd.appzoo.clip import CLIPApp
+    app = CLIPApp.__new__(CLIPApp)                                    # the method reads no state of the instance
+    g = torch.Generator().manual_seed(rows * 131 + cols)
+    s = (torch.randn(rows, cols, generator=g) * 4).to(DEV).requires_grad_(True)
+    loss = CLIPApp.contrastive_loss(app, s)
+    loss.backward()
+    sref = s.detach().double().cpu().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(sref, torch.arange(rows))
+    want.backward()
+    assert abs(loss.item() - want.item()) < 2e-6 * max(1.0, abs(want.item()))
+    assert float((s.grad.double().cpu() - sref.grad).abs().max()) < 1e-6
+    if rows == cols:
+        st = s.detach().clone().requires_grad_(True)
+        both = CLIPApp.contrastive_loss(app, st) + CLIPApp.contrastive_loss(app, st.T)
+        both.backward()
+        s2 = s.detach().clone().requires_grad_(True)
+        fused = CLIPApp.clip_loss(app, s2)
+        fused.backward()
+        assert abs(both.item() / 2 - fused.item()) < 2e-6 * max(1.0, abs(fused.item()))
+        assert float((st.grad / 2 - s2.grad).abs().max()) < 1e-6
+    else:
+        with pytest.raises(L.EzclipError):
+            CLIPApp.contrastive_loss(app, s.detach().T.contiguous())   # more rows than columns: arange(rows) has no column
+    with pytest.raises(L.EzclipError):
+        CLIPApp.contrastive_loss(app, s.detach().cpu())

@@ -19,7 +19,7 @@ def load(name):
     return z, O.CONFIGS[cfg_name], int(B), int(L), int(wseed), int(iseed)
 
 
-@pytest.mark.parametrize("name", ["tiny_b6_l24", "small_b5_l40", "p14_w256_b16_l32", "vitb16_bertbase_b4_l64"])
+@pytest.mark.parametrize("name", ["tiny_b6_l24", "small_b5_l40", "p14_w256_b16_l32", "vitb16_bertbase_b4_l64", "large_text_b24_l40"])
 def test_oracle_forward_matches_reference_golden(name):
     z, cfg, B, L, wseed, iseed = load(name)
     sd = O.make_state_dict(cfg, wseed)

@@ -130,3 +130,28 @@ def test_dropin_clipapp_with_a_resnet_tower(tmp_path, dtype):
     with torch.no_grad():                                       # single-modality calls
         only = app({"pixel_values": px}, feat=True)
         assert only["text_embeds"] is None and float((only["image_embeds"].cpu() - img).abs().max()) < (2e-5 if f32 else 2e-2)
+
+
+def test_from_config_initialises_the_resnet_tower():
+    """CLIPApp.from_config with a `vision_layers` tuple (round 4): the ModifiedResNet parameters are initialised as
+    CHINESE_CLIP.initialize_parameters does (modeling_chineseclip.py:323-334: attnpool projections at in_features^-0.5, bn3 gains
+    zero) instead of staying all-zero -- the image embeddings are finite unit vectors that depend on the image -- and the tower's
+    output equals the oracle's on those weights."""
+    cfg = dict(O.CONFIGS["tiny"], vision_layers=[1, 2, 1, 1], vision_width=16, image_resolution=64)
+    app = CLIPApp.from_config(cfg, seed=3, device="cuda", compute_dtype="fp32")
+    app.eval()
+    named = dict(app.chinese_clip.named_parameters())
+    assert float(named["visual.layer2.1.bn3.weight"].abs().max()) == 0.0 and float(named["visual.layer2.1.bn1.weight"].min()) == 1.0
+    assert float(named["visual.conv1.weight"].std()) > 0.05 and float(named["visual.attnpool.c_proj.weight"].std()) > 0.01
+    px = torch.randn(5, 3, 64, 64, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        out = app({"pixel_values": px}, feat=True)["image_embeds"].cpu()
+    assert bool(torch.isfinite(out).all()) and float((out.norm(dim=-1) - 1).abs().max()) < 1e-5
+    gram = out @ out.t()
+    assert float((gram - torch.eye(5)).abs().max()) > 1e-4          # not one constant vector ...
+    assert float(gram.min()) < 0.999999                              # ... and not all rows identical
+    sd = {n: t.detach().cpu() for n, t in list(app.chinese_clip.named_parameters()) + list(app.chinese_clip.named_buffers())
+          if n.startswith("visual.") and not n.endswith("num_batches_tracked")}
+    with torch.no_grad():
+        ref = norm(RO.modified_resnet_forward(sd, cfg["vision_layers"], 16, px))
+    assert float((out - ref).abs().max()) < 2e-5

@@ -35,6 +35,7 @@ CASES = [
     ("small_b5_l40", "small", 5, 40, 99, 7, False),
     ("p14_w256_b16_l32", "p14_w256", 16, 32, 77, 5, False),
     ("vitb16_bertbase_b4_l64", "vitb16_bertbase", 4, 64, 1234, 0, False),
+    ("large_text_b24_l40", "large_text", 24, 40, 31, 11, False),      # round 4: text width 1024 / 16 heads / FFN 4096
 ]
 
 
@@ -219,7 +220,8 @@ def run_openclip_case(name, cfg_name, B, wseed, iseed, full):
 
 OPENCLIP_CASES = [("openclip_tiny_b6", "oc_tiny", 6, 1234, 3, True), ("openclip_small_b5", "oc_small", 5, 99, 7, False)]
 
-HF_CASES = [("hf_tiny_b6_l24", "hf_tiny", 6, 24, 1234, 3, True), ("hf_small_b5_l40", "hf_small", 5, 40, 99, 7, False)]
+HF_CASES = [("hf_tiny_b6_l24", "hf_tiny", 6, 24, 1234, 3, True), ("hf_small_b5_l40", "hf_small", 5, 40, 99, 7, False),
+            ("hf_large_text_b24_l40", "hf_large_text", 24, 40, 41, 13, False)]   # round 4: the LARGE RoBERTa text tower's widths
 
 
 def run_wukong_case(name, cfg_name, B, wseed, iseed, full):

@@ -262,17 +262,31 @@ class Telemetry:
         self.period, self.samples, self._stop = period, [], threading.Event()
         self.source = None
         self._hw = None
+        # the hwmon directory of cuda:0 -- matched by PCI address (the box exposes more amdgpu cards than this process may use)
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(0)
+            want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        cands = []
         for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            dev = os.path.dirname(os.path.dirname(d))
             try:
-                if open(os.path.join(os.path.dirname(os.path.dirname(d)), "vendor")).read().strip() != "0x1002":
+                if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
                     continue
             except OSError:
                 continue
             pw = [f for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(d, f))]
             if pw and os.path.exists(os.path.join(d, "freq1_input")):
-                self._hw = (os.path.join(d, pw[0]), os.path.join(d, "freq1_input"))
-                self.source = "hwmon:" + pw[0]
-                break
+                cands.append((os.path.basename(os.path.realpath(dev)), os.path.join(d, pw[0]), os.path.join(d, "freq1_input")))
+        for addr, pwf, fqf in cands:
+            if want and addr.lower().startswith(want):
+                self._hw = (pwf, fqf)
+                self.source = "hwmon:%s@%s" % (os.path.basename(pwf), addr)
+        if self._hw is None and len(cands) == 1:
+            self._hw = cands[0][1:]
+            self.source = "hwmon:%s@%s" % (os.path.basename(cands[0][1]), cands[0][0])
         if self._hw is None:
             import shutil
             if shutil.which("rocm-smi"):

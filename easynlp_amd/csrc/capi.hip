@@ -457,9 +457,8 @@ int ezclip_op_gemm_nt_ex(const ezclip_gemm_desc* d, void* stream) {
   g.rowstat_part = d->rowstat_part_dev; g.colsum = d->colsum_dev;
   g.alpha = d->alpha; g.M = d->m; g.N = d->n; g.K = d->k; g.act = d->act; g.out_f32 = d->out_f32;
   const int fk = d->force_kernel;
-  EZ_REQUIRE(fk == -1 || fk == 0 || fk == 2 || fk == 4 || fk == 24, "ezclip_op_gemm_nt_ex: force_kernel %d", fk);
-  if (fk == 4) EZ_REQUIRE(gemm_nt_4q_eligible(g, d->dtype), "ezclip_op_gemm_nt_ex: the staged four-wave kernel does not take this problem");
-  else if (fk >= 2) EZ_REQUIRE(gemm_nt_8p_eligible(g, d->dtype), "ezclip_op_gemm_nt_ex: the 8-phase kernel does not take this problem");
+  EZ_REQUIRE(fk == -1 || fk == 0 || fk == 2 || fk == 24, "ezclip_op_gemm_nt_ex: force_kernel %d", fk);
+  if (fk >= 2) EZ_REQUIRE(gemm_nt_8p_eligible(g, d->dtype), "ezclip_op_gemm_nt_ex: the 8-phase kernel does not take this problem");
   set_gemm_variant(fk);
   const int rc = gemm_nt(g, d->dtype, S(stream));
   set_gemm_variant(-1);

@@ -186,6 +186,20 @@ __device__ __forceinline__ void mma32(f32x16_t& acc, const uint4& a, const uint4
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                 __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
+// v_mfma_f32_16x16x32_bf16 (round 4): D[16 x 16] += A[16 x 32] B[32 x 16], operands 8 bf16 per lane: lane (i = lane & 15,
+// kq = lane >> 4) holds A[i][8 kq .. 8 kq + 7] and B[8 kq .. 8 kq + 7][i]; result column j = lane & 15, rows 4 (lane >> 4) + r.
+// Same peak rate as 32x32x16 (1024 flop / cycle / SIMD) and the same operand bytes per flop out of LDS, but K = 32 per
+// instruction means half the f32 accumulator read-modify-writes per flop: under the 1 400 W socket cap that is the difference --
+// nothing but MFMAs on random register operands sustains 1.80 PFLOP/s (1.72 GHz) with 32x32x16 and 2.10 PFLOP/s (2.00 GHz) with
+// 16x16x32, 2.4 with either on all-zero operands (tools/mfma_power_probe.hip, profiles/r4_mfma_shape_power_probe.log).  It is
+// also the instruction of hipBLASLt's 256 x 256 x 64 kernel (profiles/r4_vendor_vs_ours_pmc.md).
+// EZ_MI16 = 0 rebuilds the bf16 GEMM kernels on 32x32x16 for A/B runs (tools/build_variants.py).
+#ifndef EZ_MI16
+#define EZ_MI16 1
+#endif
+__device__ __forceinline__ void mma16(f32x4_t& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
 __device__ __forceinline__ void mma32(f32x16_t& acc, const uint4& a, const uint4& b, float) {
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);

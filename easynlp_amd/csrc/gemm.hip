@@ -133,13 +133,26 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
   const char* gB = reinterpret_cast<const char*>(p.B);
   const int64_t lda_b = p.lda * (int64_t)sizeof(T), ldb_b = p.ldb * (int64_t)sizeof(T);
 
-  f32x16_t acc[TI][TJ];
+  // bf16: v_mfma_f32_16x16x32_bf16 (EZ_MI16; the accumulation order of the 8-phase kernel, which stays bit-identical to this one);
+  // f32: v_mfma_f32_32x32x2_f32
+  constexpr bool MI16 = (EZ_MI16 != 0) && std::is_same<T, bf16_t>::value;
+  f32x16_t acc[MI16 ? 1 : TI][MI16 ? 1 : TJ];
+  f32x4_t acc16[MI16 ? 2 * TI : 1][MI16 ? 2 * TJ : 1];
+  if constexpr (MI16) {
 #pragma unroll
-  for (int i = 0; i < TI; ++i)
+    for (int i = 0; i < 2 * TI; ++i)
 #pragma unroll
-    for (int j = 0; j < TJ; ++j)
+      for (int j = 0; j < 2 * TJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
 
   const int nk = p.K / BK;
   ConvRows<SH::kBM, SH::kWaves> cr;
@@ -165,6 +178,26 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
     }
     const char* tA = cur;
     const char* tB = cur + SH::kABytes;
+    if constexpr (MI16) {
+      // 16x16x32: two k-steps of 32 per tile; lane (row l15 of a 16-row block, k-quarter q4): chunk 4 s + q4
+      const int l15 = lane & 15, q4 = lane >> 4;
+      const int arow16 = wm * TI * 32 + l15, brow16 = wn * TJ * 32 + l15;
+      uint4 a[2][2 * TI], b[2][2 * TJ];
+#pragma unroll
+      for (int i = 0; i < 2 * TI; ++i) a[0][i] = read_frag(tA, arow16 + i * 16, q4);
+#pragma unroll
+      for (int j = 0; j < 2 * TJ; ++j) b[0][j] = read_frag(tB, brow16 + j * 16, q4);
+#pragma unroll
+      for (int i = 0; i < 2 * TI; ++i) a[1][i] = read_frag(tA, arow16 + i * 16, 4 + q4);
+#pragma unroll
+      for (int j = 0; j < 2 * TJ; ++j) b[1][j] = read_frag(tB, brow16 + j * 16, 4 + q4);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 2 * TI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2 * TJ; ++j) mma16(acc16[i][j], b[s][j], a[s][i]);
+    } else {
     uint4 a[2][TI], b[2][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i) a[0][i] = read_frag(tA, arow + i * 32, h);
@@ -184,6 +217,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
 #pragma unroll
         for (int j = 0; j < TJ; ++j) mma32(acc[i][j], b[s & 1][j], a[s & 1][i], T());
     }
+    }
   }
 
   // ---- epilogue: lane owns row m, 4 consecutive n per (j, q) ----
@@ -195,19 +229,25 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
   const T* U = reinterpret_cast<const T*>(p.U);
   constexpr bool kFast = IsFast<TO>::value;
   // (static_for: compile-time i/j keep the accumulators in registers whatever the unroller decides)
-  static_for<TI>([&](auto ic) {
+  // MI16: 2 TI x 2 TJ blocks of 16 x 16, lane = row l15, columns 4 (lane >> 4) .. + 3 (one quad per block);
+  // otherwise TI x TJ blocks of 32 x 32, lane = row l31, columns 8 q + 4 h .. + 3 for q = 0..3
+  constexpr int NI = MI16 ? 2 * TI : TI, NJ = MI16 ? 2 * TJ : TJ, NQ = MI16 ? 1 : 4, RB = MI16 ? 16 : 32;
+  static_for<NI>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
-    const int m = m0 + wm * TI * 32 + i * 32 + l31;
+    const int m = m0 + wm * TI * 32 + i * RB + (MI16 ? (lane & 15) : l31);
     if (m >= p.M) return;
-    static_for<TJ>([&](auto jc) {
+    static_for<NJ>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * TJ * 32 + j * 32 + q * 8 + h * 4;
+      for (int q = 0; q < NQ; ++q) {
+        const int n = n0 + wn * TJ * 32 + j * RB + (MI16 ? (lane >> 4) * 4 : q * 8 + h * 4);
         if (n >= p.N) continue;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] * scale;
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (MI16) v[e] = acc16[i][j][e] * scale;
+          else v[e] = acc[i][j][q * 4 + e] * scale;
+        }
         if (p.vec_ok) {
           if (p.bias) {
             const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
@@ -330,7 +370,6 @@ int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {
                "gemm_nt: bad implicit-convolution problem (H %d W %d C %d K %d M %d)", p.conv_H, p.conv_W, p.conv_C, p.K, p.M);
     return dtype == EZCLIP_F32 ? launch_nt_conv<float>(p, stream) : launch_nt_conv<bf16_t>(p, stream);
   }
-  if (g_gemm_variant == 4 && gemm_nt_4q_eligible(p, dtype)) return gemm_nt_4q(p, stream);     // staged experiment (gemm4q.hip)
   if (gemm_nt_uses_8p(p, dtype)) return gemm_nt_8p(p, stream);
   if (p.colsum != nullptr) {   // not the 8-phase kernel: separate column-sum pass after the GEMM
     float* cs = p.colsum;

@@ -62,11 +62,42 @@ struct Ctx {
 
 // One phase.  P: quadrant; PAR: tile parity (static slot bases); ISSUE: issue half-tile k+6;
 // VM: vmcnt to wait for afterwards (-1: none).
-template <int P, int PAR, bool ISSUE, int VM, int VMR = VM, int XLD = 0>
-__device__ __forceinline__ void phase(const Ctx& c, Frags& f, f32x16_t (&acc)[4][2], uint32_t kbyte_next1,
+// FR / ACC: Frags + f32x16_t[4][2] (v_mfma_f32_32x32x16_bf16: 8 per phase) or Frags16 + Acc16 (v_mfma_f32_16x16x32_bf16: 16 per
+// phase, EZ_MI16) -- same bytes out of LDS either way (8 / 4 ds_read_b128 per A / B half), same 256 matrix-pipe cycles.
+// FIRST (MI16 only): first K-tile of an output tile -- the first k-step's MFMAs take a literal zero as their C operand, so the
+// accumulators are never zeroed by VALU moves (128 v_mov per wave and tile in the 32x32x16 build) and carry no value from one
+// tile of the persistent loop into the next (each tile defines them afresh: no loop-carried register tuples to keep coalesced).
+template <int P, int PAR, bool ISSUE, int VM, int VMR = VM, int XLD = 0, bool FIRST = false, typename FR, typename ACC>
+__device__ __forceinline__ void phase(const Ctx& c, FR& f, ACC& acc, uint32_t kbyte_next1,
                                       uint32_t kbyte_next2, bool relaxed = false) {
   constexpr int k8 = 4 * PAR + P;                 // phase number mod 8
+  constexpr bool MI16 = std::is_same<FR, Frags16>::value;
   // ---- read segment -----------------------------------------------------------------------
+  if constexpr (MI16) {
+    if constexpr (P == 0) {
+      constexpr int sB = ((k8 + 1) & 7) * kSlot, sA = (k8 & 7) * kSlot;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) f.bl[v][s] = *reinterpret_cast<const uint4*>(c.smem + sB + v * 2048 + c.rdB[s]);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f.a[u][s] = *reinterpret_cast<const uint4*>(c.smem + sA + u * 2048 + c.rdA[s]);
+    } else if constexpr (P == 1) {
+      constexpr int sB = ((k8 + 1) & 7) * kSlot;    // B-hi is half-tile 4t+2
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) f.bh[v][s] = *reinterpret_cast<const uint4*>(c.smem + sB + v * 2048 + c.rdB[s]);
+    } else if constexpr (P == 2) {
+      constexpr int sA = ((k8 + 1) & 7) * kSlot;    // A-hi is half-tile 4t+3
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f.a[u][s] = *reinterpret_cast<const uint4*>(c.smem + sA + u * 2048 + c.rdA[s]);
+    }
+  } else {
   if constexpr (P == 0) {
     constexpr int sB = ((k8 + 1) & 7) * kSlot, sA = (k8 & 7) * kSlot;
 #pragma unroll
@@ -87,6 +118,7 @@ __device__ __forceinline__ void phase(const Ctx& c, Frags& f, f32x16_t (&acc)[4]
       f.a[0][s] = *reinterpret_cast<const uint4*>(c.smem + sA + c.rdA[s]);
       f.a[1][s] = *reinterpret_cast<const uint4*>(c.smem + sA + 4096 + c.rdA[s]);
     }
+  }
   }
   // ---- DMA for half-tile k+6 (kind (P+2)&3: P0 -> B-hi(t+1), P1 -> A-hi(t+1), P2 -> A-lo(t+2), P3 -> B-lo(t+2))
   if constexpr (ISSUE) {
@@ -116,13 +148,33 @@ __device__ __forceinline__ void phase(const Ctx& c, Frags& f, f32x16_t (&acc)[4]
   __builtin_amdgcn_sched_barrier(0);
   // ---- MFMA segment -------------------------------------------------------------------------
   __builtin_amdgcn_s_setprio(1);
-  constexpr int i0 = (P >= 2) ? 2 : 0;
   constexpr int j = (P == 1 || P == 2) ? 1 : 0;
+  if constexpr (MI16) {
+    constexpr int rb0 = (P >= 2) ? 4 : 0, cb0 = 2 * j;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const uint4& b = (j == 0) ? f.bl[s] : f.bh[s];
-    mma32(acc[i0][j], b, f.a[0][s], bf16_t());
-    mma32(acc[i0 + 1][j], b, f.a[1][s], bf16_t());
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const uint4& b = (j == 0) ? f.bl[v][s] : f.bh[v][s];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (FIRST && s == 0) {
+            f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+            mma16(z, b, f.a[u][s]);
+            acc.t[rb0 + u][cb0 + v] = z;
+          } else {
+            mma16(acc.t[rb0 + u][cb0 + v], b, f.a[u][s]);
+          }
+        }
+      }
+  } else {
+    constexpr int i0 = (P >= 2) ? 2 : 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4& b = (j == 0) ? f.bl[s] : f.bh[s];
+      mma32(acc[i0][j], b, f.a[0][s], bf16_t());
+      mma32(acc[i0 + 1][j], b, f.a[1][s], bf16_t());
+    }
   }
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
@@ -135,14 +187,15 @@ __device__ __forceinline__ void phase(const Ctx& c, Frags& f, f32x16_t (&acc)[4]
 // VMR (with relaxed = true): the count for the first K-tile of a tile whose predecessor's stores are still in the
 // queue (they sit between this tile's half-tiles 0..5 and 6.. in issue order).
 // XL (TAIL == 2 only): loads of the epilogue's block 0 issued right before this last K-tile (newer than every DMA).
-template <int PAR, int TAIL, int VMR = 8, int XL = 0>
-__device__ __forceinline__ void ktile(const Ctx& c, Frags& f, f32x16_t (&acc)[4][2], uint32_t kb1, uint32_t kb2,
+template <int PAR, int TAIL, int VMR = 8, int XL = 0, typename FR, typename ACC>
+__device__ __forceinline__ void ktile(const Ctx& c, FR& f, ACC& acc, uint32_t kb1, uint32_t kb2,
                                       bool relaxed = false) {
   if constexpr (TAIL == 0) {
-    phase<0, PAR, true, 8, VMR>(c, f, acc, kb1, kb2, relaxed);
-    phase<1, PAR, true, 8, VMR>(c, f, acc, kb1, kb2, relaxed);
-    phase<2, PAR, true, 8, VMR>(c, f, acc, kb1, kb2, relaxed);
-    phase<3, PAR, true, 8, VMR>(c, f, acc, kb1, kb2, relaxed);
+    constexpr bool FIRST = VMR != 8 && std::is_same<FR, Frags16>::value;     // (VMR != 8 marks the first K-tile of a tile)
+    phase<0, PAR, true, 8, VMR, 0, FIRST>(c, f, acc, kb1, kb2, relaxed);
+    phase<1, PAR, true, 8, VMR, 0, FIRST>(c, f, acc, kb1, kb2, relaxed);
+    phase<2, PAR, true, 8, VMR, 0, FIRST>(c, f, acc, kb1, kb2, relaxed);
+    phase<3, PAR, true, 8, VMR, 0, FIRST>(c, f, acc, kb1, kb2, relaxed);
   } else if constexpr (TAIL == 1) {
     phase<0, PAR, true, 8>(c, f, acc, kb1, kb2);
     phase<1, PAR, true, 8>(c, f, acc, kb1, kb2);
@@ -178,6 +231,21 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
   c.hiA = 64u * lda_b;
   c.hiB = 32u * ldb_b;
   c.dma_dst = wave * 2048;
+#if EZ_MI16
+  {   // 16x16x32 fragments: lane (row l15 of a 16-row block, k-quarter q4 of a 32-k step): chunk 4 s + q4; the swizzle (row >> 1) & 7
+      // of row 16 u + l15 is (l15 >> 1) & 7 for every block u, so the blocks are plain + u * 2048 offsets
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int sw = (l15 >> 1) & 7;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const uint32_t ch = (uint32_t)((4 * s + q4) ^ sw) << 4;
+      c.rdA[s] = (uint32_t)(wm * 64 + l15) * 128 + ch;
+      c.rdB[s] = (uint32_t)(wn * 32 + l15) * 128 + ch;
+    }
+    c.rdA[2] = c.rdA[3] = c.rdB[2] = c.rdB[3] = 0;
+    (void)h; (void)l31;
+  }
+#else
   {
     const int sw = (l31 >> 1) & 7;
 #pragma unroll
@@ -187,6 +255,7 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
       c.rdB[s] = (uint32_t)(wn * 32 + l31) * 128 + ch;
     }
   }
+#endif
   // Tile order.  An XCD works on 32 consecutive logical tiles at a time (xcd_remap), and what its L2 has to fetch per
   // round is one A row panel per distinct tile row + one B panel per distinct tile column.  n-fastest order makes that
   // 32 / tiles_n rows + tiles_n columns (N = 3072: 2.7 + 12); with raster_gm = g the tiles of g consecutive tile rows are
@@ -250,6 +319,9 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
   wait_role<8, 0, 0, true>();           // half-tiles 0 and 1 (this wave's pieces)
   bool first = true;
 
+#if EZ_MI16
+  using FragsT = Frags16;
+#else
   f32x16_t acc[4][2];                   // (re-zeroed block by block in the epilogue)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -257,6 +329,8 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  using FragsT = Frags;
+#endif
 
   for (;;) {
     __builtin_amdgcn_sched_barrier(0);
@@ -264,7 +338,10 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
     if (wm == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
 
-    Frags f;
+    FragsT f;
+#if EZ_MI16
+    Acc16 acc;                            // defined by the first K-tile's MFMAs (zero C operand): nothing carried between tiles
+#endif
     const int nk = p.K >> 6;              // even, >= 4 (checked by the launcher)
     uint32_t kb = 0;                      // byte offset of the current tile's k range
     // first K-tile: the previous tile's 4*NS stores may still be in flight between half-tiles 0..5 and 6..

@@ -99,6 +99,19 @@ struct Frags {
   uint4 bh[4];     // B-hi, kept from P1 to P2
 };
 
+// 16x16x32 layout of the same 128 x 64 wave tile (EZ_MI16): 8 x 4 accumulators of 16 x 16, fragments per 16 rows and 32 k
+struct Frags16 {
+  uint4 a[4][2];   // current A half: [16-row block][k-step of 32]
+  uint4 bl[2][2];  // B-lo, kept from P0 to P3: [16-column block][k-step]
+  uint4 bh[2][2];  // B-hi, kept from P1 to P2
+};
+struct Acc16 {
+  f32x4_t t[8][4]; // [16-row block][16-column block]: lane (m = lane & 15, q = lane >> 4) holds columns 4 q .. 4 q + 3 of row m
+};
+struct Acc32 {
+  f32x16_t t[4][2];
+};
+
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (N > 0) {
@@ -142,6 +155,7 @@ struct EpiCtx {
   i32x4_t srdPS;                      // row-stat partials [M][N/64][2] f32 (HAS_PS)
   uint32_t ps_row_b;                  // bytes per row of it
   float* colsum;
+  i32x4_t srdColsum;                  // [N] f32: fused column sums of the act'(U) epilogue (buffer atomics: no 64-bit lane address)
   float scale;
   int M;
 };
@@ -163,6 +177,7 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const GemmArgs& p) {
   e.scale = p.alpha;
   e.M = p.M;
   e.colsum = p.colsum;
+  e.srdColsum = make_srd(p.colsum, (HAS_U && p.colsum) ? (uint32_t)p.N * 4u : 0u);
   return e;
 }
 
@@ -183,7 +198,7 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const GemmArgs& p) {
 // lanes of each 16 when a v_pk_fma_f32 reused the data registers right after the builtin's store).
 // EZ_STG_MOD / EZ_STG_SAMEADDR: experiment hooks of tools/build_variants.py (cache-policy bits on the store; all stores
 // of a wave aimed at one 1 KiB region = same instruction stream without the DRAM write traffic).
-// EZ_ABL_NOSTORE / EZ_ABL_NOLDS / EZ_ABL_NOEPI: timing ablations (results are wrong by construction).
+// EZ_ABL_NOSTORE / EZ_ABL_NOEPI: timing ablations (results are wrong by construction).
 // Default " nt": C is a write-once stream; the non-temporal hint measured +2 % on the K=768 products and +0.9 % on the
 // forward step (profiles/README.md, store experiments); sc1 / sc0 sc1 made no difference.
 #ifndef EZ_STG_MOD
@@ -248,13 +263,42 @@ __device__ __forceinline__ void epilogue_issue_block(const EpiCtx& ec, int mw, i
 
 // HAS_LN: folded LayerNorm -- y = acc * rstd_m + (-mean_m rstd_m) * c1[n] + c2[n]  (see GemmArgs::ln_stats)
 // HAS_PS: also emit the per-row (sum, sum of squares) of this wave's 64 rounded output columns (GemmArgs::rowstat_part)
-template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, int D, bool HAS_LN = false, bool HAS_PS = false, typename IssueDma>
-__device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[4][2], int mw, int nw, char* W, int act,
-                                              EpiLoads& ld, IssueDma&& issue_dma) {
-  constexpr int NL = 4 * ((HAS_R ? 1 : 0) + (HAS_U ? 1 : 0) + (HAS_LN ? 1 : 0));   // loads per 32-row block
-  constexpr int NS = kStoresPerBlock * (1 + (HAS_C2 ? 1 : 0) + (HAS_PS ? 1 : 0));   // stores per 32-row block
-#ifdef EZ_ABL_NOEPI
-  issue_dma();
+// 32-row block I of a wave tile's accumulators -> the wave's LDS image W (row r at W + 256 r, 16-byte chunk index = column / 4
+// XORed with r & 7); the 32x32 layout zeroes them for the next tile, the 16x16 layout's first K-tile starts from a literal zero.  Two accumulator layouts: 4 x 2 MFMA 32x32 tiles (lane = row l31, columns
+// j*32 + q*8 + h*4 .. +3) and 8 x 4 MFMA 16x16 tiles (lane = row l15 of a 16-row block, columns cb*16 + (lane >> 4)*4 .. +3).
+template <int I>
+__device__ __forceinline__ void acc_block_to_lds(f32x16_t (&acc)[4][2], char* W, int eln) {
+  const int eh = eln >> 5, el31 = eln & 31;
+  const uint32_t wr_row = (uint32_t)el31 * 256u, wr_sw = (uint32_t)(el31 & 7);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t ch = (uint32_t)(j * 8 + q * 2 + eh) ^ wr_sw;
+      *reinterpret_cast<float4*>(W + wr_row + (ch << 4)) =
+          make_float4(acc[I][j][q * 4], acc[I][j][q * 4 + 1], acc[I][j][q * 4 + 2], acc[I][j][q * 4 + 3]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[I][j][r] = 0.f;
+  }
+}
+template <int I>
+__device__ __forceinline__ void acc_block_to_lds(Acc16& acc, char* W, int eln) {
+  // row 16 u + l15, chunk (4 cb + q4) ^ (row & 7): row & 7 = l15 & 7 for both u, and 4 cb / q4 occupy disjoint bits, so the byte
+  // address is ((l15 * 256 + ((q4 ^ (l15 & 7)) << 4)) ^ (cb << 6)) + 4096 u -- ONE live register, an xor per column block and
+  // the 16-row block as the instruction's immediate offset
+  const uint32_t a0 = (uint32_t)(eln & 15) * 256u + ((uint32_t)((eln >> 4) ^ (eln & 7)) << 4);
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    char* wp = W + (a0 ^ (uint32_t)(cb << 6));
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4_t& t = acc.t[2 * I + u][cb];
+      *reinterpret_cast<float4*>(wp + u * 4096) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+  }
+}
+__device__ __forceinline__ void acc_keep_and_zero(f32x16_t (&acc)[4][2]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -263,14 +307,31 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
+}
+__device__ __forceinline__ void acc_keep_and_zero(Acc16& acc) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      asm volatile("" ::"v"(acc.t[i][j]));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc.t[i][j][r] = 0.f;
+    }
+}
+
+template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, int D, bool HAS_LN = false, bool HAS_PS = false, typename ACC, typename IssueDma>
+__device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, ACC& acc, int mw, int nw, char* W, int act,
+                                              EpiLoads& ld, IssueDma&& issue_dma) {
+  constexpr int NL = 4 * ((HAS_R ? 1 : 0) + (HAS_U ? 1 : 0) + (HAS_LN ? 1 : 0));   // loads per 32-row block
+  constexpr int NS = kStoresPerBlock * (1 + (HAS_C2 ? 1 : 0) + (HAS_PS ? 1 : 0));   // stores per 32-row block
+#ifdef EZ_ABL_NOEPI
+  issue_dma();
+  acc_keep_and_zero(acc);
   return;
 #endif
   const int eln = lane_id_now();
-  const int crow = eln >> 3, g = eln & 7, eh = eln >> 5, el31 = eln & 31;
+  const int crow = eln >> 3, g = eln & 7;
   const uint32_t lane_c = (uint32_t)crow * ec.ldc_b + (uint32_t)g * 16u;
-  const uint32_t lane_r = (uint32_t)crow * ec.ldr_b + (uint32_t)g * 16u;
-  const uint32_t lane_u = (uint32_t)crow * ec.ldu_b + (uint32_t)g * 16u;
-    const uint32_t wr_row = (uint32_t)el31 * 256u, wr_sw = (uint32_t)(el31 & 7);
   u32x4_t bq[2], c1q[2], c2q[2];
   ldg16(bq[0], (uint32_t)g * 32u, ec.srdBias, (uint32_t)nw * 4u);
   ldg16(bq[1], (uint32_t)g * 32u + 16u, ec.srdBias, (uint32_t)nw * 4u);
@@ -293,29 +354,8 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
   static_for<4>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     constexpr int b = i;
-#ifdef EZ_ABL_NOLDS
-    float x[4][8];
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[it][e] = acc[i][e >> 2][it * 4 + (e & 3)];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#else
-    // accumulators -> LDS (MFMA layout: row l31, columns j*32 + q*8 + h*4 .. +3); zero them for the next tile
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t ch = (uint32_t)(j * 8 + q * 2 + eh) ^ wr_sw;
-        *reinterpret_cast<float4*>(W + wr_row + (ch << 4)) =
-            make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    }
+    // accumulators -> LDS (MFMA layout); zeroed for the next tile
+    acc_block_to_lds<i>(acc, W, eln);
     float x[4][8];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -326,7 +366,6 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
       x[it][0] = x0.x; x[it][1] = x0.y; x[it][2] = x0.z; x[it][3] = x0.w;
       x[it][4] = x1.x; x[it][5] = x1.y; x[it][6] = x1.z; x[it][7] = x1.w;
     }
-#endif
     // wait for this block's loads (block 0: also the bias)
     if constexpr (i == 0) {
 #if EZ_ROLES
@@ -466,7 +505,11 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, f32x16_t (&acc)[
         v += __shfl_xor(v, 8, 64);
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (crow == 0) unsafeAtomicAdd(ec.colsum + nw + g * 8 + e, v);
+        // f32 add without return on a buffer address (descriptor + 32-bit lane offset; lanes with crow != 0 aim out of range and
+        // are dropped by the bounds check): a flat `unsafeAtomicAdd(ptr + idx)` keeps a 64-bit index pair live across the whole
+        // tile loop -- the two registers this instantiation then spilled (with a compiler-placed vmcnt(0) in the main loop)
+        const uint32_t off = crow == 0 ? (uint32_t)(nw + g * 8 + e) * 4u : 0xFFFFFFF0u;
+        asm volatile("buffer_atomic_add_f32 %0, %1, %2, 0 offen" ::"v"(v), "v"(off), "s"(ec.srdColsum) : "memory");
       }
     }
   }

@@ -54,8 +54,6 @@ struct GemmArgs {
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream);
 // 256x256x64 8-phase bf16 kernel (gemm8p.hip): large M, N % 256 == 0, K % 128 == 0, bf16 output
 bool gemm_nt_uses_8p(const GemmArgs& p, int dtype);
-bool gemm_nt_4q_eligible(const GemmArgs& p, int dtype);      // gemm4q.hip: staged experiment (variant 4), bias / activation epilogues
-int gemm_nt_4q(const GemmArgs& p, hipStream_t stream);
 bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype);
 int gemm_nt_8p(const GemmArgs& p, hipStream_t stream);
 void set_gemm_variant(int v);   // debugging / sweeps: -1 heuristic, 0 = 128x128 tile, 1 = 256x256 tile

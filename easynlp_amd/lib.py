@@ -239,7 +239,7 @@ def op_gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, residual=None, act=A
 def op_gemm_nt_ex(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor] = None, bias=None, residual=None, u=None,
                   c2=None, ln_stats=None, ln_c1=None, ln_c2=None, rowstat_part=None, colsum=None, act=ACT_NONE,
                   alpha: float = 1.0, force_kernel: int = -1) -> torch.Tensor:
-    """Every epilogue of the NT GEMM (ezclip_op_gemm_nt_ex); force_kernel: -1 heuristic, 0 128x128, 2 persistent 8-phase, 4 the staged four-wave kernel (gemm4q.hip: bias / activation epilogues),
+    """Every epilogue of the NT GEMM (ezclip_op_gemm_nt_ex); force_kernel: -1 heuristic, 0 128x128, 2 persistent 8-phase,
     24 8-phase with one workgroup per tile."""
     lib = load()
     dt = DTYPE_BF16 if a.dtype == torch.bfloat16 else DTYPE_F32

@@ -22,16 +22,16 @@ def main():
     for spec in sys.argv[1:]:
         name, _, defs = spec.partition(":")
         name, _, which = name.partition("@")
-        which = which or "gemm8p.hip"
-        assert which in B.SOURCES, which
+        which = (which or "gemm8p.hip").split("+")          # name@a.hip+b.hip: several sources recompiled with the flags
+        assert all(w in B.SOURCES for w in which), which
         d = os.path.join(HERE, "bin", "var_" + name)
         os.makedirs(d, exist_ok=True)
         objs = []
         for src in B.SOURCES:
             o = os.path.join(csrc, "build", src.replace(".hip", ".o"))
-            if src == which:
-                o = os.path.join(d, which.replace(".hip", ".o"))
-                subprocess.check_call([B.hipcc()] + B.FLAGS + shlex.split(defs) + ["-c", os.path.join(csrc, src), "-o", o])
+            if src in which:
+                o = os.path.join(d, src.replace(".hip", ".o"))
+                subprocess.check_call([B.hipcc()] + B.FLAGS + B.FILE_FLAGS.get(src, []) + shlex.split(defs) + ["-c", os.path.join(csrc, src), "-o", o])
             objs.append(o)
         subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(d, "libezclip_hip.so")] + objs)
         print("built", d)

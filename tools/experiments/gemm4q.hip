@@ -1,3 +1,8 @@
+// RETIRED EXPERIMENT (round 4): no longer part of libezclip_hip.so.  Round 3 staged this four-wave 128 x 128-wave-tile variant of the
+// NT GEMM to test whether fewer LDS reads per MFMA lower the energy per flop under the socket power cap: they do not (its random /
+// zero-operand ratio equals the 8-phase kernel's).  Round 4 found where the energy goes -- the MFMA shape
+// (v_mfma_f32_16x16x32_bf16 vs 32x32x16: tools/mfma_power_probe.hip) -- and moved the product kernels to it; this file is kept as the
+// record of the experiment (it builds against csrc/ headers of commit 2adffaf).
 // EXPERIMENT (round 3, late; staged for round 4 -- NOT dispatched by gemm_nt unless ezclip_debug_set(0, 4) selects it).
 //
 // bf16 MFMA GEMM, 256 x 256 x 64 tile, FOUR waves of 128 x 128 (gfx950 / CDNA4 only):

@@ -340,6 +340,9 @@ class Telemetry:
                 "socket_power_w_max": round(max(x[2] for x in xs), 1)}
 
 
+# gradient all-reduce buckets of the N > 1 training workloads: float32 (what DDP's own all-reduce moves: the default) or, with
+# EZCLIP_GRAD_BUCKET_DTYPE=bf16, bf16-compressed buckets (DDP's bf16_compress_hook: half the bytes per xGMI link)
+GRAD_BUCKET_DTYPE = torch.bfloat16 if os.environ.get("EZCLIP_GRAD_BUCKET_DTYPE", "").lower() in ("bf16", "bfloat16") else None
 NBATCH = 4      # distinct synthetic batches a workload rotates through (run_workload)
 
 
@@ -435,7 +438,8 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
             # the gradient all-reduce belongs to a training step (DDP in trainer.py:101-108): buckets of the flat gradient
             # arena go out while the backward pass is still running; the embedding gradients are those of the global mean
             # loss, so ranks hold partial sums and the reduction is a SUM
-            loss = app.contrastive_step(px, ids, process_group=pg, backward=True, zero_grad=True, reduce_gradients=world > 1)
+            loss = app.contrastive_step(px, ids, process_group=pg, backward=True, zero_grad=True, reduce_gradients=world > 1,
+                                        bucket_dtype=GRAD_BUCKET_DTYPE)
             if opt is not None:
                 opt.step()
                 app._engine.mark_weights_dirty()
@@ -569,7 +573,8 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
         "roofline": roof,
     }
     if buckets:
-        out["grad_allreduce_buckets_mib"] = [round((e - s) * 4 / 2 ** 20, 1) for s, e in buckets]
+        out["grad_allreduce_buckets_mib"] = [round((e - s) * (2 if GRAD_BUCKET_DTYPE is not None else 4) / 2 ** 20, 1) for s, e in buckets]
+        out["grad_allreduce_bucket_dtype"] = "bf16" if GRAD_BUCKET_DTYPE is not None else "f32"
     if sustained:
         tf = sustained["value_second_half"] * gflop / 1e3                        # executed model TFLOP/s in the steady state
         sustained["model_mfma_frac_second_half"] = round(tf / PEAK_TFLOPS[wl["dtype"]], 4)

@@ -255,6 +255,19 @@ class HipClipEngine:
             self._arenas[which] = a
         return a
 
+    def progress_events(self, enable: bool) -> None:
+        """(Re)arm or switch off the library's progress event log (include/ezclip.h: ezclip_backward_progress_events): the
+        backward calls then record one event per finished parameter group instead of calling back into Python."""
+        L.check(self.lib.ezclip_backward_progress_events(self.handle, 1 if enable else 0), "backward_progress_events")
+
+    def drain_progress(self):
+        """[(tower, stage, event handle)] logged by the backward calls since the last drain, in completion order."""
+        cap = 2 * (len(self.names) // 4 + 8)
+        cap = 256 if cap < 256 else cap
+        tw, st, ev, n = (L.C.c_int * cap)(), (L.C.c_int * cap)(), (L.C.c_void_p * cap)(), L.C.c_int(0)
+        L.check(self.lib.ezclip_backward_progress_drain(self.handle, tw, st, ev, cap, L.C.byref(n)), "backward_progress_drain")
+        return [(int(tw[i]), int(st[i]), ev[i]) for i in range(n.value)]
+
     def set_progress_hook(self, fn) -> None:
         """fn(tower, stage) from inside ezclip_backward_* (include/ezclip.h: ezclip_set_backward_progress); None removes it."""
         if fn is None:
@@ -988,7 +1001,8 @@ class CLIPApp(Application):
 
     # ------------------------------------------------------------------------------------
     def contrastive_step(self, pixel_values, input_ids, process_group=None, backward=False, token_type_ids=None,
-                         attention_mask=None, zero_grad=False, reduce_gradients=False, bucket_bytes=64 << 20):
+                         attention_mask=None, zero_grad=False, reduce_gradients=False, bucket_bytes=64 << 20,
+                         bucket_dtype=None):
         """Fast path without autograd bookkeeping: dual-encoder forward + InfoNCE
         (+ full backward into ``.grad`` when ``backward=True``), one C call per stage.
 
@@ -1077,7 +1091,7 @@ class CLIPApp(Application):
                     if not all(arena.owns(n, g) for n, g in grads.items()):
                         raise L.EzclipError("reduce_gradients needs the gradients in the engine's arena: drop foreign "
                                             ".grad tensors first (optimizer.zero_grad(set_to_none=True))")
-                    reducer = P.OverlappedGradReducer(arena, pg, bucket_bytes)
+                    reducer = P.OverlappedGradReducer(arena, pg, bucket_bytes, bucket_dtype=bucket_dtype)
             eng.sync_params(params, with_backward=True, grads=grads)
         else:
             eng.sync_params(params, with_backward=False)
@@ -1111,21 +1125,32 @@ class CLIPApp(Application):
         main = torch.cuda.current_stream()
         side = eng.side_stream(main.device) if two else None
         if reducer is not None:
-            streams = {0: main, 1: side if two else main}
+            # The library logs one event per finished parameter group on the stream that produced it (no Python runs inside
+            # ezclip_backward_*: round 4); each tower's log is drained as soon as its backward CALL has returned -- the host is then
+            # tens of milliseconds ahead of the device -- and every bucket of the all-reduce is ordered behind the events of its groups.
+            reducer.notify(2, P.STAGE_HEAD)       # logit_scale (already final: written by the contrastive step)
+            eng.progress_events(True)
+            lib = eng.lib
 
-            def on_progress(tower, stage):        # runs inside ezclip_backward_*: order the bucket behind THAT tower's stream
-                with torch.cuda.stream(streams[tower]):
-                    reducer.notify(tower, stage)
-            reducer.notify(2, P.STAGE_HEAD)       # logit_scale
-            eng.set_progress_hook(on_progress)
+            def drain():
+                for tower, stage, ev in eng.drain_progress():
+                    reducer.notify(tower, stage, wait=lambda ev=ev: L.check(lib.ezclip_stream_wait_event(L.stream_ptr(), ev), "stream_wait_event"))
+        else:
+            def drain():
+                pass
+
+        def bwd_image(s_):
+            eng.backward_image(pixel_values, d_img_l, ws_i, stream=s_)
+            drain()
+
+        def bwd_text(s_):
+            eng.backward_text(input_ids, d_txt_l, ws_t, extras=extras, stream=s_, pack=eng.last_pack)
+            drain()
         try:
-            _run_towers(eng, two,
-                        lambda s_: eng.backward_image(pixel_values, d_img_l, ws_i, stream=s_),
-                        lambda s_: eng.backward_text(input_ids, d_txt_l, ws_t, extras=extras, stream=s_, pack=eng.last_pack),
-                        image_first=True)
+            _run_towers(eng, two, bwd_image, bwd_text, image_first=True)
         finally:
             if reducer is not None:
-                eng.set_progress_hook(None)
+                eng.progress_events(False)
         if reducer is not None:
             reducer.finish()
             self.last_grad_buckets = list(reducer.buckets)

@@ -71,6 +71,7 @@ int ezclip_create(const ezclip_config* cfg, ezclip_handle* out) { return model_c
 int ezclip_create_ex(const ezclip_config* cfg, int text_arch, ezclip_handle* out) { return model_create(cfg, out, text_arch); }
 
 void ezclip_destroy(ezclip_handle h) {
+  if (h) for (hipEvent_t ev : h->progress_pool) (void)hipEventDestroy(ev);
   if (h && h->pm_host) (void)hipHostFree(h->pm_host);
   delete h;
 }
@@ -311,6 +312,52 @@ int ezclip_set_backward_progress(ezclip_handle h, ezclip_progress_fn fn, void* u
   EZ_REQUIRE(h, "ezclip_set_backward_progress: null handle");
   h->progress_fn = fn;
   h->progress_user = user;
+  return EZ_OK;
+}
+
+// Progress of a backward pass: the legacy host callback (ezclip_set_backward_progress) and / or the event log
+// (ezclip_backward_progress_events): one hipEventRecord on the stream that has just been given the group's last kernel.  The
+// pool holds as many events as a pass has groups (<= 2 x (layers + 2)); an event is re-recorded only after the caller has
+// drained the item that referred to it (drain resets the cursor), and a failed create / record drops the item rather than the pass.
+void ezclip_model::progress(int tower, int stage, hipStream_t stream) const {
+  if (progress_fn) progress_fn(progress_user, tower, stage);
+  if (!progress_log) return;
+  if (progress_next >= progress_pool.size()) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return;
+    progress_pool.push_back(ev);
+  }
+  hipEvent_t ev = progress_pool[progress_next];
+  if (hipEventRecord(ev, stream) != hipSuccess) return;
+  ++progress_next;
+  progress_items.push_back(ProgressItem{tower, stage, ev});
+}
+
+int ezclip_backward_progress_events(ezclip_handle h, int enable) {
+  EZ_REQUIRE(h, "ezclip_backward_progress_events: null handle");
+  h->progress_log = enable != 0;
+  h->progress_items.clear();
+  h->progress_next = 0;
+  return EZ_OK;
+}
+
+int ezclip_backward_progress_drain(ezclip_handle h, int* towers, int* stages, void** events, int max_items, int* n_items) {
+  EZ_REQUIRE(h && towers && stages && events && n_items && max_items > 0, "ezclip_backward_progress_drain: null argument");
+  const int n = (int)h->progress_items.size();
+  EZ_REQUIRE(n <= max_items, "ezclip_backward_progress_drain: %d items logged, room for %d", n, max_items);
+  for (int i = 0; i < n; ++i) {
+    towers[i] = h->progress_items[i].tower;
+    stages[i] = h->progress_items[i].stage;
+    events[i] = (void*)h->progress_items[i].ev;
+  }
+  *n_items = n;
+  h->progress_items.clear();      // (the events stay valid -- and un-recorded again -- until ezclip_backward_progress_events(h, 1) rearms the log)
+  return EZ_OK;
+}
+
+int ezclip_stream_wait_event(void* stream, void* event) {
+  EZ_REQUIRE(event, "ezclip_stream_wait_event: null event");
+  EZ_HIP(hipStreamWaitEvent(S(stream), (hipEvent_t)event, 0));
   return EZ_OK;
 }
 

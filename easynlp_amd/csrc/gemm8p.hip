@@ -433,10 +433,40 @@ __device__ __forceinline__ uint4 read_tr(const char* base) {
   return make_uint4(a.x, a.y, b.x, b.y);
 }
 
-template <int P, int PAR, bool ISSUE, int VM>
-__device__ __forceinline__ void phase_tn(const CtxTN& c, Frags& f, f32x16_t (&acc)[4][2], uint32_t soff1,
+// FR / ACC as in the NT kernel's phase(): Frags + f32x16_t[4][2] (32x32x16) or Frags16 + Acc16 (16x16x32, EZ_MI16).  MI16 fragments:
+// lane (column l15 of a 16-column block, k-quarter q4) wants m = 32 s + 8 q4 + 0..7 of its column: the two transpose reads of
+// read_tr at image row 32 s + 8 q4 (+ 4); 16-column block u of an A half sits 32 u bytes further along the image row -- bit 5 is
+// an immediate, bit 6 meets the row swizzle, hence two lane addresses (u < 2, u >= 2).
+template <int P, int PAR, bool ISSUE, int VM, typename FR, typename ACC>
+__device__ __forceinline__ void phase_tn(const CtxTN& c, FR& f, ACC& acc, uint32_t soff1,
                                          uint32_t soff2) {
   constexpr int k8 = 4 * PAR + P;
+  constexpr bool MI16 = std::is_same<FR, Frags16>::value;
+  if constexpr (MI16) {
+    if constexpr (P == 0) {
+      constexpr int sB = ((k8 + 1) & 7) * kSlot, sA = (k8 & 7) * kSlot;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) f.bl[v][s] = read_tr(c.smem + sB + c.rdB + v * 32 + s * 8192);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f.a[u][s] = read_tr(c.smem + sA + c.rdA[u >> 1] + (u & 1) * 32 + s * 8192);
+    } else if constexpr (P == 1) {
+      constexpr int sB = ((k8 + 1) & 7) * kSlot;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) f.bh[v][s] = read_tr(c.smem + sB + c.rdB + v * 32 + s * 8192);
+    } else if constexpr (P == 2) {
+      constexpr int sA = ((k8 + 1) & 7) * kSlot;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f.a[u][s] = read_tr(c.smem + sA + c.rdA[u >> 1] + (u & 1) * 32 + s * 8192);
+    }
+  } else {
   if constexpr (P == 0) {
     constexpr int sB = ((k8 + 1) & 7) * kSlot, sA = (k8 & 7) * kSlot;
 #pragma unroll
@@ -457,6 +487,7 @@ __device__ __forceinline__ void phase_tn(const CtxTN& c, Frags& f, f32x16_t (&ac
       f.a[0][s] = read_tr(c.smem + sA + c.rdA[0] + s * 4096);
       f.a[1][s] = read_tr(c.smem + sA + c.rdA[1] + s * 4096);
     }
+  }
   }
   // soff1 / soff2: byte offset of the first row of K-tile t+1 / t+2 (per operand: A uses .x, B .y -- see caller)
   if constexpr (ISSUE) {
@@ -481,13 +512,25 @@ __device__ __forceinline__ void phase_tn(const CtxTN& c, Frags& f, f32x16_t (&ac
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_setprio(1);
-  constexpr int i0 = (P >= 2) ? 2 : 0;
   constexpr int j = (P == 1 || P == 2) ? 1 : 0;
+  if constexpr (MI16) {
+    constexpr int rb0 = (P >= 2) ? 4 : 0, cb0 = 2 * j;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const uint4& b = (j == 0) ? f.bl[s] : f.bh[s];
-    mma32(acc[i0][j], b, f.a[0][s], bf16_t());
-    mma32(acc[i0 + 1][j], b, f.a[1][s], bf16_t());
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const uint4& b = (j == 0) ? f.bl[v][s] : f.bh[v][s];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mma16(acc.t[rb0 + u][cb0 + v], b, f.a[u][s]);
+      }
+  } else {
+    constexpr int i0 = (P >= 2) ? 2 : 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4& b = (j == 0) ? f.bl[s] : f.bh[s];
+      mma32(acc[i0][j], b, f.a[0][s], bf16_t());
+      mma32(acc[i0 + 1][j], b, f.a[1][s], bf16_t());
+    }
   }
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
@@ -499,8 +542,8 @@ __device__ __forceinline__ void phase_tn(const CtxTN& c, Frags& f, f32x16_t (&ac
 // A offsets and the phases derive B's from the ratio-free pair below.
 struct KOff { uint32_t a1, a2, b1, b2; };
 
-template <int PAR, int TAIL>
-__device__ __forceinline__ void ktile_tn(const CtxTN& c, Frags& f, f32x16_t (&acc)[4][2], const KOff& k) {
+template <int PAR, int TAIL, typename FR, typename ACC>
+__device__ __forceinline__ void ktile_tn(const CtxTN& c, FR& f, ACC& acc, const KOff& k) {
   // P0 issues B (t+1), P1 issues A (t+1), P2 issues A (t+2), P3 issues B (t+2)
   if constexpr (TAIL == 0) {
     phase_tn<0, PAR, true, 8>(c, f, acc, k.b1, 0);
@@ -547,6 +590,26 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_tn_8p_kernel(GemmTNArgs p, 
     c.voffA[i] = (m_begin + (uint32_t)r) * lda_b + (uint32_t)p0 * 2u + ch;
     c.voffB[i] = (m_begin + (uint32_t)r) * ldb_b + (uint32_t)q0 * 2u + ch;
   }
+#if EZ_MI16
+  {
+    const int t = lane & 15, q4 = lane >> 4;
+    const int row = 8 * q4 + (t >> 2);                               // + 32*s + 4*kk via immediates
+    const uint32_t swz = (uint32_t)(t >> 2) << 6;
+    const uint32_t colA = (uint32_t)(wm * 64 + (t & 3) * 4) * 2u, colB = (uint32_t)(wn * 32 + (t & 3) * 4) * 2u;
+    c.rdA[0] = (uint32_t)row * 256u + (colA ^ swz);                  // 16-column blocks u = 0, 1 (+ 32 bytes)
+    c.rdA[1] = (uint32_t)row * 256u + ((colA + 64u) ^ swz);          // u = 2, 3
+    c.rdB = (uint32_t)row * 256u + (colB ^ swz);                     // v = 0, 1 (+ 32 bytes)
+    (void)h;
+  }
+  Acc16 acc;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc.t[i][j][r] = 0.f;
+  using FragsT = Frags16;
+#else
   {
     const int t = lane & 15, sub = (lane >> 4) & 1, g = h;
     const int row = 8 * g + (t >> 2);                                // + 16*s + 4*kk via immediates
@@ -567,6 +630,8 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_tn_8p_kernel(GemmTNArgs p, 
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  using FragsT = Frags;
+#endif
 
   const uint32_t stepA = 64u * lda_b, stepB = 64u * ldb_b;           // one K-tile further down
   {
@@ -590,7 +655,7 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_tn_8p_kernel(GemmTNArgs p, 
     __builtin_amdgcn_sched_barrier(0);
   }
 
-  Frags f;
+  FragsT f;
   const int nk = kt_per_split;          // even, >= 4
   KOff k;
   k.a1 = stepA; k.a2 = 2 * stepA; k.b1 = stepB; k.b2 = 2 * stepB;
@@ -607,19 +672,11 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_tn_8p_kernel(GemmTNArgs p, 
 
   // ---- epilogue: fp32 partial tile, row-coalesced through LDS (16 lanes x 16 B = one 256-byte row segment) ----
   char* W = smem + wave * 8192;
-  const uint32_t wr_row = (uint32_t)l31 * 256u, wr_sw = (uint32_t)(l31 & 7);
   float* out = part + (size_t)split * (size_t)p.N * (size_t)p.K;
   const int r4 = lane >> 4, c16 = lane & 15;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t ch = (uint32_t)(j * 8 + q * 2 + h) ^ wr_sw;
-        *reinterpret_cast<float4*>(W + wr_row + (ch << 4)) =
-            make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
-      }
+  static_for<4>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    acc_block_to_lds<i>(acc, W, lane);          // (the NT epilogue's image: row r at 256 r, chunk = column / 4 ^ (r & 7))
     const int prow0 = p0 + ((i >> 1) << 7) + wm * 64 + (i & 1) * 32;     // first output row of this block
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -629,7 +686,8 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_tn_8p_kernel(GemmTNArgs p, 
       const int col = q0 + ((c16 >> 3) << 7) + wn * 32 + (c16 & 7) * 4;
       *reinterpret_cast<float4*>(out + (size_t)(prow0 + rr) * (size_t)p.K + col) = v;
     }
-  }
+  });
+  (void)l31;
 }
 
 // C = (accumulate ? C : 0) + sum_s part[s]   (fixed order)

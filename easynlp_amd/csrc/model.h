@@ -82,7 +82,14 @@ struct ezclip_model {
   // ezclip_set_backward_progress: host callback after each parameter group's gradient kernels are enqueued
   ezclip_progress_fn progress_fn = nullptr;
   void* progress_user = nullptr;
-  void progress(int tower, int stage) const { if (progress_fn) progress_fn(progress_user, tower, stage); }
+  // ezclip_backward_progress_events (round 4): instead of calling into the host from inside the backward call, record an event
+  // on the producing stream per finished group and let the caller drain (tower, stage, event) after the call has returned
+  struct ProgressItem { int tower, stage; hipEvent_t ev; };
+  bool progress_log = false;
+  mutable std::vector<ProgressItem> progress_items;       // logged since the last drain, in completion order
+  mutable std::vector<hipEvent_t> progress_pool;          // events owned by the handle, reused round-robin
+  mutable size_t progress_next = 0;
+  void progress(int tower, int stage, hipStream_t stream) const;
 
   // ezclip_pack_text_meta: a ring of 8 x 4 ints of pinned, device-mapped host memory (rows, longest, prefix, ticket)
   int* pm_host = nullptr;

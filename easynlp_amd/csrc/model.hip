@@ -1250,7 +1250,7 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
   EZ_TRY(wgrad(m, gfeatT, E, ws.cls_ln, W, m->vproj_w, B, stream));
   if (m->Gp(m->vproj_b)) EZ_TRY(colsum_add(ws.gfeat, E, B, E, m->Gp(m->vproj_b), EZCLIP_F32, stream));
   if (m->opt_vision_frozen) {                  // image_embeds = vision_outputs[1].detach()   appzoo/clip/model.py:140
-    m->progress(0, EZCLIP_STAGE_HEAD);
+    m->progress(0, EZCLIP_STAGE_HEAD, stream);
     return EZ_OK;
   }
   EZ_TRY(dgrad(m, gfeatT, E, m->vproj_w, ws.gcls, W, B, nullptr, 0, ACT_NONE, nullptr, 0, stream));
@@ -1263,20 +1263,20 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
     // x_out of the last block is [B, W]; d x_out lands compact in gx (+ the block's c_proj bias gradient)
     EZ_TRY(ln_bwd(m, xl, W, ws.gcls, W, m->lnpost_w, m->lnpost_b, ws.mpost, ws.rpost, ws.gx, W, nullptr, 0, B, W, stream,
                   m->vit[nl - 1].proj_b));
-    m->progress(0, EZCLIP_STAGE_HEAD);         // visual.proj, ln_post
+    m->progress(0, EZCLIP_STAGE_HEAD, stream);         // visual.proj, ln_post
     EZ_TRY(resblock_backward_cls(m, m->vit[nl - 1], ws.layers[nl - 1], bd, bg, nl > 1 ? m->vit[nl - 2].proj_b : -1, stream));
-    m->progress(0, nl - 1);
+    m->progress(0, nl - 1, stream);
   } else {
     EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * W * esz, stream));
     // (gx is zero outside the CLS rows: its column sums are the last block's c_proj bias gradient)
     EZ_TRY(ln_bwd(m, xl, (int64_t)Lv * W, ws.gcls, W, m->lnpost_w, m->lnpost_b, ws.mpost, ws.rpost, ws.gx, (int64_t)Lv * W,
                   nullptr, 0, B, W, stream, m->vit[nl - 1].proj_b));
-    m->progress(0, EZCLIP_STAGE_HEAD);
+    m->progress(0, EZCLIP_STAGE_HEAD, stream);
   }
   for (int i = nl - (cls_train ? 2 : 1); i >= 0; --i) {
     // (block i's c_proj bias gradient was written by block i + 1's last LayerNorm backward: everything of block i is final)
     EZ_TRY(resblock_backward(m, m->vit[i], ws.layers[i], bd, bg, i > 0 ? m->vit[i - 1].proj_b : -1, stream));
-    m->progress(0, i);
+    m->progress(0, i, stream);
   }
   // x = ln_pre(cat(cls, conv(patches)) + pos)                                          :237-242
   EZ_TRY(ln_bwd(m, ws.x0, W, ws.gx, W, m->lnpre_w, m->lnpre_b, ws.m0, ws.r0, ws.gx2, W, nullptr, 0, M, W, stream));
@@ -1296,7 +1296,7 @@ int backward_image(ezclip_model* m, const float* pixels, int B, const float* d_e
       EZ_TRY(add_cols_f32(m->Gp(m->conv_w.p), m->Kpatch, ws.gconv, m->Kpad, W, m->Kpatch, stream));
     }
   }
-  m->progress(0, EZCLIP_STAGE_EMBED);          // class / positional embedding, conv1, ln_pre
+  m->progress(0, EZCLIP_STAGE_EMBED, stream);          // class / positional embedding, conv1, ln_pre
   return EZ_OK;
 }
 
@@ -1364,19 +1364,19 @@ static int backward_text_clip(ezclip_model* m, const int64_t* ids, int B, int L,
   // d x_eot (+ the last block's c_proj bias gradient = its column sums: every other row of d x is zero)
   EZ_TRY(ln_bwd(m, ws.eot_rows, W, ws.gcls, W, m->lnf_w, m->lnf_b, ws.mpost, ws.rpost, ws.geot, W, nullptr, 0, B, W, stream,
                 m->ttx[nl - 1].proj_b));
-  m->progress(1, EZCLIP_STAGE_HEAD);           // text_projection, ln_final
+  m->progress(1, EZCLIP_STAGE_HEAD, stream);           // text_projection, ln_final
   EZ_HIP(hipMemsetAsync(ws.gx, 0, (size_t)M * W * esz, stream));
   EZ_TRY(gather_rows(ws.geot, ws.eot, ws.gx, B, L, W, 1, dt, stream));
   const BlockDims bd{M, W, B, L, m->theads, 1};
   const BlockGrads bg{ws.gx, ws.gx2, ws.gtmp, ws.gqkv, ws.gbig, ws.gbpart};
   for (int i = nl - 1; i >= 0; --i) {
     EZ_TRY(resblock_backward(m, m->ttx[i], ws.layers[i], bd, bg, i > 0 ? m->ttx[i - 1].proj_b : -1, stream));
-    m->progress(1, i);
+    m->progress(1, i, stream);
   }
   // x = token_embedding[ids] + positional_embedding: index-add and batch sum of d x
   if (m->Gp(m->tok_p)) EZ_TRY(bert_word_grad(ids, ws.gx, m->Gp(m->tok_p), M, W, m->cfg.vocab_size, dt, stream, -1));
   if (m->Gp(m->tpos2_p)) EZ_TRY(batch_sum_add(ws.gx, B, L, L, W, m->Gp(m->tpos2_p), dt, stream));
-  m->progress(1, EZCLIP_STAGE_EMBED);
+  m->progress(1, EZCLIP_STAGE_EMBED, stream);
   return EZ_OK;
 }
 
@@ -1429,10 +1429,10 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     EZ_TRY(wgrad(m, gfeatT, E, xl, xl_ld, m->tproj_w, B, stream));
   }
   if (cls_gather) EZ_TRY(gather_rows(ws.gcls, ex->cu, ws.gx, B, 0, H, 1, dt, stream));      // d x_out[cu[b]] = d cls[b]
-  m->progress(1, EZCLIP_STAGE_HEAD);           // text_projection (+ bias), pooler
+  m->progress(1, EZCLIP_STAGE_HEAD, stream);           // text_projection (+ bias), pooler
   if (cls_train) {
     EZ_TRY(bert_last_layer_cls_backward(m, m->bert[nlayers - 1], ws.layers[nlayers - 1], ws, B, L, stream, ex));
-    m->progress(1, nlayers - 1);
+    m->progress(1, nlayers - 1, stream);
   }
   for (int i = nlayers - (cls_train ? 2 : 1); i >= 0; --i) {
     const auto& Lw = m->bert[i];
@@ -1493,7 +1493,7 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
       EZ_TRY(bgrad(m, gq + H * esz, 3 * H, M, H, Lw.k_b, stream));
       EZ_TRY(bgrad(m, gq + 2 * H * esz, 3 * H, M, H, Lw.v_b, stream));
     }
-    m->progress(1, i);
+    m->progress(1, i, stream);
   }
   // embeddings: dropout(LN(word[ids] + type[0] + pos[t]))                       modeling_bert.py:117-128
   if (hp > 0.f) EZ_TRY(dropout_rows(ws.gx, H, nullptr, 0, ws.gx, H, M, H, make_drop(hp, seed, drop_sid_embed()), dt, stream, ex->rowmap));
@@ -1515,7 +1515,7 @@ int backward_text(ezclip_model* m, const int64_t* ids, int B, int L, const float
     else
       EZ_TRY(batch_sum_add(ws.gx2, B, L, L, H, m->Gp(m->tpos_p), dt, stream));
   }
-  m->progress(1, EZCLIP_STAGE_EMBED);
+  m->progress(1, EZCLIP_STAGE_EMBED, stream);
   return EZ_OK;
 }
 

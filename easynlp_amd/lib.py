@@ -125,6 +125,9 @@ SIGNATURES = {
     "ezclip_op_gemm_nt_ex": (_i, [C.POINTER(EzclipGemmDesc), _vp]),
     "ezclip_op_layernorm_stats": (_i, [_vp, _i64, _f, _i, _i, _i, _vp, _vp]),
     "ezclip_set_backward_progress": (_i, [_vp, _vp, _vp]),
+    "ezclip_backward_progress_events": (_i, [_vp, _i]),
+    "ezclip_backward_progress_drain": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "ezclip_stream_wait_event": (_i, [_vp, _vp]),
     "ezclip_op_gemm_tn": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "ezclip_op_layernorm": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     "ezclip_op_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

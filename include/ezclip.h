@@ -309,6 +309,18 @@ int ezclip_backward_text(ezclip_handle h, const int64_t* input_ids_dev, int batc
 #define EZCLIP_STAGE_EMBED (-1)
 typedef void (*ezclip_progress_fn)(void* user, int tower, int stage);
 int ezclip_set_backward_progress(ezclip_handle h, ezclip_progress_fn fn, void* user);
+/* The same progress WITHOUT host code inside the backward call (round 4; what CLIPApp.contrastive_step(reduce_gradients=True)
+ * uses): while the log is enabled, ezclip_backward_image / _text record one event (hipEventDisableTiming, owned by the handle)
+ * on the producing stream per finished group and append (tower, stage, event) to a list.  After the backward call has RETURNED
+ * -- its kernels are merely enqueued; the host runs tens of milliseconds ahead of the device -- the caller drains the list and
+ * orders its collective behind each event (ezclip_stream_wait_event, or hipStreamWaitEvent on the handle it was given: the
+ * events are plain hipEvent_t).  ezclip_backward_progress_events(h, 1) (re)arms the log and recycles the events: call it once
+ * per training step, before the backward calls; (h, 0) switches it off.  Drained events stay valid until the next rearm.
+ * max_items: room in the three arrays (a pass logs at most layers + 2 groups per tower). */
+int ezclip_backward_progress_events(ezclip_handle h, int enable);
+int ezclip_backward_progress_drain(ezclip_handle h, int* towers, int* stages, void** events, int max_items, int* n_items);
+/* hipStreamWaitEvent(stream, event): lets a host that has no HIP binding of its own order a stream behind a drained event. */
+int ezclip_stream_wait_event(void* stream, void* event);
 
 /* ---- input pipeline (image half) ---------------------------------------------------- */
 /* CLIPDataset.convert_single_row_to_example's image branch on the GPU (easynlp/appzoo/clip/data.py:256-262):

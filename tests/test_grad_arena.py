@@ -134,6 +134,20 @@ def _worker(rank, world, port, q):
             r2.notify(*grp)
         r2.finish()
         assert torch.allclose(a.flat, want / world, atol=1e-6)
+        # bf16 buckets (round 4; DDP's bf16_compress_hook): half the wire bytes, every hop of the sum rounded to bf16 -- the result
+        # is the float32 sum within bf16 rounding of the partial sums, and every bucket that went out was a bf16 tensor
+        a.flat.copy_(full[rank])
+        sent = []
+        r3 = P.OverlappedGradReducer(a, None, bucket_bytes=8 << 10, bucket_dtype=torch.bfloat16,
+                                     all_reduce=lambda t: (sent.append((t.dtype, t.numel())), dist.all_reduce(t, async_op=True))[1])
+        waits = []
+        for grp in progress_sequence(cfg):
+            r3.notify(*grp, wait=lambda grp=grp: waits.append(grp))          # (the event-log route: an explicit wait per group)
+        r3.finish()
+        assert sent and all(dt == torch.bfloat16 for dt, _ in sent) and sum(n for _, n in sent) == a.total
+        assert set(waits) == set(progress_sequence(cfg))                     # every group's producer was waited for before its bucket left
+        scale_ = sum(f.abs() for f in full)
+        assert float(((a.flat - want).abs() / (scale_ + 1e-6)).max()) < (world + 1) * 2.0 ** -8      # (one rounding -- half a bf16 ulp, 2^-8 relative -- per input and per hop)
         # the evaluator's sharded recall ranks: every rank fills its slice, one all-gather into a SEPARATE buffer
         from easynlp_amd.appzoo.clip.evaluator import gather_rank_shards
         n_q = 4 * world - 1                                   # (the last rank's slice is ragged)

@@ -46,6 +46,10 @@ __device__ __forceinline__ void dma16_one(uint32_t lds_dst, uint32_t voff, const
       : "memory");
 }
 __device__ __forceinline__ void dma16(uint32_t lds_dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
+#ifdef EZ_ABL_NODMA         // timing ablation (results wrong by construction): no global -> LDS traffic at all; the counted waits see an empty queue
+  asm volatile("" ::"s"(lds_dst), "v"(voff), "s"(soff));
+  return;
+#endif
 #if EZ_ROLES
   if (!ez_dma_role()) return;
   dma16_one(lds_dst, voff, srd, soff);
@@ -319,9 +323,15 @@ __device__ __forceinline__ void acc_keep_and_zero(Acc16& acc) {
     }
 }
 
-template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, int D, bool HAS_LN = false, bool HAS_PS = false, typename ACC, typename IssueDma>
-__device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, ACC& acc, int mw, int nw, char* W, int act,
+// ACT >= 0: the activation is this compile-time constant (the `act` argument is ignored and every test on it folds away: straight-line
+// code, no phi copies of the eight outputs per row); ACT < 0: `act` is read at run time.
+// ISSUE0: request block 0's loads here, first thing (same queue order), instead of one K-tile earlier by the caller -- for the two
+// instantiations whose registers do not hold 16 more values across the last K-tile (R + row-stat partials, U + erf-GELU').
+template <bool FAST, bool HAS_R, bool HAS_U, bool HAS_C2, int D, bool HAS_LN = false, bool HAS_PS = false, int ACT = -1, bool ISSUE0 = false,
+          typename ACC, typename IssueDma>
+__device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, ACC& acc, int mw, int nw, char* W, int act_rt,
                                               EpiLoads& ld, IssueDma&& issue_dma) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   constexpr int NL = 4 * ((HAS_R ? 1 : 0) + (HAS_U ? 1 : 0) + (HAS_LN ? 1 : 0));   // loads per 32-row block
   constexpr int NS = kStoresPerBlock * (1 + (HAS_C2 ? 1 : 0) + (HAS_PS ? 1 : 0));   // stores per 32-row block
 #ifdef EZ_ABL_NOEPI
@@ -333,6 +343,7 @@ __device__ __forceinline__ void epilogue_rows(const EpiCtx& ec, ACC& acc, int mw
   const int crow = eln >> 3, g = eln & 7;
   const uint32_t lane_c = (uint32_t)crow * ec.ldc_b + (uint32_t)g * 16u;
   u32x4_t bq[2], c1q[2], c2q[2];
+  if constexpr (ISSUE0 && (HAS_R || HAS_U || HAS_LN)) epilogue_issue_block<HAS_R, HAS_U, HAS_LN, 0, 0>(ec, mw, nw, ld);
   ldg16(bq[0], (uint32_t)g * 32u, ec.srdBias, (uint32_t)nw * 4u);
   ldg16(bq[1], (uint32_t)g * 32u + 16u, ec.srdBias, (uint32_t)nw * 4u);
   if constexpr (HAS_LN) {

@@ -128,10 +128,17 @@ def test_pipelined_gemm_isa_audit(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "easynlp_amd", "csrc")
-    for src in ("gemm8p.hip",):
-        out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps",
+    import concurrent.futures
+
+    def compile_one(src):
+        return src, subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps",
                               "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(csrc, src), "-I", csrc,
                               "-o", str(tmp_path / (src + ".o"))], cwd=str(tmp_path), capture_output=True, text=True)
+
+    # the weight-gradient kernel + dispatcher, and the three translation units holding the NT kernel's instantiations
+    with concurrent.futures.ThreadPoolExecutor(4) as ex:
+        results = list(ex.map(compile_one, ("gemm8p.hip", "gemm8p_nt_a.hip", "gemm8p_nt_b.hip", "gemm8p_nt_c.hip")))
+    for src, out in results:
         assert out.returncode == 0, out.stderr[-2000:]
         spills = [l for l in out.stderr.splitlines() if "VGPRs Spill" in l and not l.rstrip().endswith("Spill: 0 [-Rpass-analysis=kernel-resource-usage]")]
         assert not spills, spills

@@ -50,6 +50,9 @@ __device__ __forceinline__ void dma16(uint32_t lds_dst, uint32_t voff, const i32
   asm volatile("" ::"s"(lds_dst), "v"(voff), "s"(soff));
   return;
 #endif
+#ifdef EZ_ABL_DMASAME       // timing ablation: the same instruction stream, every DMA aimed at the first KiB of the operand (L1 / L2 hits:
+  voff &= 0x3f0u; soff = 0;  // issue cost and LDS writes stay, L2 / fabric / HBM traffic goes)
+#endif
 #if EZ_ROLES
   if (!ez_dma_role()) return;
   dma16_one(lds_dst, voff, srd, soff);

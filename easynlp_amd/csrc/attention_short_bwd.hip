@@ -427,6 +427,399 @@ __global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBw
   }
 }
 
+
+// =====================================================================================================
+// Round 4: every score tile ONCE.  The two-pass kernel above forms each 32 x 32 tile of S, P and dS twice -- once with the
+// queries in the lanes (dQ), once with the keys (dK, dV): 28 MFMAs and 32 exponentials per lane and tile pair.  Here a wave owns a
+// KEY block for the whole kernel (K / V row fragments and the K^T fragments of its 32 keys in registers, dK^T / dV^T in its
+// accumulators) and sweeps the query tiles:
+//     S = mfma(Q_t, K_w), dP = mfma(dO_t, V_w) - D      (lane = key, 16 queries in registers: the layout of pass B above)
+//     P = 2^(S c - lse), dS = P o dP;   dV^T += mfma(dO_t^T, P),  dK^T += mfma(Q_t^T, dS)
+// and dQ, the one product that contracts over the KEYS, takes dS through a 2-KiB wave-private LDS tile ([key][query] bf16, written
+// as four 8-byte pieces per lane, read back with the transpose read as the B operand): dQ_t^T += mfma(K_w^T, dS^T).  20 MFMAs and
+// 16 exponentials per lane and tile pair.  dQ_t is summed over the key-block waves in an LDS float image (it takes the place of
+// the K / V images once their fragments sit in registers): in step s wave w works on query tile (w + s) mod nt, so no two waves
+// touch the same rows in a step, a workgroup barrier separates the steps, and the order in which a tile receives its
+// contributions is fixed -- the gradients stay bit-reproducible.  (Summation order of dQ differs from the two-pass kernel: equal
+// within float32 rounding of the partial sums, not bit for bit.)
+// The key-projection bias gradient sum_k dK[k] = scale Q^T r with r_q = sum_k dS[q][k] = sum_k P (dP - D) = D - D: exactly zero
+// in exact arithmetic (softmax is shift-invariant; 1e-9 of rounding noise in the reference) -- written as zeros here.
+// L <= 256 (at most eight waves: 2 per SIMD, 256 registers); longer sequences stay on the two-pass kernel.
+constexpr int kOnceWave = 2304;     // per-wave LDS: 2048 B dS^T tile + 256 B keep words; afterwards the bias-gradient area (kRedWave floats)
+
+template <bool HAS_KB, bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(512) void attn_bwd_once_kernel(AttnBwdArgs a, int nt, int ra) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const AttnArgs& f = a.f;
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int nwaves = nt;
+  const int keep_words = nt;
+  const int L = f.lens ? f.lens[b] : f.L, LKP = 32 * nt;
+  const int64_t row0 = f.cu ? (int64_t)f.cu[b] : (int64_t)b * f.L;
+  nt = (L + 31) >> 5;
+  // LDS: Q image | dO image | zeroed pad (the last tile's rows beyond `ra` of the dO image) | region X | per-row floats | per-wave areas
+  // region X: first the K and V images (2 ra rows of 128 B), then -- their fragments loaded -- the float32 dQ image (ra rows of 256 B)
+  const int IMG = ra * 128, padb = (LKP - ra) * 128;
+  char* imgQ = smem;
+  char* imgG = smem + IMG;
+  char* pad = smem + 2 * IMG;
+  char* imgK = pad + padb;
+  char* imgV = imgK + IMG;
+  char* dqimg = imgK;
+  float* lseA = reinterpret_cast<float*>(imgK + 2 * IMG);
+  float* dA = lseA + LKP;
+  float* kb = dA + LKP;
+  char* wv = reinterpret_cast<char*>(kb + LKP) + wave * kOnceWave;
+  float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(kb + LKP));      // [waves][kOnceWave / 4]: used as [kRedWave] after the loop
+  for (int i = tid * 16; i < padb; i += 64 * nwaves * 16) *reinterpret_cast<uint4*>(pad + i) = make_uint4(0u, 0u, 0u, 0u);
+  const bool want_db = a.db_part != nullptr;
+  const int64_t rs = f.row_stride * 2, cs = f.ctx_stride * 2;
+  const int64_t base = (row0 * f.row_stride + head * 64) * 2;
+  const int64_t cbase = (row0 * f.ctx_stride + head * 64) * 2;
+
+  const int nload = 32 * nt < ra ? 32 * nt : ra;
+  dma_rows_f(imgQ, reinterpret_cast<const char*>(f.q) + base, rs, nload, L, wave, nwaves, lane);
+  dma_rows_f(imgK, reinterpret_cast<const char*>(f.k) + base, rs, nload, L, wave, nwaves, lane);
+  dma_rows_f(imgV, reinterpret_cast<const char*>(f.v) + base, rs, nload, L, wave, nwaves, lane);
+  dma_rows_f(imgG, reinterpret_cast<const char*>(a.dctx) + cbase, cs, nload, L, wave, nwaves, lane);
+  constexpr float kLog2e = 1.4426950408889634f;
+  for (int key = tid; key < 32 * nt; key += 64 * nwaves)
+    kb[key] = key < L ? (HAS_KB ? f.key_bias[row0 + key] * kLog2e : 0.f) : -INFINITY;
+
+  const int blk = wave;
+  const bool active = blk * 32 < L;
+  const int row = blk * 32 + l31;                 // this lane's QUERY in the prologue / epilogue, its KEY in the sweep
+  const int rowc = row < L ? row : L - 1;
+  uint4 of[4];
+  float lse_q = INFINITY;
+  if (active) {
+    const char* op = reinterpret_cast<const char*>(f.ctx) + cbase + (int64_t)rowc * cs;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) of[s] = *reinterpret_cast<const uint4*>(op + (2 * s + h) * 16);
+    if (row < L) lse_q = f.lse[((int64_t)b * f.H + head) * f.L + row];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int fl = swz_f(l31);
+  uint32_t roff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) roff[s] = (uint32_t)l31 * 128u + ((uint32_t)((2 * s + h) ^ fl) << 4);
+  const int t16 = lane & 15, sub = (lane >> 4) & 1;
+  const uint32_t tch = (uint32_t)((((t16 >> 3) & 1) << 2) | (sub << 1) | (((t16 & 3) >> 1) ^ h));
+  const uint32_t trow = (uint32_t)(4 * h + (t16 >> 2)) * 128u + (uint32_t)(t16 & 1) * 8u;
+  auto tr_frag = [&](const char* tile, int u, int dt) -> uint4 {
+    const uint2 lo = tr4(tile + u * 2048 + trow + ((tch ^ (uint32_t)(dt << 2)) << 4));
+    const uint2 hi = tr4(tile + u * 2048 + 1024 + trow + ((tch ^ (uint32_t)((dt << 2) | 2)) << 4));
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+  };
+
+  // D_q = <dO_q, O_q> of this wave's 32 queries, -lse log2 e: the per-row floats every key-block wave reads in the sweep
+  if (active) {
+    float d_q = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4 g4 = *reinterpret_cast<const uint4*>(imgG + blk * 4096 + roff[s]);
+      float gv[8], ov[8];
+      unpack_chunk(g4, gv, bf16_t());
+      unpack_chunk(of[s], ov, bf16_t());
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d_q += gv[e] * ov[e];
+    }
+    d_q += __shfl_xor(d_q, 32, 64);
+    if (h == 0) { lseA[row] = -lse_q * kLog2e; dA[row] = row < L ? -d_q : 0.f; }
+  }
+  // this wave's KEY block: K / V row fragments, K^T fragments (the A operand of the dQ product)
+  uint4 xf[4], gf[4], ktf[2][2];
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      xf[s] = *reinterpret_cast<const uint4*>(imgK + blk * 4096 + roff[s]);
+      gf[s] = *reinterpret_cast<const uint4*>(imgV + blk * 4096 + roff[s]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) ktf[u][dt] = tr_frag(imgK + blk * 4096, u, dt);
+  }
+  // (the bias gradient of the query projection needs the K block once more at the very end: keep its 4 KiB in the wave's registers?
+  //  no -- sum_q dQ = scale K^T c is formed from ktf: see below)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                 // every wave holds its fragments: region X becomes the dQ image
+
+  const float scale = f.scale;
+  const float c = scale * kLog2e;
+  const float kb_key = (row < LKP) ? kb[row] : -INFINITY;        // this lane's key: real bias (HAS_KB), 0, or -inf for keys >= L
+  const bool ragged_blk = blk * 32 + 32 > L;                      // the wave whose block holds keys >= L masks them in the exponent
+  f32x16_t dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
+  float cs4[4] = {0.f, 0.f, 0.f, 0.f};            // c_k = sum over queries of dS[q][k]
+  const uint32_t sbits_b = __float_as_uint(f.drop.scale);
+  uint32_t* kwl = reinterpret_cast<uint32_t*>(wv + 2048);
+  auto keep_word_of = [&](int t) -> uint32_t {
+    const int qq = 32 * t + l31;
+    return f.keep_bits[((row0 + (qq < L ? qq : L - 1)) * f.H + head) * keep_words + blk];
+  };
+  // dS^T tile of the wave: [key 32][query 32] bf16, 64-byte rows, 8-byte slot index XORed with (key >> 2) & 7
+  const uint32_t ws_row = (uint32_t)l31 * 64u, ws_x = (uint32_t)((l31 >> 2) & 7);
+  // ... read back as B-operand fragments (lane = query l31, keys 16 u + 4 h + {0..3} and + 8): transpose reads of 4 keys x 16 queries
+  const uint32_t rs_slot = (uint32_t)(sub * 4 + (t16 & 3));
+  uint32_t rs_off[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      const uint32_t r0 = (uint32_t)(16 * u + 8 * part + 4 * h);                  // first of the four key rows (multiple of 4)
+      rs_off[u][part] = (r0 + (uint32_t)(t16 >> 2)) * 64u + ((rs_slot ^ ((r0 >> 2) & 7u)) << 3);
+    }
+  // dQ image: row q = 256 bytes, 16-byte chunk index (= d / 4) XORed with q & 15
+  auto dq_addr = [&](int q, int chunk) -> char* { return dqimg + (uint32_t)q * 256u + ((uint32_t)(chunk ^ (q & 15)) << 4); };
+
+  uint32_t kwq_next = 0u;
+  int t = blk;
+  if (DROP && active) kwq_next = keep_word_of(t);
+#pragma unroll 1
+  for (int step = 0; step < nt; ++step) {
+    if (active) {
+      f32x16_t sacc, pacc;
+      if (DROP) {
+        if (h == 0) kwl[l31] = kwq_next;
+        int tn = t + 1; if (tn >= nt) tn -= nt;
+        if (step + 1 < nt) kwq_next = keep_word_of(tn);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+      } else {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const float4 d4 = *reinterpret_cast<const float4*>(dA + 32 * t + 8 * qd + 4 * h);
+          pacc[4 * qd] = d4.x; pacc[4 * qd + 1] = d4.y; pacc[4 * qd + 2] = d4.z; pacc[4 * qd + 3] = d4.w;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      const char* qt = imgQ + t * 4096;
+      const char* gt = imgG + t * 4096;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        mma32(sacc, *reinterpret_cast<const uint4*>(qt + roff[s]), xf[s], bf16_t());     // S[q][key]
+        mma32(pacc, *reinterpret_cast<const uint4*>(gt + roff[s]), gf[s], bf16_t());     // dP[q][key] - D[q]
+      }
+      float p[16], ds[16];
+      const bool with_kb = HAS_KB || ragged_blk;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const float4 l4 = *reinterpret_cast<const float4*>(lseA + 32 * t + 8 * qd + 4 * h);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+        float nd[4] = {0.f, 0.f, 0.f, 0.f};
+        uint32_t kwv[4] = {0u, 0u, 0u, 0u};
+        if (DROP) {
+          const float4 d4 = *reinterpret_cast<const float4*>(dA + 32 * t + 8 * qd + 4 * h);
+          nd[0] = d4.x; nd[1] = d4.y; nd[2] = d4.z; nd[3] = d4.w;
+          const uint4 w4 = *reinterpret_cast<const uint4*>(kwl + 8 * qd + 4 * h);
+          kwv[0] = w4.x; kwv[1] = w4.y; kwv[2] = w4.z; kwv[3] = w4.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // (keys >= L: kb_key = -inf -> p = 0 exactly, so that neither dK / dV nor dQ sees them; queries >= L: lse = inf -> 0)
+          float pe = __builtin_amdgcn_exp2f(fmaf(sacc[4 * qd + e], c, with_kb ? kb_key + lv[e] : lv[e]));
+          if (CAUSAL && row > 32 * t + 8 * qd + 4 * h + e) pe = 0.f;
+          if (DROP) {
+            const float mk = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)kwv[e], l31, 1) & sbits_b);
+            p[4 * qd + e] = pe * mk;
+            ds[4 * qd + e] = pe * fmaf(pacc[4 * qd + e], mk, nd[e]);
+          } else {
+            p[4 * qd + e] = pe;
+            ds[4 * qd + e] = pe * pacc[4 * qd + e];
+          }
+          cs4[e] += ds[4 * qd + e];
+        }
+      }
+      uint4 pc[2], dc[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        pc[u].x = pack_bf16x2(p[8 * u + 0], p[8 * u + 1]);   dc[u].x = pack_bf16x2(ds[8 * u + 0], ds[8 * u + 1]);
+        pc[u].y = pack_bf16x2(p[8 * u + 2], p[8 * u + 3]);   dc[u].y = pack_bf16x2(ds[8 * u + 2], ds[8 * u + 3]);
+        pc[u].z = pack_bf16x2(p[8 * u + 4], p[8 * u + 5]);   dc[u].z = pack_bf16x2(ds[8 * u + 4], ds[8 * u + 5]);
+        pc[u].w = pack_bf16x2(p[8 * u + 6], p[8 * u + 7]);   dc[u].w = pack_bf16x2(ds[8 * u + 6], ds[8 * u + 7]);
+      }
+      // dS^T -> the wave's LDS tile: lane (key, h) holds queries 8 qd + 4 h + {0..3} in dc[qd >> 1].{xy | zw}: slot 2 qd + h
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const uint2 v2 = (qd & 1) ? make_uint2(dc[qd >> 1].z, dc[qd >> 1].w) : make_uint2(dc[qd >> 1].x, dc[qd >> 1].y);
+        *reinterpret_cast<uint2*>(wv + ws_row + (((uint32_t)(2 * qd + h) ^ ws_x) << 3)) = v2;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        mma32(dv[0], tr_frag(gt, u, 0), pc[u], bf16_t());      // dV^T[d][key] += dO^T . P
+        mma32(dv[1], tr_frag(gt, u, 1), pc[u], bf16_t());
+        mma32(dk[0], tr_frag(qt, u, 0), dc[u], bf16_t());      // dK^T[d][key] += Q^T . dS
+        mma32(dk[1], tr_frag(qt, u, 1), dc[u], bf16_t());
+      }
+      // dQ_t^T[d][q] += K_w^T . dS^T: the tile's previous partial sum comes out of the LDS image (step 0: this wave is the first)
+      const int q = 32 * t + l31;
+      const bool qin = q < ra;
+      f32x16_t dq[2];
+      if (step > 0 && qin) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const float4 v4 = *reinterpret_cast<const float4*>(dq_addr(q, dt * 8 + 2 * qd + h));
+            dq[dt][4 * qd] = v4.x; dq[dt][4 * qd + 1] = v4.y; dq[dt][4 * qd + 2] = v4.z; dq[dt][4 * qd + 3] = v4.w;
+          }
+      } else {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+      }
+      __builtin_amdgcn_wave_barrier();              // (the dS^T tile is written by this wave only; LDS executes a wave's accesses in order)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint2 lo = tr4(wv + rs_off[u][0]), hi = tr4(wv + rs_off[u][1]);
+        const uint4 dsf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        mma32(dq[0], ktf[u][0], dsf, bf16_t());
+        mma32(dq[1], ktf[u][1], dsf, bf16_t());
+      }
+      if (qin) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd)
+            *reinterpret_cast<float4*>(dq_addr(q, dt * 8 + 2 * qd + h)) =
+                make_float4(dq[dt][4 * qd], dq[dt][4 * qd + 1], dq[dt][4 * qd + 2], dq[dt][4 * qd + 3]);
+      }
+      ++t; if (t >= nt) t -= nt;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // the tiles rotate: next step another wave owns these rows
+  }
+
+  // ------------------------------------------------ outputs -------------------------------------------------------
+  float* red_w = red + wave * (kOnceWave / 4);
+  if (active) {
+    // dK / dV of this wave's keys (lane = key)
+    if (row < L) {
+      bf16_t* dkp = reinterpret_cast<bf16_t*>(a.dk) + (row0 + row) * f.row_stride + head * 64;
+      bf16_t* dvp = reinterpret_cast<bf16_t*>(a.dv) + (row0 + row) * f.row_stride + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          float vk[4], vv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vk[e] = dk[dt][4 * qd + e] * scale; vv[e] = dv[dt][4 * qd + e]; }
+          st4(dkp + dt * 32 + 8 * qd + 4 * h, vk);
+          st4(dvp + dt * 32 + 8 * qd + 4 * h, vv);
+        }
+    }
+    // dQ of this wave's QUERY block out of the LDS image, row-coalesced: lane (row r8 = lane >> 3, c8 = lane & 7) takes 8 columns
+    {
+      const int r8 = lane >> 3, c8 = lane & 7;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int q = blk * 32 + it * 8 + r8;
+        if (q < L) {
+          const float4 x0 = *reinterpret_cast<const float4*>(dq_addr(q, 2 * c8));
+          const float4 x1 = *reinterpret_cast<const float4*>(dq_addr(q, 2 * c8 + 1));
+          const uint4 o = make_uint4(pack_bf16x2(x0.x * scale, x0.y * scale), pack_bf16x2(x0.z * scale, x0.w * scale),
+                                     pack_bf16x2(x1.x * scale, x1.y * scale), pack_bf16x2(x1.z * scale, x1.w * scale));
+          bf16_t* dqp = reinterpret_cast<bf16_t*>(a.dq) + (row0 + q) * f.row_stride + head * 64 + c8 * 8;
+          if ((f.row_stride & 7) == 0 && ((uintptr_t)a.dq & 15) == 0) {
+            *reinterpret_cast<uint4*>(dqp) = o;
+          } else {
+            *reinterpret_cast<uint2*>(dqp) = make_uint2(o.x, o.y);
+            *reinterpret_cast<uint2*>(dqp + 4) = make_uint2(o.z, o.w);
+          }
+        }
+      }
+    }
+  }
+  if (want_db) {
+    // per-wave shares of the three bias gradients into red_w[0..63] (q), [128..191] (k), [256..319] (v), column 1 at +64 as above:
+    //   sum_q dQ = scale K^T c over this wave's KEYS; sum_k dK = 0 (see the header); sum_k dV = column sums of this wave's dV^T
+    if (active) {      // (red_w is this wave's own LDS area -- its dS^T tile until now)
+      float cc = (cs4[0] + cs4[1]) + (cs4[2] + cs4[3]);
+      cc += __shfl_xor(cc, 32, 64);
+      if (h == 0) red_w[384 + l31] = cc;
+      __builtin_amdgcn_wave_barrier();
+      // K^T c: the K block's image is gone (region X holds dQ) -- the product runs on the K^T fragments kept in registers
+      {
+        f32x16_t acc[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint4 bf = vec_frag(red_w + 384, u, h, l31);
+          mma32(acc[0], ktf[u][0], bf, bf16_t());
+          mma32(acc[1], ktf[u][1], bf, bf16_t());
+        }
+        if (l31 < 2) {
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+              *reinterpret_cast<float4*>(red_w + l31 * 64 + dt * 32 + 8 * qd + 4 * h) =
+                  make_float4(acc[dt][4 * qd] * scale, acc[dt][4 * qd + 1] * scale, acc[dt][4 * qd + 2] * scale, acc[dt][4 * qd + 3] * scale);
+        }
+      }
+      if (DROP) {
+        // sum_k dV[k] = dO^T rowsum(P o M s): the row sums run over the keys = over the lanes here, so take the column sums of this
+        // wave's dV^T accumulators instead (16 lanes by DPP, the other 16 by one exchange) -- once per kernel, dropout builds only
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = row16_sum(row < L ? dv[dt][r] : 0.f);
+            v += __shfl_xor(v, 16, 64);
+            if (l31 == 0) red_w[256 + dt * 32 + 8 * (r >> 2) + 4 * h + (r & 3)] = v;
+          }
+        if (lane < 64) red_w[320 + lane] = 0.f;
+      } else {
+        // rows of P sum to one: sum_k dV[k] = dO^T 1 over this wave's QUERY block (the dO image is still in LDS)
+        if (h == 0) red_w[416 + l31] = row < L ? 1.f : 0.f;
+        __builtin_amdgcn_wave_barrier();
+        f32x16_t acc[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint4 bf = vec_frag(red_w + 416, u, h, l31);
+          mma32(acc[0], tr_frag(imgG + blk * 4096, u, 0), bf, bf16_t());
+          mma32(acc[1], tr_frag(imgG + blk * 4096, u, 1), bf, bf16_t());
+        }
+        if (l31 < 2) {
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+              *reinterpret_cast<float4*>(red_w + 256 + l31 * 64 + dt * 32 + 8 * qd + 4 * h) =
+                  make_float4(acc[dt][4 * qd], acc[dt][4 * qd + 1], acc[dt][4 * qd + 2], acc[dt][4 * qd + 3]);
+        }
+      }
+      if (lane < 64) { red_w[128 + lane] = 0.f; red_w[192 + lane] = 0.f; }     // dbk = 0 (both columns)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int i = tid; i < 192; i += 64 * nwaves) {
+      float s = 0.f;
+      const int o = (i >> 6) * 128 + (i & 63);
+      for (int w = 0; w < nt; ++w) s += red[w * (kOnceWave / 4) + o] + red[w * (kOnceWave / 4) + o + 64];
+      a.db_part[((int64_t)b * 3 + (i >> 6)) * (f.H * 64) + head * 64 + (i & 63)] = s;
+    }
+  }
+}
+
 }  // namespace
 
 // LDS of the fused backward for sequences of at most L tokens: four images of round_up(L, 8) rows, the pad behind the last
@@ -440,20 +833,33 @@ bool attention_short_eligible(const AttnArgs& a, int dtype) {       // fused bac
   return dtype == EZCLIP_BF16 && a.L <= 288 && a.L >= 1 && bwd_short_lds_bytes(a.L) <= 160 * 1024 && a.B <= 65535;
 }
 
+static int bwd_once_lds_bytes(int L) {
+  const int nt = (L + 31) / 32, ra = (L + 7) / 8 * 8;
+  return 2 * ra * 128 + (32 * nt - ra) * 128 + 2 * ra * 128 + nt * (3 * 32 * 4) + nt * kOnceWave;
+}
+
+static int g_attn_bwd_once = 1;      // ezclip_debug_set(10, v): 1 (default) the score-tile-once kernel where it applies, 0 the two-pass kernel
+void set_attention_bwd_once(int v) { g_attn_bwd_once = v; }
+
 int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
   const int nt = (a.f.L + 31) / 32, ra = (a.f.L + 7) / 8 * 8;
-  const int bytes = bwd_short_lds_bytes(a.f.L);
-  static LdsOptIn lds_opt[8];
+  const bool once = g_attn_bwd_once && nt <= 8 && bwd_once_lds_bytes(a.f.L) <= 160 * 1024;
+  const int bytes = once ? bwd_once_lds_bytes(a.f.L) : bwd_short_lds_bytes(a.f.L);
+  static LdsOptIn lds_opt[16];
   const int vi = (a.f.key_bias != nullptr ? 1 : 0) + (a.f.causal ? 2 : 0) + (a.f.drop.thr != 0 ? 4 : 0);
   EZ_REQUIRE(a.f.drop.thr == 0 || (a.f.keep_bits != nullptr && a.f.keep_words == nt && nt <= 8),
              "attention_bwd_short: dropout needs the keep bits of the forward (keep_words = ceil(L / 32)) and L <= 256");
   using K = void (*)(AttnBwdArgs, int, int);
-  static const K kerns[8] = {&attn_bwd_short_kernel<false, false, false>, &attn_bwd_short_kernel<true, false, false>,
-                             &attn_bwd_short_kernel<false, true, false>,  &attn_bwd_short_kernel<true, true, false>,
-                             &attn_bwd_short_kernel<false, false, true>,  &attn_bwd_short_kernel<true, false, true>,
-                             &attn_bwd_short_kernel<false, true, true>,   &attn_bwd_short_kernel<true, true, true>};
-  const K kern = kerns[vi];
-  EZ_ENSURE_LDS(kern, lds_opt[vi], bytes);
+  static const K kerns[16] = {&attn_bwd_short_kernel<false, false, false>, &attn_bwd_short_kernel<true, false, false>,
+                              &attn_bwd_short_kernel<false, true, false>,  &attn_bwd_short_kernel<true, true, false>,
+                              &attn_bwd_short_kernel<false, false, true>,  &attn_bwd_short_kernel<true, false, true>,
+                              &attn_bwd_short_kernel<false, true, true>,   &attn_bwd_short_kernel<true, true, true>,
+                              &attn_bwd_once_kernel<false, false, false>,  &attn_bwd_once_kernel<true, false, false>,
+                              &attn_bwd_once_kernel<false, true, false>,   &attn_bwd_once_kernel<true, true, false>,
+                              &attn_bwd_once_kernel<false, false, true>,   &attn_bwd_once_kernel<true, false, true>,
+                              &attn_bwd_once_kernel<false, true, true>,    &attn_bwd_once_kernel<true, true, true>};
+  const K kern = kerns[vi + (once ? 8 : 0)];
+  EZ_ENSURE_LDS(kern, lds_opt[vi + (once ? 8 : 0)], bytes);
   {
     ProfScope ps(PROF_ATTN, 10.0 * a.f.B * a.f.H * (double)a.f.L * a.f.L * 64, stream);   // 5 L x L x 64 products
     hipLaunchKernelGGL(kern, dim3(a.f.H, a.f.B), dim3(64 * nt), bytes, stream, a, nt, ra);

@@ -377,7 +377,10 @@ int ezclip_recall_ranks_rows(const float* text_rows_dev, const float* image_dev,
  * separate statistics pass);  key 3: last-block CLS-only evaluation on the inference path (1 on, 0 off);  key 4: the same on the training path;  key 5: resampling window
  * tables of ezclip_preprocess_images built on the device (1, default) or on the host (0);  key 6: tile order of the persistent
  * GEMM (0 column-fastest, g > 0 super-rows of g row tiles walked column by column, -1 the built-in default);  key 7: BERT
- * query / key / value projections as one N = 3 * hidden product on the bf16 path (1, default) or three products (0). */
+ * query / key / value projections as one N = 3 * hidden product on the bf16 path (1, default) or three products (0);
+ * key 8: the CLS-only last ViT block projects its queries for the CLS rows only (1, default);  key 9: short attention forward:
+ * bit 0 short last tile, bit 1 row sums on the matrix pipe (3, default);  key 10: fused attention backward for sequences up to
+ * 256 tokens: 1 (default) the score-tile-once kernel (round 4), 0 the two-pass kernel of rounds 2-3. */
 int ezclip_debug_set(int key, int value);
 int ezclip_profile_begin(void);
 int ezclip_profile_end(int kernel_class, double* total_ms, double* total_work, int* launches);

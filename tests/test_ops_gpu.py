@@ -741,3 +741,69 @@ def test_contrastive_loss_one_direction(rows, cols):
             CLIPApp.contrastive_loss(app, s.detach().T.contiguous())   # more rows than columns: arange(rows) has no column
     with pytest.raises(L.EzclipError):
         CLIPApp.contrastive_loss(app, s.detach().cpu())
+
+
+# ----------------------------------------------------------------------------- round 4: attention backward, every score tile once
+
+@pytest.mark.parametrize("B_,Lq,H", [(5, 197, 3), (7, 64, 2), (3, 26, 1), (2, 256, 2), (4, 33, 2), (3, 224, 1)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention_bwd_score_tile_once_against_two_pass_and_fp64(B_, Lq, H, masked):
+    """The fused backward of round 4 (a wave owns a key block, dS goes through a wave-private LDS tile for the dQ product, dQ is
+    summed over the waves in an LDS float image in a fixed, barrier-ordered rotation) against the two-pass kernel it replaces
+    (ezclip_debug_set(10, 0)) and the float64 reference: dq / dk / dv and the three projection-bias gradients; two runs give the
+    same bits (the rotation fixes the summation order)."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(B_ * 1000 + Lq * 3 + H)
+    D = H * 64
+    qkv = torch.randn(B_ * Lq, 3 * D, generator=g).bfloat16()
+    dctx = torch.randn(B_ * Lq, D, generator=g).bfloat16()
+    kb = None
+    if masked:
+        lens = torch.randint(1, Lq + 1, (B_,), generator=g)
+        lens[0] = Lq
+        kb = torch.zeros(B_, Lq)
+        for i in range(B_):
+            kb[i, lens[i]:] = -10000.0
+        if B_ > 1:
+            kb[1, :] = -10000.0
+        kb = kb.reshape(-1)
+    qd = qkv.double().requires_grad_(True)
+    ref, _ = ref_attention(qd, B_, Lq, H, kb)
+    ref.backward(dctx.double())
+    ref_db = qd.grad.sum(0)
+    qg, dg_, kbg = qkv.to(DEV), dctx.to(DEV), (None if kb is None else kb.to(DEV))
+    ctx, lse = L.op_attention(qg, B_, Lq, H, key_bias=kbg, want_lse=True)
+    esz = 2
+    base = qg.data_ptr()
+    scratch = torch.empty(B_ * 3 * D, dtype=torch.float32, device=DEV)
+    outs = {}
+    try:
+        for variant in (1, 0, 1):
+            L.check(lib.ezclip_debug_set(10, variant))
+            dqkv = torch.zeros_like(qg)
+            db = torch.zeros(3 * D, device=DEV)
+            dbase, bb = dqkv.data_ptr(), db.data_ptr()
+            L.check(lib.ezclip_op_attention_bwd_bias(base, base + D * esz, base + 2 * D * esz, 3 * D, ctx.data_ptr(), dg_.data_ptr(), D,
+                                                     L.ptr(kbg), lse.data_ptr(), dbase, dbase + D * esz, dbase + 2 * D * esz,
+                                                     bb, bb + 4 * D, bb + 8 * D, scratch.data_ptr(), B_, Lq, H, L.DTYPE_BF16, None,
+                                                     L.stream_ptr()))
+            torch.cuda.synchronize()
+            if variant == 1 and 1 in outs:
+                assert torch.equal(outs[1][0], dqkv) and torch.equal(outs[1][1], db), "not bit-reproducible"
+            outs[variant] = (dqkv, db)
+    finally:
+        L.check(lib.ezclip_debug_set(10, 1))
+    scale = float(qd.grad.abs().max())
+    for variant in (1, 0):
+        got = outs[variant][0].float().cpu()
+        assert max_err(got, qd.grad) < 0.04 * max(1.0, scale), variant
+        assert rel_err(got, qd.grad) < 0.02, variant
+    # the two kernels agree far inside that bound (same products, another summation order for dQ, then one bf16 rounding)
+    assert float((outs[1][0].float() - outs[0][0].float()).abs().max()) < 0.02 * max(1.0, scale)
+    # bias gradients: q and v against the column sums of the reference; the k part is zero in exact arithmetic (rows of dS sum to zero)
+    # -- the new kernel writes exact zeros, the two-pass kernel and the reference their rounding noise
+    bscale = float(ref_db.abs().max())
+    got_db = outs[1][1].cpu().double()
+    assert float((got_db[:D] - ref_db[:D]).abs().max()) < 0.03 * max(1.0, bscale)
+    assert float((got_db[2 * D:] - ref_db[2 * D:]).abs().max()) < 0.03 * max(1.0, bscale)
+    assert float(got_db[D:2 * D].abs().max()) == 0.0 and float(ref_db[D:2 * D].abs().max()) < 1e-6 * max(1.0, bscale)

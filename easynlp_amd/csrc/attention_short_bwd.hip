@@ -461,8 +461,10 @@ __global__ __launch_bounds__(512) void attn_bwd_once_kernel(AttnBwdArgs a, int n
   const int L = f.lens ? f.lens[b] : f.L, LKP = 32 * nt;
   const int64_t row0 = f.cu ? (int64_t)f.cu[b] : (int64_t)b * f.L;
   nt = (L + 31) >> 5;
-  // LDS: Q image | dO image | zeroed pad (the last tile's rows beyond `ra` of the dO image) | region X | per-row floats | per-wave areas
-  // region X: first the K and V images (2 ra rows of 128 B), then -- their fragments loaded -- the float32 dQ image (ra rows of 256 B)
+  // LDS: Q image | dO image | zeroed pad | region X | zeroed pad | per-row floats | per-wave areas
+  // region X: first the K and V images (2 ra rows of 128 B), then -- their fragments loaded -- the float32 dQ image (ra rows of 256 B).
+  // The pads take the last tile's rows beyond `ra` of the dO and of the V image (the Q and K images run over into the image behind
+  // them: finite bf16 data, always multiplied by an exact zero; float words read as bf16 pairs would not be: -inf, NaN patterns).
   const int IMG = ra * 128, padb = (LKP - ra) * 128;
   char* imgQ = smem;
   char* imgG = smem + IMG;
@@ -470,12 +472,16 @@ __global__ __launch_bounds__(512) void attn_bwd_once_kernel(AttnBwdArgs a, int n
   char* imgK = pad + padb;
   char* imgV = imgK + IMG;
   char* dqimg = imgK;
-  float* lseA = reinterpret_cast<float*>(imgK + 2 * IMG);
+  char* pad2 = imgK + 2 * IMG;
+  float* lseA = reinterpret_cast<float*>(pad2 + padb);
   float* dA = lseA + LKP;
   float* kb = dA + LKP;
   char* wv = reinterpret_cast<char*>(kb + LKP) + wave * kOnceWave;
   float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(kb + LKP));      // [waves][kOnceWave / 4]: used as [kRedWave] after the loop
-  for (int i = tid * 16; i < padb; i += 64 * nwaves * 16) *reinterpret_cast<uint4*>(pad + i) = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid * 16; i < padb; i += 64 * nwaves * 16) {
+    *reinterpret_cast<uint4*>(pad + i) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(pad2 + i) = make_uint4(0u, 0u, 0u, 0u);
+  }
   const bool want_db = a.db_part != nullptr;
   const int64_t rs = f.row_stride * 2, cs = f.ctx_stride * 2;
   const int64_t base = (row0 * f.row_stride + head * 64) * 2;
@@ -835,15 +841,21 @@ bool attention_short_eligible(const AttnArgs& a, int dtype) {       // fused bac
 
 static int bwd_once_lds_bytes(int L) {
   const int nt = (L + 31) / 32, ra = (L + 7) / 8 * 8;
-  return 2 * ra * 128 + (32 * nt - ra) * 128 + 2 * ra * 128 + nt * (3 * 32 * 4) + nt * kOnceWave;
+  return 2 * ra * 128 + 2 * (32 * nt - ra) * 128 + 2 * ra * 128 + nt * (3 * 32 * 4) + nt * kOnceWave;
 }
 
-static int g_attn_bwd_once = 1;      // ezclip_debug_set(10, v): 1 (default) the score-tile-once kernel where it applies, 0 the two-pass kernel
+// ezclip_debug_set(10, v): 1 (default) the score-tile-once kernel where it is the faster one -- up to 128 tokens (BERT's and the packed
+// text tower's lengths: 0.221 vs 0.239 ms at 64 tokens, 0.423 vs 0.445 at 128, B = 1024 x 12 heads, same box; at 197 tokens it
+// measures 1.10-1.14 against 1.03-1.10 ms and at 256 tokens 0.67 against 0.63: its LDS traffic per tile pair is 44 KB against the
+// two-pass kernel's 36 KB -- the dQ read-modify-write and the dS^T round trip cost more than the second S / dP pass they replace --
+// and its waves move in lockstep, one barrier per step; profiles/r4_attention_bwd_once_ab.log), 2 wherever it is eligible (tests,
+// A/B), 0 never.
+static int g_attn_bwd_once = 1;
 void set_attention_bwd_once(int v) { g_attn_bwd_once = v; }
 
 int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
   const int nt = (a.f.L + 31) / 32, ra = (a.f.L + 7) / 8 * 8;
-  const bool once = g_attn_bwd_once && nt <= 8 && bwd_once_lds_bytes(a.f.L) <= 160 * 1024;
+  const bool once = g_attn_bwd_once != 0 && nt <= (g_attn_bwd_once == 2 ? 8 : 4) && bwd_once_lds_bytes(a.f.L) <= 160 * 1024;
   const int bytes = once ? bwd_once_lds_bytes(a.f.L) : bwd_short_lds_bytes(a.f.L);
   static LdsOptIn lds_opt[16];
   const int vi = (a.f.key_bias != nullptr ? 1 : 0) + (a.f.causal ? 2 : 0) + (a.f.drop.thr != 0 ? 4 : 0);

@@ -34,7 +34,7 @@ for name, B, Lq, H, masked in (("vit-b/16", 1024, 197, 12, False), ("bert 64", 1
     scratch = torch.empty(B * 3 * D, dtype=torch.float32, device="cuda")
     for rep in range(3):
         for v in (1, 0):
-            L.check(lib.ezclip_debug_set(10, v))
+            L.check(lib.ezclip_debug_set(10, 2 if v else 0))
             dqkv = torch.zeros_like(qkv)
             db = torch.zeros(3 * D, device="cuda")
             for _ in range(3):

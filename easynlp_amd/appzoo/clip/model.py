@@ -1241,10 +1241,14 @@ class CLIPApp(Application):
         if feat is True:
             return {"image_embeds": image_embeds, "text_embeds": text_embeds}
         if self.contrastive_scope == "global" and self.training:
-            # the [n, N] logits stay inside the fused kernel's workspace: the dict carries the loss instead
+            # the [n, N] logits of the global batch stay inside the fused kernel's workspace: the dict carries the loss.  What a caller
+            # can still LOG is this rank's own [n, n] block -- the tensor the reference returns under DDP (model.py:148) -- detached:
+            # the gradient flows through `loss` (round 4; rounds 2-3 returned None here, which broke callers that read the logits)
             eng = self._engine
             loss = _GlobalInfoNCEFn.apply(lambda *a: fused_infonce_shard(eng, *a), None, text_embeds, image_embeds, self.logit_scale)
-            return {"loss": loss, "logits_per_text": None, "logits_per_image": None,
+            with torch.no_grad():
+                local_logits = _SimilarityFn.apply(text_embeds.detach(), image_embeds.detach(), self.logit_scale.detach())
+            return {"loss": loss, "logits_per_text": local_logits, "logits_per_image": local_logits.T,
                     "image_embeds": image_embeds, "text_embeds": text_embeds}
         logits_per_text = _SimilarityFn.apply(text_embeds, image_embeds, self.logit_scale)
         logits_per_image = logits_per_text.T

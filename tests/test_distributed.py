@@ -151,6 +151,10 @@ def _ddp_worker(rank, world, port, ckpt, q):
                     O.encode_text(sd, self.raw_config, input_ids) if input_ids is not None else None)
         CM.CLIPApp.encode = oracle_encode
         CM.fused_infonce_shard = lambda eng, *a: _oracle_shard(*a)
+
+        class OracleSimilarity:          # (the rank's own [n, n] logits the global-scope forward hands out for logging, detached)
+            apply = staticmethod(lambda txt, img, ls: (txt @ img.t()) * ls.exp())
+        CM._SimilarityFn = OracleSimilarity
         cfg = O.CONFIGS["tiny"]
         n = 3
         px, ids = O.make_inputs(cfg, world * n, 16, 21)

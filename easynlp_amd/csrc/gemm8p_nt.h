@@ -131,8 +131,8 @@ __device__ __forceinline__ void phase(const Ctx& c, FR& f, ACC& acc, uint32_t kb
     constexpr int slot = ((k8 + 6) & 7) * kSlot;
     const uint32_t dst = c.lds_base + slot + c.dma_dst;
     if constexpr (P == 0) {
-      dma16(dst, c.voffB[0], c.srdB, kbyte_next1 + c.hiB);
-      dma16(dst + 1024, c.voffB[1], c.srdB, kbyte_next1 + c.hiB);
+      dma16<1>(dst, c.voffB[0], c.srdB, kbyte_next1 + c.hiB);
+      dma16<1>(dst + 1024, c.voffB[1], c.srdB, kbyte_next1 + c.hiB);
     } else if constexpr (P == 1) {
       dma16(dst, c.voffA[0], c.srdA, kbyte_next1 + c.hiA);
       dma16(dst + 1024, c.voffA[1], c.srdA, kbyte_next1 + c.hiA);
@@ -140,8 +140,8 @@ __device__ __forceinline__ void phase(const Ctx& c, FR& f, ACC& acc, uint32_t kb
       dma16(dst, c.voffA[0], c.srdA, kbyte_next2);
       dma16(dst + 1024, c.voffA[1], c.srdA, kbyte_next2);
     } else {
-      dma16(dst, c.voffB[0], c.srdB, kbyte_next2);
-      dma16(dst + 1024, c.voffB[1], c.srdB, kbyte_next2);
+      dma16<1>(dst, c.voffB[0], c.srdB, kbyte_next2);
+      dma16<1>(dst + 1024, c.voffB[1], c.srdB, kbyte_next2);
     }
   }
   if constexpr (VMR != VM) {   // first K-tile of a tile: the previous tile's stores may still be queued (see ktile)
@@ -303,16 +303,16 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
     const uint32_t d = c.lds_base + c.dma_dst;
     dma16(d + 0 * kSlot, c.voffA[0], c.srdA, 0);
     dma16(d + 0 * kSlot + 1024, c.voffA[1], c.srdA, 0);
-    dma16(d + 1 * kSlot, c.voffB[0], c.srdB, 0);
-    dma16(d + 1 * kSlot + 1024, c.voffB[1], c.srdB, 0);
-    dma16(d + 2 * kSlot, c.voffB[0], c.srdB, c.hiB);
-    dma16(d + 2 * kSlot + 1024, c.voffB[1], c.srdB, c.hiB);
+    dma16<1>(d + 1 * kSlot, c.voffB[0], c.srdB, 0);
+    dma16<1>(d + 1 * kSlot + 1024, c.voffB[1], c.srdB, 0);
+    dma16<1>(d + 2 * kSlot, c.voffB[0], c.srdB, c.hiB);
+    dma16<1>(d + 2 * kSlot + 1024, c.voffB[1], c.srdB, c.hiB);
     dma16(d + 3 * kSlot, c.voffA[0], c.srdA, c.hiA);
     dma16(d + 3 * kSlot + 1024, c.voffA[1], c.srdA, c.hiA);
     dma16(d + 4 * kSlot, c.voffA[0], c.srdA, 128);
     dma16(d + 4 * kSlot + 1024, c.voffA[1], c.srdA, 128);
-    dma16(d + 5 * kSlot, c.voffB[0], c.srdB, 128);
-    dma16(d + 5 * kSlot + 1024, c.voffB[1], c.srdB, 128);
+    dma16<1>(d + 5 * kSlot, c.voffB[0], c.srdB, 128);
+    dma16<1>(d + 5 * kSlot + 1024, c.voffB[1], c.srdB, 128);
   };
 
 #ifdef EZ_DEPHASE

@@ -33,18 +33,39 @@ __device__ __forceinline__ bool ez_store_role() { return __builtin_amdgcn_readfi
 #define EZ_ROLES 0
 #endif
 
+// Cache-policy bits of the LDS-DMA loads, per operand (experiment hooks of tools/build_variants.py: -DEZ_DMA_A_MOD='" nt"' etc.; default none).
+#ifndef EZ_DMA_A_MOD
+#define EZ_DMA_A_MOD ""
+#endif
+#ifndef EZ_DMA_B_MOD
+#define EZ_DMA_B_MOD ""
+#endif
+template <int OPERAND>   // 0: A (activations: streamed once per column tile), 1: B (weights: re-read by every row tile)
 __device__ __forceinline__ void dma16_one(uint32_t lds_dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
   uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %1\n\t"
-      "s_nop 0\n\t"
-      "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff)
-      : "memory");
+  if constexpr (OPERAND == 0) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen" EZ_DMA_A_MOD " lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff)
+        : "memory");
+  } else {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen" EZ_DMA_B_MOD " lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff)
+        : "memory");
+  }
 }
+template <int OPERAND = 0>
 __device__ __forceinline__ void dma16(uint32_t lds_dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
 #ifdef EZ_ABL_NODMA         // timing ablation (results wrong by construction): no global -> LDS traffic at all; the counted waits see an empty queue
   asm volatile("" ::"s"(lds_dst), "v"(voff), "s"(soff));
@@ -55,10 +76,10 @@ __device__ __forceinline__ void dma16(uint32_t lds_dst, uint32_t voff, const i32
 #endif
 #if EZ_ROLES
   if (!ez_dma_role()) return;
-  dma16_one(lds_dst, voff, srd, soff);
-  dma16_one(lds_dst + 8192u, voff, srd, soff);     // the partner wave's region of the half-tile image
+  dma16_one<OPERAND>(lds_dst, voff, srd, soff);
+  dma16_one<OPERAND>(lds_dst + 8192u, voff, srd, soff);     // the partner wave's region of the half-tile image
 #else
-  dma16_one(lds_dst, voff, srd, soff);
+  dma16_one<OPERAND>(lds_dst, voff, srd, soff);
 #endif
 }
 

@@ -505,7 +505,7 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": (traffic or {}).get("bytes_per_launch"),
                     "traffic_detail": traffic,
-                    "kernel": ("ezclip::gemm_nt_8p_kernel / gemm_tn_8p_kernel (bf16, 256x256x64 8-phase)"
+                    "kernel": ("ezclip::gemm_nt_8p_kernel / gemm_tn_8p_kernel (bf16, 256x256x64 8-phase, v_mfma_f32_16x16x32_bf16)"
                                if wl["dtype"] == "bf16" else "ezclip::gemm_nt_kernel<fp32> (128x128, exact-f32 MFMA)"),
                     "launches_per_step": n // nprof, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
                     "algorithmic_gflop_per_launch": round(flops / max(n, 1) / 1e9, 3)}

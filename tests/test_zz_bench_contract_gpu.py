@@ -40,8 +40,8 @@ def _oracle_loss(batch):
 
 
 def test_bench_prints_one_contract_line():
-    out = _run("--also", "bf16_b1024_train,bf16_b1024_fwd_loss_autograd,bf16_b1024_train_autograd,bf16_b1024_train_opt",
-               "--also-steps", "1")
+    out = _run("--also", "bf16_b1024_train,bf16_b1024_fwd_loss_autograd,bf16_b1024_train_autograd,bf16_b1024_train_opt,"
+               "bf16_b1024_fwd_loss_padded_text", "--also-steps", "1", "--sustained-steps", "50")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "also", "loss"):
         assert k in out, k
@@ -65,6 +65,13 @@ def test_bench_prints_one_contract_line():
         # (the AdamW workload has already moved the weights by the time its timed step reports a loss)
         assert abs(a["loss"] - ref) < (5e-2 if name.endswith("_opt") else 5e-3), (name, a["loss"], ref)
     assert out["also"]["bf16_b1024_train_autograd"]["path"] == "autograd"
+    # the `sustained` block (round 4): the same step for N more steps, with the clock / power the chip ran at -- in the headline and
+    # in the padded-text workload
+    for blk in (out["sustained"], out["also"]["bf16_b1024_fwd_loss_padded_text"]["sustained"]):
+        assert blk["steps"] == 50 and blk["ms_per_step"] > 0 and blk["ms_per_step_second_half"] > 0 and blk["value_second_half"] > 0
+        assert 0 < blk["model_mfma_frac_second_half"] < 1
+        tel = blk["telemetry"]
+        assert tel["source"] and (tel["samples"] == 0 or (100 < tel["shader_clock_mhz_mean"] < 3000 and 50 < tel["socket_power_w_mean"] < 2000))
 
 
 def test_bench_self_launches_under_torch_distributed_run():

@@ -427,20 +427,32 @@ def test_config5_batch_of_512_pairs_size_independent_properties(flavour):
     torch.cuda.empty_cache()
 
 
-def test_directional_derivatives_at_1024_pairs_fp32():
-    """Gradient check at the headline size, float32 pipeline (the bf16 pipeline is tied to it at 64 / 256 pairs above): for six
-    parameters spread over both towers and the heads, the directional derivative <dL/dp, d> of ONE fused training step over 1 024 pairs
+_DD_CASES = {
+    # the headline towers at the headline batch
+    "vitb16_b1024": (VITB16, 1024, ["text_projection", "visual.proj", "visual.transformer.resblocks.5.mlp.c_fc.weight", "visual.positional_embedding",
+                                   "bert.encoder.layer.6.attention.self.query.weight", "bert.encoder.layer.11.output.dense.weight", "logit_scale"]),
+    # BASELINE config 5's towers at full depth (24 ViT-L/14 blocks, 257 tokens; round 4): 256 pairs -- the float32
+    # pipeline keeps 16 M D floats per block for the backward pass, 104 GB at this size (207 GB at 512 pairs)
+    "vitl14_b256": (dict(O.CONFIGS["vitl14_robertabase"]), 256,
+                    ["visual.proj", "visual.transformer.resblocks.12.mlp.c_fc.weight", "visual.transformer.resblocks.23.attn.in_proj_weight",
+                     "visual.conv1.weight", "bert.encoder.layer.6.attention.self.query.weight", "text_projection"]),
+}
+
+
+@pytest.mark.parametrize("case", ["vitb16_b1024", "vitl14_b256"])
+def test_directional_derivatives_at_1024_pairs_fp32(case):
+    """Gradient check at the benchmark's sizes, float32 pipeline (the bf16 pipeline is tied to it at 64 / 256 pairs above): for
+    parameters spread over both towers and the heads, the directional derivative <dL/dp, d> of ONE fused training step
     (autograd of core/trainer.py:658-661 through the kernels' backward) against the central difference (L(p + h d) - L(p - h d)) / 2h of
     two forward steps.  A size-independent property: no oracle run of this size is needed, and every kernel of the backward pass sees
-    the row counts of the benchmark (201 728 ViT rows, weight-gradient contractions over all of them)."""
+    the row counts of the benchmark (201 728 ViT rows at 1 024 pairs of ViT-B/16; 65 792 rows x 24 blocks of ViT-L/14)."""
     from easynlp_amd.appzoo.clip import CLIPApp
-    B, S = 1024, 64
+    cfg, B, names = _DD_CASES[case]
+    S = 64
     px, ids = _synth(B, S, seed=1000)
-    app = CLIPApp.from_config(VITB16, seed=1234, device=DEV, compute_dtype="fp32")
-    app.train()                                   # (dropout probabilities are 0 in VITB16)
+    app = CLIPApp.from_config(cfg, seed=1234, device=DEV, compute_dtype="fp32")
+    app.train()                                   # (dropout probabilities are 0 in these configs)
     loss0, grads = _train_step(app, px, ids)
-    names = ["text_projection", "visual.proj", "visual.transformer.resblocks.5.mlp.c_fc.weight", "visual.positional_embedding",
-             "bert.encoder.layer.6.attention.self.query.weight", "bert.encoder.layer.11.output.dense.weight", "logit_scale"]
     g = torch.Generator(device=DEV).manual_seed(77)
     report = []
     for n in names:

@@ -75,7 +75,7 @@ __device__ __forceinline__ void swap_halves(float v, float& x0, float& x1) {
 // where that third workgroup becomes resident (nt = 5..7, plain instantiation), it overlaps one head's loads with two others' math
 // instead of one (tools/attn_ab.py 11; ezclip_debug_set(11, 0) launches one wave per query block as before).
 template <bool HAS_KB, bool CAUSAL, bool DROP, bool TWO = false>
-__global__ __launch_bounds__(TWO ? 256 : 576, TWO ? 3 : 1) void attn_fwd_short_kernel(AttnArgs a, int nt, int ra) {
+__global__ __launch_bounds__(TWO ? 320 : 576, TWO ? 3 : 1) void attn_fwd_short_kernel(AttnArgs a, int nt, int ra) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int head = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x;
@@ -372,10 +372,17 @@ int attention_fwd_short(const AttnArgs& a_in, hipStream_t stream) {
   const int nt = (a.L + 31) / 32, ra = (a.L + 7) / 8 * 8;
   const int kbi = (a.key_bias != nullptr ? 1 : 0) + (a.causal ? 2 : 0) + (a.drop.thr != 0 ? 4 : 0);
   const int bytes = 2 * ra * 128 + (32 * nt - ra) * 128 + (kbi & 1 ? nt * 32 * 4 : 0);
-  // waves: one per query block, or -- when the images of THREE workgroups fit the CU's LDS only then worth it (five to seven query
-  // blocks: a fourth workgroup would not fit anyway) -- one per two blocks: 12 waves of three heads instead of 14 of two on a CU
+  // waves: one per query block, or one per TWO blocks where that makes one more workgroup resident on a CU -- 197 tokens: 7-wave
+  // workgroups are two per CU by waves (16 at 124 registers) although three fit by LDS; 4-wave workgroups are three (12 waves at 166
+  // registers).  257 tokens (ViT-L/14): 9-wave workgroups are ONE per CU by waves, 5-wave workgroups two.
   int waves = nt;
-  if (g_attn_fwd_three && kbi == 0 && nt >= 5 && nt <= 8 && 3 * (bytes + 512) <= 160 * 1024) waves = (nt + 1) / 2;
+  if (g_attn_fwd_three && kbi == 0 && nt >= 3) {
+    const int by_lds = (160 * 1024) / (bytes + 512);
+    const int res1 = by_lds < 16 / nt ? by_lds : 16 / nt;
+    const int w2 = (nt + 1) / 2;
+    const int res2 = by_lds < 12 / w2 ? by_lds : 12 / w2;
+    if (res2 > res1) waves = w2;
+  }
   static LdsOptIn lds_opt[8];
   EZ_REQUIRE(a.drop.thr == 0 || a.keep_bits == nullptr || a.keep_words == nt, "attention_fwd_short: keep_words must be ceil(L / 32)");
   using K = void (*)(AttnArgs, int, int);

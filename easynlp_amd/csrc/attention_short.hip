@@ -69,13 +69,8 @@ __device__ __forceinline__ void swap_halves(float v, float& x0, float& x1) {
 // tile in four consecutive registers = the four words of ONE Philox call (colquad = 8 t + 2 qd + h): four calls per tile and
 // lane.  The row sum l runs over the undropped exponentials, the P V product over the kept ones scaled by 1 / (1 - p); the
 // keep bits of the tile (32 keys, both half-waves) are written out for the backward kernel (AttnArgs::keep_bits).
-// Round 4: (1) the images hold `ra` = round_up(longest L, 8) rows, not 32 nt (the last tile's rows beyond `ra` fall on the V image's first
-// rows -- finite -- for K and on a zeroed pad for V: always multiplied by an exact 0): 51.2 + 3 KB instead of 57.3 KB at 197 tokens, so
-// that THREE workgroups fit a CU's 160 KB; (2) a wave walks the query blocks wave, wave + nwaves, ...: launched with ceil(nt / 2) waves
-// where that third workgroup becomes resident (nt = 5..7, plain instantiation), it overlaps one head's loads with two others' math
-// instead of one (tools/attn_ab.py 11; ezclip_debug_set(11, 0) launches one wave per query block as before).
-template <bool HAS_KB, bool CAUSAL, bool DROP, bool TWO = false>
-__global__ __launch_bounds__(TWO ? 320 : 576, TWO ? 3 : 1) void attn_fwd_short_kernel(AttnArgs a, int nt, int ra) {
+template <bool HAS_KB, bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int head = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x;
@@ -89,41 +84,34 @@ __global__ __launch_bounds__(TWO ? 320 : 576, TWO ? 3 : 1) void attn_fwd_short_k
   const int keep_words = nt;      // (of the launch)
   nt = (L + 31) >> 5;
   char* kimg = smem;
-  char* vimg = smem + ra * 128;
-  char* vpad = smem + 2 * ra * 128;
-  const int padb = (LKP - ra) * 128;
-  float* kb = reinterpret_cast<float*>(vpad + padb);
-  for (int i = tid * 16; i < padb; i += (int)blockDim.x * 16) *reinterpret_cast<uint4*>(vpad + i) = make_uint4(0u, 0u, 0u, 0u);
+  char* vimg = smem + LKP * 128;
+  float* kb = reinterpret_cast<float*>(smem + 2 * LKP * 128);
   const int64_t rs = a.row_stride * 2;
   const int64_t base = (row0 * a.row_stride + head * 64) * 2;
   constexpr float kLog2e = 1.4426950408889634f;
 
   const int nwaves = (int)(blockDim.x >> 6);
-  const int nload = 32 * nt < ra ? 32 * nt : ra;
-  dma_rows<0>(kimg, reinterpret_cast<const char*>(a.k) + base, rs, nload, L, wave, nwaves, lane);
-  dma_rows<1>(vimg, reinterpret_cast<const char*>(a.v) + base, rs, nload, L, wave, nwaves, lane);
+  dma_rows<0>(kimg, reinterpret_cast<const char*>(a.k) + base, rs, 32 * nt, L, wave, nwaves, lane);
+  dma_rows<1>(vimg, reinterpret_cast<const char*>(a.v) + base, rs, 32 * nt, L, wave, nwaves, lane);
   if constexpr (HAS_KB) {      // key bias in base-2 units; keys >= L: -inf
     for (int key = tid; key < 32 * nt; key += (int)blockDim.x)
       kb[key] = key < L ? a.key_bias[row0 + key] * kLog2e : -INFINITY;
   }
 
-  // this wave's query blocks: wave, wave + nwaves (at most two: the launcher starts ceil(nt / 2) waves or nt); their Q fragments are
-  // requested up front, under the images' DMA
-  constexpr int NB = TWO ? 2 : 1;      // (TWO: the instantiation launched with ceil(nt / 2) waves; otherwise one block per wave as before)
-  uint4 qfa[NB][4];
+  // this wave's 32 queries
+  const int qb = wave;
+  const bool active = qb * 32 < L;
+  const int q = qb * 32 + l31;
+  const int qc = q < L ? q : L - 1;
+  uint4 qf[4];
+  if (active) {
+    const char* qp = reinterpret_cast<const char*>(a.q) + base + (int64_t)qc * rs;
 #pragma unroll
-  for (int it = 0; it < NB; ++it) {
-    const int qb_ = wave + it * nwaves;
-    if (qb_ * 32 < L) {
-      const int q_ = qb_ * 32 + l31;
-      const char* qp = reinterpret_cast<const char*>(a.q) + base + (int64_t)(q_ < L ? q_ : L - 1) * rs;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) qfa[it][s] = *reinterpret_cast<const uint4*>(qp + (2 * s + h) * 16);
-    }
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(qp + (2 * s + h) * 16);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (wave * 32 >= L) return;
+  if (!active) return;
 
   // per-lane LDS offsets
   const int sw = (l31 >> 1) & 7;
@@ -135,14 +123,6 @@ __global__ __launch_bounds__(TWO ? 320 : 576, TWO ? 3 : 1) void attn_fwd_short_k
   const uint32_t voff0 = (uint32_t)(4 * h + (t16 >> 2)) * 128u + (vsw << 6) + (uint32_t)sub * 32u + (uint32_t)(t16 & 3) * 8u;
   const uint32_t voff1 = voff0 ^ 64u;     // d tile 1
 
-#pragma unroll 1
-  for (int it = 0; it < NB; ++it) {
-  const int qb = wave + it * nwaves;
-  if (qb * 32 >= L) break;
-  const int q = qb * 32 + l31;
-  uint4 qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = (TWO && it == 1) ? qfa[NB - 1][s] : qfa[0][s];
   f32x16_t o[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -349,7 +329,6 @@ __global__ __launch_bounds__(TWO ? 320 : 576, TWO ? 3 : 1) void attn_fwd_short_k
     // log-sum-exp of the scaled scores (natural log), as the backward kernels expect it
     if (a.lse != nullptr && h == 0) a.lse[((int64_t)b * a.H + head) * a.L + q] = m * 0.6931471805599453f + logf(l);
   }
-  }   // query blocks of this wave
 }
 
 
@@ -362,41 +341,25 @@ bool attention_short_fwd_eligible(const AttnArgs& a, int dtype) {   // forward: 
 static int g_attn_short_tail = 3;      // ezclip_debug_set(9, v): bit 0 short last tile, bit 1 row sums on the matrix pipe (A/B)
 void set_attention_short_tail(int v) { g_attn_short_tail = v & 3; }
 
-static int g_attn_fwd_three = 1;      // ezclip_debug_set(11, v): 1 (default) half as many waves where a third workgroup then fits a CU, 0 one wave per query block
-void set_attention_fwd_three(int v) { g_attn_fwd_three = v; }
-
 int attention_fwd_short(const AttnArgs& a_in, hipStream_t stream) {
   AttnArgs a = a_in;
   a.short_tail = g_attn_short_tail & 1;
   a.mfma_rowsum = (g_attn_short_tail >> 1) & 1;
-  const int nt = (a.L + 31) / 32, ra = (a.L + 7) / 8 * 8;
-  const int kbi = (a.key_bias != nullptr ? 1 : 0) + (a.causal ? 2 : 0) + (a.drop.thr != 0 ? 4 : 0);
-  const int bytes = 2 * ra * 128 + (32 * nt - ra) * 128 + (kbi & 1 ? nt * 32 * 4 : 0);
-  // waves: one per query block, or one per TWO blocks where that makes one more workgroup resident on a CU -- 197 tokens: 7-wave
-  // workgroups are two per CU by waves (16 at 124 registers) although three fit by LDS; 4-wave workgroups are three (12 waves at 166
-  // registers).  257 tokens (ViT-L/14): 9-wave workgroups are ONE per CU by waves, 5-wave workgroups two.
-  int waves = nt;
-  if (g_attn_fwd_three && kbi == 0 && nt >= 3) {
-    const int by_lds = (160 * 1024) / (bytes + 512);
-    const int res1 = by_lds < 16 / nt ? by_lds : 16 / nt;
-    const int w2 = (nt + 1) / 2;
-    const int res2 = by_lds < 12 / w2 ? by_lds : 12 / w2;
-    if (res2 > res1) waves = w2;
-  }
+  const int nt = (a.L + 31) / 32;
+  const int bytes = nt * (2 * 32 * 128 + 32 * 4);
   static LdsOptIn lds_opt[8];
+  const int kbi = (a.key_bias != nullptr ? 1 : 0) + (a.causal ? 2 : 0) + (a.drop.thr != 0 ? 4 : 0);
   EZ_REQUIRE(a.drop.thr == 0 || a.keep_bits == nullptr || a.keep_words == nt, "attention_fwd_short: keep_words must be ceil(L / 32)");
-  using K = void (*)(AttnArgs, int, int);
+  using K = void (*)(AttnArgs, int);
   static const K kerns[8] = {&attn_fwd_short_kernel<false, false, false>, &attn_fwd_short_kernel<true, false, false>,
                              &attn_fwd_short_kernel<false, true, false>,  &attn_fwd_short_kernel<true, true, false>,
                              &attn_fwd_short_kernel<false, false, true>,  &attn_fwd_short_kernel<true, false, true>,
                              &attn_fwd_short_kernel<false, true, true>,   &attn_fwd_short_kernel<true, true, true>};
-  const bool two = waves != nt;
-  const K kern = two ? &attn_fwd_short_kernel<false, false, false, true> : kerns[kbi];
-  static LdsOptIn lds_opt_two;
-  EZ_ENSURE_LDS(kern, two ? lds_opt_two : lds_opt[kbi], bytes);
+  const K kern = kerns[kbi];
+  EZ_ENSURE_LDS(kern, lds_opt[kbi], bytes);
   {
     ProfScope ps(PROF_ATTN, 4.0 * a.B * a.H * (double)a.L * a.L * 64, stream);   // QK^T + PV, unpadded
-    hipLaunchKernelGGL(kern, dim3(a.H, a.B), dim3(64 * waves), bytes, stream, a, nt, ra);
+    hipLaunchKernelGGL(kern, dim3(a.H, a.B), dim3(64 * nt), bytes, stream, a, nt);
   }
   EZ_LAUNCH_CHECK();
   return EZ_OK;

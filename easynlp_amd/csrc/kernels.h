@@ -111,7 +111,6 @@ bool attention_short_fwd_eligible(const AttnArgs& a, int dtype);
 int attention_fwd_short(const AttnArgs& a, hipStream_t stream);
 void set_attention_variant(int v);   // -1 auto, 0: attention.hip kernels only
 void set_attention_short_tail(int on);
-void set_attention_fwd_three(int on);  // 1 (default): short forward with ceil(nt / 2) waves where three workgroups then fit a CU
 void set_attention_bwd_once(int mode);  // fused backward: 1 (default) score-tile-once up to 128 tokens, 2 wherever eligible (<= 256), 0 two-pass only
 void set_rn_buffer_bound_mib(int mib);   // ModifiedResNet tower: bound of one activation buffer (resnet.hip)
 

@@ -381,8 +381,7 @@ int ezclip_recall_ranks_rows(const float* text_rows_dev, const float* image_dev,
  * key 8: the CLS-only last ViT block projects its queries for the CLS rows only (1, default);  key 9: short attention forward:
  * bit 0 short last tile, bit 1 row sums on the matrix pipe (3, default);  key 10: fused attention backward for sequences up to
  * 256 tokens: 1 (default) the score-tile-once kernel (round 4) up to 128 tokens -- where it measures faster -- and the two-pass
- * kernel of rounds 2-3 beyond, 2 the score-tile-once kernel wherever it is eligible (<= 256 tokens), 0 the two-pass kernel only;
- * key 11: short attention forward with one wave per TWO query blocks where three workgroups then fit a CU (1, default), 0 one wave per block. */
+ * kernel of rounds 2-3 beyond, 2 the score-tile-once kernel wherever it is eligible (<= 256 tokens), 0 the two-pass kernel only. */
 int ezclip_debug_set(int key, int value);
 int ezclip_profile_begin(void);
 int ezclip_profile_end(int kernel_class, double* total_ms, double* total_work, int* launches);

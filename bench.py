@@ -652,7 +652,7 @@ def main():
     if os.environ.get("EZCLIP_CLS_Q_ONLY"):     # A/B switch: 0 = the CLS-only last ViT block projects its queries for every token
         L.check(L.load().ezclip_debug_set(8, int(os.environ["EZCLIP_CLS_Q_ONLY"])))
     if os.environ.get("EZCLIP_ATTN_BWD_ONCE"):  # A/B switch: 0 = the two-pass fused attention backward only, 2 = score-tile-once wherever eligible
-        L.check(L.load().ezclip_debug_set(10, int(os.environ["EZCLIP_ATTN_BWD_ONCE"])))
+        L.check(L.load().ezclip_debug_set(11, int(os.environ["EZCLIP_ATTN_BWD_ONCE"])))
     if os.environ.get("EZCLIP_FUSE_QKV"):       # A/B switch: 0 = BERT q / k / v as three products
         L.check(L.load().ezclip_debug_set(7, int(os.environ["EZCLIP_FUSE_QKV"])))
 

@@ -844,7 +844,7 @@ static int bwd_once_lds_bytes(int L) {
   return 2 * ra * 128 + 2 * (32 * nt - ra) * 128 + 2 * ra * 128 + nt * (3 * 32 * 4) + nt * kOnceWave;
 }
 
-// ezclip_debug_set(10, v): 1 (default) the score-tile-once kernel where it is the faster one -- up to 128 tokens (BERT's and the packed
+// ezclip_debug_set(11, v): 1 (default) the score-tile-once kernel where it is the faster one -- up to 128 tokens (BERT's and the packed
 // text tower's lengths: 0.222 vs 0.248 ms at 64 tokens, 0.422 vs 0.457 at 128, B = 1024 x 12 heads, same box; at 197 tokens it
 // measures 1.11-1.15 against 1.03-1.12 ms and at 256 tokens 0.69 against 0.65: its LDS traffic per tile pair is 44 KB against the
 // two-pass kernel's 36 KB -- the dQ read-modify-write and the dS^T round trip cost more than the second S / dP pass they replace --

@@ -475,8 +475,8 @@ int ezclip_debug_set(int key, int value) {
   if (key == 7) { set_fuse_bert_qkv(value); return EZ_OK; }
   if (key == 8) { set_cls_q_only(value); return EZ_OK; }
   if (key == 9) { set_attention_short_tail(value); return EZ_OK; }
-  if (key == 10) { set_attention_bwd_once(value); return EZ_OK; }
   if (key == 10) { set_rn_buffer_bound_mib(value); return EZ_OK; }
+  if (key == 11) { set_attention_bwd_once(value); return EZ_OK; }
   set_error("ezclip_debug_set: unknown key %d", key);
   return EZ_ERR_INVALID;
 }

@@ -379,7 +379,8 @@ int ezclip_recall_ranks_rows(const float* text_rows_dev, const float* image_dev,
  * GEMM (0 column-fastest, g > 0 super-rows of g row tiles walked column by column, -1 the built-in default);  key 7: BERT
  * query / key / value projections as one N = 3 * hidden product on the bf16 path (1, default) or three products (0);
  * key 8: the CLS-only last ViT block projects its queries for the CLS rows only (1, default);  key 9: short attention forward:
- * bit 0 short last tile, bit 1 row sums on the matrix pipe (3, default);  key 10: fused attention backward for sequences up to
+ * bit 0 short last tile, bit 1 row sums on the matrix pipe (3, default);  key 10: ModifiedResNet tower: bound of one activation
+ * buffer in MiB (256; tests lower it to walk a small batch in chunks);  key 11: fused attention backward for sequences up to
  * 256 tokens: 1 (default) the score-tile-once kernel (round 4) up to 128 tokens -- where it measures faster -- and the two-pass
  * kernel of rounds 2-3 beyond, 2 the score-tile-once kernel wherever it is eligible (<= 256 tokens), 0 the two-pass kernel only. */
 int ezclip_debug_set(int key, int value);

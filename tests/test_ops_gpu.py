@@ -750,7 +750,7 @@ def test_contrastive_loss_one_direction(rows, cols):
 def test_attention_bwd_score_tile_once_against_two_pass_and_fp64(B_, Lq, H, masked):
     """The fused backward of round 4 (a wave owns a key block, dS goes through a wave-private LDS tile for the dQ product, dQ is
     summed over the waves in an LDS float image in a fixed, barrier-ordered rotation) against the two-pass kernel it replaces
-    (ezclip_debug_set(10, 0)) and the float64 reference: dq / dk / dv and the three projection-bias gradients; two runs give the
+    (ezclip_debug_set(11, 0)) and the float64 reference: dq / dk / dv and the three projection-bias gradients; two runs give the
     same bits (the rotation fixes the summation order)."""
     lib = L.load()
     g = torch.Generator().manual_seed(B_ * 1000 + Lq * 3 + H)
@@ -779,7 +779,7 @@ def test_attention_bwd_score_tile_once_against_two_pass_and_fp64(B_, Lq, H, mask
     outs = {}
     try:
         for variant in (2, 0, 2):
-            L.check(lib.ezclip_debug_set(10, variant))
+            L.check(lib.ezclip_debug_set(11, variant))
             dqkv = torch.zeros_like(qg)
             db = torch.zeros(3 * D, device=DEV)
             dbase, bb = dqkv.data_ptr(), db.data_ptr()
@@ -792,7 +792,7 @@ def test_attention_bwd_score_tile_once_against_two_pass_and_fp64(B_, Lq, H, mask
                 assert torch.equal(outs[2][0], dqkv) and torch.equal(outs[2][1], db), "not bit-reproducible"
             outs[variant] = (dqkv, db)
     finally:
-        L.check(lib.ezclip_debug_set(10, 1))
+        L.check(lib.ezclip_debug_set(11, 1))
     scale = float(qd.grad.abs().max())
     for variant in (2, 0):
         got = outs[variant][0].float().cpu()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Same-box A/B of the fused attention backward: the score-tile-once kernel of round 4 (ezclip_debug_set(10, 1), default) against the
-two-pass kernel of rounds 2-3 (ezclip_debug_set(10, 0)) -- op-level timing on the towers' shapes (with the q / k / v bias gradients, as
+"""Same-box A/B of the fused attention backward: the score-tile-once kernel of round 4 (ezclip_debug_set(11, 1), default) against the
+two-pass kernel of rounds 2-3 (ezclip_debug_set(11, 0)) -- op-level timing on the towers' shapes (with the q / k / v bias gradients, as
 the towers call it), interleaved rounds, and the difference of the outputs (summation order of dQ differs: not bit for bit)."""
 import os
 import sys
@@ -34,7 +34,7 @@ for name, B, Lq, H, masked in (("vit-b/16", 1024, 197, 12, False), ("bert 64", 1
     scratch = torch.empty(B * 3 * D, dtype=torch.float32, device="cuda")
     for rep in range(3):
         for v in (1, 0):
-            L.check(lib.ezclip_debug_set(10, 2 if v else 0))
+            L.check(lib.ezclip_debug_set(11, 2 if v else 0))
             dqkv = torch.zeros_like(qkv)
             db = torch.zeros(3 * D, device="cuda")
             for _ in range(3):
@@ -51,7 +51,7 @@ for name, B, Lq, H, masked in (("vit-b/16", 1024, 197, 12, False), ("bert 64", 1
             run(dqkv, db, scratch)
             torch.cuda.synchronize()
             outs[v] = (dqkv.float().clone(), db.clone())
-    L.check(lib.ezclip_debug_set(10, 1))
+    L.check(lib.ezclip_debug_set(11, 1))
     d = float((outs[0][0] - outs[1][0]).abs().max())
     s = float(outs[0][0].abs().max())
     dbd = float((outs[0][1] - outs[1][1]).abs().max())

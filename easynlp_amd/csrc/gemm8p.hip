@@ -105,23 +105,23 @@ __device__ __forceinline__ void phase_tn(const CtxTN& c, FR& f, ACC& acc, uint32
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int v = 0; v < 2; ++v) f.bl[v][s] = read_tr(c.smem + sB + c.rdB + v * 32 + s * 8192);
+        for (int v = 0; v < 2; ++v) f.bl[v][s] = read_tr(c.smem + sB + (c.rdB ^ (uint32_t)(v << 5)) + s * 8192);
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) f.a[u][s] = read_tr(c.smem + sA + c.rdA[u >> 1] + (u & 1) * 32 + s * 8192);
+        for (int u = 0; u < 4; ++u) f.a[u][s] = read_tr(c.smem + sA + (c.rdA[0] ^ (uint32_t)(u << 5)) + s * 8192);
     } else if constexpr (P == 1) {
       constexpr int sB = ((k8 + 1) & 7) * kSlot;
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int v = 0; v < 2; ++v) f.bh[v][s] = read_tr(c.smem + sB + c.rdB + v * 32 + s * 8192);
+        for (int v = 0; v < 2; ++v) f.bh[v][s] = read_tr(c.smem + sB + (c.rdB ^ (uint32_t)(v << 5)) + s * 8192);
     } else if constexpr (P == 2) {
       constexpr int sA = ((k8 + 1) & 7) * kSlot;
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) f.a[u][s] = read_tr(c.smem + sA + c.rdA[u >> 1] + (u & 1) * 32 + s * 8192);
+        for (int u = 0; u < 4; ++u) f.a[u][s] = read_tr(c.smem + sA + (c.rdA[0] ^ (uint32_t)(u << 5)) + s * 8192);
     }
   } else {
   if constexpr (P == 0) {
@@ -243,19 +243,29 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_tn_8p_kernel(GemmTNArgs p, 
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (wave * 2 + i) * 4 + (lane >> 4);                 // image row (m within the K-tile)
+#if EZ_MI16
+    // 16x16x32 fragments: a 32-lane pass of the transpose read covers rows 8 q + {0..3} for TWO k-quarters q at one 32-byte column
+    // block -- eight rows that must land on eight different 32-byte slots of the 256-byte bank row: the slot index is XORed with
+    // f(m) = (m & 3) | ((m >> 3) & 1) << 2  (the 64-byte-granule swizzle of the 32x32x16 layout left rows m and m + 8 on the same banks:
+    // two-way conflicts on every fragment read, 22-87 M conflict cycles per launch in profiles/r4_gemm_pmc.md before this)
+    const uint32_t ch = (uint32_t)((lane & 15) ^ ((((r & 3) | (((r >> 3) & 1) << 2))) << 1)) << 4;
+#else
     const uint32_t ch = (uint32_t)((lane & 15) ^ ((r & 3) << 2)) << 4;   // logical 16-byte chunk of the 256-byte row
+#endif
     c.voffA[i] = (m_begin + (uint32_t)r) * lda_b + (uint32_t)p0 * 2u + ch;
     c.voffB[i] = (m_begin + (uint32_t)r) * ldb_b + (uint32_t)q0 * 2u + ch;
   }
 #if EZ_MI16
   {
     const int t = lane & 15, q4 = lane >> 4;
-    const int row = 8 * q4 + (t >> 2);                               // + 32*s + 4*kk via immediates
-    const uint32_t swz = (uint32_t)(t >> 2) << 6;
+    const int row = 8 * q4 + (t >> 2);                               // + 32*s + 4*kk via immediates (neither touches bits 0, 1, 3 of m)
+    const uint32_t swz = (uint32_t)((t >> 2) | ((q4 & 1) << 2)) << 5;    // f(m) << 5: the 32-byte slot swizzle of the DMA above
     const uint32_t colA = (uint32_t)(wm * 64 + (t & 3) * 4) * 2u, colB = (uint32_t)(wn * 32 + (t & 3) * 4) * 2u;
-    c.rdA[0] = (uint32_t)row * 256u + (colA ^ swz);                  // 16-column blocks u = 0, 1 (+ 32 bytes)
-    c.rdA[1] = (uint32_t)row * 256u + ((colA + 64u) ^ swz);          // u = 2, 3
-    c.rdB = (uint32_t)row * 256u + (colB ^ swz);                     // v = 0, 1 (+ 32 bytes)
+    // 16-column block u (v) of the half is 32 u bytes along the row: bits 5-6 (5), which the swizzle also moves -- xor, not add:
+    // address(u) = rdA ^ (u << 5), a compile-time constant per fragment (one v_xor in a loop whose vector ALU is idle)
+    c.rdA[0] = (uint32_t)row * 256u + (colA ^ swz);
+    c.rdA[1] = 0;
+    c.rdB = (uint32_t)row * 256u + (colB ^ swz);
     (void)h;
   }
   Acc16 acc;

@@ -3,9 +3,12 @@
 
 Same contract: ``evaluate(model) -> [("mean_recall", float)]`` with text->image
 R@1/5/10 over the whole validation set.  The per-row Python loop with a full
-``torch.sort`` (evaluator.py:53-61) is replaced by one HIP call that builds the
-similarity matrix on the f32 MFMA GEMM and counts, per query, how many images
-score above the paired one (``ezclip_recall_ranks``): hit@k  <=>  rank < k.
+``torch.sort`` (evaluator.py:53-61) is replaced by a fused HIP sweep: the f32
+MFMA kernel that computes a similarity tile compares it, in registers, with the
+paired scores and counts, per query, how many images score above the paired one
+(``ezclip_recall_ranks_fused``): hit@k  <=>  rank < k.  No similarity block is
+materialised, and the image->text ranks come out of the same sweep on request
+(``both_directions=True``; the reference reports text->image only).
 """
 from __future__ import annotations
 
@@ -33,16 +36,22 @@ class Evaluator(object):
 
 
 def recall_ranks(text_embeds: torch.Tensor, image_embeds: torch.Tensor, block_rows: int = 4096, group=None,
-                 shard: bool = False) -> torch.Tensor:
-    """rank[i] = #{j : <t_i, v_j> > <t_i, v_i>} (+ ties with j < i) on the GPU, ``block_rows`` queries at a time: the only
-    scratch is one [block_rows, n] similarity block (never n x n).  ``shard=True`` under an initialised process group:
-    every rank holds the same embeddings (the reference evaluator runs the whole validation set on each rank,
-    core/evaluator.py:20-27), ranks split the query blocks and exchange the integer ranks with one all-gather."""
+                 shard: bool = False, both_directions: bool = False, materialise: bool = False):
+    """rank[i] = #{j : <t_i, v_j> > <t_i, v_i>} (+ ties with j < i) on the GPU, ``block_rows`` queries at a time, compared inside the
+    similarity kernel (``ezclip_recall_paired_scores`` + ``ezclip_recall_ranks_fused``: no scratch at all).
+    ``both_directions=True`` returns ``(text->image ranks, image->text ranks)``; the latter count, for image j, the texts i with
+    <t_i, v_j> > <t_j, v_j> (+ ties with i < j).  ``materialise=True`` keeps the older two-kernel form (a [block_rows, n] similarity
+    block in scratch, ``ezclip_recall_ranks_rows``; text->image only) -- the cross-check of the tests.
+    ``shard=True`` under an initialised process group: every rank holds the same embeddings (the reference evaluator runs the
+    whole validation set on each rank, core/evaluator.py:20-27), ranks split the query blocks, exchange the text->image ranks with
+    one all-gather and sum the image->text counts with one all-reduce."""
     import torch.distributed as dist
     lib = L.load()
     t = text_embeds.detach().float().contiguous()
     v = image_embeds.detach().float().contiguous()
     n, e = t.shape
+    if materialise and both_directions:
+        raise ValueError("recall_ranks: the materialising form computes text->image ranks only")
     world, me = 1, 0
     if shard and dist.is_available() and dist.is_initialized():
         world, me = dist.get_world_size(group), dist.get_rank(group)
@@ -50,15 +59,26 @@ def recall_ranks(text_embeds: torch.Tensor, image_embeds: torch.Tensor, block_ro
     lo, hi = min(n, me * per), min(n, (me + 1) * per)
     rank = torch.zeros(per * world if world > 1 else n, dtype=torch.int32, device=t.device)
     rows_max = max(1, min(int(block_rows), hi - lo)) if hi > lo else 1
-    scratch = torch.empty(rows_max * n, dtype=torch.float32, device=t.device)
+    cols = torch.zeros(n, dtype=torch.int32, device=t.device) if both_directions else None
+    if materialise:
+        scratch = torch.empty(rows_max * n, dtype=torch.float32, device=t.device)
+    else:
+        paired = torch.empty(n, dtype=torch.float32, device=t.device)
+        L.check(lib.ezclip_recall_paired_scores(L.ptr(t), L.ptr(v), n, e, L.ptr(paired), L.stream_ptr()), "recall_paired_scores")
     for r0 in range(lo, hi, rows_max):
         rows = min(rows_max, hi - r0)
         out = rank[(me * per if world > 1 else 0) + (r0 - lo):]
-        L.check(lib.ezclip_recall_ranks_rows(L.ptr(t[r0:r0 + rows]), L.ptr(v), rows, r0, n, e, out.data_ptr(), L.ptr(scratch),
-                                             L.stream_ptr()), "recall_ranks_rows")
+        if materialise:
+            L.check(lib.ezclip_recall_ranks_rows(L.ptr(t[r0:r0 + rows]), L.ptr(v), rows, r0, n, e, out.data_ptr(), L.ptr(scratch),
+                                                 L.stream_ptr()), "recall_ranks_rows")
+        else:
+            L.check(lib.ezclip_recall_ranks_fused(L.ptr(t[r0:r0 + rows]), L.ptr(v), rows, r0, n, e, L.ptr(paired), out.data_ptr(),
+                                                  cols.data_ptr() if cols is not None else None, L.stream_ptr()), "recall_ranks_fused")
     if world > 1:
         rank = gather_rank_shards(rank, me, per, n, group)
-    return rank
+        if cols is not None:
+            dist.all_reduce(cols, group=group)
+    return (rank, cols) if both_directions else rank
 
 
 def gather_rank_shards(rank: torch.Tensor, me: int, per: int, n: int, group=None) -> torch.Tensor:
@@ -72,23 +92,39 @@ def gather_rank_shards(rank: torch.Tensor, me: int, per: int, n: int, group=None
     return gathered[:n]
 
 
-def recall_at_k(text_embeds, image_embeds, ks=(1, 5, 10)):
-    rank = recall_ranks(text_embeds, image_embeds)
+def _recall_from_ranks(rank, ks):
     n = rank.numel()
     stats = [int((rank < k).sum().item()) for k in ks]
     rs = [s * 1.0 / n for s in stats]
     return (sum(rs) / len(rs),) + tuple(rs), stats
 
 
-def recall_report(text_embeds, gallery_embeds, spent_seconds: float):
+def recall_at_k(text_embeds, image_embeds, ks=(1, 5, 10), both_directions: bool = False):
+    """((mean_recall, r@k...), hit counts) of text->image retrieval; with ``both_directions`` a pair of those: (text->image, image->text)"""
+    if not both_directions:
+        return _recall_from_ranks(recall_ranks(text_embeds, image_embeds), ks)
+    t2i, i2t = recall_ranks(text_embeds, image_embeds, both_directions=True)
+    return _recall_from_ranks(t2i, ks), _recall_from_ranks(i2t, ks)
+
+
+def recall_report(text_embeds, gallery_embeds, spent_seconds: float, both_directions: bool = False):
     """text -> gallery R@1/5/10 + mean, printed the way the reference evaluators do (clip/evaluator.py:62-72), returned as the
-    metric list the Trainer compares (``[("mean_recall", fraction)]``)"""
+    metric list the Trainer compares (``[("mean_recall", fraction)]``: text -> gallery, as in the reference).  ``both_directions`` adds
+    one line for gallery -> text (same sweep of the similarity kernel) and an ``("i2t_mean_recall", fraction)`` entry AFTER the first."""
     n = text_embeds.shape[0]
-    (mean_recall, r1, r5, r10), hits = recall_at_k(text_embeds, gallery_embeds)
+    extra = []
+    if both_directions:
+        ((mean_recall, r1, r5, r10), hits), ((m2, q1, q5, q10), hits2) = recall_at_k(text_embeds, gallery_embeds, both_directions=True)
+    else:
+        (mean_recall, r1, r5, r10), hits = recall_at_k(text_embeds, gallery_embeds)
     print(" ".join("r%d_num:%d" % (k, h) for k, h in zip((1, 5, 10), hits)), "query_num:" + str(n))
     print(" ".join("%s(%%):%s" % (name, v * 100) for name, v in (("r1", r1), ("r5", r5), ("r10", r10), ("mean_recall", mean_recall))))
+    if both_directions:
+        print("image->text", " ".join("r%d_num:%d" % (k, h) for k, h in zip((1, 5, 10), hits2)),
+              " ".join("%s(%%):%s" % (name, v * 100) for name, v in (("r1", q1), ("r5", q5), ("r10", q10), ("mean_recall", m2))))
+        extra = [("i2t_mean_recall", m2)]
     print("Inference time = {:.2f}s, [{:.4f} ms / sample] ".format(spent_seconds, spent_seconds * 1000 / max(n, 1)))
-    return [("mean_recall", mean_recall)]
+    return [("mean_recall", mean_recall)] + extra
 
 
 class CLIPEvaluator(Evaluator):
@@ -97,6 +133,7 @@ class CLIPEvaluator(Evaluator):
         super().__init__(valid_dataset, **kwargs)
         self.metrics = ["accuracy", "f1"]
         self.before = 0.0
+        self.both_directions = bool(kwargs.get("both_directions", False))      # (not in the reference: it reports text -> image only)
 
     def evaluate(self, model):
         model.eval()
@@ -115,4 +152,4 @@ class CLIPEvaluator(Evaluator):
             text_embeds_all.append(outputs["text_embeds"])
         image_embeds_tensor = torch.cat(image_embeds_all, dim=0)
         text_embeds_tensor = torch.cat(text_embeds_all, dim=0)
-        return recall_report(text_embeds_tensor, image_embeds_tensor, total_spent_time)
+        return recall_report(text_embeds_tensor, image_embeds_tensor, total_spent_time, both_directions=self.both_directions)

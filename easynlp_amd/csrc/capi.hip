@@ -464,6 +464,25 @@ int ezclip_recall_ranks_rows(const float* text_rows, const float* image, int row
   return recall_ranks(scratch, rows, n, row0, rank_out, S(stream));
 }
 
+int ezclip_recall_paired_scores(const float* text, const float* image, int n, int e, float* paired, void* stream) {
+  EZ_REQUIRE(text && image && paired && n > 0 && e > 0, "ezclip_recall_paired_scores: null/empty argument");
+  GemmRankArgs g;
+  g.A = text; g.lda = e; g.B = image; g.ldb = e; g.M = n; g.N = n; g.K = e;
+  g.rank_mode = 1; g.rank_row0 = 0; g.rank_diag_out = paired;
+  return gemm_nt_rank(g, S(stream));
+}
+
+int ezclip_recall_ranks_fused(const float* text_rows, const float* image, int rows, int row0, int n, int e, const float* paired,
+                              int32_t* rank_t2i, int32_t* rank_i2t, void* stream) {
+  EZ_REQUIRE(text_rows && image && paired && rank_t2i && rows > 0 && row0 >= 0 && row0 + rows <= n,
+             "ezclip_recall_ranks_fused: bad block rows=%d row0=%d n=%d", rows, row0, n);
+  EZ_HIP(hipMemsetAsync(rank_t2i, 0, (size_t)rows * sizeof(int32_t), S(stream)));
+  GemmRankArgs g;
+  g.A = text_rows; g.lda = e; g.B = image; g.ldb = e; g.M = rows; g.N = n; g.K = e;
+  g.rank_mode = 2; g.rank_row0 = row0; g.rank_diag = paired; g.rank_rows = rank_t2i; g.rank_cols = rank_i2t;
+  return gemm_nt_rank(g, S(stream));
+}
+
 int ezclip_debug_set(int key, int value) {
   if (key == 0) { set_gemm_variant(value); return EZ_OK; }
   if (key == 1) { set_attention_variant(value); return EZ_OK; }

@@ -114,8 +114,9 @@ struct ConvRows {
   }
 };
 
-template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool CONV = false>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void gemm_nt_kernel(GemmArgs p) {
+// RANK (f32 only): 0 = the GEMM; 1 / 2 = GemmArgs::rank_mode (paired scores / rank counts instead of storing C)
+template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool CONV = false, int RANK = 0>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void gemm_nt_kernel(std::conditional_t<RANK != 0, GemmRankArgs, GemmArgs> p) {
   using SH = Shape<WM, WN, TI, TJ>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BK = 128 / (int)sizeof(T);
@@ -126,6 +127,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
   const int t = xcd_remap(blockIdx.x, nwg);
   const int m0 = (t / tiles_n) * SH::kBM;
   const int n0 = (t % tiles_n) * SH::kBN;
+  if constexpr (RANK == 1) {       // columns n0 .. n0 + kBN - 1 against paired columns rank_row0 + m0 .. + kBM - 1
+    if (n0 + SH::kBN <= p.rank_row0 + m0 || n0 >= p.rank_row0 + m0 + SH::kBM) return;
+  }
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, l31 = lane & 31;
 
@@ -232,6 +236,69 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
   // MI16: 2 TI x 2 TJ blocks of 16 x 16, lane = row l15, columns 4 (lane >> 4) .. + 3 (one quad per block);
   // otherwise TI x TJ blocks of 32 x 32, lane = row l31, columns 8 q + 4 h .. + 3 for q = 0..3
   constexpr int NI = MI16 ? 2 * TI : TI, NJ = MI16 ? 2 * TJ : TJ, NQ = MI16 ? 1 : 4, RB = MI16 ? 16 : 32;
+  if constexpr (RANK != 0) {
+    static_assert(RANK == 0 || (!MI16 && std::is_same<T, float>::value), "rank epilogues: f32 only");
+    // Lane = row l31 of every 32-row block i; its columns are n0 + wn*TJ*32 + j*32 + q*8 + h*4 + e.  The values compared are the
+    // ones ezclip_similarity would have stored (same kernel, same accumulation order); counts are integers, so the atomics that
+    // combine waves and workgroups are order-independent.
+    int colc[TJ][4][4];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) colc[j][q][e] = 0;
+    static_for<TI>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int m = m0 + wm * TI * 32 + i * 32 + l31;
+      const bool mok = m < p.M;
+      const int ig = p.rank_row0 + m;                       // this query's index in the whole set = its paired column
+      float d = 0.f;
+      if constexpr (RANK == 2) d = mok ? p.rank_diag[ig] : 0.f;
+      int cr = 0;
+      static_for<TJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = n0 + wn * TJ * 32 + j * 32 + q * 8 + h * 4 + e;
+            const float v = acc[i][j][q * 4 + e] * scale;
+            if (!mok || n >= p.N) continue;
+            if constexpr (RANK == 1) {
+              if (n == ig) p.rank_diag_out[ig] = v;
+            } else {
+              cr += (v > d || (v == d && n < ig)) ? 1 : 0;
+              if (p.rank_cols != nullptr) {
+                const float dc = p.rank_diag[n];
+                colc[j][q][e] += (v > dc || (v == dc && ig < n)) ? 1 : 0;
+              }
+            }
+          }
+      });
+      if constexpr (RANK == 2) {
+        cr += __shfl_xor(cr, 32, 64);                       // the two half-waves hold the two column halves of a row
+        if (h == 0 && mok && cr != 0) atomicAdd(p.rank_rows + m, cr);
+      }
+    });
+    if constexpr (RANK == 2) {
+      if (p.rank_cols != nullptr) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              int c = colc[j][q][e];                        // sum over the 32 rows (lanes l31) of the wave's row blocks
+              c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64);
+              c += __shfl_xor(c, 8, 64); c += __shfl_xor(c, 16, 64);
+              const int n = n0 + wn * TJ * 32 + j * 32 + q * 8 + h * 4 + e;
+              if (l31 == 0 && n < p.N && c != 0) atomicAdd(p.rank_cols + n, c);
+            }
+      }
+    }
+    return;
+  }
   static_for<NI>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     const int m = m0 + wm * TI * 32 + i * RB + (MI16 ? (lane & 15) : l31);
@@ -293,15 +360,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
   });
 }
 
-template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool CONV = false>
-int launch_nt_shape(const GemmArgs& p, hipStream_t stream) {
+template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool CONV = false, int RANK = 0>
+int launch_nt_shape(const std::conditional_t<RANK != 0, GemmRankArgs, GemmArgs>& p, hipStream_t stream) {
   using SH = Shape<WM, WN, TI, TJ>;
   const int tiles = ((p.M + SH::kBM - 1) / SH::kBM) * ((p.N + SH::kBN - 1) / SH::kBN);
   static LdsOptIn lds_opt;
-  EZ_ENSURE_LDS((&gemm_nt_kernel<T, TO, WM, WN, TI, TJ, CONV>), lds_opt, SH::kLds);
+  EZ_ENSURE_LDS((&gemm_nt_kernel<T, TO, WM, WN, TI, TJ, CONV, RANK>), lds_opt, SH::kLds);
   {
     ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, TI, TJ, CONV>), dim3(tiles), dim3(SH::kThreadsS), SH::kLds, stream, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, TI, TJ, CONV, RANK>), dim3(tiles), dim3(SH::kThreadsS), SH::kLds, stream, p);
   }
   EZ_LAUNCH_CHECK();
   return EZ_OK;
@@ -350,6 +417,18 @@ bool gemm_nt_uses_8p(const GemmArgs& p, int dtype) {
   // are launch-bound; those stay on the 8-phase kernel so that small batches run the code large ones do.)
   const int64_t tiles = (int64_t)((p.M + 255) >> 8) * (p.N >> 8);
   return tiles >= 16 || p.M < 512;
+}
+
+int gemm_nt_rank(GemmRankArgs p, hipStream_t stream) {
+  EZ_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && (p.K * 4) % 128 == 0 && (p.lda * 4) % 16 == 0 && (p.ldb * 4) % 16 == 0 &&
+                 ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0,
+             "gemm_nt_rank: bad operands (M %d N %d K %d: K must be a multiple of 32, rows 16-byte aligned)", p.M, p.N, p.K);
+  EZ_REQUIRE(p.conv_H == 0 && !p.colsum && !p.rowstat_part && !p.ln_stats && !p.bias && !p.R && !p.U && !p.scale_log &&
+                 p.act == ACT_NONE && p.rank_row0 >= 0 && p.rank_row0 + p.M <= p.N &&
+                 ((p.rank_mode == 1 && p.rank_diag_out) || (p.rank_mode == 2 && p.rank_diag && p.rank_rows)),
+             "gemm_nt_rank: bad fused-rank problem (mode %d, row0 %d, M %d, N %d)", p.rank_mode, p.rank_row0, p.M, p.N);
+  return p.rank_mode == 1 ? launch_nt_shape<float, float, 2, 2, 2, 2, false, 1>(p, stream)
+                          : launch_nt_shape<float, float, 2, 2, 2, 2, false, 2>(p, stream);
 }
 
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream) {

@@ -149,7 +149,7 @@ __device__ __forceinline__ void phase_tn(const CtxTN& c, FR& f, ACC& acc, uint32
   // soff1 / soff2: byte offset of the first row of K-tile t+1 / t+2 (per operand: A uses .x, B .y -- see caller)
   if constexpr (ISSUE) {
     constexpr int slot = ((k8 + 6) & 7) * kSlot;
-    const uint32_t dst = c.lds_base + slot + c.dma_dst;
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(c.lds_base + slot + c.dma_dst));   // (wave-uniform by construction; the allocator otherwise parks it in a VGPR here)
     if constexpr (P == 0) {          // B-hi(t+1)
       dma16(dst, c.voffB[0], c.srdB, soff1 + 256);
       dma16(dst + 1024, c.voffB[1], c.srdB, soff1 + 256);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_tn_8p_kernel(GemmTNArgs p, 
 
   const uint32_t stepA = 64u * lda_b, stepB = 64u * ldb_b;           // one K-tile further down
   {
-    const uint32_t d = c.lds_base + c.dma_dst;
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)(c.lds_base + c.dma_dst));
     dma16(d + 0 * kSlot, c.voffA[0], c.srdA, 0);
     dma16(d + 0 * kSlot + 1024, c.voffA[1], c.srdA, 0);
     dma16(d + 1 * kSlot, c.voffB[0], c.srdB, 0);

@@ -43,7 +43,6 @@ __device__ __forceinline__ bool ez_store_role() { return __builtin_amdgcn_readfi
 template <int OPERAND>   // 0: A (activations: streamed once per column tile), 1: B (weights: re-read by every row tile)
 __device__ __forceinline__ void dma16_one(uint32_t lds_dst, uint32_t voff, const i32x4_t& srd, uint32_t soff) {
   uint32_t keep;
-  lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);   // wave-uniform by construction; folds away when the compiler already knows
   if constexpr (OPERAND == 0) {
     asm volatile(
         "s_mov_b32 %0, m0\n\t"

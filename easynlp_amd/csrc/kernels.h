@@ -50,6 +50,21 @@ struct GemmArgs {
   int vec_ok = 0;                             // (set by the launcher)
   int raster_gm = 0;                          // (set by the 8-phase launcher) tile order: 0 n-fastest; g > 0: super-rows of g row tiles, m-fastest inside
 };
+// Fused retrieval ranks (f32, 128x128 kernel; CLIPEvaluator's sort loop, appzoo/clip/evaluator.py:47-67): the similarity tile is
+// compared in registers, nothing is written to C.  Query row m of this call is query i = rank_row0 + m of the whole set, its paired
+// gallery item is column i.  (A struct of its own: GemmArgs is the by-value kernel argument of the 8-phase kernels, whose register
+// allocation sits at the limit -- two of their instantiations spilled when these fields lived there.)
+//   rank_mode 1: rank_diag_out[i] = S[m][i]                        (workgroups whose tile misses the diagonal exit at once)
+//   rank_mode 2: rank_rows[m] += #{n : S[m][n] > d_i or (S[m][n] == d_i and n < i)},  d = rank_diag      (text -> image)
+//                rank_cols[n] += #{m : S[m][n] > d_n or (S[m][n] == d_n and i < n)}   (optional: image -> text, summed over calls)
+struct GemmRankArgs : GemmArgs {
+  int rank_mode = 0, rank_row0 = 0;
+  const float* rank_diag = nullptr;
+  float* rank_diag_out = nullptr;
+  int32_t* rank_rows = nullptr;
+  int32_t* rank_cols = nullptr;
+};
+int gemm_nt_rank(GemmRankArgs p, hipStream_t stream);
 // C = act(alpha * exp(scale) * A.B^T + bias) + R
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream);
 // 256x256x64 8-phase bf16 kernel (gemm8p.hip): large M, N % 256 == 0, K % 128 == 0, bf16 output

@@ -118,6 +118,8 @@ SIGNATURES = {
     "ezclip_backward_text": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ezclip_recall_ranks": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ezclip_recall_ranks_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ezclip_recall_paired_scores": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "ezclip_recall_ranks_fused": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ezclip_debug_set": (_i, [_i, _i]),
     "ezclip_profile_begin": (_i, []),
     "ezclip_profile_end": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),

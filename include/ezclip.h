@@ -364,6 +364,21 @@ int ezclip_recall_ranks(const float* text_dev, const float* image_dev, int n, in
 int ezclip_recall_ranks_rows(const float* text_rows_dev, const float* image_dev, int rows, int row0, int n, int e,
                              int32_t* rank_out_dev, float* scratch_dev, void* stream);
 
+/* Fused form: the similarity tile is compared in the registers of the f32 MFMA kernel that computes it --
+ * no similarity block is written or read back, and both retrieval directions come out of one sweep.  Two steps:
+ *   ezclip_recall_paired_scores   paired_dev[i] = <text i, image i> for all n pairs, by the tiles on the diagonal only
+ *                                 (the values are the ones the sweep recomputes: same kernel, same accumulation order);
+ *   ezclip_recall_ranks_fused     queries row0 .. row0 + rows - 1 against all n images:
+ *        rank_t2i_dev[r]   = #{j : s(i, j) > s(i, i) or (== and j < i)},  i = row0 + r      (overwritten; CLIPEvaluator's sort loop,
+ *                                                                          reference appzoo/clip/evaluator.py:53-61)
+ *        rank_i2t_dev[j]  += #{i in the block : s(i, j) > s(j, j) or (== and i < j)}         (optional, may be NULL: image -> text;
+ *                            int32 [n], ZEROED BY THE CALLER, complete after every block of queries has been swept -- by one
+ *                            process, or summed over the ranks that shared the blocks)
+ * text_rows_dev: [rows, e] f32; image_dev: [n, e] f32; paired_dev: [n] f32.  e * 4 must be a multiple of 128 bytes. */
+int ezclip_recall_paired_scores(const float* text_dev, const float* image_dev, int n, int e, float* paired_dev, void* stream);
+int ezclip_recall_ranks_fused(const float* text_rows_dev, const float* image_dev, int rows, int row0, int n, int e,
+                              const float* paired_dev, int32_t* rank_t2i_dev, int32_t* rank_i2t_dev, void* stream);
+
 /* ---- measurement hooks ---------------------------------------------------------------- */
 /* Between begin and end every launch of the hot kernels is bracketed by HIP events on its
  * own stream.  kernel_class: 0 = MFMA GEMM (work = algorithmic FLOPs), 1 = fused attention

@@ -473,6 +473,24 @@ def recall_at_k(text_embeds, image_embeds, ks=(1, 5, 10)):
     return (sum(rs) / len(rs),) + tuple(rs)
 
 
+def recall_ranks(text_embeds, image_embeds):
+    """Ranks behind ``recall_at_k``, both retrieval directions, as int64 tensors:
+    ``t2i[i]`` = position of image i in the descending STABLE sort of row i of ``text @ image.T`` (the reference's loop,
+    easynlp/appzoo/clip/evaluator.py:53-61, sorts unstably: equal scores may fall either way there; the stable order -- ties
+    resolved by index -- is the one the HIP path defines), ``i2t[j]`` = position of text j in the stable sort of column j
+    (image -> text: not in the reference)."""
+    agreement = text_embeds @ image_embeds.t()
+    n = agreement.shape[0]
+    t2i = torch.empty(n, dtype=torch.int64)
+    i2t = torch.empty(n, dtype=torch.int64)
+    for idx in range(n):
+        order = torch.sort(agreement[idx], descending=True, stable=True).indices
+        t2i[idx] = int((order == idx).nonzero()[0, 0])
+        order = torch.sort(agreement[:, idx], descending=True, stable=True).indices
+        i2t[idx] = int((order == idx).nonzero()[0, 0])
+    return t2i, i2t
+
+
 def to_dtype(sd, dtype):
     return {k: v.to(dtype) for k, v in sd.items()}
 

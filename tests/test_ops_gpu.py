@@ -256,6 +256,44 @@ def test_recall_ranks_in_row_blocks_equal_the_sort_loop():
     assert torch.equal(one.cpu().long(), want)
     for block in (1, 7, 64, 200, 516):
         assert torch.equal(recall_ranks(td, vd, block_rows=block), full), block
+        assert torch.equal(recall_ranks(td, vd, block_rows=block, materialise=True), full), block
+
+
+@pytest.mark.parametrize("n,e", [(517, 64), (128, 512), (1000, 512), (2500, 128)])
+def test_fused_recall_ranks_both_directions(n, e):
+    """ezclip_recall_paired_scores + ezclip_recall_ranks_fused: the similarity tile is compared in the registers of
+    the kernel that computes it.  Text -> image ranks equal the materialising form's bit for bit (same kernel, same scores) and the
+    oracle's stable sort; the image -> text ranks of the same sweep equal the oracle's column sort; exact ties (duplicated gallery
+    rows AND duplicated queries) fall by index in both directions; any split into query blocks gives the same counts."""
+    from easynlp_amd.appzoo.clip.evaluator import recall_ranks, recall_at_k
+    g = torch.Generator().manual_seed(n + e)
+    t = torch.nn.functional.normalize(torch.randn(n, e, generator=g), dim=-1)
+    v = torch.nn.functional.normalize(t + 0.8 * torch.randn(n, e, generator=g), dim=-1)
+    v[5] = v[100]; v[101] = v[100]; t[7] = t[90]; t[91] = t[90]
+    td, vd = t.to(DEV), v.to(DEV)
+    t2i, i2t = recall_ranks(td, vd, both_directions=True)
+    assert torch.equal(t2i, recall_ranks(td, vd, materialise=True))
+    assert torch.equal(t2i, recall_ranks(td, vd))
+    # oracle on the GPU's own f32 similarity (ezclip_similarity: the scores the ranks are defined on); the f64 -> f32 CPU product
+    # differs from it in the last bit here and there, which moves ranks only where two different scores are that close
+    ls = torch.zeros((), device=DEV)
+    sim = L.similarity(td, vd, ls).cpu()
+    idx = torch.arange(n)
+    d = sim.diagonal()
+    want_r = ((sim > d[:, None]) | ((sim == d[:, None]) & (idx[None, :] < idx[:, None]))).sum(1)
+    want_c = ((sim > d[None, :]) | ((sim == d[None, :]) & (idx[:, None] < idx[None, :]))).sum(0)
+    assert torch.equal(t2i.cpu().long(), want_r)
+    assert torch.equal(i2t.cpu().long(), want_c)
+    if n <= 600:
+        o_r, o_c = O.recall_ranks(t.double(), v.double())
+        assert (t2i.cpu().long() != o_r).sum() <= 2 and (i2t.cpu().long() != o_c).sum() <= 2
+        for i in (5, 100, 101, 7, 90, 91):                     # the constructed ties: exact in f32 and f64 alike
+            assert int(t2i[i]) == int(o_r[i]) and int(i2t[i]) == int(o_c[i]), i
+    for block in (1, 100, 129, n - 1):
+        a, b = recall_ranks(td, vd, block_rows=block, both_directions=True)
+        assert torch.equal(a, t2i) and torch.equal(b, i2t), block
+    (fwd, _), (bwd, _) = recall_at_k(td, vd, both_directions=True)
+    assert abs(fwd[1] - float((want_r < 1).sum()) / n) < 1e-12 and abs(bwd[3] - float((want_c < 10).sum()) / n) < 1e-12
 
 
 @pytest.mark.parametrize("n,N,off,e", [(4, 12, 4, 64), (8, 8, 0, 128), (32, 128, 64, 512), (100, 300, 200, 64),

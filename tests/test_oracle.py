@@ -110,6 +110,24 @@ def test_oracle_recall_matches_bruteforce():
     assert abs(mean - (r1 + r5 + r10) / 3) < 1e-12
 
 
+def test_oracle_recall_ranks_both_directions_against_counting():
+    """stable-sort position == number of strictly larger scores + equal scores at a smaller index, for rows (text -> image) and
+    columns (image -> text); duplicated gallery / query rows make the ties real"""
+    g = torch.Generator().manual_seed(6)
+    t = torch.nn.functional.normalize(torch.randn(37, 16, generator=g), dim=-1)
+    v = torch.nn.functional.normalize(t + 0.7 * torch.randn(37, 16, generator=g), dim=-1)
+    v[3] = v[20]; v[21] = v[20]; t[8] = t[30]
+    t2i, i2t = O.recall_ranks(t, v)
+    sim = t @ v.t()
+    idx = torch.arange(37)
+    d = sim.diagonal()
+    want_r = ((sim > d[:, None]) | ((sim == d[:, None]) & (idx[None, :] < idx[:, None]))).sum(1)
+    want_c = ((sim > d[None, :]) | ((sim == d[None, :]) & (idx[:, None] < idx[None, :]))).sum(0)
+    assert torch.equal(t2i, want_r) and torch.equal(i2t, want_c)
+    mean, r1, r5, r10 = O.recall_at_k(t, v)
+    assert abs(r1 - float((t2i < 1).sum()) / 37) < 1e-12 and abs(r10 - float((t2i < 10).sum()) / 37) < 1e-12
+
+
 def test_global_loss_shards_sum_to_full_loss():
     g = torch.Generator().manual_seed(1)
     t = torch.nn.functional.normalize(torch.randn(12, 8, generator=g), dim=-1)

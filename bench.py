@@ -10,7 +10,7 @@ started under an external launcher (WORLD_SIZE set) it uses that one.
 A "step" = one pass of the hot path over one synthetic batch that is already resident in HBM: encode_image +
 encode_text (+ RCCL all-gather of both embedding sets when N > 1) + similarity (both directions) + InfoNCE.  Rank 0
 prints ONE JSON line.  The headline (`value`) is the default workload; the same line carries every other BASELINE.json
-configuration this box can run under `also` (a few steps each):
+configuration this box can run under `also` (three warm-up + eight timed steps each):
 
   bf16_b1024_fwd_loss        (default, headline) ViT-B/16 + BERT-base, bf16 MFMA, 1024 pairs/GPU, 64 tokens; the text tower
                              runs on the unmasked tokens only (same embeddings: masked keys carry -10000, only x[:, 0] is read)
@@ -595,7 +595,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="only the headline workload (no `also` object)")
     ap.add_argument("--also", default="", help="comma-separated workloads for the `also` object (default: every BASELINE config)")
-    ap.add_argument("--also-steps", type=int, default=5)
+    ap.add_argument("--also-steps", type=int, default=8)
+    ap.add_argument("--also-warmup", type=int, default=3,
+                    help="untimed steps of every `also` workload (the autograd path's second gradient arena and the allocator's growth are "
+                         "paid in its first THREE steps: with two warm-up steps and five timed ones it read 4 %% slow, "
+                         "profiles/r4_train_vs_autograd_trace.log)")
     ap.add_argument("--launcher", action="store_true", help="self-launch under torch.distributed.run even for --gpus 1")
     ap.add_argument("--sustained-steps", type=int, default=300,
                     help="steps of the `sustained` leg of the headline and padded-text workloads (0: off; also capped at 20 s each)")
@@ -667,7 +671,7 @@ def main():
             if n == args.workload:
                 continue
             try:
-                r = run_workload(n, c, args.also_steps, 2, args.batch, args.text_dropout,
+                r = run_workload(n, c, args.also_steps, args.also_warmup, args.batch, args.text_dropout,
                                  sustained_steps=sus if n == "bf16_b1024_fwd_loss_padded_text" else 0)
             except Exception as e:          # one configuration failing (e.g. out of memory) must not lose the headline
                 torch.cuda.empty_cache()

@@ -35,6 +35,22 @@ class Evaluator(object):
         raise NotImplementedError
 
 
+def _paired_scores(t: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """paired[i] = <t_i, v_i> by the diagonal tiles of the f32 similarity kernel (``ezclip_recall_paired_scores``)"""
+    n, e = t.shape
+    paired = torch.empty(n, dtype=torch.float32, device=t.device)
+    L.check(L.load().ezclip_recall_paired_scores(L.ptr(t), L.ptr(v), n, e, L.ptr(paired), L.stream_ptr()), "recall_paired_scores")
+    return paired
+
+
+def _ranks_block(t_rows: torch.Tensor, v: torch.Tensor, row0: int, paired: torch.Tensor, out: torch.Tensor, cols) -> None:
+    """one sweep of queries row0 .. row0 + rows - 1 over the gallery (``ezclip_recall_ranks_fused``): ``out[:rows]`` = their
+    text -> image ranks, ``cols`` (int32 [n] or None) += the block's image -> text counts"""
+    rows, e = t_rows.shape
+    L.check(L.load().ezclip_recall_ranks_fused(L.ptr(t_rows), L.ptr(v), rows, row0, v.shape[0], e, L.ptr(paired), out.data_ptr(),
+                                               cols.data_ptr() if cols is not None else None, L.stream_ptr()), "recall_ranks_fused")
+
+
 def recall_ranks(text_embeds: torch.Tensor, image_embeds: torch.Tensor, block_rows: int = 4096, group=None,
                  shard: bool = False, both_directions: bool = False, materialise: bool = False):
     """rank[i] = #{j : <t_i, v_j> > <t_i, v_i>} (+ ties with j < i) on the GPU, ``block_rows`` queries at a time, compared inside the
@@ -46,7 +62,6 @@ def recall_ranks(text_embeds: torch.Tensor, image_embeds: torch.Tensor, block_ro
     whole validation set on each rank, core/evaluator.py:20-27), ranks split the query blocks, exchange the text->image ranks with
     one all-gather and sum the image->text counts with one all-reduce."""
     import torch.distributed as dist
-    lib = L.load()
     t = text_embeds.detach().float().contiguous()
     v = image_embeds.detach().float().contiguous()
     n, e = t.shape
@@ -63,17 +78,15 @@ def recall_ranks(text_embeds: torch.Tensor, image_embeds: torch.Tensor, block_ro
     if materialise:
         scratch = torch.empty(rows_max * n, dtype=torch.float32, device=t.device)
     else:
-        paired = torch.empty(n, dtype=torch.float32, device=t.device)
-        L.check(lib.ezclip_recall_paired_scores(L.ptr(t), L.ptr(v), n, e, L.ptr(paired), L.stream_ptr()), "recall_paired_scores")
+        paired = _paired_scores(t, v)
     for r0 in range(lo, hi, rows_max):
         rows = min(rows_max, hi - r0)
         out = rank[(me * per if world > 1 else 0) + (r0 - lo):]
         if materialise:
-            L.check(lib.ezclip_recall_ranks_rows(L.ptr(t[r0:r0 + rows]), L.ptr(v), rows, r0, n, e, out.data_ptr(), L.ptr(scratch),
-                                                 L.stream_ptr()), "recall_ranks_rows")
+            L.check(L.load().ezclip_recall_ranks_rows(L.ptr(t[r0:r0 + rows]), L.ptr(v), rows, r0, n, e, out.data_ptr(), L.ptr(scratch),
+                                                      L.stream_ptr()), "recall_ranks_rows")
         else:
-            L.check(lib.ezclip_recall_ranks_fused(L.ptr(t[r0:r0 + rows]), L.ptr(v), rows, r0, n, e, L.ptr(paired), out.data_ptr(),
-                                                  cols.data_ptr() if cols is not None else None, L.stream_ptr()), "recall_ranks_fused")
+            _ranks_block(t[r0:r0 + rows], v, r0, paired, out, cols)
     if world > 1:
         rank = gather_rank_shards(rank, me, per, n, group)
         if cols is not None:

@@ -156,6 +156,33 @@ def _worker(rank, world, port, q):
         mine[rank * per:(rank + 1) * per] = torch.arange(rank * per, (rank + 1) * per, dtype=torch.int32) * 3 + 1
         got = gather_rank_shards(mine, rank, per, n_q)
         assert torch.equal(got, torch.arange(n_q, dtype=torch.int32) * 3 + 1)
+        # ... and the whole sharded sweep, both directions (round 4): ranks split the query blocks, all-gather the text -> image
+        # ranks, all-reduce the image -> text counts.  The two device calls are stood in for by the counting definition on the CPU.
+        import easynlp_amd.appzoo.clip.evaluator as EV
+        from oracle import clip_oracle as ORC
+        def paired_cpu(t, v):
+            return (t * v).sum(-1)
+        def block_cpu(t_rows, v, row0, paired, out, cols):
+            sim = t_rows @ v.t()
+            rows, n = sim.shape
+            i = torch.arange(row0, row0 + rows)[:, None]
+            j = torch.arange(n)[None, :]
+            d = sim[torch.arange(rows), torch.arange(row0, row0 + rows)][:, None]
+            out[:rows] = ((sim > d) | ((sim == d) & (j < i))).sum(1).to(torch.int32)
+            if cols is not None:
+                dc = torch.stack([v[c] @ text_all[c] for c in range(n)])[None, :]
+                cols += ((sim > dc) | ((sim == dc) & (i < j))).sum(0).to(torch.int32)
+        g = torch.Generator().manual_seed(3)
+        n_p = 8 * world + 3
+        # small integer embeddings: every score is exact in float32 whatever the summation order, and ties abound
+        text_all = torch.randint(-3, 4, (n_p, 16), generator=g).float()
+        img_all = text_all + torch.randint(-2, 3, (n_p, 16), generator=g).float()
+        img_all[1] = img_all[n_p - 2]
+        EV._paired_scores, EV._ranks_block = paired_cpu, block_cpu
+        t2i, i2t = EV.recall_ranks(text_all, img_all, block_rows=3, shard=True, both_directions=True)
+        want_r, want_c = ORC.recall_ranks(text_all, img_all)
+        assert torch.equal(t2i.long(), want_r) and torch.equal(i2t.long(), want_c), (rank, t2i, want_r, i2t, want_c)
+        assert torch.equal(EV.recall_ranks(text_all, img_all, block_rows=5, shard=True).long(), want_r)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback

@@ -394,6 +394,13 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
         wl["batch"] = batch_override
     B, S = wl["batch"], wl["seq"]
     world, rank, device = c.world, c.rank, c.device
+    # The models of the workloads that ran before this one in the same process are garbage by now, but cyclic garbage: collect it here,
+    # outside any timed region, and give its device memory back, rather than leave it to a collection inside this workload's timed steps.
+    # (Hygiene; it did NOT explain why the autograd training step reads 3-4 % slower as the 7th workload of the default line than alone
+    # or right after the headline -- profiles/r4_train_vs_autograd_trace.log)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     app, model_name = build_app(wl, device, text_dropout)
     if wl.get("pack_text") is False:
         app._engine.pack_text = False
@@ -597,9 +604,7 @@ def main():
     ap.add_argument("--also", default="", help="comma-separated workloads for the `also` object (default: every BASELINE config)")
     ap.add_argument("--also-steps", type=int, default=8)
     ap.add_argument("--also-warmup", type=int, default=3,
-                    help="untimed steps of every `also` workload (the autograd path's second gradient arena and the allocator's growth are "
-                         "paid in its first THREE steps: with two warm-up steps and five timed ones it read 4 %% slow, "
-                         "profiles/r4_train_vs_autograd_trace.log)")
+                    help="untimed steps of every `also` workload")
     ap.add_argument("--launcher", action="store_true", help="self-launch under torch.distributed.run even for --gpus 1")
     ap.add_argument("--sustained-steps", type=int, default=300,
                     help="steps of the `sustained` leg of the headline and padded-text workloads (0: off; also capped at 20 s each)")

@@ -2,8 +2,12 @@
 import this module).
 
 Follows easynlp/modelzoo/models/clip/modeling_chineseclip.py: ``Bottleneck`` :27-74, ``AttentionPool2d`` :77-108,
-``ModifiedResNet`` :110-167 (the tower CHINESE_CLIP builds when ``vision_layers`` is a tuple, :279-287), in EVAL mode --
-BatchNorm with its running statistics, which is what evaluation and prediction run.  Written as plain functions over a
+``ModifiedResNet`` :110-167 (the tower CHINESE_CLIP builds when ``vision_layers`` is a tuple, :279-287).  EVAL mode --
+BatchNorm with its running statistics -- is what evaluation and prediction run and what the HIP tower implements; TRAIN mode
+(``train=True``: BatchNorm normalises with the statistics of the batch and moves the running statistics towards them,
+nn.BatchNorm2d defaults momentum 0.1, biased variance for the normalisation, unbiased for the running update) is the oracle-first
+step of the tower's training row (no HIP kernel consumes it yet: DESIGN.md section 7).  Gradients come from torch autograd over
+this restatement.  Written as plain functions over a
 state dict (names as in the reference checkpoint, prefix ``visual.``) so that every step can be compared with a kernel:
 
     stem:   3 x [conv3x3 (the first with stride 2) -> BN -> ReLU], AvgPool2d(2)
@@ -13,8 +17,8 @@ state dict (names as in the reference checkpoint, prefix ``visual.``) so that ev
             QUERY is the mean token; output projection -> [B, output_dim]
 
 Pinned against the real reference by tests/test_resnet_oracle.py: live (when /root/reference is importable) and through
-tests/golden/rn_tiny_b3.npz (generated from the reference by tools/make_golden_resnet.py).  No HIP tower consumes it yet
-(DESIGN.md section 7): this is the oracle-first step of that row."""
+tests/golden/rn_tiny_b3.npz / rn_tiny_train_b4.npz (generated from the reference by tools/make_golden_resnet.py: eval-mode
+outputs; train-mode outputs, every parameter gradient and the updated running statistics)."""
 from __future__ import annotations
 
 import math
@@ -25,6 +29,7 @@ import torch
 import torch.nn.functional as F
 
 BN_EPS = 1e-5          # nn.BatchNorm2d default
+BN_MOMENTUM = 0.1      # nn.BatchNorm2d default
 
 
 def param_shapes(layers: Sequence[int], width: int, output_dim: int, resolution: int) -> Dict[str, tuple]:
@@ -84,24 +89,36 @@ def make_state_dict(layers, width, output_dim, resolution, seed=7) -> Dict[str, 
     return sd
 
 
-def _bn(sd, name, x):
-    """BatchNorm2d.eval(): (x - running_mean) / sqrt(running_var + eps) * weight + bias, per channel."""
-    scale = sd[name + ".weight"] / torch.sqrt(sd[name + ".running_var"] + BN_EPS)
-    shift = sd[name + ".bias"] - sd[name + ".running_mean"] * scale
-    return x * scale[None, :, None, None] + shift[None, :, None, None]
+def _bn(sd, name, x, new_stats=None):
+    """BatchNorm2d.  ``new_stats is None`` -- eval(): (x - running_mean) / sqrt(running_var + eps) * weight + bias, per channel.
+    ``new_stats`` a dict -- train(): the mean and the BIASED variance of this batch over (N, H, W) normalise it, and the entries
+    ``name.running_mean`` / ``name.running_var`` receive (1 - momentum) * running + momentum * (batch mean / UNBIASED batch variance),
+    torch/nn/modules/batchnorm.py + aten batch_norm semantics."""
+    if new_stats is None:
+        scale = sd[name + ".weight"] / torch.sqrt(sd[name + ".running_var"] + BN_EPS)
+        shift = sd[name + ".bias"] - sd[name + ".running_mean"] * scale
+        return x * scale[None, :, None, None] + shift[None, :, None, None]
+    n = x.shape[0] * x.shape[2] * x.shape[3]
+    mean = x.mean(dim=(0, 2, 3))
+    var = ((x - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))
+    with torch.no_grad():
+        new_stats[name + ".running_mean"] = (1 - BN_MOMENTUM) * sd[name + ".running_mean"] + BN_MOMENTUM * mean.detach()
+        new_stats[name + ".running_var"] = (1 - BN_MOMENTUM) * sd[name + ".running_var"] + BN_MOMENTUM * var.detach() * (n / (n - 1.0))
+    xh = (x - mean[None, :, None, None]) / torch.sqrt(var + BN_EPS)[None, :, None, None]
+    return xh * sd[name + ".weight"][None, :, None, None] + sd[name + ".bias"][None, :, None, None]
 
 
-def bottleneck(sd, p, x, stride):
+def bottleneck(sd, p, x, stride, new_stats=None):
     """Bottleneck.forward (:59-74)"""
-    out = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"])))
-    out = F.relu(_bn(sd, p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], padding=1)))
+    out = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"]), new_stats))
+    out = F.relu(_bn(sd, p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], padding=1), new_stats))
     if stride > 1:
         out = F.avg_pool2d(out, stride)
-    out = _bn(sd, p + ".bn3", F.conv2d(out, sd[p + ".conv3.weight"]))
+    out = _bn(sd, p + ".bn3", F.conv2d(out, sd[p + ".conv3.weight"]), new_stats)
     identity = x
     if (p + ".downsample.0.weight") in sd:
         identity = F.avg_pool2d(x, stride) if stride > 1 else x
-        identity = _bn(sd, p + ".downsample.1", F.conv2d(identity, sd[p + ".downsample.0.weight"]))
+        identity = _bn(sd, p + ".downsample.1", F.conv2d(identity, sd[p + ".downsample.0.weight"]), new_stats)
     return F.relu(out + identity)
 
 
@@ -125,18 +142,33 @@ def attention_pool(sd, x, heads):
     return o @ sd[p + "c_proj.weight"].t() + sd[p + "c_proj.bias"]
 
 
-def modified_resnet_forward(sd, layers, width, x, taps=None):
-    """ModifiedResNet.forward (:153-167), eval mode.  x: [B, 3, R, R] float.  ``taps``: optional dict filled with the stem output
-    and every layer's output (NCHW)."""
+def modified_resnet_forward(sd, layers, width, x, taps=None, train=False, new_stats=None):
+    """ModifiedResNet.forward (:153-167).  x: [B, 3, R, R] float.  ``taps``: optional dict filled with the stem output and every
+    layer's output (NCHW).  ``train=True``: BatchNorm in training mode (see ``_bn``); ``new_stats`` (a dict, optional) receives the
+    updated running statistics of every BatchNorm -- ``sd`` itself is never written."""
     heads = width * 32 // 64                                              # CHINESE_CLIP.__init__ :280
+    ns = (new_stats if new_stats is not None else {}) if train else None
     for i, stride in ((1, 2), (2, 1), (3, 1)):
-        x = F.relu(_bn(sd, "visual.bn%d" % i, F.conv2d(x, sd["visual.conv%d.weight" % i], stride=stride, padding=1)))
+        x = F.relu(_bn(sd, "visual.bn%d" % i, F.conv2d(x, sd["visual.conv%d.weight" % i], stride=stride, padding=1), ns))
     x = F.avg_pool2d(x, 2)
     if taps is not None:
         taps["stem"] = x
     for li, nblocks in enumerate(layers, start=1):
         for bi in range(nblocks):
-            x = bottleneck(sd, "visual.layer%d.%d" % (li, bi), x, 2 if (li > 1 and bi == 0) else 1)
+            x = bottleneck(sd, "visual.layer%d.%d" % (li, bi), x, 2 if (li > 1 and bi == 0) else 1, ns)
         if taps is not None:
             taps["layer%d" % li] = x
     return attention_pool(sd, x, heads)
+
+
+def train_step_grads(sd, layers, width, x, probe):
+    """One training-mode pass and its backward: loss = sum(features * probe) (``probe``: a fixed [B, output_dim] tensor, so that
+    every output element has its own weight).  Returns (features, {parameter name: gradient} for every tensor of ``sd`` that is
+    not a running statistic, {running statistic name: updated value})."""
+    leaves = {k: (v.detach().clone().requires_grad_(True) if not k.endswith(("running_mean", "running_var")) else v.detach().clone())
+              for k, v in sd.items()}
+    new_stats = {}
+    out = modified_resnet_forward(leaves, layers, width, x, train=True, new_stats=new_stats)
+    (out * probe).sum().backward()
+    grads = {k: v.grad.detach() for k, v in leaves.items() if v.requires_grad}
+    return out.detach(), grads, new_stats

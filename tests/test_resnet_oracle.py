@@ -63,3 +63,62 @@ def test_oracle_matches_the_live_reference(layers, width, e, res, B):
         want = m(px)
         got = RO.modified_resnet_forward(sd, layers, width, px)
     assert float((got - want).abs().max()) < 3e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_train_mode_oracle_matches_the_reference_fixture():
+    """BatchNorm in training mode (batch statistics, running-statistic update) and the backward of the whole tower: features, every
+    parameter gradient and every updated running statistic of oracle/resnet_oracle.py against the reference module's own
+    (tests/golden/rn_tiny_train_b4.npz: nn.BatchNorm2d.train() + torch autograd on the REFERENCE ModifiedResNet)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import make_golden_resnet as G
+    z = np.load(os.path.join(HERE, "golden", "rn_tiny_train_b4.npz"))
+    c = json.loads(bytes(z["meta"]).decode())
+    sd = RO.make_state_dict(c["layers"], c["width"], c["output_dim"], c["resolution"], c["wseed"])
+    out, grads, stats = RO.train_step_grads(sd, c["layers"], c["width"], torch.from_numpy(z["pixels"]), torch.from_numpy(z["probe"]))
+    assert float((out - torch.from_numpy(z["image_features"])).abs().max()) < 3e-5
+    names = [k for k in sd if not k.endswith(("running_mean", "running_var"))]
+    assert set(grads) == set(names) and len(names) == 75
+    seen = 0
+    for k in names:
+        g = grads[k]
+        if ("grad:" + k) in z.files:
+            ref = torch.from_numpy(z["grad:" + k])
+            err = float((g - ref).norm())
+            assert err <= 2e-4 * float(ref.norm()) + 1e-5, (k, err, float(ref.norm()))
+        else:
+            ref_norm = float(z["gnorm:" + k])
+            samp = torch.from_numpy(z["gsamp:" + k])
+            idx = torch.from_numpy(G.sample_index(k, g.numel()))
+            assert abs(float(g.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-6, k
+            assert float((g.reshape(-1)[idx] - samp).abs().max()) <= 2e-4 * ref_norm / (g.numel() ** 0.5) * 30 + 1e-6, k
+        seen += 1
+    assert seen == 75
+    stat_names = [k for k in sd if k.endswith(("running_mean", "running_var"))]
+    assert set(stats) == set(stat_names) and len(stat_names) == 44
+    for k in stat_names:
+        ref = torch.from_numpy(z["stat:" + k])
+        assert float((stats[k] - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), k
+        assert float((stats[k] - sd[k]).abs().max()) > 1e-4, k          # (the update moved it: the fixture is not the eval path)
+    # eval mode on the same weights is a different function (running statistics instead of the batch's)
+    with torch.no_grad():
+        ev = RO.modified_resnet_forward(sd, c["layers"], c["width"], torch.from_numpy(z["pixels"]))
+    assert float((ev - out).abs().max()) > 1e-3
+
+
+@pytest.mark.skipif(not R.reference_available(), reason="reference checkout not present")
+def test_train_mode_oracle_matches_the_live_reference():
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import make_golden_resnet as G
+    cfg = dict(layers=(2, 1, 1, 2), width=8, output_dim=16, resolution=64)
+    sd = RO.make_state_dict(cfg["layers"], cfg["width"], cfg["output_dim"], cfg["resolution"], 21)
+    g = torch.Generator().manual_seed(8)
+    px = torch.randn(5, 3, 64, 64, generator=g)
+    probe = torch.randn(5, 16, generator=g)
+    want_out, want_g, want_s = G.reference_train_step(cfg, sd, px, probe)
+    out, grads, stats = RO.train_step_grads(sd, cfg["layers"], cfg["width"], px, probe)
+    assert float((out - want_out).abs().max()) < 3e-5 * max(1.0, float(want_out.abs().max()))
+    assert set(grads) == set(want_g) and set(stats) == set(want_s)
+    for k in grads:        # (attnpool.k_proj.bias: a constant added to every key -- its exact gradient is 0, both sides hold rounding noise)
+        assert float((grads[k] - want_g[k]).norm()) <= 2e-4 * float(want_g[k].norm()) + 1e-5, k
+    for k in stats:
+        assert float((stats[k] - want_s[k]).abs().max()) <= 1e-5 * max(1.0, float(want_s[k].abs().max())), k

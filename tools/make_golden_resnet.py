@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""Golden fixture of the reference's ModifiedResNet tower (eval mode) for oracle/resnet_oracle.py:
+"""Golden fixtures of the reference's ModifiedResNet tower for oracle/resnet_oracle.py:
     python tools/make_golden_resnet.py        (build container only: imports /root/reference)
-writes tests/golden/rn_tiny_b3.npz = {pixels, image_features, stem, layer4, meta}."""
+writes tests/golden/rn_tiny_b3.npz = {pixels, image_features, stem, layer4, meta}  (eval mode) and
+tests/golden/rn_tiny_train_b4.npz = {pixels, probe, image_features, grad:<name> for every parameter, stat:<name> for every updated
+running statistic, meta}  (train mode: BatchNorm batch statistics, loss = sum(features * probe), torch autograd of the REFERENCE module)."""
 import json
 import os
 import sys
@@ -28,6 +30,47 @@ def reference_tower(cfg, sd):
     return m.eval()
 
 
+TRAIN_CFG = dict(layers=(1, 2, 1, 1), width=16, output_dim=24, resolution=64, wseed=9, iseed=5, batch=4)
+
+
+def reference_train_step(cfg, sd, px, probe):
+    """(features, {visual.<name>: grad}, {visual.<name>: updated running statistic}) of the reference module in train() mode"""
+    m = reference_tower(cfg, sd).train()
+    out = m(px)
+    (out * probe).sum().backward()
+    grads = {"visual." + k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    stats = {"visual." + k: v.detach().clone() for k, v in m.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+    return out.detach(), grads, stats
+
+
+def sample_index(name, numel, k=64):
+    """64 positions of a flattened tensor, seeded by its name (shared with tests/test_resnet_oracle.py)"""
+    import zlib
+    return np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff).choice(numel, size=k, replace=False).astype(np.int64)
+
+
+def main_train():
+    c = TRAIN_CFG
+    sd = RO.make_state_dict(c["layers"], c["width"], c["output_dim"], c["resolution"], c["wseed"])
+    g = torch.Generator().manual_seed(c["iseed"])
+    px = torch.randn(c["batch"], 3, c["resolution"], c["resolution"], generator=g)
+    probe = torch.randn(c["batch"], c["output_dim"], generator=g)
+    out, grads, stats = reference_train_step(c, sd, px, probe)
+    path = os.path.join(ROOT, "tests", "golden", "rn_tiny_train_b4.npz")
+    arrays = dict(pixels=px.numpy(), probe=probe.numpy(), image_features=out.numpy(),
+                  meta=np.frombuffer(json.dumps(c).encode(), dtype=np.uint8))
+    for k, v in grads.items():             # small tensors whole; large ones as (L2 norm, 64 entries at seeded positions)
+        if v.numel() <= 4096:
+            arrays["grad:" + k] = v.numpy()
+        else:
+            idx = sample_index(k, v.numel())
+            arrays["gnorm:" + k] = np.float64(v.double().norm().item())
+            arrays["gsamp:" + k] = v.reshape(-1)[torch.from_numpy(idx)].numpy()
+    arrays.update({"stat:" + k: v.numpy() for k, v in stats.items()})
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, out.shape, len(grads), "gradients", len(stats), "running statistics", os.path.getsize(path), "bytes")
+
+
 def main():
     c = CFG
     sd = RO.make_state_dict(c["layers"], c["width"], c["output_dim"], c["resolution"], c["wseed"])
@@ -49,3 +92,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main_train()

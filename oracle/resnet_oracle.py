@@ -172,3 +172,189 @@ def train_step_grads(sd, layers, width, x, probe):
     (out * probe).sum().backward()
     grads = {k: v.grad.detach() for k, v in leaves.items() if v.requires_grad}
     return out.detach(), grads, new_stats
+
+
+# ---- the backward pass, step by step ---------------------------------------------------------------------------------------------
+# The same gradients as ``train_step_grads`` WITHOUT autograd: every step is the formula a kernel (or a GEMM call) of the HIP tower's
+# training path will implement, in the decomposition it will use -- BatchNorm backward from two per-channel column moments, the
+# input gradient of a 3x3 convolution as a 3x3 convolution of the output gradient with the tap-flipped, in/out-transposed weights,
+# the weight gradient as im2col(x)^T . dz (one TN product), the anti-aliasing average pool as a broadcast, the attention pool as a
+# one-query attention.  tests/test_resnet_oracle.py checks it against autograd of the restatement above and, through it, against
+# the reference module.  (NCHW torch tensors here; the formulas do not depend on the layout.)
+
+def _bn_train_fwd(x, gamma, beta):
+    mean = x.mean(dim=(0, 2, 3))
+    var = ((x - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))
+    rstd = 1.0 / torch.sqrt(var + BN_EPS)
+    xh = (x - mean[None, :, None, None]) * rstd[None, :, None, None]
+    return xh * gamma[None, :, None, None] + beta[None, :, None, None], (xh, rstd)
+
+
+def _bn_train_bwd(dy, xh, rstd, gamma):
+    """dgamma = sum dy * xhat, dbeta = sum dy (per channel, over N, H, W: the two column moments);
+    dx = gamma * rstd * (dy - dbeta / n - xhat * dgamma / n)"""
+    n = dy.shape[0] * dy.shape[2] * dy.shape[3]
+    dgamma = (dy * xh).sum(dim=(0, 2, 3))
+    dbeta = dy.sum(dim=(0, 2, 3))
+    dx = (gamma * rstd)[None, :, None, None] * (dy - dbeta[None, :, None, None] / n - xh * dgamma[None, :, None, None] / n)
+    return dx, dgamma, dbeta
+
+
+def _conv_bwd(x, w, dz, stride, padding):
+    """(dx, dw) of z = conv2d(x, w, stride, padding), bias-free.
+    dw[co, ci, ky, kx] = sum_p dz[p, co] * x[p * stride + (ky, kx) - padding, ci]  =  dz^T . im2col(x)   (one TN product over pixels)
+    dx: stride 1 -- a convolution of dz (same padding) with w flipped in both taps and transposed in (co, ci);
+        stride 2 (the stem's first conv only) -- the same after dz has been spread onto the stride grid (zeros in between)."""
+    B, Ci, H, W = x.shape
+    Co, _, kh, kw = w.shape
+    cols = F.unfold(x, (kh, kw), padding=padding, stride=stride)                    # [B, Ci*kh*kw, P]
+    dzf = dz.reshape(B, Co, -1)                                                     # [B, Co, P]
+    dw = torch.einsum("bop,bkp->ok", dzf, cols).reshape(Co, Ci, kh, kw)
+    if stride > 1:
+        up = torch.zeros(B, Co, (dz.shape[2] - 1) * stride + 1, (dz.shape[3] - 1) * stride + 1, dtype=dz.dtype)
+        up[:, :, ::stride, ::stride] = dz
+        # the forward read x at rows oy * stride + ky - padding: the spread gradient needs kh - 1 - padding of padding on the low side
+        # and whatever restores H on the high side
+        lo = kh - 1 - padding
+        hi_h = H - (up.shape[2] + lo - (kh - 1))
+        hi_w = W - (up.shape[3] + lo - (kw - 1))
+        up = F.pad(up, (lo, hi_w, lo, hi_h))
+        dx = F.conv2d(up, w.flip(2, 3).transpose(0, 1))
+    else:
+        dx = F.conv2d(dz, w.flip(2, 3).transpose(0, 1), padding=kh - 1 - padding)
+    return dx, dw
+
+
+def _avgpool_bwd(dy, s):
+    """AvgPool2d(s) backward: every input pixel of an s x s window receives dy / s^2"""
+    return dy.repeat_interleave(s, dim=2).repeat_interleave(s, dim=3) / float(s * s)
+
+
+def _attention_pool_fwd_bwd(sd, x, heads, d_out):
+    """AttentionPool2d forward + backward by hand.  Returns (out, dx, {param: grad})."""
+    p = "visual.attnpool."
+    B, C, Hh, Ww = x.shape
+    hw = Hh * Ww
+    t0 = x.reshape(B, C, hw).permute(0, 2, 1)
+    tok = torch.cat([t0.mean(dim=1, keepdim=True), t0], dim=1)
+    t = tok + sd[p + "positional_embedding"][None]
+    Wq, Wk, Wv, Wc = (sd[p + n + ".weight"] for n in ("q_proj", "k_proj", "v_proj", "c_proj"))
+    q = t[:, 0] @ Wq.t() + sd[p + "q_proj.bias"]                                     # [B, C]
+    k = t @ Wk.t() + sd[p + "k_proj.bias"]                                           # [B, L, C]
+    v = t @ Wv.t() + sd[p + "v_proj.bias"]
+    hd = C // heads
+    scale = hd ** -0.5
+    qh = q.reshape(B, heads, hd) * scale
+    kh = k.reshape(B, -1, heads, hd)
+    vh = v.reshape(B, -1, heads, hd)
+    s = torch.einsum("bhd,blhd->bhl", qh, kh)
+    a = torch.softmax(s, dim=-1)
+    o = torch.einsum("bhl,blhd->bhd", a, vh).reshape(B, C)
+    out = o @ Wc.t() + sd[p + "c_proj.bias"]
+    # ---- backward
+    g = {}
+    g[p + "c_proj.bias"] = d_out.sum(0)
+    g[p + "c_proj.weight"] = d_out.t() @ o
+    do = (d_out @ Wc).reshape(B, heads, hd)
+    da = torch.einsum("bhd,blhd->bhl", do, vh)
+    dvh = torch.einsum("bhl,bhd->blhd", a, do)
+    ds = a * (da - (a * da).sum(-1, keepdim=True))                                   # softmax backward, one query row per head
+    dqh = torch.einsum("bhl,blhd->bhd", ds, kh)
+    dkh = torch.einsum("bhl,bhd->blhd", ds, qh)
+    dq = (dqh * scale).reshape(B, C)
+    dk = dkh.reshape(B, -1, C)
+    dv = dvh.reshape(B, -1, C)
+    g[p + "q_proj.bias"] = dq.sum(0); g[p + "q_proj.weight"] = dq.t() @ t[:, 0]
+    g[p + "k_proj.bias"] = dk.sum((0, 1)); g[p + "k_proj.weight"] = torch.einsum("blo,bli->oi", dk, t)
+    g[p + "v_proj.bias"] = dv.sum((0, 1)); g[p + "v_proj.weight"] = torch.einsum("blo,bli->oi", dv, t)
+    dt = dk @ Wk + dv @ Wv
+    dt[:, 0] += dq @ Wq
+    g[p + "positional_embedding"] = dt.sum(0)
+    dt0 = dt[:, 1:] + dt[:, :1] / hw                                                 # the mean token spreads its gradient over the positions
+    dx = dt0.permute(0, 2, 1).reshape(B, C, Hh, Ww)
+    return out, dx, g
+
+
+def train_step_grads_by_steps(sd, layers, width, x, probe):
+    """``train_step_grads`` by explicit forward and backward formulas (no autograd).  Returns (features, grads) with the same keys."""
+    heads = width * 32 // 64
+    g = {}
+    tape = []                         # (kind, saved...) in forward order
+
+    def conv_bn(x_in, conv, bn, stride, padding, relu, residual=None):
+        z = F.conv2d(x_in, sd[conv + ".weight"], stride=stride, padding=padding)
+        y, (xh, rstd) = _bn_train_fwd(z, sd[bn + ".weight"], sd[bn + ".bias"])
+        if residual is not None:
+            y = y + residual
+        if relu:
+            y = F.relu(y)
+        tape.append(("conv_bn", conv, bn, stride, padding, relu, x_in, xh, rstd, y))
+        return y
+
+    with torch.no_grad():
+        h = x
+        for i, stride in ((1, 2), (2, 1), (3, 1)):
+            h = conv_bn(h, "visual.conv%d" % i, "visual.bn%d" % i, stride, 1, True)
+        h = F.avg_pool2d(h, 2); tape.append(("pool", 2))
+        blocks = []
+        for li, nblocks in enumerate(layers, start=1):
+            for bi in range(nblocks):
+                blocks.append(("visual.layer%d.%d" % (li, bi), 2 if (li > 1 and bi == 0) else 1))
+        # the blocks are unrolled by hand below (two branches meet at the residual add), so their tape is a list of dicts
+        btape = []
+        for p_, stride in blocks:
+            rec = {"p": p_, "stride": stride, "x": h}
+            t_ = []
+            def cb(x_in, conv, bn, padding, relu):
+                z = F.conv2d(x_in, sd[conv + ".weight"], padding=padding)
+                y, (xh, rstd) = _bn_train_fwd(z, sd[bn + ".weight"], sd[bn + ".bias"])
+                t_.append((conv, bn, padding, x_in, xh, rstd))
+                return F.relu(y) if relu else y
+            o1 = cb(h, p_ + ".conv1", p_ + ".bn1", 0, True)
+            o2 = cb(o1, p_ + ".conv2", p_ + ".bn2", 1, True)
+            o2p = F.avg_pool2d(o2, stride) if stride > 1 else o2
+            o3 = cb(o2p, p_ + ".conv3", p_ + ".bn3", 0, False)
+            rec.update(o1=o1, o2=o2, main=t_[:])
+            if (p_ + ".downsample.0.weight") in sd:
+                xi = F.avg_pool2d(h, stride) if stride > 1 else h
+                t_.clear()
+                ident = cb(xi, p_ + ".downsample.0", p_ + ".downsample.1", 0, False)
+                rec["down"] = t_[0]
+            else:
+                ident = h
+            h = F.relu(o3 + ident)
+            rec["y"] = h
+            btape.append(rec)
+        out, dx, ga = _attention_pool_fwd_bwd(sd, h, heads, probe)
+        g.update(ga)
+
+        def cb_bwd(dy, rec_):
+            conv, bn, padding, x_in, xh, rstd = rec_
+            dz, g[bn + ".weight"], g[bn + ".bias"] = _bn_train_bwd(dy, xh, rstd, sd[bn + ".weight"])
+            dxi, g[conv + ".weight"] = _conv_bwd(x_in, sd[conv + ".weight"], dz, 1, padding)
+            return dxi
+
+        for rec in reversed(btape):
+            dsum = dx * (rec["y"] > 0)                                    # ReLU after the residual add
+            stride = rec["stride"]
+            m1, m2, m3 = rec["main"]
+            d = cb_bwd(dsum, m3)
+            if stride > 1:
+                d = _avgpool_bwd(d, stride)
+            d = d * (rec["o2"] > 0)
+            d = cb_bwd(d, m2)
+            d = d * (rec["o1"] > 0)
+            d = cb_bwd(d, m1)
+            if "down" in rec:
+                di = cb_bwd(dsum, rec["down"])
+                if stride > 1:
+                    di = _avgpool_bwd(di, stride)
+            else:
+                di = dsum
+            dx = d + di
+        dx = _avgpool_bwd(dx, 2)
+        for kind, conv, bn, stride, padding, relu, x_in, xh, rstd, y in reversed([t for t in tape if t[0] == "conv_bn"]):
+            dx = dx * (y > 0)
+            dz, g[bn + ".weight"], g[bn + ".bias"] = _bn_train_bwd(dx, xh, rstd, sd[bn + ".weight"])
+            dx, g[conv + ".weight"] = _conv_bwd(x_in, sd[conv + ".weight"], dz, stride, padding)
+    return out, g

@@ -122,3 +122,21 @@ def test_train_mode_oracle_matches_the_live_reference():
         assert float((grads[k] - want_g[k]).norm()) <= 2e-4 * float(want_g[k].norm()) + 1e-5, k
     for k in stats:
         assert float((stats[k] - want_s[k]).abs().max()) <= 1e-5 * max(1.0, float(want_s[k].abs().max())), k
+
+
+@pytest.mark.parametrize("layers,width,e,res,B", [((1, 2, 1, 1), 16, 24, 64, 4), ((2, 1, 1, 2), 8, 16, 96, 3)])
+def test_backward_by_steps_equals_autograd(layers, width, e, res, B):
+    """The explicit backward formulas the HIP training path will implement (BatchNorm backward from two column moments, 3x3 input
+    gradient as a convolution with flipped / transposed weights, weight gradient as im2col^T . dz, average-pool broadcast, one-query
+    attention pool) against autograd of the restatement -- which the fixture above ties to the reference module."""
+    sd = RO.make_state_dict(layers, width, e, res, 13)
+    g = torch.Generator().manual_seed(2)
+    px = torch.randn(B, 3, res, res, generator=g)
+    probe = torch.randn(B, e, generator=g)
+    out, grads, _ = RO.train_step_grads(sd, layers, width, px, probe)
+    out2, grads2 = RO.train_step_grads_by_steps(sd, layers, width, px, probe)
+    assert float((out - out2).abs().max()) < 1e-5 * max(1.0, float(out.abs().max()))
+    assert set(grads) == set(grads2)
+    for k in grads:
+        assert grads2[k].shape == grads[k].shape, k
+        assert float((grads2[k] - grads[k]).norm()) <= 3e-4 * float(grads[k].norm()) + 1e-5, (k, float((grads2[k] - grads[k]).norm()), float(grads[k].norm()))

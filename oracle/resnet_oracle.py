@@ -358,3 +358,58 @@ def train_step_grads_by_steps(sd, layers, width, x, probe):
             dz, g[bn + ".weight"], g[bn + ".bias"] = _bn_train_bwd(dx, xh, rstd, sd[bn + ".weight"])
             dx, g[conv + ".weight"] = _conv_bwd(x_in, sd[conv + ".weight"], dz, stride, padding)
     return out, g
+
+
+# ---- the same steps in the HIP tower's data layout -----------------------------------------------------------------------------------
+# NHWC activations [B * H * W, Cp] (channels zero-padded to Cp), packed weights [Opad][9 * Cp] with K index (ky * 3 + kx) * Cp + c
+# (csrc/resnet.hip: rn_pack_conv_kernel), the implicit 3x3 convolution of csrc/gemm.hip (GemmArgs::conv_*: output row m = pixel
+# (b, y, x), the A tile of tap (ky, kx) is the channel slice of the pixel shifted by (ky - 1, kx - 1), zeros outside the image).
+# These pin the index conventions of the training path's packing kernels before any of them exists:
+#   input gradient  = the same implicit convolution of dz with  Wd[c][(ky * 3 + kx) * Opad + o] = W[o][c][2 - ky][2 - kx]
+#   weight gradient = dz^T . im2col(x)  ->  dWp[o][(ky * 3 + kx) * Cp + c]  (the packed layout again), unpacked to [O, I, 3, 3]
+
+def to_nhwc(x, cp):
+    """[B, C, H, W] -> [B * H * W, cp] (zero-padded channels)"""
+    B, C, H, W = x.shape
+    out = torch.zeros(B * H * W, cp, dtype=x.dtype)
+    out[:, :C] = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    return out
+
+
+def from_nhwc(m, B, C, H, W):
+    return m[:, :C].reshape(B, H, W, C).permute(0, 3, 1, 2)
+
+
+def pack_conv3x3(w, cp, opad):
+    """rn_pack_conv_kernel without a BatchNorm fold: [O, I, 3, 3] -> [opad, 9 * cp], K index (ky * 3 + kx) * cp + c"""
+    O, I = w.shape[:2]
+    p = torch.zeros(opad, 9, cp, dtype=w.dtype)
+    p[:O, :, :I] = w.reshape(O, I, 9).permute(0, 2, 1)
+    return p.reshape(opad, 9 * cp)
+
+
+def pack_conv3x3_dgrad(w, cp, opad):
+    """weights of the input-gradient convolution: [cp, 9 * opad] with Wd[c][(ky * 3 + kx) * opad + o] = W[o][c][2 - ky][2 - kx]"""
+    O, I = w.shape[:2]
+    p = torch.zeros(cp, 9, opad, dtype=w.dtype)
+    p[:I, :, :O] = w.flip(2, 3).reshape(O, I, 9).permute(1, 2, 0)
+    return p.reshape(cp, 9 * opad)
+
+
+def im2col3x3_nhwc(a, B, H, W):
+    """[B * H * W, cp] -> [B * H * W, 9 * cp]: column block (ky * 3 + kx) holds the pixel shifted by (ky - 1, kx - 1), zeros outside"""
+    cp = a.shape[1]
+    img = a.reshape(B, H, W, cp)
+    pad = F.pad(img, (0, 0, 1, 1, 1, 1))
+    cols = [pad[:, ky:ky + H, kx:kx + W, :] for ky in range(3) for kx in range(3)]
+    return torch.cat(cols, dim=-1).reshape(B * H * W, 9 * cp)
+
+
+def implicit_conv3x3_nhwc(a, wp, B, H, W):
+    """what gemm_nt computes in convolution mode: out[m][o] = sum_k im2col(a)[m][k] * wp[o][k]"""
+    return im2col3x3_nhwc(a, B, H, W) @ wp.t()
+
+
+def unpack_wgrad3x3(dwp, O, I, cp):
+    """[opad, 9 * cp] (the packed K order) -> [O, I, 3, 3]"""
+    return dwp.reshape(dwp.shape[0], 9, cp)[:O, :, :I].permute(0, 2, 1).reshape(O, I, 3, 3)

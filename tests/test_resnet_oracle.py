@@ -140,3 +140,32 @@ def test_backward_by_steps_equals_autograd(layers, width, e, res, B):
     for k in grads:
         assert grads2[k].shape == grads[k].shape, k
         assert float((grads2[k] - grads[k]).norm()) <= 3e-4 * float(grads[k].norm()) + 1e-5, (k, float((grads2[k] - grads[k]).norm()), float(grads[k].norm()))
+
+
+@pytest.mark.parametrize("B,I,O,H", [(2, 8, 16, 6), (3, 24, 8, 5)])
+def test_training_path_layout_conventions(B, I, O, H):
+    """The index conventions the training path's packing kernels will use, in the HIP tower's data layout (NHWC rows, channels padded
+    to 64, packed weights [Opad][9 * Cp], the implicit 3x3 convolution of gemm.hip): forward, input gradient (the same implicit
+    convolution with tap-flipped, in/out-transposed weights) and weight gradient (dz^T . im2col(x), packed K order) against
+    torch's convolution and the step-by-step backward above."""
+    g = torch.Generator().manual_seed(B * 100 + I)
+    x = torch.randn(B, I, H, H, generator=g, dtype=torch.float64)
+    w = torch.randn(O, I, 3, 3, generator=g, dtype=torch.float64)
+    dz = torch.randn(B, O, H, H, generator=g, dtype=torch.float64)
+    cp, opad = 64, 64
+    xa = RO.to_nhwc(x, cp)
+    z = RO.implicit_conv3x3_nhwc(xa, RO.pack_conv3x3(w, cp, opad), B, H, H)
+    want = torch.nn.functional.conv2d(x, w, padding=1)
+    assert float((RO.from_nhwc(z, B, O, H, H) - want).abs().max()) < 1e-10
+    assert float(z[:, O:].abs().max()) == 0.0                                # padded output channels stay zero
+    dx_want, dw_want = RO._conv_bwd(x, w, dz, 1, 1)
+    da = RO.to_nhwc(dz, opad)
+    dx = RO.implicit_conv3x3_nhwc(da, RO.pack_conv3x3_dgrad(w, cp, opad), B, H, H)
+    assert float((RO.from_nhwc(dx, B, I, H, H) - dx_want).abs().max()) < 1e-10
+    assert float(dx[:, I:].abs().max()) == 0.0
+    dwp = da.t() @ RO.im2col3x3_nhwc(xa, B, H, H)                             # one TN product over the pixels
+    assert float((RO.unpack_wgrad3x3(dwp, O, I, cp) - dw_want).abs().max()) < 1e-9
+    # autograd agrees with all of it
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    (torch.nn.functional.conv2d(xr, wr, padding=1) * dz).sum().backward()
+    assert float((xr.grad - dx_want).abs().max()) < 1e-10 and float((wr.grad - dw_want).abs().max()) < 1e-9

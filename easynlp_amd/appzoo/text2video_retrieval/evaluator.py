@@ -1,5 +1,6 @@
 """Drop-in for ``easynlp.appzoo.text2video_retrieval.evaluator.Text2VideoRetrievalEvaluator`` (evaluator.py:28-73):
-text->video R@1/5/10 and their mean over the validation set; the per-query sort loop is ``ezclip_recall_ranks``."""
+text->video R@1/5/10 and their mean over the validation set; the per-query sort loop is the fused rank sweep
+(``ezclip_recall_ranks_fused``; ``both_directions=True`` adds video->text)."""
 from __future__ import annotations
 
 import time
@@ -16,6 +17,7 @@ class Text2VideoRetrievalEvaluator(Evaluator):
         super().__init__(valid_dataset, **kwargs)
         self.metrics = ["accuracy", "f1"]
         self.before = 0.0
+        self.both_directions = bool(kwargs.get("both_directions", False))
 
     def evaluate(self, model):
         model.eval()
@@ -29,4 +31,4 @@ class Text2VideoRetrievalEvaluator(Evaluator):
             video_all.append(outputs["video_embeds"])
             text_all.append(outputs["text_embeds"])
         video_embeds, text_embeds = torch.cat(video_all, dim=0), torch.cat(text_all, dim=0)
-        return _clip_evaluator.recall_report(text_embeds, video_embeds, total_spent_time)
+        return _clip_evaluator.recall_report(text_embeds, video_embeds, total_spent_time, both_directions=self.both_directions)

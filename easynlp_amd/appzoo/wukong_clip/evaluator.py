@@ -1,6 +1,7 @@
 """Drop-in for ``easynlp.appzoo.wukong_clip.evaluator.WukongCLIPEvaluator`` (wukong_clip/evaluator.py:26-80): same
 text->image R@1/5/10 + mean recall as the clip evaluator, over ``outputs['image_features'] / ['text_features']`` of the
-tuple WukongCLIP.forward returns; the per-query sort loop is the library's rank kernel (``ezclip_recall_ranks``).
+tuple WukongCLIP.forward returns; the per-query sort loop is the library's fused rank sweep (``ezclip_recall_ranks_fused``;
+``both_directions=True`` adds the image->text ranks of the same sweep, as in the clip evaluator).
 ``cosine_similarity == 'True'`` prints the mean paired similarity and returns None, as the reference does (:57-62)."""
 from __future__ import annotations
 
@@ -20,6 +21,7 @@ class WukongCLIPEvaluator(Evaluator):
         self.metrics = ["accuracy", "f1"]
         self.before = 0.0
         self.cal_sim = udp.get("cosine_similarity") == "True"
+        self.both_directions = bool(kwargs.get("both_directions", False))
 
     def evaluate(self, model):
         model.eval()
@@ -39,4 +41,4 @@ class WukongCLIPEvaluator(Evaluator):
             print(similarity)
             print("averaged consine similarity ", similarity.mean())
             return None
-        return _clip_evaluator.recall_report(text_embeds, image_embeds, total_spent_time)
+        return _clip_evaluator.recall_report(text_embeds, image_embeds, total_spent_time, both_directions=self.both_directions)

@@ -447,3 +447,39 @@ def test_huggingface_flavour_predictor_agrees_with_the_reference(tmp_path, monke
         a = np.array([[float(x) for x in o[key].split("\t")] for o in ref_out], np.float32)
         b = np.array([[float(x) for x in o[key].split("\t")] for o in my_out], np.float32)
         assert a.shape == b.shape == (7, 64) and np.abs(a - b).max() < 2e-6, key
+
+
+def test_recall_report_both_directions_on_stubbed_device_calls(monkeypatch, capsys):
+    """``recall_report(..., both_directions=True)``: the reference's text -> image line and metric first, unchanged; one more printed
+    line and an ``("i2t_mean_recall", ...)`` entry after it.  The two device calls of the fused sweep are stood in for by their counting
+    definition on the CPU; small integer embeddings make every score exact and ties frequent."""
+    import torch
+    from oracle import clip_oracle as O
+    import easynlp_amd.appzoo.clip.evaluator as EV
+    g = torch.Generator().manual_seed(12)
+    n = 23
+    t = torch.randint(-3, 4, (n, 16), generator=g).float()
+    v = t + torch.randint(-2, 3, (n, 16), generator=g).float()
+
+    def block_cpu(t_rows, vv, row0, paired, out, cols):
+        sim = t_rows @ vv.t()
+        rows = sim.shape[0]
+        i = torch.arange(row0, row0 + rows)[:, None]
+        j = torch.arange(n)[None, :]
+        d = paired[row0:row0 + rows][:, None]
+        out[:rows] = ((sim > d) | ((sim == d) & (j < i))).sum(1).to(torch.int32)
+        if cols is not None:
+            dc = paired[None, :]
+            cols += ((sim > dc) | ((sim == dc) & (i < j))).sum(0).to(torch.int32)
+
+    monkeypatch.setattr(EV, "_paired_scores", lambda a, b: (a * b).sum(-1))
+    monkeypatch.setattr(EV, "_ranks_block", block_cpu)
+    want_r, want_c = O.recall_ranks(t, v)
+    res = EV.recall_report(t, v, 0.5, both_directions=True)
+    assert [k for k, _ in res] == ["mean_recall", "i2t_mean_recall"]
+    mean = lambda r: sum(float((r < k).sum()) / n for k in (1, 5, 10)) / 3
+    assert abs(res[0][1] - mean(want_r)) < 1e-12 and abs(res[1][1] - mean(want_c)) < 1e-12
+    out = capsys.readouterr().out
+    assert "query_num:%d" % n in out and "image->text" in out
+    one = EV.recall_report(t, v, 0.5)
+    assert one == [("mean_recall", res[0][1])]

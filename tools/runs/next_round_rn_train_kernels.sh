@@ -7,3 +7,8 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
 T=${1:-r5c}
 timeout 900 python -m pytest -q -m gpu tests/test_00_canary_gpu.py tests/test_resnet_train_ops_gpu.py --maxfail=20 2>&1 | tail -40 | tee gpurun_out/pytest_rn_train_ops_$T.log
+# Step 2 (tools/experiments/rn_train_tower.patch INSTEAD of rn_train_kernels.patch: it contains the kernels and adds the tower's training
+# forward / backward -- ezclip_rn_encode_image_train, ezclip_rn_backward, RnEngine.encode_image_train / backward -- and its engine-level tests)
+if [ -f tests/test_resnet_train_gpu.py ]; then
+  timeout 900 python -m pytest -q -m gpu tests/test_resnet_train_gpu.py tests/test_resnet_gpu.py --maxfail=20 2>&1 | tail -40 | tee gpurun_out/pytest_rn_train_tower_$T.log
+fi

@@ -111,16 +111,27 @@ GFLOP_TRAIN_PER_PAIR_HF_VITL14 = 162.03 + 3 * 11.025      # frozen vision tower:
 GFLOP_TRAIN_PER_PAIR_HF_VITL14_LARGE = 162.03 + 3 * 39.06   # text: 24 layers x 64 tokens x (8 H^2 + 4 H F + 4 L H), H 1024, F 4096
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 
-# launches of the dominant kernel in one forward step at 1024 pairs (shape names of tools/gemm_bench):
-FWD_GEMM_MIX = {"vit.qkv": 12, "vit.out+res": 12, "vit.fc+qgelu": 12, "vit.proj+res": 12, "bert.qkv": 12, "bert.qkvo+res": 12,
-                "bert.ffn1+gelu": 12, "bert.ffn2+res": 12, "patch": 1}
+# The 101 launches of the dominant kernel (ProfScope PROF_GEMM) in one forward step at 1024 pairs -- the set the roofline's time
+# average runs over (round 4 listed 97 of them).  Blocks 0..10 of each tower run the four big products of tools/gemm_bench; the LAST
+# block of each tower is evaluated for the CLS rows only (k | v for every token, everything else for 1024 rows); then the two
+# projections into the joint space.  Packed text: M = the unmasked tokens (~36 k of 65 536); the summaries were taken at 65 536.
+FWD_GEMM_MIX = {"vit.qkv": 11, "vit.out+res": 11, "vit.fc+qgelu": 11, "vit.proj+res": 11, "bert.qkv": 11, "bert.qkvo+res": 11,
+                "bert.ffn1+gelu": 11, "bert.ffn2+res": 11, "patch": 1}
+# (scale of a measured shape, count): the last blocks' k | v products = two thirds of the q | k | v product of the same tower
+FWD_GEMM_MIX_SCALED = {"vit.kv(last)": ("vit.qkv", 2.0 / 3.0, 1), "bert.kv(last)": ("bert.qkv", 2.0 / 3.0, 1)}
+# (M, N, K, count) of the small launches: CLS-row products of the two last blocks (q, out, fc / ffn1, proj / ffn2) and the two
+# projections; their traffic is taken as their algorithmic bytes (1-5 MB each against ~0.9 GB for a big product)
+FWD_GEMM_MIX_SMALL = [(1024, 768, 768, 4), (1024, 3072, 768, 2), (1024, 768, 3072, 2), (1024, 512, 768, 2)]
+FWD_GEMM_LAUNCHES = sum(FWD_GEMM_MIX.values()) + sum(v[2] for v in FWD_GEMM_MIX_SCALED.values()) + sum(v[3] for v in FWD_GEMM_MIX_SMALL)
+assert FWD_GEMM_LAUNCHES == 101
 
 
 def pmc_traffic(workload):
     """Average HBM-side bytes per launch of the dominant kernel (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc passes of
     tools/pmc_gemm.sh summarised by tools/pmc_summary.py into profiles/*_gemm_traffic.json; MALL hits are counted as
-    fetches on gfx950).  Measured offline with the same kernels, shapes and batch: bench.py cannot run a profiler
-    around itself.  None when no summary is committed or the workload is not the 1024-pair forward."""
+    fetches on gfx950), averaged over the SAME 101 launches as the roofline's time average (FWD_GEMM_MIX*).  Measured offline with
+    the same kernels, shapes and batch, one cool launch per shape: bench.py cannot run a profiler around itself.  None when no
+    summary is committed or the workload is not the 1024-pair forward."""
     if workload != "bf16_b1024_fwd_loss":
         return None
     import glob
@@ -130,14 +141,21 @@ def pmc_traffic(workload):
     t = json.load(open(files[-1]))
     if "bert.qkv" not in t and "bert.qkvo+res" in t:       # summaries taken before the q | k | v products were merged
         t = dict(t, **{"bert.qkv": {k: 3 * v for k, v in t["bert.qkvo+res"].items()}})
-    tot, n = 0.0, 0
+    tot, alg = 0.0, 0.0
     for name, cnt in FWD_GEMM_MIX.items():
         if name not in t:
             return None
         tot += cnt * (t[name]["fetch_bytes"] + t[name]["write_bytes"])
-        n += cnt
-    return {"bytes_per_launch": round(tot / n), "algorithmic_bytes_per_launch":
-            round(sum(c * t[k]["algorithmic_bytes"] for k, c in FWD_GEMM_MIX.items()) / n),
+        alg += cnt * t[name]["algorithmic_bytes"]
+    for name, (src, scale, cnt) in FWD_GEMM_MIX_SCALED.items():
+        tot += cnt * scale * (t[src]["fetch_bytes"] + t[src]["write_bytes"])
+        alg += cnt * scale * t[src]["algorithmic_bytes"]
+    for M, N, K, cnt in FWD_GEMM_MIX_SMALL:
+        b = 2.0 * (M * K + N * K + M * N)
+        tot += cnt * b
+        alg += cnt * b
+    n = FWD_GEMM_LAUNCHES
+    return {"bytes_per_launch": round(tot / n), "algorithmic_bytes_per_launch": round(alg / n), "launches": n,
             "source": os.path.basename(files[-1])}
 
 
@@ -249,6 +267,68 @@ def relaunch(args):
 
 class Ctx:
     pass
+
+
+def preflight(world, rank, device, backend, use_dist):
+    """`bench.py --gpus N --preflight`: the collectives of the N > 1 path (parallel.py: one all-gather of [n, 2E], one
+    reduce-scatter, 64 MiB gradient buckets), each on its own, each timed, each inside its own try -- a first 8-GPU run that fails
+    reports the stage it failed in (`failed_at`) instead of a stack from inside a training step.  No model, no kernels of this library."""
+    import torch.distributed as dist
+    res = {"preflight": True, "rccl_ranks": world if use_dist else 0, "collective_backend": backend if use_dist else None,
+           "device": torch.cuda.get_device_name(device), "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+           "stages": {}, "failed_at": None}
+
+    def timed(name, fn, reps=5):
+        if res["failed_at"]:
+            return
+        try:
+            fn()                                                  # first call: communicator / channel set-up
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            res["stages"][name] = {"ms": round((time.perf_counter() - t0) / reps * 1e3, 4)}
+        except Exception as e:      # noqa: BLE001 -- the point of the preflight is to name the failing stage
+            res["failed_at"] = name
+            res["error"] = "%s: %s" % (type(e).__name__, str(e)[:500])
+
+    n, e2 = 1024, 1024                                            # [n, 2E] bf16-free: float32 embeddings, 4 MiB per rank
+    mine = torch.randn(n, e2, device=device)
+    if use_dist and world > 1:
+        gathered = torch.empty(world * n, e2, device=device)
+        timed("all_gather_4MiB", lambda: dist.all_gather_into_tensor(gathered, mine))
+        if not res["failed_at"]:
+            ok = bool(torch.equal(gathered[rank * n:(rank + 1) * n], mine))
+            res["stages"]["all_gather_4MiB"]["own_rows_intact"] = ok
+        back = torch.empty(n, e2, device=device)
+        if backend == "gloo":
+            timed("reduce_scatter_4MiB(all_reduce on gloo)", lambda: dist.all_reduce(gathered))
+        else:
+            timed("reduce_scatter_4MiB", lambda: dist.reduce_scatter_tensor(back, gathered, op=dist.ReduceOp.SUM))
+        bucket = torch.ones(16 << 20, device=device)              # one 64 MiB float32 gradient bucket
+        timed("all_reduce_64MiB", lambda: dist.all_reduce(bucket, op=dist.ReduceOp.SUM))
+        if not res["failed_at"]:
+            st = res["stages"]["all_reduce_64MiB"]
+            st["bus_gbps"] = round(2 * (world - 1) / world * 64 * 2 ** 20 / (st["ms"] * 1e-3) / 1e9, 1)
+            torch.cuda.synchronize()
+            res["stages"]["all_reduce_64MiB"]["finite"] = bool(torch.isfinite(bucket[:16]).all())
+        timed("barrier", lambda: dist.barrier(), reps=3)
+    else:
+        res["note"] = "world size 1: nothing to exchange (run with --gpus N, N > 1)"
+    ok = torch.tensor([0 if res["failed_at"] else 1], device=device)
+    if use_dist and world > 1 and not res["failed_at"]:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    res["all_ranks_ok"] = bool(int(ok.item()))
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if use_dist:
+        try:
+            dist.destroy_process_group()
+        except Exception:      # noqa: BLE001
+            pass
 
 
 class Telemetry:
@@ -608,6 +688,9 @@ def main():
     ap.add_argument("--launcher", action="store_true", help="self-launch under torch.distributed.run even for --gpus 1")
     ap.add_argument("--sustained-steps", type=int, default=300,
                     help="steps of the `sustained` leg of the headline and padded-text workloads (0: off; also capped at 20 s each)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="N > 1 only: initialise RCCL, time one all-gather (4 MiB), one reduce-scatter and one 64 MiB all-reduce, print ONE "
+                         "JSON line with the per-collective times and exit -- so that a first multi-GPU run that fails says WHERE")
     ap.add_argument("--text-dropout", type=float, default=0.0,
                     help="BERT hidden / attention dropout probability and train() mode (reference default 0.1; BASELINE runs 0)")
     args = ap.parse_args()
@@ -645,6 +728,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)   # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend=backend)
+
+    if args.preflight:
+        preflight(world, rank, device, backend, use_dist)
+        return
 
     from easynlp_amd import lib as L
     if os.environ.get("EZCLIP_NO_LNFOLD"):      # A/B switch: separate LayerNorm kernels in the inference path too
@@ -714,6 +801,15 @@ def main():
                 out[k] = head[k]
         if also:
             out["also"] = also
+        # The reference-shaped forward, at top level beside `value`: `value` lets the text tower skip padded positions
+        # (same embeddings); `value_padded_text` feeds every padded position through it, as the reference does.  Both are measured.
+        pt = also.get("bf16_b1024_fwd_loss_padded_text") if args.workload == "bf16_b1024_fwd_loss" else None
+        if pt and "value" in pt:
+            out["value_padded_text"] = pt["value"]
+            out["ms_per_step_padded_text"] = pt["ms_per_step"]
+            out["model_mfma_frac_padded_text"] = pt.get("model_mfma_frac")
+            out["value_note"] = ("value: text tower over the unmasked tokens only (packed rows, same embeddings); value_padded_text: every padded "
+                                 "position goes through the text tower, the reference's shape of the work; model_mfma_frac* count EXECUTED flops")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -739,6 +739,11 @@ class CLIPApp(Application):
         self.contrastive_scope = str(kwargs.get("contrastive_scope", udp.get("contrastive_scope", "local")))
         if self.contrastive_scope not in ("local", "global"):
             raise L.EzclipError("contrastive_scope must be 'local' or 'global', got %r" % self.contrastive_scope)
+        # contrastive_scope='global' only: also return this rank's own [n, n] logits block in the training forward's dict (for
+        # logging; DETACHED -- the gradient flows through `loss`, unlike the reference's differentiable logits_per_text).  It
+        # costs one extra [n, n, E] f32 product per step that the loss does not use: user_defined_parameters
+        # global_scope_logits=0 drops it (the dict then carries None under both logits keys).
+        self.global_scope_logits = bool(int(kwargs.get("global_scope_logits", udp.get("global_scope_logits", 1))))
         self._engine = None
         self._params: Dict[str, nn.Parameter] = {}
         # image tower on the current stream, text tower on a second one (they meet at the similarity): on by default,
@@ -947,8 +952,11 @@ class CLIPApp(Application):
                     p.copy_(torch.randn(p.shape, generator=g, device=device) * std)
             if app._rn is not None:
                 # ModifiedResNet tower (CHINESE_CLIP.initialize_parameters, modeling_chineseclip.py:323-334): attnpool projections
-                # N(0, in_features^-0.5), every bn3 gain zero; convolutions at fan-in scale (nn.Conv2d's default has that variance),
-                # attnpool.positional_embedding randn / sqrt(embed) (:62), BatchNorm gains / statistics at their defaults (_build).
+                # N(0, in_features^-0.5), every bn3 gain zero; convolutions drawn uniform(-fan_in^-0.5, fan_in^-0.5) -- nn.Conv2d's default
+                # kaiming_uniform(a = sqrt 5), variance 1 / (3 fan_in) -- attnpool.positional_embedding randn / sqrt(embed) (:62),
+                # BatchNorm gains / statistics at their defaults (_build).  Deviation kept: the attnpool BIASES are zero here, the
+                # reference leaves nn.Linear's uniform(-in^-0.5, in^-0.5) default.  from_config only (bench / smoke): a checkpoint
+                # load overwrites all of it.
                 both = dict(app.chinese_clip.named_parameters())
                 attn_std = None
                 for n in app._rn.names:
@@ -967,7 +975,8 @@ class CLIPApp(Application):
                     elif n == "visual.attnpool.positional_embedding":
                         p.copy_(torch.randn(p.shape, generator=g, device=device) * (p.shape[1] ** -0.5))
                     elif p.dim() == 4:
-                        p.copy_(torch.randn(p.shape, generator=g, device=device) * ((p.shape[1] * p.shape[2] * p.shape[3]) ** -0.5))
+                        bound = (p.shape[1] * p.shape[2] * p.shape[3]) ** -0.5
+                        p.copy_((torch.rand(p.shape, generator=g, device=device) * 2.0 - 1.0) * bound)
                     else:
                         p.copy_(torch.randn(p.shape, generator=g, device=device) * (p.shape[-1] ** -0.5))
                 app._rn.mark_dirty()
@@ -1246,9 +1255,11 @@ class CLIPApp(Application):
             # the gradient flows through `loss` (round 4; rounds 2-3 returned None here, which broke callers that read the logits)
             eng = self._engine
             loss = _GlobalInfoNCEFn.apply(lambda *a: fused_infonce_shard(eng, *a), None, text_embeds, image_embeds, self.logit_scale)
-            with torch.no_grad():
-                local_logits = _SimilarityFn.apply(text_embeds.detach(), image_embeds.detach(), self.logit_scale.detach())
-            return {"loss": loss, "logits_per_text": local_logits, "logits_per_image": local_logits.T,
+            local_logits = None
+            if self.global_scope_logits:
+                with torch.no_grad():
+                    local_logits = _SimilarityFn.apply(text_embeds.detach(), image_embeds.detach(), self.logit_scale.detach())
+            return {"loss": loss, "logits_per_text": local_logits, "logits_per_image": None if local_logits is None else local_logits.T,
                     "image_embeds": image_embeds, "text_embeds": text_embeds}
         logits_per_text = _SimilarityFn.apply(text_embeds, image_embeds, self.logit_scale)
         logits_per_image = logits_per_text.T

@@ -309,6 +309,35 @@ __global__ __launch_bounds__(576) void attn_fwd_short_kernel(AttnArgs a, int nt)
       }
       pk[dt][j][0] = lo[0]; pk[dt][j][1] = lo[1]; pk[dt][j][2] = hi[0]; pk[dt][j][3] = hi[1];
     }
+  // Round 5 (profiles/r5_attention_fullline_ab.log): the register-layout stores below cover 32 rows x 32 bytes per wave instruction -- every
+  // 128-byte line of the output in FOUR pieces, from lanes that are not neighbours, and the write path merges neighbouring lanes only.
+  // With a.fullline_store the wave's 32 x 64 tile goes through its own 4 KiB of the (dead) K image -- after a barrier: every wave reads
+  // every K tile -- and leaves as 8 full rows per store instruction: ViT-B/16 0.346 -> 0.333 ms, BERT (64 tokens) 0.090 -> 0.082 ms per
+  // layer.  The barrier costs more than the lines win once nine waves wait for each other (257 tokens: 0.400 -> 0.45 ms), so the
+  // launcher sets the flag for <= 7 key tiles only.
+  if (a.fullline_store) {               // (uniform: a property of the launch; waves that returned early do not count at the barrier)
+    __syncthreads();
+    char* tile = kimg + qb * 4096;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t cidx = (uint32_t)(4 * dt + 2 * j + h);
+        *reinterpret_cast<uint4*>(tile + l31 * 128 + ((cidx ^ (uint32_t)(l31 & 7)) << 4)) =
+            make_uint4(pk[dt][j][0], pk[dt][j][1], pk[dt][j][2], pk[dt][j][3]);
+      }
+    // (wave-private tile: the wave's own ds_write / ds_read are ordered by lgkmcnt, no barrier)
+    const int cr = lane >> 3, cc = lane & 7;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int r = ps * 8 + cr;
+      const uint4 v = *reinterpret_cast<const uint4*>(tile + r * 128 + (((uint32_t)cc ^ (uint32_t)(r & 7)) << 4));
+      const int qq = qb * 32 + r;
+      if (qq < L) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.ctx) + (row0 + qq) * a.ctx_stride + head * 64 + cc * 8) = v;
+    }
+    if (q < L && a.lse != nullptr && h == 0) a.lse[((int64_t)b * a.H + head) * a.L + q] = m * 0.6931471805599453f + logf(l);
+    return;
+  }
   if (q < L) {
     bf16_t* cp = reinterpret_cast<bf16_t*>(a.ctx) + (row0 + q) * a.ctx_stride + head * 64;
     if ((a.ctx_stride & 7) == 0 && ((uintptr_t)a.ctx & 15) == 0) {
@@ -338,14 +367,15 @@ bool attention_short_fwd_eligible(const AttnArgs& a, int dtype) {   // forward: 
   return dtype == EZCLIP_BF16 && a.L <= 288 && a.B <= 65535;
 }
 
-static int g_attn_short_tail = 3;      // ezclip_debug_set(9, v): bit 0 short last tile, bit 1 row sums on the matrix pipe (A/B)
-void set_attention_short_tail(int v) { g_attn_short_tail = v & 3; }
+static int g_attn_short_tail = 3;      // ezclip_debug_set(9, v): bit 0 short last tile, bit 1 row sums on the matrix pipe, bit 2 NO full-line stores (A/B)
+void set_attention_short_tail(int v) { g_attn_short_tail = v & 7; }
 
 int attention_fwd_short(const AttnArgs& a_in, hipStream_t stream) {
   AttnArgs a = a_in;
   a.short_tail = g_attn_short_tail & 1;
   a.mfma_rowsum = (g_attn_short_tail >> 1) & 1;
   const int nt = (a.L + 31) / 32;
+  a.fullline_store = (g_attn_short_tail >> 2 & 1) == 0 && nt <= 7 && (a.ctx_stride & 7) == 0 && ((uintptr_t)a.ctx & 15) == 0;
   const int bytes = nt * (2 * 32 * 128 + 32 * 4);
   static LdsOptIn lds_opt[8];
   const int kbi = (a.key_bias != nullptr ? 1 : 0) + (a.causal ? 2 : 0) + (a.drop.thr != 0 ? 4 : 0);

@@ -317,18 +317,29 @@ int ezclip_set_backward_progress(ezclip_handle h, ezclip_progress_fn fn, void* u
 
 // Progress of a backward pass: the legacy host callback (ezclip_set_backward_progress) and / or the event log
 // (ezclip_backward_progress_events): one hipEventRecord on the stream that has just been given the group's last kernel.  The
-// pool holds as many events as a pass has groups (<= 2 x (layers + 2)); an event is re-recorded only after the caller has
-// drained the item that referred to it (drain resets the cursor), and a failed create / record drops the item rather than the pass.
+// events come from a ring of at most kProgressRing (a pass has <= 2 x (layers + 2) groups, far fewer): the cursor wraps, so a
+// caller that drains every step without re-arming the log does not grow the pool, and an event is re-recorded only after
+// kProgressRing later records -- long after the drained item that referred to it has been waited on.  An undrained log is
+// capped at the ring's size too.  A dropped item (event create / record failed, log full) is reported through the thread's
+// error message: the pass itself goes on, the caller sees the group missing from the drain.
+static constexpr size_t kProgressRing = 256;
 void ezclip_model::progress(int tower, int stage, hipStream_t stream) const {
   if (progress_fn) progress_fn(progress_user, tower, stage);
   if (!progress_log) return;
+  if (progress_items.size() >= kProgressRing) {
+    set_error("backward progress log full (%zu undrained items): group (%d, %d) dropped -- drain after every pass", progress_items.size(), tower, stage);
+    return;
+  }
+  if (progress_next >= kProgressRing) progress_next = 0;
   if (progress_next >= progress_pool.size()) {
     hipEvent_t ev = nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return;
+    const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) { set_error("backward progress: hipEventCreate failed (%s): group (%d, %d) dropped", hipGetErrorString(e), tower, stage); return; }
     progress_pool.push_back(ev);
   }
   hipEvent_t ev = progress_pool[progress_next];
-  if (hipEventRecord(ev, stream) != hipSuccess) return;
+  const hipError_t e = hipEventRecord(ev, stream);
+  if (e != hipSuccess) { set_error("backward progress: hipEventRecord failed (%s): group (%d, %d) dropped", hipGetErrorString(e), tower, stage); return; }
   ++progress_next;
   progress_items.push_back(ProgressItem{tower, stage, ev});
 }
@@ -351,7 +362,7 @@ int ezclip_backward_progress_drain(ezclip_handle h, int* towers, int* stages, vo
     events[i] = (void*)h->progress_items[i].ev;
   }
   *n_items = n;
-  h->progress_items.clear();      // (the events stay valid -- and un-recorded again -- until ezclip_backward_progress_events(h, 1) rearms the log)
+  h->progress_items.clear();      // (the events stay valid and un-re-recorded for the next kProgressRing - n records: the ring's cursor is NOT reset here)
   return EZ_OK;
 }
 

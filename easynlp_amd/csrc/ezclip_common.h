@@ -253,6 +253,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 namespace ezclip {
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
+int launch_check(const char* file, int line);      // EZ_LAUNCH_CHECK (model.hip; EZCLIP_SYNC_LAUNCHES=1|2: synchronise after every launch)
 }  // namespace ezclip
 
 #define EZ_HIP(expr)                                                   \
@@ -261,7 +262,11 @@ int check_hip(hipError_t e, const char* what);
     if (_rc != EZ_OK) return _rc;                                      \
   } while (0)
 
-#define EZ_LAUNCH_CHECK() EZ_HIP(hipGetLastError())
+#define EZ_LAUNCH_CHECK()                                              \
+  do {                                                                 \
+    int _rc = ::ezclip::launch_check(__FILE__, __LINE__);              \
+    if (_rc != EZ_OK) return _rc;                                      \
+  } while (0)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE).  Every launcher that needs more than the default
 // 64 KiB keeps one LdsOptIn per kernel instantiation: the largest size already granted per device, read and written atomically

@@ -412,7 +412,7 @@ bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype) {
 int g_gemm8p_ablate = 0;
 void set_gemm8p_ablate(int v) { g_gemm8p_ablate = v; }
 #ifndef EZ_RASTER_GM_DEFAULT
-#define EZ_RASTER_GM_DEFAULT 0
+#define EZ_RASTER_GM_DEFAULT 106      // super-columns of 6 tile columns (gemm8p_nt.h tile_origin); identical to n-fastest order for N <= 1536
 #endif
 int g_gemm8p_raster = EZ_RASTER_GM_DEFAULT;
 void set_gemm_raster(int gm) { g_gemm8p_raster = gm < 0 ? EZ_RASTER_GM_DEFAULT : gm; }

@@ -273,7 +273,21 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
   auto tile_origin = [&](int v, int& m0, int& n0) {
     const int t = xcd_remap(v, ntiles);
     int tm, tn;
-    if (p.raster_gm > 0) {
+    if (p.raster_gm >= 100) {
+      // SUPER-COLUMN order (round 5, the default for N >= 2304: gemm8p.hip): the logical order is [super-column of w tile columns]
+      // [tile row][column inside it], and xcd_remap hands every XCD one contiguous eighth of it -- an XCD stays inside ONE super-column
+      // for (almost) its whole walk, so the w B panels it needs (w x 256 x K x 2 bytes: 2.4 MB at w = 6, K = 768) stay resident in its
+      // 4 MiB L2 while the A row panels stream through once per super-column.  n-fastest order needs ALL tiles_n B panels per 32-tile
+      // round (4.7 MB at N = 3072: they do not fit, and are re-fetched through the fabric every round -- the 1.9-2.4 x traffic of the
+      // N >= 2304 products in profiles/r4_gemm_traffic.json).  w = 6: vit.qkv 0.612 -> 0.603 ms, vit.fc 0.888 -> 0.871 ms, forward step
+      // +0.7 % (profiles/r5_gemm_supercolumn.log); w = 3 and w = 4 lose (A is then fetched by 3-4 groups of XCDs).
+      const int w = p.raster_gm - 100;
+      const int per = tiles_m * w;
+      const int sc = t / per, u = t - sc * per;
+      const int wsz = min(w, tiles_n - sc * w);
+      tm = u / wsz;
+      tn = sc * w + (u - tm * wsz);
+    } else if (p.raster_gm > 0) {
       const int per = p.raster_gm * tiles_n;
       const int grp = t / per, u = t - grp * per;
       const int first = grp * p.raster_gm;

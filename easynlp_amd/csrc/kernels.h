@@ -48,7 +48,7 @@ struct GemmArgs {
   int act = 0;                                // ezclip::Act
   int out_f32 = 0;                            // bf16 inputs, f32 output
   int vec_ok = 0;                             // (set by the launcher)
-  int raster_gm = 0;                          // (set by the 8-phase launcher) tile order: 0 n-fastest; g > 0: super-rows of g row tiles, m-fastest inside
+  int raster_gm = 0;                          // (set by the 8-phase launcher) tile order: 0 n-fastest; 0 < g < 100: super-rows of g row tiles, m-fastest inside; 100 + w: super-columns of w tile columns
 };
 // Fused retrieval ranks (f32, 128x128 kernel; CLIPEvaluator's sort loop, appzoo/clip/evaluator.py:47-67): the similarity tile is
 // compared in registers, nothing is written to C.  Query row m of this call is query i = rank_row0 + m of the whole set, its paired
@@ -115,6 +115,7 @@ struct AttnArgs {
   int drop_L = 0;
   int short_tail = 1;             // (set by attention_fwd_short) short epilogue for a last key tile of <= 8 keys
   int mfma_rowsum = 1;            // (set by attention_fwd_short) plain kernel: row sums of P as an MFMA product with ones
+  int fullline_store = 0;         // (set by attention_fwd_short) output rows leave as full 128-byte lines through the dead K image
 };
 int attention_fwd(const AttnArgs& a, int dtype, hipStream_t stream);
 // one query per sample (the CLS row of the last block): q_cls [B, q_stride], ctx_cls [B, ctx_stride]; k / v / key_bias of `a`

@@ -39,6 +39,22 @@ int check_hip(hipError_t e, const char* what) {
   return EZ_ERR_HIP;
 }
 
+// EZ_LAUNCH_CHECK(): hipGetLastError() after every kernel launch of the library.  EZCLIP_SYNC_LAUNCHES=1 in the environment turns
+// each of them into a device-wide synchronise as well, so that an asynchronous failure is reported by the launch that caused it
+// (file:line in the message) instead of by some later call; =2 also prints the site to stderr BEFORE waiting -- a memory access
+// fault aborts the process inside the runtime, and the last line printed names the kernel.  Debugging only (serialises everything).
+int launch_check(const char* file, int line) {
+  static const int mode = [] { const char* e = getenv("EZCLIP_SYNC_LAUNCHES"); return e ? atoi(e) : 0; }();
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && mode > 0) {
+    if (mode > 1) { fprintf(stderr, "[ezclip] launch %s:%d\n", file, line); fflush(stderr); }
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) return EZ_OK;
+  set_error("HIP error %d (%s) after the kernel launch at %s:%d", (int)e, hipGetErrorString(e), file, line);
+  return EZ_ERR_HIP;
+}
+
 // ------------------------------------------------------------------ arena ---
 namespace {
 

@@ -43,12 +43,13 @@ def scatter_embedding_grads(d_img_all: torch.Tensor, d_txt_all: torch.Tensor, n_
     e = d_img_all.shape[1]
     both = torch.cat([d_img_all, d_txt_all], dim=1).contiguous()
     mine = torch.empty((n_local, 2 * e), dtype=both.dtype, device=both.device)
-    try:
-        dist.reduce_scatter_tensor(mine, both, op=dist.ReduceOp.SUM, group=group)
-    except (RuntimeError, NotImplementedError):
-        # backends without reduce-scatter (gloo): all-reduce and keep the local slice
+    if dist.get_backend(group) == "gloo":
+        # gloo (the CPU tests) has no reduce-scatter: all-reduce and keep the local slice.  Decided by the backend's NAME, not
+        # by catching an exception: an RCCL error must surface as an RCCL error, not as a silent all-reduce
         dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
         mine = both[rank * n_local:(rank + 1) * n_local].clone()
+    else:
+        dist.reduce_scatter_tensor(mine, both, op=dist.ReduceOp.SUM, group=group)
     return mine[:, :e].contiguous(), mine[:, e:].contiguous()
 
 
@@ -264,7 +265,10 @@ class OverlappedGradReducer:
             wait = lambda ev=ev: torch.cuda.current_stream().wait_event(ev)     # noqa: E731
         self._done[(tower, stage)] = wait
         end = self._frontier()
-        if (end - self._sent) * 4 >= self.bucket_bytes:
+        # bucket_bytes counts bytes ON THE WIRE: with bf16 buckets an element is 2 bytes there, so a bucket holds twice the
+        # elements and the number of collectives stays what bucket_bytes asks for
+        wire = 4 if self.bucket_dtype is None else torch.empty((), dtype=self.bucket_dtype).element_size()
+        if (end - self._sent) * wire >= self.bucket_bytes:
             self._launch(end)
 
     def finish(self) -> None:
@@ -275,7 +279,13 @@ class OverlappedGradReducer:
                 if w is not None:
                     w.wait()
             self._works = []
-            raise RuntimeError("a gradient bucket could not be launched from the backward progress hook") from err
+            # the buckets that did go out are complete sums: copy them back so the arena is not left half bf16-staged, and
+            # drop the staging list (the arena still mixes reduced and unreduced groups: the step must be abandoned)
+            for piece, staged in self._staged:
+                piece.copy_(staged)
+            self._staged = []
+            raise RuntimeError("a gradient bucket could not be launched from the backward progress hook; the arena holds a mix "
+                               "of reduced and unreduced gradients -- discard this step") from err
         self._launch(self.arena.total)
         for w in self._works:
             if w is not None:

@@ -315,7 +315,10 @@ int ezclip_set_backward_progress(ezclip_handle h, ezclip_progress_fn fn, void* u
  * -- its kernels are merely enqueued; the host runs tens of milliseconds ahead of the device -- the caller drains the list and
  * orders its collective behind each event (ezclip_stream_wait_event, or hipStreamWaitEvent on the handle it was given: the
  * events are plain hipEvent_t).  ezclip_backward_progress_events(h, 1) (re)arms the log and recycles the events: call it once
- * per training step, before the backward calls; (h, 0) switches it off.  Drained events stay valid until the next rearm.
+ * per training step, before the backward calls; (h, 0) switches it off.  The events come from a ring of 256 owned by the
+ * handle: a drained event stays un-re-recorded until 256 later groups have been logged (several passes), whether or not the
+ * log is re-armed in between, and a log that is never drained stops at 256 items (further groups are dropped, with the
+ * thread's error message set; so is a group whose event could not be created or recorded).
  * max_items: room in the three arrays (a pass logs at most layers + 2 groups per tower). */
 int ezclip_backward_progress_events(ezclip_handle h, int enable);
 int ezclip_backward_progress_drain(ezclip_handle h, int* towers, int* stages, void** events, int max_items, int* n_items);

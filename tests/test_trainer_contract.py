@@ -21,6 +21,8 @@ from oracle import ref_harness as R
 _SCRIPT = r'''
 import sys, os, json
 ROOT, WORK, FLAVOUR = sys.argv[1], sys.argv[2], sys.argv[3]
+AMP = FLAVOUR.endswith("+amp")          # --use_amp (trainer.py:57-62 GradScaler, :297-299 autocast, :327-329, :658-659)
+FLAVOUR = FLAVOUR.split("+")[0]
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from oracle import ref_harness as R, clip_oracle as O, preprocess_oracle as P
@@ -89,10 +91,11 @@ sys.argv = ["x", "--mode", "train", "--tables", tsv + "," + tsv, "--input_schema
             "--learning_rate", "1e-4", "--epoch_num", "1", "--random_seed", "42", "--save_checkpoint_steps", "2",
             "--sequence_length", "20", "--micro_batch_size", "3" if FLAVOUR in ("wukong", "text2video") else "4",
             "--app_name", {"wukong": "wukong_clip", "text2video": "clip4clip"}.get(FLAVOUR, "clip"), "--worker_gpu", "0",
-            "--user_defined_parameters", "pretrain_model_name_or_path=" + ck]
+            "--user_defined_parameters", "pretrain_model_name_or_path=" + ck] + (["--use_amp"] if AMP else [])
 from easynlp.utils import initialize_easynlp
 args = initialize_easynlp()
 from easynlp.core.trainer import Trainer
+assert bool(args.use_amp) == AMP
 SCHEMA = dict(input_schema="text:str:1,image:str:1", first_sequence="text", second_sequence="image")
 
 SCORES = {}
@@ -100,6 +103,7 @@ def train(app, ds, out, evaluator):
     args.checkpoint_dir = out
     os.makedirs(out, exist_ok=True)
     tr = Trainer(model=app, train_dataset=ds, evaluator=evaluator)
+    assert hasattr(tr, "_scaler") == AMP          # (on this CPU the scaler and autocast are constructed and disable themselves)
     torch.manual_seed(123)                       # the RandomSampler draws its permutation from the global generator
     tr.train()                                   # evaluates at step 2 and saves the best checkpoint itself (trainer.py:367-384)
     SCORES[out] = (evaluator.best_valid_score, os.path.exists(os.path.join(out, "pytorch_model.bin")))
@@ -204,7 +208,7 @@ print("RESULT " + json.dumps({"files_equal": fa == fb, "files": fa, "keys_equal"
 
 
 @pytest.mark.skipif(not R.reference_available(), reason="reference checkout not present")
-@pytest.mark.parametrize("flavour", ["chinese_clip", "huggingface_clip", "open_clip", "wukong", "text2video"])
+@pytest.mark.parametrize("flavour", ["chinese_clip", "chinese_clip+amp", "huggingface_clip", "open_clip", "wukong", "text2video"])
 def test_reference_trainer_trains_the_dropin_like_the_reference(tmp_path, flavour):
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

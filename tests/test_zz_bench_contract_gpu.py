@@ -65,6 +65,8 @@ def test_bench_prints_one_contract_line():
         # (the AdamW workload has already moved the weights by the time its timed step reports a loss)
         assert abs(a["loss"] - ref) < (5e-2 if name.endswith("_opt") else 5e-3), (name, a["loss"], ref)
     assert out["also"]["bf16_b1024_train_autograd"]["path"] == "autograd"
+    # the reference-shaped forward (every padded position through the text tower) at top level, beside `value`
+    assert out["value_padded_text"] == out["also"]["bf16_b1024_fwd_loss_padded_text"]["value"] and "value_note" in out
     # the `sustained` block (round 4): the same step for N more steps, with the clock / power the chip ran at -- in the headline and
     # in the padded-text workload
     for blk in (out["sustained"], out["also"]["bf16_b1024_fwd_loss_padded_text"]["sustained"]):
@@ -97,3 +99,16 @@ def test_bench_two_rank_code_path_dry_run_on_one_gpu():
     r = out["ms_per_step_ranks"]
     assert r["min"] <= r["max"] + 1e-9 and r["max"] == out["ms_per_step"]
     assert abs(out["loss"] - math.log(128)) < 0.3                 # this rank's rows against the 128 columns of the global batch
+
+
+def test_bench_preflight_names_the_collectives():
+    """`bench.py --gpus 2 --preflight` (round 5): process-group init, one all-gather, one reduce-scatter (an all-reduce on gloo), one
+    64 MiB all-reduce, each timed on its own, ONE JSON line -- here two ranks on this one GPU through gloo; the driver's 8-GPU box is
+    the first time it meets RCCL."""
+    env = {"EZCLIP_BENCH_ONE_GPU": "1", "EZCLIP_BENCH_BACKEND": "gloo", "EZCLIP_NO_CANARY": "1"}
+    out = _run("--gpus", "2", "--preflight", env=env)
+    assert out["preflight"] and out["rccl_ranks"] == 2 and out["failed_at"] is None and out["all_ranks_ok"], out
+    st = out["stages"]
+    assert st["all_gather_4MiB"]["ms"] > 0 and st["all_gather_4MiB"]["own_rows_intact"]
+    assert st["all_reduce_64MiB"]["ms"] > 0 and st["all_reduce_64MiB"]["finite"] and st["all_reduce_64MiB"]["bus_gbps"] > 0
+    assert any(k.startswith("reduce_scatter_4MiB") for k in st) and st["barrier"]["ms"] >= 0

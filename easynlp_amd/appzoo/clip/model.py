@@ -566,6 +566,27 @@ class _EncodeFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(out)
 
 
+class _RnEncodeFn(torch.autograd.Function):
+    """ModifiedResNet image tower in training mode: ``RnEngine.encode_image_train`` / ``backward`` (csrc/resnet.hip); the gradient
+    tensors are allocated here and WRITTEN by the library, autograd accumulates them into ``.grad``."""
+
+    @staticmethod
+    def forward(ctx, app, pixels, names, *params):
+        out = app._rn.encode_image_train(pixels)
+        ctx.app, ctx.names = app, names
+        ctx.need = [p.requires_grad for p in params]
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (out,) = ctx.saved_tensors
+        rn = ctx.app._rn
+        grads = {n: torch.empty(rn.shapes[n], dtype=torch.float32, device=out.device) for n in ctx.names}
+        rn.backward(out, d_out, grads)
+        return (None, None, None) + tuple(grads[n] if need else None for n, need in zip(ctx.names, ctx.need))
+
+
 class _SimilarityFn(torch.autograd.Function):
     """logits_per_text = T @ I^T * exp(logit_scale)  (model.py:148) on the f32 MFMA GEMM."""
 
@@ -751,6 +772,10 @@ class CLIPApp(Application):
         self.two_streams = str(kwargs.get("two_streams", udp.get("clip_two_streams", os.environ.get("EZCLIP_TWO_STREAMS", "1")))) \
             not in ("0", "False", "false")
         self._pack_text_opt = kwargs.get("pack_text", udp.get("clip_pack_text"))
+        # ModifiedResNet image tower: trained as the reference trains it (default since round 5: BatchNorm batch statistics and moving
+        # running statistics in train() mode, gradients for visual.*: modeling_chineseclip.py:27-167 under core/trainer.py:658-661);
+        # 'clip_rn_train=0' = a frozen, eval-mode tower (LiT-style tuning of the text tower; the behaviour of rounds 3-4)
+        self.rn_train = str(kwargs.get("rn_train", udp.get("clip_rn_train", "1"))) not in ("0", "False", "false")
         if pretrained_model_name_or_path is None:
             return
         path = pretrained_model_name_or_path
@@ -844,8 +869,8 @@ class CLIPApp(Application):
             eng.pack_text = str(self._pack_text_opt) not in ("0", "False", "false")
         named = dict(tree.named_parameters())
         self._params = {n: named[n] for n in eng.names}
-        if self._rn is not None:
-            for n in self._rn.names:                                    # frozen tower: no backward pass exists for it
+        if self._rn is not None and not getattr(self, "rn_train", False):
+            for n in self._rn.names:                                    # 'clip_rn_train=0': frozen tower
                 if n in named:
                     named[n].requires_grad_(False)
 
@@ -854,7 +879,13 @@ class CLIPApp(Application):
         ``.cuda()`` REPLACE a module's buffers (the BatchNorm statistics), so references taken at construction go stale."""
         both = dict(self.chinese_clip.named_parameters())
         both.update(self.chinese_clip.named_buffers())
-        self._rn.sync({n: both[n] for n in self._rn.names})
+        tensors = {n: both[n] for n in self._rn.names}
+        if getattr(self, "rn_train", False) and self.training:
+            # the reference module in train() mode: batch statistics, running statistics moved, autograd through the tower
+            names = [n for n in self._rn.names if not self._rn.is_statistic(n)]
+            self._rn.sync_train(tensors)
+            return _RnEncodeFn.apply(self, pixel_values, names, *[tensors[n] for n in names])
+        self._rn.sync(tensors)
         with torch.no_grad():
             return self._rn.encode_image(pixel_values)
 
@@ -918,11 +949,11 @@ class CLIPApp(Application):
         return super().load_state_dict(state_dict, strict=strict, **kwargs)
 
     @classmethod
-    def from_config(cls, config: dict, seed: int = 0, device="cuda", compute_dtype="bf16"):
+    def from_config(cls, config: dict, seed: int = 0, device="cuda", compute_dtype="bf16", **kwargs):
         """Random-init model of a given architecture directly on the device (benchmarks,
         smoke tests): reference-like init scales (VisualTransformer.__init__
         modeling_chineseclip.py:226-234, BertPreTrainedModel._init_weights modeling_bert.py:624-638)."""
-        app = cls(None, compute_dtype=compute_dtype)
+        app = cls(None, compute_dtype=compute_dtype, **kwargs)
         app.raw_config = dict(config)
         app.model_type = "chinese_clip"
         app.config = Config_Wrapper(app.raw_config)
@@ -1032,7 +1063,7 @@ class CLIPApp(Application):
         lib = eng.lib
         if getattr(self, "_rn", None) is not None:
             raise L.EzclipError("contrastive_step drives the ViT image tower; a ModifiedResNet model goes through forward() / "
-                                "compute_loss() (frozen image tower, the text tower trains)")
+                                "compute_loss() / backward() (the autograd path the reference Trainer drives)")
         hf = getattr(self, "model_type", None) == "huggingface_clip"
         extras, transposed = None, []
         pixel_values = pixel_values.contiguous()

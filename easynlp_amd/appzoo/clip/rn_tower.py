@@ -93,3 +93,53 @@ class RnEngine:
         L.check(self.lib.ezclip_rn_encode_image(self.handle, L.ptr(pixels), B, L.ptr(out), L.ptr(ws), ws.numel(),
                                                 L.stream_ptr(stream)), "rn_encode_image")
         return out
+
+    # ---- training path (BatchNorm batch statistics, backward pass) -------------------------------------------------------------
+    def sync_train(self, tensors: Dict[str, torch.Tensor]) -> None:
+        """``sync`` + the unfolded / input-gradient copies of the training path (re-packed whenever a parameter changed)"""
+        before = self._sig
+        self.sync(tensors)
+        dev = tensors[self.names[0]].device
+        if getattr(self, "_tshadow", None) is None or self._tshadow.device != dev:
+            self._tshadow = L.alloc_bytes(self.lib.ezclip_rn_train_shadow_bytes(self.handle), dev)
+            L.check(self.lib.ezclip_rn_set_train_shadow(self.handle, L.ptr(self._tshadow), self._tshadow.numel()), "rn_set_train_shadow")
+            before = None
+        if before != self._sig or not getattr(self, "_tfresh", False):
+            L.check(self.lib.ezclip_rn_refresh_train_weights(self.handle, L.stream_ptr()), "rn_refresh_train_weights")
+            self._tfresh = True
+
+    def _train_buffers(self, B: int, device):
+        key = (B, str(device))
+        if getattr(self, "_tkey", None) != key:
+            self._saved = L.alloc_bytes(self.lib.ezclip_rn_train_saved_bytes(self.handle, B), device)
+            self._scratch = L.alloc_bytes(self.lib.ezclip_rn_train_scratch_bytes(self.handle, B), device)
+            self._tkey = key
+        return self._saved, self._scratch
+
+    def encode_image_train(self, pixels: torch.Tensor) -> torch.Tensor:
+        """Forward with BatchNorm batch statistics (``module.train()`` semantics): moves the bound running statistics, keeps the
+        activations for ``backward``.  The inference copies are stale afterwards (the statistics changed): marked dirty here."""
+        pixels = pixels.contiguous().float()
+        B = pixels.shape[0]
+        if tuple(pixels.shape[1:]) != (3, self.resolution, self.resolution):
+            raise L.EzclipError("pixel_values must be [B,3,%d,%d], got %s" % (self.resolution, self.resolution, tuple(pixels.shape)))
+        saved, scratch = self._train_buffers(B, pixels.device)
+        out = torch.empty((B, self.output_dim), dtype=torch.float32, device=pixels.device)
+        L.check(self.lib.ezclip_rn_encode_image_train(self.handle, L.ptr(pixels), B, L.ptr(out), L.ptr(saved), saved.numel(), L.ptr(scratch),
+                                                      scratch.numel(), L.stream_ptr()), "rn_encode_image_train")
+        self.mark_dirty()
+        return out
+
+    def backward(self, features: torch.Tensor, d_features: torch.Tensor, grads: Dict[str, torch.Tensor]) -> None:
+        """Gradients of every parameter (float32 tensors of ``grads``, WRITTEN) for the last ``encode_image_train``"""
+        B = features.shape[0]
+        for n in self.names:
+            if self.is_statistic(n):
+                continue
+            g = grads[n]
+            if g.dtype != torch.float32 or tuple(g.shape) != self.shapes[n] or not g.is_contiguous():
+                raise L.EzclipError("ModifiedResNet gradient %s: expected contiguous float32 %s" % (n, self.shapes[n]))
+            L.check(self.lib.ezclip_rn_bind_grad(self.handle, n.encode(), L.ptr(g)), "rn_bind_grad")
+        _, scratch = self._train_buffers(B, features.device)
+        L.check(self.lib.ezclip_rn_backward(self.handle, L.ptr(features.contiguous()), L.ptr(d_features.contiguous().float()), B, L.ptr(scratch),
+                                            scratch.numel(), L.stream_ptr()), "rn_backward")

@@ -11,7 +11,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "gemm8p.hip", "gemm8p_nt_a.hip", "gemm8p_nt_b.hip", "gemm8p_nt_c.hip", "attention.hip", "attention_short.hip", "attention_short_bwd.hip", "rowops.hip", "preprocess.hip", "loss.hip", "nce.hip", "packmeta.hip", "resnet.hip", "profile.hip", "model.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "gemm8p.hip", "gemm8p_nt_a.hip", "gemm8p_nt_b.hip", "gemm8p_nt_c.hip", "attention.hip", "attention_short.hip", "attention_short_bwd.hip", "rowops.hip", "preprocess.hip", "loss.hip", "nce.hip", "packmeta.hip", "resnet.hip", "resnet_train.hip", "profile.hip", "model.hip", "capi.hip"]
 HEADERS = ["ezclip_common.h", "kernels.h", "model.h", "gemm_pipe.h", "gemm8p_nt.h", "dropout.h", "../../include/ezclip.h"]
 LIB = os.path.join(HERE, "libezclip_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

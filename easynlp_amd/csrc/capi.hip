@@ -494,6 +494,42 @@ int ezclip_recall_ranks_fused(const float* text_rows, const float* image, int ro
   return gemm_nt_rank(g, S(stream));
 }
 
+// ---- ModifiedResNet training path, operator level (tests; the tower's training orchestration will call the same functions)
+size_t ezclip_op_rn_bn_scratch_bytes(int64_t rows, int cp) { return rn_bn_scratch_bytes(rows, cp); }
+int ezclip_op_rn_bn_train_fwd(const void* z, int64_t rows, int c, int cp, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float momentum, float eps, const void* residual, int relu, void* y, float* mean,
+                              float* rstd, float* scratch, int dtype, void* stream) {
+  return rn_bn_train_fwd(z, rows, c, cp, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, y, mean, rstd, scratch, dtype,
+                         S(stream));
+}
+int ezclip_op_rn_bn_train_bwd(const void* dy, const void* y, const void* z, int64_t rows, int c, int cp, const float* gamma,
+                              const float* mean, const float* rstd, void* dz, void* dres, float* dgamma, float* dbeta, int accumulate,
+                              float* scratch, int dtype, void* stream) {
+  return rn_bn_train_bwd(dy, y, z, rows, c, cp, gamma, mean, rstd, dz, dres, dgamma, dbeta, accumulate, scratch, dtype, S(stream));
+}
+int ezclip_op_rn_avgpool2_bwd(const void* dy, int b, int h, int w, int cp, void* dx, int dtype, void* stream) {
+  return rn_avgpool2_bwd(dy, b, h, w, cp, dx, dtype, S(stream));
+}
+int ezclip_op_rn_im2col3x3(const void* x, int b, int h, int w, int cp, void* col, int dtype, void* stream) {
+  return rn_im2col3x3(x, b, h, w, cp, col, dtype, S(stream));
+}
+int ezclip_op_rn_pack_conv_dgrad(const float* w, int o, int i, int k, int opad, int ipad, void* dst, int dtype, void* stream) {
+  return rn_pack_conv_dgrad(w, o, i, k, opad, ipad, dst, dtype, S(stream));
+}
+int ezclip_op_rn_unpack_wgrad(const float* dwp, int64_t ldp, int o, int i, int k, int cp, int accumulate, float* dw, void* stream) {
+  return rn_unpack_wgrad(dwp, ldp, o, i, k, cp, accumulate, dw, S(stream));
+}
+// the implicit 3x3 convolution (pad 1, stride 1) of the tower on NHWC rows: out [b*h*w, n] = conv(x [b*h*w, cp]; wp [n][9*cp])
+int ezclip_op_conv3x3_nhwc(const void* x, int b, int h, int w, int cp, const void* wp, int n, void* out, const void* zero256, int dtype,
+                           void* stream) {
+  EZ_REQUIRE(x && wp && out && zero256 && b > 0 && h > 0 && w > 0 && cp % 64 == 0 && n % 64 == 0, "ezclip_op_conv3x3_nhwc: bad shape");
+  GemmArgs g;
+  g.A = x; g.lda = cp; g.B = wp; g.ldb = 9 * (int64_t)cp; g.C = out; g.ldc = n;
+  g.M = b * h * w; g.N = n; g.K = 9 * cp;
+  g.conv_H = h; g.conv_W = w; g.conv_C = cp; g.conv_zero = zero256;
+  return gemm_nt(g, dtype, S(stream));
+}
+
 int ezclip_debug_set(int key, int value) {
   if (key == 0) { set_gemm_variant(value); return EZ_OK; }
   if (key == 1) { set_attention_variant(value); return EZ_OK; }

@@ -65,6 +65,19 @@ struct GemmRankArgs : GemmArgs {
   int32_t* rank_cols = nullptr;
 };
 int gemm_nt_rank(GemmRankArgs p, hipStream_t stream);
+// ---- ModifiedResNet training path (resnet_train.hip): row-matrix kernels on NHWC activations [rows, cp]
+size_t rn_bn_scratch_bytes(int64_t rows, int cp);
+int rn_bn_train_fwd(const void* z, int64_t rows, int C, int cp, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, const void* residual, int relu, void* y, float* mean, float* rstd,
+                    float* scratch, int dtype, hipStream_t st);
+int rn_bn_train_bwd(const void* dy, const void* y, const void* z, int64_t rows, int C, int cp, const float* gamma, const float* mean,
+                    const float* rstd, void* dz, void* dres, float* dgamma, float* dbeta, int accumulate, float* scratch, int dtype,
+                    hipStream_t st);
+int rn_avgpool2_bwd(const void* dy, int B, int H, int W, int cp, void* dx, int dtype, hipStream_t st);
+int rn_add_inplace(void* a, const void* b, int64_t n, int dtype, hipStream_t st);
+int rn_im2col3x3(const void* x, int B, int H, int W, int cp, void* col, int dtype, hipStream_t st);
+int rn_pack_conv_dgrad(const float* W, int O, int I, int k, int opad, int ipad, void* dst, int dtype, hipStream_t st);
+int rn_unpack_wgrad(const float* dwp, int64_t ldp, int O, int I, int k, int cp, int accumulate, float* dw, hipStream_t st);
 // C = act(alpha * exp(scale) * A.B^T + bias) + R
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream);
 // 256x256x64 8-phase bf16 kernel (gemm8p.hip): large M, N % 256 == 0, K % 128 == 0, bf16 output

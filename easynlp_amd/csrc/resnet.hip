@@ -15,6 +15,7 @@
 // projects keys / values for all tokens and the query for the mean token only, and runs the one-query attention kernel of the
 // towers' CLS-only last blocks (head dim 64: heads = width * 32 / 64).  Output: L2-normalised [B, output_dim] float32, as
 // ezclip_encode_image returns it (CHINESE_CLIP.forward :360).
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -139,7 +140,7 @@ using namespace ezclip;
 struct ezclip_rn {
   ezclip_rn_config cfg;
   int dtype = 0, esz = 2;
-  struct Param { std::string name; std::vector<int64_t> shape; const float* w = nullptr; };
+  struct Param { std::string name; std::vector<int64_t> shape; const float* w = nullptr; float* g = nullptr; };   // g: gradient buffer (training path)
   std::vector<Param> params;
   struct Conv {             // one convolution (+ BatchNorm) or Linear, with its packed copy
     int w = -1, bn = -1, lin_b = -1;     // param indices: weight; bn.weight (bias, running_mean, running_var follow); Linear bias
@@ -148,6 +149,17 @@ struct ezclip_rn {
     int cfirst = 0;
     void* s = nullptr;
     float* bias = nullptr;
+    // ---- training path (ezclip_rn_train_*): unfolded weight [Opad][ldk] (no BatchNorm in it), input-gradient weight
+    // [Cp][k*k*Opad] (null: the stem's first convolution, whose input is the pixels), and what the training forward saved
+    void* st = nullptr;
+    void* sd = nullptr;
+    const void* in = nullptr;            // input activation [Min, Cp] (NHWC rows) -- or the explicit im2col for the stem's first conv
+    void* z = nullptr;                   // convolution output [M, Opad]
+    void* y = nullptr;                   // after BatchNorm (+ identity) (+ ReLU) [M, Opad]
+    float* mean = nullptr;               // [Opad] batch statistics
+    float* rstd = nullptr;
+    int64_t M = 0;                       // rows of z / y
+    int H = 0;                           // spatial side of the grid the convolution runs on
   };
   Conv stem[3];
   struct Block { Conv c1, c2, c3, down; bool has_down = false; int stride = 1; };
@@ -159,6 +171,20 @@ struct ezclip_rn {
   size_t shadow_bytes = 0;
   bool fresh = false;
   void* zero = nullptr;                  // 256 zero bytes inside the shadow (padding taps of the implicit convolutions)
+  // ---- training path
+  void* tshadow = nullptr;
+  size_t tshadow_bytes = 0;
+  bool tfresh = false;
+  float* junk_bias = nullptr;            // [2048] floats the packing kernel writes its (unused) bias row to
+  struct Saved {                         // of the last training forward
+    int B = 0;
+    void* col0 = nullptr;                // stem: explicit im2col of the pixels
+    void* pool0 = nullptr;               // stem: after AvgPool2d(2)
+    std::vector<void*> o2p, idp;         // per block (flattened order): pooled conv2 output / pooled block input (stride-2 blocks)
+    void *tok = nullptr, *kk = nullptr, *vv = nullptr, *qc = nullptr, *ctx = nullptr;
+    float *feat = nullptr, *inv_norm = nullptr;
+    const void* last = nullptr;          // the tower's last activation (input of the attention pool)
+  } saved;
 };
 
 namespace {
@@ -334,6 +360,429 @@ int rn_forward_chunk(ezclip_rn* m, const float* px, int bc, float* out, char* ws
   return l2_normalize_fwd(feat, out, nullptr, bc, m->cfg.output_dim, st);
 }
 
+
+// ==== training path =================================================================================================================
+// BatchNorm in training mode and the tower's backward pass (reference: nn.BatchNorm2d.train() + autograd through Bottleneck / ModifiedResNet /
+// AttentionPool2d, modeling_chineseclip.py:27-167; the steps are those of the tests' CPU restatement, train_step_grads_by_steps).
+// The whole batch runs at once (the statistics are the batch's); every convolution output z and every activation y is kept in the SAVED
+// workspace until the backward pass has used it.  Convolutions run on unfolded packed weights, then rn_bn_train_fwd (resnet_train.hip).
+
+size_t rn_train_shadow_layout(ezclip_rn* m, char* base) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { void* p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; };
+  float* junk = (float*)take(2048 * 4);
+  if (base) m->junk_bias = junk;
+  bool first = true;
+  rn_for_each(m, [&](ezclip_rn::Conv& c) {
+    const bool conv = c.bn >= 0;
+    void* st = conv ? take((size_t)c.Opad * c.ldk * m->esz) : nullptr;                       // (Linear layers use the eval copy: no BatchNorm to unfold)
+    void* sd = (first && conv) ? nullptr : take((size_t)c.Cp * c.k * c.k * rup(c.Opad, 64) * m->esz);
+    if (base) { c.st = st; c.sd = sd; }
+    first = false;
+  });
+  return off + 256;
+}
+
+struct RnBump {                          // bump allocator over a workspace; null base: size query
+  char* base; size_t off = 0;
+  explicit RnBump(void* b) : base((char*)b) {}
+  void* take(size_t bytes) { void* p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; }
+};
+
+// bytes of the saved workspace of one training forward over B images (also the order rn_train_forward allocates in)
+template <typename F>
+void rn_train_plan(ezclip_rn* m, int B, RnBump& a, F&& on_conv) {
+  const int R = m->cfg.image_resolution;
+  const size_t e = m->esz;
+  int H = R / 2;
+  int64_t M = (int64_t)B * H * H;
+  m->saved.col0 = a.take((size_t)M * m->stem[0].ldk * e);
+  for (int i = 0; i < 3; ++i) on_conv(m->stem[i], M, H);
+  m->saved.pool0 = a.take((size_t)(M / 4) * m->stem[2].Opad * e);
+  H /= 2; M /= 4;
+  m->saved.o2p.clear(); m->saved.idp.clear();
+  for (auto& L : m->blocks)
+    for (auto& b : L) {
+      on_conv(b.c1, M, H);
+      on_conv(b.c2, M, H);
+      int64_t Mo = M; int Ho = H;
+      void *o2p = nullptr, *idp = nullptr;
+      if (b.stride > 1) {
+        Mo = M / 4; Ho = H / 2;
+        o2p = a.take((size_t)Mo * b.c2.Opad * e);
+        idp = a.take((size_t)Mo * b.c1.Cp * e);
+      }
+      m->saved.o2p.push_back(o2p); m->saved.idp.push_back(idp);
+      if (b.has_down) on_conv(b.down, Mo, Ho);
+      on_conv(b.c3, Mo, Ho);
+      M = Mo; H = Ho;
+    }
+  const int Lt = m->sp * m->sp + 1, C = m->embed;
+  m->saved.tok = a.take((size_t)B * Lt * C * e);
+  m->saved.kk = a.take((size_t)B * Lt * C * e);
+  m->saved.vv = a.take((size_t)B * Lt * C * e);
+  m->saved.qc = a.take((size_t)B * C * e);
+  m->saved.ctx = a.take((size_t)B * C * e);
+  m->saved.feat = (float*)a.take((size_t)B * m->cfg.output_dim * 4);
+  m->saved.inv_norm = (float*)a.take((size_t)B * 4);
+}
+
+size_t rn_train_saved_bytes(ezclip_rn* m, int B) {
+  RnBump a(nullptr);
+  const ezclip_rn::Saved keep = m->saved;            // (a size query between a forward and its backward must not touch what was saved)
+  rn_train_plan(m, B, a, [&](ezclip_rn::Conv& c, int64_t M, int) {
+    a.take((size_t)M * c.Opad * m->esz); a.take((size_t)M * c.Opad * m->esz); a.take((size_t)c.Opad * 4); a.take((size_t)c.Opad * 4);
+  });
+  m->saved = keep;
+  return a.off + 256;
+}
+
+// largest NHWC activation / gradient of a batch, and the largest explicit im2col of a 3x3 convolution's input
+size_t rn_train_max_act_bytes(const ezclip_rn* m, int B) { return rn_act_bytes(m, B); }
+size_t rn_train_max_col_bytes(const ezclip_rn* m, int B) {
+  const int R = m->cfg.image_resolution;
+  size_t mx = (size_t)B * (R / 2) * (R / 2) * 9 * m->stem[1].Cp;                 // stem conv2 / conv3 inputs
+  int H = R / 4;
+  for (const auto& L : m->blocks)
+    for (const auto& b : L) {
+      const size_t v = (size_t)B * H * H * 9 * b.c2.Cp;
+      if (v > mx) mx = v;
+      if (b.stride > 1) H /= 2;
+    }
+  return (mx * m->esz + 255) / 256 * 256;
+}
+constexpr int kRnTrainBufs = 6;
+// largest packed weight gradient [Opad][ldk] f32 of a CONVOLUTION (the attention pool's Linear layers write their gradients
+// straight into the bound buffers).  One function for the size query and for the backward pass: round 5's first GPU run of this
+// path faulted because the backward pass also counted the Linear layers (2048 x 2048 x 4 B at width 64) and carved more than
+// rn_train_scratch_bytes had reserved -- the BatchNorm scratch behind it then lay outside the buffer.
+size_t rn_train_wgrad_bytes(const ezclip_rn* m) {
+  size_t wg = 0;
+  auto upd = [&](const ezclip_rn::Conv& c) { const size_t v = (size_t)rup(c.Opad, 64) * c.ldk * 4; if (v > wg) wg = v; };
+  for (const auto& c : m->stem) upd(c);
+  for (const auto& L : m->blocks) for (const auto& b : L) { upd(b.c1); upd(b.c2); upd(b.c3); if (b.has_down) upd(b.down); }
+  return (wg + 255) / 256 * 256;
+}
+size_t rn_train_scratch_bytes(const ezclip_rn* m, int B) {
+  const int Lt = m->sp * m->sp + 1;
+  const size_t wg = rn_train_wgrad_bytes(m);
+  const size_t act = rn_train_max_act_bytes(m, B);
+  const size_t tokb = ((size_t)B * Lt * m->embed * m->esz + 255) / 256 * 256;
+  const size_t bn = rn_bn_scratch_bytes((int64_t)B * (m->cfg.image_resolution / 2) * (m->cfg.image_resolution / 2), 2048) + 256;
+  return kRnTrainBufs * (act > tokb ? act : tokb) + rn_train_max_col_bytes(m, B) + wg + bn + 4096;
+}
+
+// convolution on the unfolded weight: z = conv(x) (no bias, no activation)
+int rn_gemm_t(const ezclip_rn* m, const void* A, int64_t lda, int64_t M, const ezclip_rn::Conv& c, void* C, int convH, hipStream_t st) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.B = c.st; g.ldb = c.ldk; g.C = C; g.ldc = c.Opad;
+  g.M = (int)M; g.N = c.Opad; g.K = c.ldk; g.act = ACT_NONE;
+  if (convH > 0) { g.conv_H = convH; g.conv_W = convH; g.conv_C = c.Cp; g.conv_zero = m->zero; }
+  return gemm_nt(g, m->dtype, st);
+}
+
+template <typename T>
+int rn_train_forward(ezclip_rn* m, const float* px, int B, float* out, char* saved_ws, size_t saved_bytes, float* bn_scratch, hipStream_t st) {
+  const int R = m->cfg.image_resolution;
+  RnBump a(saved_ws);
+  int rc = EZ_OK;
+  // one convolution + BatchNorm(train) [+ identity] [+ ReLU]; allocates z, y, mean, rstd in plan order
+  auto conv_bn = [&](ezclip_rn::Conv& c, const void* in, int64_t lda, int64_t M, int H, int convH, const void* identity, int relu) {
+    c.in = in; c.M = M; c.H = H;
+    c.z = a.take((size_t)M * c.Opad * m->esz);
+    c.y = a.take((size_t)M * c.Opad * m->esz);
+    c.mean = (float*)a.take((size_t)c.Opad * 4);
+    c.rstd = (float*)a.take((size_t)c.Opad * 4);
+    if (rc != EZ_OK) return;
+    rc = rn_gemm_t(m, in, lda, M, c, c.z, convH, st);
+    if (rc != EZ_OK) return;
+    rc = rn_bn_train_fwd(c.z, M, c.O, c.Opad, m->params[c.bn].w, m->params[c.bn + 1].w, const_cast<float*>(m->params[c.bn + 2].w),
+                         const_cast<float*>(m->params[c.bn + 3].w), 0.1f, kBnEps, identity, relu, c.y, c.mean, c.rstd, bn_scratch, m->dtype, st);
+  };
+  // ---- the allocation order below must be rn_train_plan's
+  int H = R / 2;
+  int64_t M = (int64_t)B * H * H;
+  m->saved.B = B;
+  m->saved.col0 = a.take((size_t)M * m->stem[0].ldk * m->esz);
+  RN_TRY(launch1d(rn_stem_im2col_kernel<T>, M * m->stem[0].ldk, st, px, B, R, H, m->stem[0].ldk, (T*)m->saved.col0));
+  conv_bn(m->stem[0], m->saved.col0, m->stem[0].ldk, M, H, 0, nullptr, 1);
+  conv_bn(m->stem[1], m->stem[0].y, m->stem[0].Opad, M, H, H, nullptr, 1);
+  conv_bn(m->stem[2], m->stem[1].y, m->stem[1].Opad, M, H, H, nullptr, 1);
+  RN_TRY(rc);
+  int C = m->stem[2].Opad;
+  m->saved.pool0 = a.take((size_t)(M / 4) * C * m->esz);
+  RN_TRY(launch1d(rn_avgpool2_kernel<T>, M / 4 * (C / 4), st, (const T*)m->stem[2].y, M / 4 * (C / 4), H, H, C, (T*)m->saved.pool0));
+  H /= 2; M /= 4;
+  const void* x = m->saved.pool0;
+  m->saved.o2p.clear(); m->saved.idp.clear();
+  for (auto& L : m->blocks)
+    for (auto& b : L) {
+      conv_bn(b.c1, x, C, M, H, 0, nullptr, 1);
+      conv_bn(b.c2, b.c1.y, b.c1.Opad, M, H, H, nullptr, 1);
+      RN_TRY(rc);
+      int64_t Mo = M; int Ho = H;
+      const void* o2 = b.c2.y;
+      const void* idn = x;
+      void *o2p = nullptr, *idp = nullptr;
+      if (b.stride > 1) {
+        Mo = M / 4; Ho = H / 2;
+        const int Cm = b.c2.Opad;
+        o2p = a.take((size_t)Mo * Cm * m->esz);
+        idp = a.take((size_t)Mo * C * m->esz);
+        RN_TRY(launch1d(rn_avgpool2_kernel<T>, Mo * (Cm / 4), st, (const T*)b.c2.y, Mo * (Cm / 4), H, H, Cm, (T*)o2p));
+        RN_TRY(launch1d(rn_avgpool2_kernel<T>, Mo * (C / 4), st, (const T*)x, Mo * (C / 4), H, H, C, (T*)idp));
+        o2 = o2p; idn = idp;
+      }
+      m->saved.o2p.push_back(o2p); m->saved.idp.push_back(idp);
+      const void* identity = idn;
+      if (b.has_down) {
+        conv_bn(b.down, idn, C, Mo, Ho, 0, nullptr, 0);
+        identity = b.down.y;
+      }
+      conv_bn(b.c3, o2, b.c2.Opad, Mo, Ho, 0, identity, 1);
+      RN_TRY(rc);
+      x = b.c3.y; C = b.c3.Opad; M = Mo; H = Ho;
+    }
+  // ---- AttentionPool2d (as rn_forward_chunk, everything kept)
+  EZ_REQUIRE(H == m->sp && C == m->embed, "rn_train_forward: tower ends at %d x %d x %d, attention pool expects %d x %d x %d", H, H, C, m->sp,
+             m->sp, m->embed);
+  m->saved.last = x;
+  const int P = H * H, Lt = P + 1;
+  m->saved.tok = a.take((size_t)B * Lt * C * m->esz);
+  m->saved.kk = a.take((size_t)B * Lt * C * m->esz);
+  m->saved.vv = a.take((size_t)B * Lt * C * m->esz);
+  m->saved.qc = a.take((size_t)B * C * m->esz);
+  m->saved.ctx = a.take((size_t)B * C * m->esz);
+  m->saved.feat = (float*)a.take((size_t)B * m->cfg.output_dim * 4);
+  m->saved.inv_norm = (float*)a.take((size_t)B * 4);
+  EZ_REQUIRE(a.off <= saved_bytes, "rn_train_forward: the pass saves %zu bytes into a workspace of %zu (rn_train_plan is out of step)", a.off, saved_bytes);
+  hipLaunchKernelGGL(rn_attnpool_tokens_kernel<T>, dim3(B), dim3(256), 0, st, (const T*)x, m->params[m->pos_p].w, P, C, (T*)m->saved.tok);
+  EZ_LAUNCH_CHECK();
+  RN_TRY(rn_gemm(m, m->saved.tok, C, B * Lt, m->kproj, m->saved.kk, C, ACT_NONE, nullptr, 0, 0, 0, false, st));
+  RN_TRY(rn_gemm(m, m->saved.tok, C, B * Lt, m->vproj, m->saved.vv, C, ACT_NONE, nullptr, 0, 0, 0, false, st));
+  RN_TRY(rn_gemm(m, m->saved.tok, (int64_t)Lt * C, B, m->qproj, m->saved.qc, C, ACT_NONE, nullptr, 0, 0, 0, false, st));
+  AttnArgs at;
+  at.k = m->saved.kk; at.v = m->saved.vv; at.row_stride = C; at.B = B; at.L = Lt; at.H = m->heads; at.scale = 0.125f;
+  RN_TRY(attention_cls_fwd(at, m->saved.qc, C, m->saved.ctx, C, m->dtype, st));
+  RN_TRY(rn_gemm(m, m->saved.ctx, C, B, m->cproj, m->saved.feat, m->cfg.output_dim, ACT_NONE, nullptr, 0, 0, 0, true, st));
+  return l2_normalize_fwd(m->saved.feat, out, m->saved.inv_norm, B, m->cfg.output_dim, st);
+}
+
+// d tok[b][0] += dq[b] . Wq  is a GEMM with a residual; d x[b][p] = d tok[b][1 + p] + d tok[b][0] / P
+template <typename T>
+__global__ __launch_bounds__(256) void rn_attnpool_tokens_bwd_kernel(const T* __restrict__ dtok, int P, int C, T* __restrict__ dx) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float m0 = Elem<T>::ld(dtok + (int64_t)b * (P + 1) * C + c) / (float)P;
+    for (int p = 0; p < P; ++p)
+      Elem<T>::st(dx + ((int64_t)b * P + p) * C + c, Elem<T>::ld(dtok + ((int64_t)b * (P + 1) + 1 + p) * C + c) + m0);
+  }
+}
+
+// f32 [rows, cols] -> T [rows, ld] with the columns cols .. ld - 1 zeroed (the contraction dimension of a product must be a multiple of 64)
+template <typename T>
+__global__ __launch_bounds__(256) void rn_pad_cast_rows_kernel(const float* __restrict__ src, int64_t n, int cols, int ld, T* __restrict__ dst) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const int c = (int)(idx % ld);
+  const int64_t r = idx / ld;
+  Elem<T>::st(dst + idx, c < cols ? src[r * cols + c] : 0.f);
+}
+
+// input gradient of a convolution: dx = dz (*) Wd  (1x1: plain product on the transposed weight; 3x3: the implicit convolution)
+int rn_dgrad(const ezclip_rn* m, const ezclip_rn::Conv& c, const void* dz, int64_t M, int H, void* dx, const void* add, hipStream_t st) {
+  GemmArgs g;
+  const int opad64 = rup(c.Opad, 64);
+  g.A = dz; g.lda = c.Opad; g.B = c.sd; g.ldb = (int64_t)c.k * c.k * opad64; g.C = dx; g.ldc = c.Cp;
+  g.M = (int)M; g.N = c.Cp; g.K = c.k * c.k * opad64;
+  g.R = add; g.ldr = c.Cp;
+  if (c.k == 3) { g.conv_H = H; g.conv_W = H; g.conv_C = opad64; g.conv_zero = m->zero; }
+  return gemm_nt(g, m->dtype, st);
+}
+
+// weight gradient of a convolution into its bound gradient buffer: dW = dz^T . x (1x1) / dz^T . im2col(x) (3x3; explicit im2col in `col`)
+template <typename T>
+int rn_wgrad(const ezclip_rn* m, const ezclip_rn::Conv& c, const void* dz, const void* x, int64_t M, int H, int B, void* col, float* dwp,
+             hipStream_t st) {
+  float* gw = m->params[c.w].g;
+  const void* bsrc = x;
+  int64_t ldb = c.Cp;
+  if (c.cfirst) { ldb = c.ldk; }                         // the stem's first convolution: x IS its explicit im2col [M, ldk]
+  else if (c.k == 3) {
+    RN_TRY(rn_im2col3x3(x, B, H, H, c.Cp, col, m->dtype, st));
+    bsrc = col; ldb = 9 * (int64_t)c.Cp;
+  }
+  GemmTNArgs t;
+  t.A = dz; t.lda = c.Opad; t.B = bsrc; t.ldb = ldb; t.C = dwp; t.ldc = c.ldk;
+  t.M = (int)M; t.N = c.Opad; t.K = c.ldk; t.accumulate = 0;
+  RN_TRY(gemm_tn(t, m->dtype, st));
+  if (c.cfirst) {
+    // K index (c, ky, kx) = the weight's own [I][3][3] order: a strided copy of the first I * 9 columns
+    EZ_HIP(hipMemcpy2DAsync(gw, (size_t)c.I * 9 * 4, dwp, (size_t)c.ldk * 4, (size_t)c.I * 9 * 4, c.O, hipMemcpyDeviceToDevice, st));
+    return EZ_OK;
+  }
+  return rn_unpack_wgrad(dwp, c.ldk, c.O, c.I, c.k, c.Cp, 0, gw, st);
+}
+
+template <typename T>
+int rn_train_backward(ezclip_rn* m, const float* features, const float* d_features, int B, char* scratch, size_t scratch_bytes, hipStream_t st) {
+  const int E = m->cfg.output_dim, C = m->embed, P = m->sp * m->sp, Lt = P + 1;
+  RnBump a(scratch);
+  const size_t act = rn_train_max_act_bytes(m, B);
+  const size_t tokb = ((size_t)B * Lt * C * m->esz + 255) / 256 * 256;
+  const size_t bufb = act > tokb ? act : tokb;
+  void* buf[kRnTrainBufs];
+  for (auto& b : buf) b = a.take(bufb);
+  void* col = a.take(rn_train_max_col_bytes(m, B));
+  float* dwp = (float*)a.take(rn_train_wgrad_bytes(m));                           // (the SAME bytes rn_train_scratch_bytes reserved)
+  float* bn_scratch = (float*)a.take(rn_bn_scratch_bytes((int64_t)B * (m->cfg.image_resolution / 2) * (m->cfg.image_resolution / 2), 2048));
+  EZ_REQUIRE(a.off <= scratch_bytes, "rn_train_backward: the pass carves %zu bytes out of a scratch of %zu (rn_train_scratch_bytes is out of step)", a.off, scratch_bytes);
+  auto G = [&](int pi) { return m->params[pi].g; };
+
+  // ---- attention pool --------------------------------------------------------------------------------------------------------
+  float* dfeat = (float*)buf[0];                                                   // [B, E] f32
+  RN_TRY(l2_normalize_bwd(features, d_features, m->saved.inv_norm, dfeat, B, E, st));
+  const int E64 = rup(E, 64);
+  T* dfeat_t = (T*)buf[1];                                                         // [B, E64], zero beyond E
+  RN_TRY(launch1d(rn_pad_cast_rows_kernel<T>, (int64_t)B * E64, st, (const float*)dfeat, (int64_t)B * E64, E, E64, dfeat_t));
+  // c_proj: feat = ctx . Wc^T + bc
+  if (G(m->cproj.lin_b)) { EZ_HIP(hipMemsetAsync(G(m->cproj.lin_b), 0, (size_t)E * 4, st)); RN_TRY(colsum_add(dfeat, E, B, E, G(m->cproj.lin_b), EZCLIP_F32, st)); }
+  if (G(m->cproj.w)) {
+    GemmTNArgs t; t.A = dfeat_t; t.lda = E64; t.B = m->saved.ctx; t.ldb = C; t.C = G(m->cproj.w); t.ldc = C; t.M = B; t.N = E; t.K = C;
+    RN_TRY(gemm_tn(t, m->dtype, st));
+  }
+  T* dctx = (T*)buf[2];                                                            // [B, C]
+  { GemmArgs g; g.A = dfeat_t; g.lda = E64; g.B = m->cproj.sd; g.ldb = E64; g.C = dctx; g.ldc = C; g.M = B; g.N = C; g.K = E64;
+    RN_TRY(gemm_nt(g, m->dtype, st)); }
+  // one-query attention backward
+  T* dk = (T*)buf[3]; T* dv = (T*)buf[4]; T* dq = (T*)buf[5];
+  AttnBwdArgs ab;
+  ab.f.k = m->saved.kk; ab.f.v = m->saved.vv; ab.f.row_stride = C; ab.f.B = B; ab.f.L = Lt; ab.f.H = m->heads; ab.f.scale = 0.125f;
+  ab.dk = dk; ab.dv = dv;
+  RN_TRY(attention_cls_bwd(ab, m->saved.qc, C, m->saved.ctx, dctx, C, m->dtype, st, dq, C));
+  // projections: bias gradients = column sums, weight gradients = d^T . tok, token gradient = dk . Wk + dv . Wv (+ dq . Wq on row 0)
+  auto lin_grads = [&](const ezclip_rn::Conv& c, const T* d, int64_t rows, const void* x, int64_t ldx) -> int {
+    if (G(c.lin_b)) { EZ_HIP(hipMemsetAsync(G(c.lin_b), 0, (size_t)c.O * 4, st)); RN_TRY(colsum_add(d, C, (int)rows, c.O, G(c.lin_b), m->dtype, st)); }
+    if (G(c.w)) { GemmTNArgs t; t.A = d; t.lda = C; t.B = x; t.ldb = ldx; t.C = G(c.w); t.ldc = c.I; t.M = (int)rows; t.N = c.O; t.K = c.I; RN_TRY(gemm_tn(t, m->dtype, st)); }
+    return EZ_OK;
+  };
+  RN_TRY(lin_grads(m->kproj, dk, (int64_t)B * Lt, m->saved.tok, C));
+  RN_TRY(lin_grads(m->vproj, dv, (int64_t)B * Lt, m->saved.tok, C));
+  RN_TRY(lin_grads(m->qproj, dq, B, m->saved.tok, (int64_t)Lt * C));
+  T* dtok = (T*)buf[0];                                                            // (dfeat is dead) [B * Lt, C]
+  { GemmArgs g; g.A = dk; g.lda = C; g.B = m->kproj.sd; g.ldb = C; g.C = dtok; g.ldc = C; g.M = B * Lt; g.N = C; g.K = C; RN_TRY(gemm_nt(g, m->dtype, st)); }
+  { GemmArgs g; g.A = dv; g.lda = C; g.B = m->vproj.sd; g.ldb = C; g.C = dtok; g.ldc = C; g.M = B * Lt; g.N = C; g.K = C; g.R = dtok; g.ldr = C;
+    RN_TRY(gemm_nt(g, m->dtype, st)); }
+  { GemmArgs g; g.A = dq; g.lda = C; g.B = m->qproj.sd; g.ldb = C; g.C = dtok; g.ldc = (int64_t)Lt * C; g.M = B; g.N = C; g.K = C; g.R = dtok;
+    g.ldr = (int64_t)Lt * C; RN_TRY(gemm_nt(g, m->dtype, st)); }
+  if (G(m->pos_p)) {
+    EZ_HIP(hipMemsetAsync(G(m->pos_p), 0, (size_t)Lt * C * 4, st));
+    RN_TRY(batch_sum_add(dtok, B, Lt, Lt, C, G(m->pos_p), m->dtype, st));
+  }
+  T* dx = (T*)buf[1];                                                              // gradient of the tower's last activation [B * P, C]
+  hipLaunchKernelGGL(rn_attnpool_tokens_bwd_kernel<T>, dim3(B), dim3(256), 0, st, (const T*)dtok, P, C, dx);
+  EZ_LAUNCH_CHECK();
+  int dxi = 1;
+
+  // ---- one convolution + BatchNorm backwards: dy (gradient of y; masked by [y > 0] when `relu`) -> dz, BatchNorm / weight gradients,
+  //      input gradient into `dst` (+ `add`); dres (optional): the masked dy, i.e. the gradient of the identity input
+  // EZCLIP_RN_DEBUG=1: print the sum of squares of every intermediate of the pass (host copy, synchronous): two runs on the same
+  // saved state must print the same numbers -- the first line that differs names a stage that is not deterministic
+  static const bool dbg = getenv("EZCLIP_RN_DEBUG") != nullptr;
+  int dbg_no = 0;
+  auto dsum = [&](const char* what, const void* p, int64_t n) {
+    if (!dbg || p == nullptr) return;
+    std::vector<T> h((size_t)n);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), p, (size_t)n * sizeof(T), hipMemcpyDeviceToHost);
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+      double v;
+      if constexpr (sizeof(T) == 4) v = (double)*reinterpret_cast<const float*>(&h[(size_t)i]);
+      else { const uint32_t w = (uint32_t)*reinterpret_cast<const uint16_t*>(&h[(size_t)i]) << 16; v = (double)__builtin_bit_cast(float, w); }
+      s += v * v;
+    }
+    fprintf(stderr, "[rn-dbg] %3d %-24s n %9lld  sumsq %.17g\n", dbg_no, what, (long long)n, s);
+    // EZCLIP_RN_DEBUG_DUMP=<n>: the intermediates of lines 0 .. n as raw elements into /tmp/rn_dbg_<line>.bin
+    static const int dump = getenv("EZCLIP_RN_DEBUG_DUMP") ? atoi(getenv("EZCLIP_RN_DEBUG_DUMP")) : -1;
+    if (dbg_no <= dump) {
+      char path[64];
+      snprintf(path, sizeof(path), "/tmp/rn_dbg_%d.bin", dbg_no);
+      if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), sizeof(T), (size_t)n, f); fclose(f); }
+    }
+    ++dbg_no;
+  };
+  auto conv_bn_bwd = [&](ezclip_rn::Conv& c, const void* dy, bool relu, void* dz, void* dres, void* dst, const void* add) -> int {
+    dsum("dy", dy, c.M * c.Opad);
+    RN_TRY(rn_bn_train_bwd(dy, relu ? c.y : nullptr, c.z, c.M, c.O, c.Opad, m->params[c.bn].w, c.mean, c.rstd, dz, dres, G(c.bn), G(c.bn + 1), 0,
+                           bn_scratch, m->dtype, st));
+    dsum("dz", dz, c.M * c.Opad);
+    dsum("dres", dres, c.M * c.Opad);
+    RN_TRY(rn_wgrad<T>(m, c, dz, c.in, c.M, c.H, B, col, dwp, st));
+    if (dst != nullptr && c.sd != nullptr) {
+      RN_TRY(rn_dgrad(m, c, dz, c.M, c.H, dst, add, st));
+      dsum("dx", dst, c.M * c.Cp);
+    }
+    return EZ_OK;
+  };
+  // free buffer picker: any index not in `used`
+  auto pick = [&](std::initializer_list<int> used) { for (int i = 0; i < kRnTrainBufs; ++i) { bool u = false; for (int v : used) u |= (v == i); if (!u) return i; } return -1; };
+
+  // ---- blocks, last to first -------------------------------------------------------------------------------------------------
+  std::vector<ezclip_rn::Block*> order;
+  for (auto& L : m->blocks) for (auto& b : L) order.push_back(&b);
+  for (int bi = (int)order.size() - 1; bi >= 0; --bi) {
+    ezclip_rn::Block& b = *order[bi];
+    const int i_dz = pick({dxi}), i_g = pick({dxi, i_dz}), i_t = pick({dxi, i_dz, i_g}), i_u = pick({dxi, i_dz, i_g, i_t});
+    // conv3 + bn3 (+ identity, ReLU): g = dy * [y3 > 0] is also the identity branch's gradient
+    void* d_o2 = buf[i_t];                                                         // gradient of conv3's input [Mo, C2p]
+    RN_TRY(conv_bn_bwd(b.c3, buf[dxi], true, buf[i_dz], buf[i_g], d_o2, nullptr));
+    // main branch: (pool) conv2, conv1
+    const int64_t Min = b.c1.M;
+    const int Hin = b.c1.H;
+    void* d_y2 = d_o2;
+    int i_y2 = i_t;
+    if (b.stride > 1) {
+      RN_TRY(rn_avgpool2_bwd(d_o2, B, Hin, Hin, b.c2.Opad, buf[i_u], m->dtype, st));
+      d_y2 = buf[i_u]; i_y2 = i_u;
+    }
+    const int i_a = pick({dxi, i_g, i_y2}), i_b = pick({dxi, i_g, i_y2, i_a});
+    RN_TRY(conv_bn_bwd(b.c2, d_y2, true, buf[i_a], nullptr, buf[i_b], nullptr));   // -> d y1 in buf[i_b]
+    const int i_c = pick({dxi, i_g, i_b}), i_d = pick({dxi, i_g, i_b, i_c});
+    RN_TRY(conv_bn_bwd(b.c1, buf[i_b], true, buf[i_c], nullptr, buf[i_d], nullptr));   // -> main-branch d x in buf[i_d]
+    // identity branch
+    int i_out = i_d;
+    if (b.has_down) {
+      const int i_e = pick({i_d, i_g}), i_f = pick({i_d, i_g, i_e});
+      RN_TRY(conv_bn_bwd(b.down, buf[i_g], false, buf[i_e], nullptr, buf[i_f], nullptr));   // -> d (pooled) x
+      if (b.stride > 1) {
+        const int i_h = pick({i_d, i_f});
+        RN_TRY(rn_avgpool2_bwd(buf[i_f], B, Hin, Hin, b.c1.Cp, buf[i_h], m->dtype, st));
+        RN_TRY(rn_add_inplace(buf[i_d], buf[i_h], Min * b.c1.Cp, m->dtype, st));
+      } else {
+        RN_TRY(rn_add_inplace(buf[i_d], buf[i_f], Min * b.c1.Cp, m->dtype, st));
+      }
+    } else {
+      RN_TRY(rn_add_inplace(buf[i_d], buf[i_g], Min * b.c1.Cp, m->dtype, st));
+    }
+    dxi = i_out;
+    dsum("block dx (sum)", buf[dxi], Min * b.c1.Cp);
+  }
+  // ---- stem -------------------------------------------------------------------------------------------------------------------
+  {
+    const int R = m->cfg.image_resolution, H = R / 2;
+    const int i_p = pick({dxi});
+    RN_TRY(rn_avgpool2_bwd(buf[dxi], B, H, H, m->stem[2].Opad, buf[i_p], m->dtype, st));
+    const int i_a = pick({i_p}), i_b = pick({i_p, i_a});
+    RN_TRY(conv_bn_bwd(m->stem[2], buf[i_p], true, buf[i_a], nullptr, buf[i_b], nullptr));
+    const int i_c = pick({i_b}), i_d = pick({i_b, i_c});
+    RN_TRY(conv_bn_bwd(m->stem[1], buf[i_b], true, buf[i_c], nullptr, buf[i_d], nullptr));
+    const int i_e = pick({i_d});
+    RN_TRY(conv_bn_bwd(m->stem[0], buf[i_d], true, buf[i_e], nullptr, nullptr, nullptr));
+  }
+  return EZ_OK;
+}
+
 }  // namespace
 
 namespace ezclip {
@@ -401,7 +850,7 @@ int ezclip_rn_bind_param(ezclip_rn_handle h, const char* name, const float* dev)
   EZ_REQUIRE(h && name && dev, "ezclip_rn_bind_param: null argument");
   for (auto& p : h->params)
     if (p.name == name) {
-      if (p.w != dev) h->fresh = false;
+      if (p.w != dev) { h->fresh = false; h->tfresh = false; }
       p.w = dev;
       return EZ_OK;
     }
@@ -439,6 +888,70 @@ int ezclip_rn_refresh_weights(ezclip_rn_handle h, void* stream) {
   if (rc == EZ_OK) h->fresh = true;
   return rc;
 }
+// ---- training path ------------------------------------------------------------------------------------------------------------
+size_t ezclip_rn_train_shadow_bytes(ezclip_rn_handle h) { return h ? rn_train_shadow_layout(h, nullptr) : 0; }
+int ezclip_rn_set_train_shadow(ezclip_rn_handle h, void* shadow, size_t bytes) {
+  EZ_REQUIRE(h && shadow && ((uintptr_t)shadow % 256) == 0, "ezclip_rn_set_train_shadow: null / unaligned buffer");
+  EZ_REQUIRE(bytes >= rn_train_shadow_layout(h, nullptr), "ezclip_rn_set_train_shadow: buffer too small");
+  rn_train_shadow_layout(h, (char*)shadow);
+  h->tshadow = shadow; h->tshadow_bytes = bytes; h->tfresh = false;
+  return EZ_OK;
+}
+int ezclip_rn_refresh_train_weights(ezclip_rn_handle h, void* stream) {
+  EZ_REQUIRE(h && h->tshadow, "ezclip_rn_refresh_train_weights: no training shadow buffer (ezclip_rn_set_train_shadow)");
+  for (auto& p : h->params) EZ_REQUIRE(p.w != nullptr, "ezclip_rn_refresh_train_weights: parameter %s is not bound", p.name.c_str());
+  hipStream_t st = (hipStream_t)stream;
+  int rc = EZ_OK;
+  rn_for_each(h, [&](ezclip_rn::Conv& c) {
+    if (rc != EZ_OK) return;
+    const float* W = h->params[c.w].w;
+    if (c.st != nullptr) {        // the convolution's own weight, packed as for inference but with no BatchNorm folded in
+      if (h->dtype == EZCLIP_BF16)
+        hipLaunchKernelGGL(rn_pack_conv_kernel<bf16_t>, dim3(c.Opad), dim3(256), 0, st, W, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, c.O, c.I, c.k, c.k, c.Opad, c.Cp, c.ldk, c.cfirst,
+                           (bf16_t*)c.st, h->junk_bias);
+      else
+        hipLaunchKernelGGL(rn_pack_conv_kernel<float>, dim3(c.Opad), dim3(256), 0, st, W, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, c.O, c.I, c.k, c.k, c.Opad, c.Cp, c.ldk, c.cfirst,
+                           (float*)c.st, h->junk_bias);
+      rc = check_hip(hipGetLastError(), "rn_pack_conv_kernel (training)");
+      if (rc != EZ_OK) return;
+    }
+    if (c.sd != nullptr) rc = rn_pack_conv_dgrad(W, c.O, c.I, c.k, rup(c.Opad, 64), c.Cp, c.sd, h->dtype, st);
+  });
+  if (rc == EZ_OK) h->tfresh = true;
+  return rc;
+}
+int ezclip_rn_bind_grad(ezclip_rn_handle h, const char* name, float* dev) {
+  EZ_REQUIRE(h && name, "ezclip_rn_bind_grad: null argument");
+  for (auto& p : h->params)
+    if (p.name == name) { p.g = dev; return EZ_OK; }
+  set_error("ezclip_rn_bind_grad: unknown parameter %s", name);
+  return EZ_ERR_INVALID;
+}
+size_t ezclip_rn_train_saved_bytes(ezclip_rn_handle h, int batch) { return (h && batch > 0) ? rn_train_saved_bytes(h, batch) : 0; }
+size_t ezclip_rn_train_scratch_bytes(ezclip_rn_handle h, int batch) { return (h && batch > 0) ? rn_train_scratch_bytes(h, batch) : 0; }
+int ezclip_rn_encode_image_train(ezclip_rn_handle h, const float* pixels, int batch, float* out, void* saved_ws, size_t saved_bytes,
+                                 void* scratch, size_t scratch_bytes, void* stream) {
+  EZ_REQUIRE(h && pixels && out && saved_ws && scratch && batch > 1, "ezclip_rn_encode_image_train: null argument / batch < 2 (batch statistics)");
+  EZ_REQUIRE(h->fresh && h->tfresh, "ezclip_rn_encode_image_train: weights not packed (ezclip_rn_refresh_weights + ezclip_rn_refresh_train_weights)");
+  EZ_REQUIRE(((uintptr_t)saved_ws % 256) == 0 && saved_bytes >= rn_train_saved_bytes(h, batch) && ((uintptr_t)scratch % 256) == 0 &&
+                 scratch_bytes >= rn_train_scratch_bytes(h, batch), "ezclip_rn_encode_image_train: workspace too small / unaligned");
+  return h->dtype == EZCLIP_BF16 ? rn_train_forward<bf16_t>(h, pixels, batch, out, (char*)saved_ws, saved_bytes, (float*)scratch, (hipStream_t)stream)
+                                 : rn_train_forward<float>(h, pixels, batch, out, (char*)saved_ws, saved_bytes, (float*)scratch, (hipStream_t)stream);
+}
+int ezclip_rn_backward(ezclip_rn_handle h, const float* features, const float* d_features, int batch, void* scratch, size_t scratch_bytes,
+                       void* stream) {
+  EZ_REQUIRE(h && features && d_features && scratch && batch > 1 && h->saved.B == batch, "ezclip_rn_backward: no matching training forward (batch %d)", batch);
+  EZ_REQUIRE(((uintptr_t)scratch % 256) == 0 && scratch_bytes >= rn_train_scratch_bytes(h, batch), "ezclip_rn_backward: scratch too small / unaligned");
+  for (auto& p : h->params) {
+    const bool stat = p.name.size() > 12 && (p.name.rfind(".running_mean") == p.name.size() - 13 || p.name.rfind(".running_var") == p.name.size() - 12);
+    EZ_REQUIRE(stat || p.g != nullptr, "ezclip_rn_backward: no gradient buffer bound for %s (ezclip_rn_bind_grad)", p.name.c_str());
+  }
+  return h->dtype == EZCLIP_BF16 ? rn_train_backward<bf16_t>(h, features, d_features, batch, (char*)scratch, scratch_bytes, (hipStream_t)stream)
+                                 : rn_train_backward<float>(h, features, d_features, batch, (char*)scratch, scratch_bytes, (hipStream_t)stream);
+}
+
 size_t ezclip_rn_workspace_bytes(ezclip_rn_handle h, int batch) {
   if (!h || batch <= 0) return 0;
   return kRnBufs * rn_act_bytes(h, rn_chunk(h, batch)) + 256;

@@ -1,0 +1,371 @@
+// ModifiedResNet image tower, TRAINING path: the row-matrix kernels around the convolutions (the convolutions themselves are the
+// GEMMs of gemm.hip / gemm8p.hip).
+//
+// Reference: easynlp/modelzoo/models/clip/modeling_chineseclip.py -- Bottleneck :27-74, ModifiedResNet :110-167 with nn.BatchNorm2d in
+// train() mode (batch statistics, running statistics moved by momentum 0.1), and torch autograd through it (core/trainer.py:658-661).
+// Restated step by step by the tests' CPU restatement of the tower (train_step_grads_by_steps; the data-layout conventions of the packing
+// kernels in pack_conv3x3_dgrad / im2col3x3_nhwc / unpack_wgrad3x3): every kernel below is one of those steps.
+//
+// Layout as in resnet.hip: activations NHWC, [rows = B * H * W, cp] row-major in the compute dtype, channels padded to a multiple of 64
+// with EXACT zeros (every kernel here keeps them zero: padded channels get scale = shift = 0 and gradient 0).
+//
+//   bn_train_fwd     z -> (sum z, sum z^2 per channel: two-stage, fixed order, bit-reproducible) -> mean, biased var, rstd;
+//                    running statistics moved with the UNBIASED variance; y = [relu](z * scale + shift [+ residual])
+//   bn_train_bwd     g = dy * [y > 0];  (sum g, sum g * xhat) -> dgamma, dbeta;  dz = gamma * rstd * (g - sum g / n - xhat * sum(g xhat) / n);
+//                    optionally dres = g (the gradient of the residual input)
+//   avgpool2_bwd     dx[b, y, x, :] = dy[b, y / 2, x / 2, :] / 4
+//   im2col3x3        col[m][(ky * 3 + kx) * cp + c] = x[pixel m shifted by (ky - 1, kx - 1)][c], zeros outside the image
+//   pack_conv_dgrad  Wd[c][(ky * k + kx) * opad + o] = W[o][c][k - 1 - ky][k - 1 - kx]     (k = 1: the transpose)
+//   unpack_wgrad     dW[o][c][ky][kx] (+)= dWp[o][(ky * k + kx) * cp + c]                  (dWp = dz^T . im2col(x): gemm_tn's output)
+#include "../../include/ezclip.h"
+#include "ezclip_common.h"
+#include "kernels.h"
+
+namespace ezclip {
+namespace {
+
+constexpr int kMomentSlabRows = 64;     // rows per slab at least; at most kMaxSlabs slabs
+constexpr int kMaxSlabs = 1024;
+
+// ---- per-channel moments -----------------------------------------------------------------------------------------------------
+// grid (slabs, cp / 256): a block owns one slab of rows and 256 channels = 64 channel quads x 4 row lanes.
+// MODE 0: (u, v) = (z, z^2).   MODE 1: g = dy * [y > 0] (y == nullptr: no mask), xhat = (z - mean) * rstd: (u, v) = (g, g * xhat).
+// part[slab][2][cp] float.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void rn_moments_kernel(const T* __restrict__ z, const T* __restrict__ dy, const T* __restrict__ y,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd, int64_t rows,
+                                                          int cp, int rows_per_slab, float* __restrict__ part) {
+  __shared__ float red[2][4][256];
+  const int quad = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 256 + quad * 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
+  int64_t r1 = r0 + rows_per_slab;
+  if (r1 > rows) r1 = rows;
+  float su[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < cp) {
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { mu[e] = mean[c + e]; rs[e] = rstd[c + e]; }
+    }
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      float zv[4];
+      ld4(z + r * cp + c, zv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { su[e] += zv[e]; sv[e] = fmaf(zv[e], zv[e], sv[e]); }
+      } else {
+        float gv[4], yv[4] = {1.f, 1.f, 1.f, 1.f};
+        ld4(dy + r * cp + c, gv);
+        if (y != nullptr) ld4(y + r * cp + c, yv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = yv[e] > 0.f ? gv[e] : 0.f;
+          su[e] += g;
+          sv[e] = fmaf(g, (zv[e] - mu[e]) * rs[e], sv[e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][rl][quad * 4 + e] = su[e]; red[1][rl][quad * 4 + e] = sv[e]; }
+  __syncthreads();
+  // fixed order over the four row lanes
+  const int ch = threadIdx.x;                       // 256 channels of this block
+  if (blockIdx.y * 256 + ch < cp) {
+    const float a = (red[0][0][ch] + red[0][1][ch]) + (red[0][2][ch] + red[0][3][ch]);
+    const float b = (red[1][0][ch] + red[1][1][ch]) + (red[1][2][ch] + red[1][3][ch]);
+    float* p = part + (int64_t)blockIdx.x * 2 * cp + blockIdx.y * 256 + ch;
+    p[0] = a;
+    p[cp] = b;
+  }
+}
+
+// forward statistics: one thread per channel sums the slabs in order (double), writes mean / rstd / scale / shift and moves the
+// running statistics.  Channels c >= C (padding): everything 0.
+__global__ __launch_bounds__(256) void rn_bn_finalize_fwd_kernel(const float* __restrict__ part, int slabs, int cp, int C, int64_t n,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float* running_mean, float* running_var, float momentum, float eps,
+                                                                  float* __restrict__ mean, float* __restrict__ rstd,
+                                                                  float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cp) return;
+  if (c >= C) { mean[c] = 0.f; rstd[c] = 0.f; scale[c] = 0.f; shift[c] = 0.f; return; }
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < slabs; ++s) { s1 += (double)part[(int64_t)s * 2 * cp + c]; s2 += (double)part[(int64_t)s * 2 * cp + cp + c]; }
+  const double m = s1 / (double)n;
+  double var = s2 / (double)n - m * m;
+  if (var < 0.0) var = 0.0;
+  const float r = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)m;
+  rstd[c] = r;
+  const float sc = gamma[c] * r;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)m * sc;
+  if (running_mean != nullptr) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    const double unbiased = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// y = [relu](z * scale + shift [+ residual]); one thread per channel quad of one row
+template <typename T>
+__global__ __launch_bounds__(256) void rn_bn_apply_kernel(const T* __restrict__ z, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const T* __restrict__ residual, int relu,
+                                                           int64_t quads, int cp, T* __restrict__ y) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= quads) return;
+  const int cq = cp >> 2;
+  const int c = (int)(q % cq) * 4;
+  const int64_t off = (q / cq) * cp + c;
+  float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
+  ld4(z + off, v);
+  if (residual != nullptr) ld4(residual + off, r);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float t = fmaf(v[e], scale[c + e], shift[c + e]) + r[e];
+    if (relu) t = fmaxf(t, 0.f);
+    v[e] = t;
+  }
+  st4(y + off, v);
+}
+
+// backward statistics: dgamma = sum g xhat, dbeta = sum g (written, or added when `accumulate`), and the two per-channel
+// coefficients of the apply kernel: k1 = sum g / n, k2 = sum(g xhat) / n
+__global__ __launch_bounds__(256) void rn_bn_finalize_bwd_kernel(const float* __restrict__ part, int slabs, int cp, int C, int64_t n,
+                                                                  float* dgamma, float* dbeta, int accumulate,
+                                                                  float* __restrict__ k1, float* __restrict__ k2) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cp) return;
+  if (c >= C) { k1[c] = 0.f; k2[c] = 0.f; return; }
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < slabs; ++s) { s1 += (double)part[(int64_t)s * 2 * cp + c]; s2 += (double)part[(int64_t)s * 2 * cp + cp + c]; }
+  if (accumulate) { dbeta[c] += (float)s1; dgamma[c] += (float)s2; }
+  else { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+  k1[c] = (float)(s1 / (double)n);
+  k2[c] = (float)(s2 / (double)n);
+}
+
+// dz = gamma * rstd * (g - k1 - xhat * k2), g = dy * [y > 0]; dres = g (optional).  Padded channels: gamma is not read (c >= C -> 0).
+template <typename T>
+__global__ __launch_bounds__(256) void rn_bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ z,
+                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ k1,
+                                                               const float* __restrict__ k2, int64_t quads, int cp, int C,
+                                                               T* __restrict__ dz, T* __restrict__ dres) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= quads) return;
+  const int cq = cp >> 2;
+  const int c = (int)(q % cq) * 4;
+  const int64_t off = (q / cq) * cp + c;
+  float gv[4], zv[4], yv[4] = {1.f, 1.f, 1.f, 1.f}, o[4], g4[4];
+  ld4(dy + off, gv);
+  ld4(z + off, zv);
+  if (y != nullptr) ld4(y + off, yv);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float g = yv[e] > 0.f ? gv[e] : 0.f;
+    g4[e] = g;
+    const float a = (c + e < C) ? gamma[c + e] * rstd[c + e] : 0.f;
+    const float xh = (zv[e] - mean[c + e]) * rstd[c + e];
+    o[e] = a * (g - k1[c + e] - xh * k2[c + e]);
+  }
+  st4(dz + off, o);
+  if (dres != nullptr) st4(dres + off, g4);
+}
+
+// AvgPool2d(2) backward on NHWC: dx [B, H, W, cp] from dy [B, H/2, W/2, cp]; a thread owns 4 channels of one INPUT pixel
+template <typename T>
+__global__ __launch_bounds__(256) void rn_avgpool2_bwd_kernel(const T* __restrict__ dy, int64_t quads, int H, int W, int cp,
+                                                               T* __restrict__ dx) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= quads) return;
+  const int cq = cp >> 2;
+  const int c = (int)(q % cq) * 4;
+  const int64_t pix = q / cq;
+  const int x = (int)(pix % W), yy = (int)((pix / W) % H);
+  const int64_t b = pix / ((int64_t)W * H);
+  const int Ho = H >> 1, Wo = W >> 1;
+  float v[4];
+  ld4(dy + ((b * Ho + (yy >> 1)) * Wo + (x >> 1)) * (int64_t)cp + c, v);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] *= 0.25f;
+  st4(dx + pix * cp + c, v);
+}
+
+// a += b (gradient fan-in at the residual add), 4 elements per thread
+template <typename T>
+__global__ __launch_bounds__(256) void rn_add_kernel(T* __restrict__ a, const T* __restrict__ b, int64_t quads) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= quads) return;
+  float x[4], y[4];
+  ld4(a + q * 4, x);
+  ld4(b + q * 4, y);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) x[e] += y[e];
+  st4(a + q * 4, x);
+}
+
+// explicit im2col of a 3x3, pad 1, stride 1 convolution on NHWC: col [B*H*W, 9 * cp]; a thread owns 4 channels of one (pixel, tap)
+template <typename T>
+__global__ __launch_bounds__(256) void rn_im2col3x3_kernel(const T* __restrict__ x, int64_t quads, int H, int W, int cp, T* __restrict__ col) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= quads) return;
+  const int cq = cp >> 2;
+  const int c = (int)(q % cq) * 4;
+  const int tap = (int)((q / cq) % 9);
+  const int64_t pix = q / ((int64_t)cq * 9);
+  const int xx = (int)(pix % W), yy = (int)((pix / W) % H);
+  const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) ld4(x + (pix + (int64_t)(sy - yy) * W + (sx - xx)) * cp + c, v);
+  st4(col + pix * 9 * (int64_t)cp + (int64_t)tap * cp + c, v);
+}
+
+// weights of the input-gradient product: dst [ipad][k*k*opad], dst[c][(ky*k + kx)*opad + o] = W[o][c][k-1-ky][k-1-kx]; zeros elsewhere
+template <typename T>
+__global__ __launch_bounds__(256) void rn_pack_conv_dgrad_kernel(const float* __restrict__ W, int O, int I, int k, int opad, int ipad,
+                                                                  T* __restrict__ dst) {
+  const int c = blockIdx.x;                   // row of dst: input channel
+  const int ld = k * k * opad;
+  for (int j = threadIdx.x; j < ld; j += blockDim.x) {
+    const int tap = j / opad, o = j - tap * opad;
+    float v = 0.f;
+    if (c < I && o < O) {
+      const int ky = tap / k, kx = tap - ky * k;
+      v = W[(((int64_t)o * I + c) * k + (k - 1 - ky)) * k + (k - 1 - kx)];
+    }
+    Elem<T>::st(dst + (int64_t)c * ld + j, v);
+  }
+  (void)ipad;
+}
+
+// dW[o][c][ky][kx] (+)= dWp[o][(ky*k + kx)*cp + c]
+__global__ __launch_bounds__(256) void rn_unpack_wgrad_kernel(const float* __restrict__ dwp, int64_t ldp, int O, int I, int k, int cp,
+                                                               int accumulate, float* __restrict__ dw) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int taps = k * k;
+  if (idx >= (int64_t)O * I * taps) return;
+  const int t = (int)(idx % taps);
+  const int c = (int)((idx / taps) % I);
+  const int64_t o = idx / ((int64_t)taps * I);
+  const float v = dwp[o * ldp + (int64_t)t * cp + c];
+  if (accumulate) dw[idx] += v; else dw[idx] = v;
+}
+
+template <typename K, typename... A>
+int launch_quads(K kernel, int64_t quads, hipStream_t st, A... a) {
+  if (quads <= 0) return EZ_OK;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a...);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int moment_slabs(int64_t rows, int* rows_per_slab) {
+  int64_t slabs = (rows + kMomentSlabRows - 1) / kMomentSlabRows;
+  if (slabs > kMaxSlabs) slabs = kMaxSlabs;
+  const int64_t per = (rows + slabs - 1) / slabs;
+  *rows_per_slab = (int)per;
+  return (int)((rows + per - 1) / per);
+}
+
+}  // namespace
+
+#define RN_DISPATCH_T(dtype, ...)                                                    \
+  do {                                                                               \
+    if ((dtype) == EZCLIP_F32) { using T = float; __VA_ARGS__; }                     \
+    else if ((dtype) == EZCLIP_BF16) { using T = bf16_t; __VA_ARGS__; }              \
+    else { set_error("bad dtype %d", (int)(dtype)); return EZ_ERR_INVALID; }         \
+  } while (0)
+
+// scratch: float [slabs][2][cp] partial moments + 4 * cp per-channel vectors (mean / rstd are outputs of their own)
+size_t rn_bn_scratch_bytes(int64_t rows, int cp) {
+  int per;
+  const int slabs = moment_slabs(rows, &per);
+  return ((size_t)slabs * 2 * cp + (size_t)2 * cp) * sizeof(float);
+}
+
+int rn_bn_train_fwd(const void* z, int64_t rows, int C, int cp, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, const void* residual, int relu, void* y, float* mean, float* rstd,
+                    float* scratch, int dtype, hipStream_t st) {
+  EZ_REQUIRE(z && y && gamma && beta && mean && rstd && scratch && rows > 0 && C > 0 && C <= cp && cp % 64 == 0,
+             "rn_bn_train_fwd: bad arguments (rows %lld, C %d, cp %d)", (long long)rows, C, cp);
+  int per;
+  const int slabs = moment_slabs(rows, &per);
+  float* part = scratch;
+  float* scale = scratch + (size_t)slabs * 2 * cp;
+  float* shift = scale + cp;
+  RN_DISPATCH_T(dtype, hipLaunchKernelGGL((rn_moments_kernel<T, 0>), dim3(slabs, (cp + 255) / 256), dim3(256), 0, st, (const T*)z,
+                                           (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, rows, cp, per,
+                                           part));
+  EZ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rn_bn_finalize_fwd_kernel, dim3((cp + 255) / 256), dim3(256), 0, st, part, slabs, cp, C, rows, gamma, beta,
+                     running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
+  EZ_LAUNCH_CHECK();
+  const int64_t quads = rows * (cp / 4);
+  RN_DISPATCH_T(dtype, return launch_quads(rn_bn_apply_kernel<T>, quads, st, (const T*)z, (const float*)scale, (const float*)shift,
+                                           (const T*)residual, relu, quads, cp, (T*)y));
+  return EZ_OK;
+}
+
+int rn_bn_train_bwd(const void* dy, const void* y, const void* z, int64_t rows, int C, int cp, const float* gamma, const float* mean,
+                    const float* rstd, void* dz, void* dres, float* dgamma, float* dbeta, int accumulate, float* scratch, int dtype,
+                    hipStream_t st) {
+  EZ_REQUIRE(dy && z && dz && gamma && mean && rstd && dgamma && dbeta && scratch && rows > 0 && C > 0 && C <= cp && cp % 64 == 0,
+             "rn_bn_train_bwd: bad arguments (rows %lld, C %d, cp %d)", (long long)rows, C, cp);
+  int per;
+  const int slabs = moment_slabs(rows, &per);
+  float* part = scratch;
+  float* k1 = scratch + (size_t)slabs * 2 * cp;
+  float* k2 = k1 + cp;
+  RN_DISPATCH_T(dtype, hipLaunchKernelGGL((rn_moments_kernel<T, 1>), dim3(slabs, (cp + 255) / 256), dim3(256), 0, st, (const T*)z,
+                                           (const T*)dy, (const T*)y, mean, rstd, rows, cp, per, part));
+  EZ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rn_bn_finalize_bwd_kernel, dim3((cp + 255) / 256), dim3(256), 0, st, part, slabs, cp, C, rows, dgamma, dbeta,
+                     accumulate, k1, k2);
+  EZ_LAUNCH_CHECK();
+  const int64_t quads = rows * (cp / 4);
+  RN_DISPATCH_T(dtype, return launch_quads(rn_bn_bwd_apply_kernel<T>, quads, st, (const T*)dy, (const T*)y, (const T*)z, gamma, mean, rstd,
+                                           (const float*)k1, (const float*)k2, quads, cp, C, (T*)dz, (T*)dres));
+  return EZ_OK;
+}
+
+int rn_avgpool2_bwd(const void* dy, int B, int H, int W, int cp, void* dx, int dtype, hipStream_t st) {
+  EZ_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && cp % 4 == 0, "rn_avgpool2_bwd: bad shape %d x %d x %d x %d", B, H,
+             W, cp);
+  const int64_t quads = (int64_t)B * H * W * (cp / 4);
+  RN_DISPATCH_T(dtype, return launch_quads(rn_avgpool2_bwd_kernel<T>, quads, st, (const T*)dy, quads, H, W, cp, (T*)dx));
+  return EZ_OK;
+}
+
+int rn_add_inplace(void* a, const void* b, int64_t n, int dtype, hipStream_t st) {
+  EZ_REQUIRE(a && b && n >= 0 && n % 4 == 0, "rn_add_inplace: n = %lld must be a multiple of 4", (long long)n);
+  RN_DISPATCH_T(dtype, return launch_quads(rn_add_kernel<T>, n / 4, st, (T*)a, (const T*)b, n / 4));
+  return EZ_OK;
+}
+
+int rn_im2col3x3(const void* x, int B, int H, int W, int cp, void* col, int dtype, hipStream_t st) {
+  EZ_REQUIRE(x && col && B > 0 && H > 0 && W > 0 && cp % 4 == 0, "rn_im2col3x3: bad shape %d x %d x %d x %d", B, H, W, cp);
+  const int64_t quads = (int64_t)B * H * W * 9 * (cp / 4);
+  RN_DISPATCH_T(dtype, return launch_quads(rn_im2col3x3_kernel<T>, quads, st, (const T*)x, quads, H, W, cp, (T*)col));
+  return EZ_OK;
+}
+
+int rn_pack_conv_dgrad(const float* W, int O, int I, int k, int opad, int ipad, void* dst, int dtype, hipStream_t st) {
+  EZ_REQUIRE(W && dst && O > 0 && I > 0 && (k == 1 || k == 3) && opad >= O && ipad >= I, "rn_pack_conv_dgrad: bad shape O %d I %d k %d", O, I, k);
+  RN_DISPATCH_T(dtype, hipLaunchKernelGGL((rn_pack_conv_dgrad_kernel<T>), dim3(ipad), dim3(256), 0, st, W, O, I, k, opad, ipad, (T*)dst));
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+int rn_unpack_wgrad(const float* dwp, int64_t ldp, int O, int I, int k, int cp, int accumulate, float* dw, hipStream_t st) {
+  EZ_REQUIRE(dwp && dw && O > 0 && I > 0 && (k == 1 || k == 3) && cp >= I && ldp >= (int64_t)k * k * cp, "rn_unpack_wgrad: bad shape O %d I %d k %d cp %d",
+             O, I, k, cp);
+  const int64_t n = (int64_t)O * I * k * k;
+  hipLaunchKernelGGL(rn_unpack_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dwp, ldp, O, I, k, cp, accumulate, dw);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+}  // namespace ezclip

@@ -120,6 +120,22 @@ SIGNATURES = {
     "ezclip_recall_ranks_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ezclip_recall_paired_scores": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ezclip_recall_ranks_fused": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ezclip_rn_train_shadow_bytes": (_sz, [_vp]),
+    "ezclip_rn_set_train_shadow": (_i, [_vp, _vp, _sz]),
+    "ezclip_rn_refresh_train_weights": (_i, [_vp, _vp]),
+    "ezclip_rn_bind_grad": (_i, [_vp, C.c_char_p, _vp]),
+    "ezclip_rn_train_saved_bytes": (_sz, [_vp, _i]),
+    "ezclip_rn_train_scratch_bytes": (_sz, [_vp, _i]),
+    "ezclip_rn_encode_image_train": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "ezclip_rn_backward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "ezclip_op_rn_bn_scratch_bytes": (_sz, [_i64, _i]),
+    "ezclip_op_rn_bn_train_fwd": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ezclip_op_rn_bn_train_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "ezclip_op_rn_avgpool2_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "ezclip_op_rn_im2col3x3": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "ezclip_op_rn_pack_conv_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "ezclip_op_rn_unpack_wgrad": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ezclip_op_conv3x3_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "ezclip_debug_set": (_i, [_i, _i]),
     "ezclip_profile_begin": (_i, []),
     "ezclip_profile_end": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),

@@ -287,6 +287,27 @@ size_t ezclip_rn_workspace_bytes(ezclip_rn_handle h, int batch);         /* boun
 int ezclip_rn_encode_image(ezclip_rn_handle h, const float* pixels_dev, int batch, float* out_dev, void* workspace_dev,
                            size_t workspace_bytes, void* stream);
 
+/* Training path of the tower (BatchNorm in training mode, backward pass: modeling_chineseclip.py:27-167 under module.train() and
+ * torch autograd).  The whole batch runs at once (batch statistics): no chunking, batch >= 2.
+ *   ezclip_rn_set_train_shadow / ezclip_rn_refresh_train_weights   unfolded packed convolution weights and the packed weights of the
+ *                                  input-gradient products; refresh after every parameter update (besides ezclip_rn_refresh_weights)
+ *   ezclip_rn_bind_grad            float32 gradient buffer of a parameter (every parameter but the running statistics; WRITTEN, not
+ *                                  added to, by ezclip_rn_backward)
+ *   ezclip_rn_encode_image_train   forward with batch statistics; moves the bound running_mean / running_var buffers (momentum 0.1);
+ *                                  keeps every activation in saved_ws (ezclip_rn_train_saved_bytes) until the backward has run.
+ *                                  After it the inference copies are stale: call ezclip_rn_refresh_weights before ezclip_rn_encode_image.
+ *   ezclip_rn_backward             features_dev = the forward's output, d_features_dev [batch, output_dim] f32 its gradient */
+size_t ezclip_rn_train_shadow_bytes(ezclip_rn_handle h);
+int ezclip_rn_set_train_shadow(ezclip_rn_handle h, void* shadow_dev, size_t bytes);
+int ezclip_rn_refresh_train_weights(ezclip_rn_handle h, void* stream);
+int ezclip_rn_bind_grad(ezclip_rn_handle h, const char* name, float* grad_dev);
+size_t ezclip_rn_train_saved_bytes(ezclip_rn_handle h, int batch);
+size_t ezclip_rn_train_scratch_bytes(ezclip_rn_handle h, int batch);
+int ezclip_rn_encode_image_train(ezclip_rn_handle h, const float* pixels_dev, int batch, float* out_dev, void* saved_dev, size_t saved_bytes,
+                                 void* scratch_dev, size_t scratch_bytes, void* stream);
+int ezclip_rn_backward(ezclip_rn_handle h, const float* features_dev, const float* d_features_dev, int batch, void* scratch_dev,
+                       size_t scratch_bytes, void* stream);
+
 /* ---- backward ------------------------------------------------------------------- */
 /* Gradients are ACCUMULATED (+=) into the grad buffers bound with ezclip_bind_param (float32),
  * like autograd does; parameters bound without a grad buffer are skipped.
@@ -489,6 +510,33 @@ int ezclip_op_attention_cls_bwd(const void* q_cls_dev, int64_t q_stride, const v
                                 const float* key_bias_dev, const void* ctx_cls_dev, const void* dctx_cls_dev, int64_t ctx_stride,
                                 void* dq_dev, void* dk_dev, void* dv_dev, void* dq_cls_dev, int64_t dq_stride, int batch,
                                 int seq_len, int heads, int dtype, void* stream);
+/* ---- ModifiedResNet tower, training path: the row-matrix steps around the convolutions (reference: nn.BatchNorm2d in train() mode and
+ * autograd through Bottleneck / ModifiedResNet, modelzoo/models/clip/modeling_chineseclip.py:27-74,110-167; the tests' CPU restatement
+ * walks the same steps: train_step_grads_by_steps).  Activations are NHWC rows [rows = B*H*W, cp] in `dtype`, channels padded to a
+ * multiple of 64 with exact zeros (kept zero by every call).  scratch_dev: ezclip_op_rn_bn_scratch_bytes(rows, cp) bytes.
+ *   bn_train_fwd   mean / rstd [cp] of z over the rows (biased variance), running statistics moved by `momentum` with the unbiased
+ *                  variance (NULL: not touched), y = [relu](z * gamma * rstd + (beta - mean * gamma * rstd) [+ residual])
+ *   bn_train_bwd   g = dy * [y > 0] (y NULL: no mask); dgamma = sum g xhat, dbeta = sum g (written or added); dz = gamma rstd (g - mean(g)
+ *                  - xhat mean(g xhat)); dres (optional) = g
+ *   avgpool2_bwd   dx [b, h, w, cp] = dy [b, h/2, w/2, cp] / 4 broadcast
+ *   im2col3x3      col [rows, 9 * cp], column block (ky*3 + kx) = the pixel shifted by (ky - 1, kx - 1), zeros outside
+ *   pack_conv_dgrad  dst [ipad][k*k*opad]: dst[c][(ky*k + kx)*opad + o] = w[o][c][k-1-ky][k-1-kx] -- the weights whose (implicit) convolution
+ *                  with dz is the input gradient
+ *   unpack_wgrad   dw [o, i, k, k] (+)= dwp[o][(ky*k + kx)*cp + c]   (dwp = dz^T . im2col(x) from ezclip_op_gemm_tn, row stride ldp)
+ *   conv3x3_nhwc   the tower's implicit 3x3 convolution as an operator: out [rows, n] = conv(x; wp [n][9*cp]); zero256_dev: 256 zero bytes */
+size_t ezclip_op_rn_bn_scratch_bytes(int64_t rows, int cp);
+int ezclip_op_rn_bn_train_fwd(const void* z_dev, int64_t rows, int c, int cp, const float* gamma_dev, const float* beta_dev,
+                              float* running_mean_dev, float* running_var_dev, float momentum, float eps, const void* residual_dev,
+                              int relu, void* y_dev, float* mean_dev, float* rstd_dev, float* scratch_dev, int dtype, void* stream);
+int ezclip_op_rn_bn_train_bwd(const void* dy_dev, const void* y_dev, const void* z_dev, int64_t rows, int c, int cp,
+                              const float* gamma_dev, const float* mean_dev, const float* rstd_dev, void* dz_dev, void* dres_dev,
+                              float* dgamma_dev, float* dbeta_dev, int accumulate, float* scratch_dev, int dtype, void* stream);
+int ezclip_op_rn_avgpool2_bwd(const void* dy_dev, int b, int h, int w, int cp, void* dx_dev, int dtype, void* stream);
+int ezclip_op_rn_im2col3x3(const void* x_dev, int b, int h, int w, int cp, void* col_dev, int dtype, void* stream);
+int ezclip_op_rn_pack_conv_dgrad(const float* w_dev, int o, int i, int k, int opad, int ipad, void* dst_dev, int dtype, void* stream);
+int ezclip_op_rn_unpack_wgrad(const float* dwp_dev, int64_t ldp, int o, int i, int k, int cp, int accumulate, float* dw_dev, void* stream);
+int ezclip_op_conv3x3_nhwc(const void* x_dev, int b, int h, int w, int cp, const void* wp_dev, int n, void* out_dev,
+                           const void* zero256_dev, int dtype, void* stream);
 int ezclip_op_cast_from_f32(const float* src_dev, void* dst_dev, int64_t n, int dtype, void* stream);
 int ezclip_op_cast_to_f32(const void* src_dev, float* dst_dev, int64_t n, int dtype, void* stream);
 

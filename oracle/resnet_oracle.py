@@ -275,11 +275,33 @@ def _attention_pool_fwd_bwd(sd, x, heads, d_out):
     return out, dx, g
 
 
-def train_step_grads_by_steps(sd, layers, width, x, probe):
-    """``train_step_grads`` by explicit forward and backward formulas (no autograd).  Returns (features, grads) with the same keys."""
+def train_step_grads_by_steps(sd, layers, width, x, probe, flips=None, near_zero=None, delta=0.0):
+    """``train_step_grads`` by explicit forward and backward formulas (no autograd).  Returns (features, grads) with the same keys.
+
+    ReLU decisions (round 5).  A pre-activation within float32 rounding of zero is a coin toss for any float32 implementation: the
+    device may take the other branch than this float64 evaluation, and ONE such decision moves every gradient upstream of it by
+    0.3-1 % (the BatchNorm behind it spreads it over the whole channel).  ``near_zero`` (a list, filled) receives
+    (site, flat index, value) of every pre-activation with |value| < ``delta``; ``flips`` (a set of (site, flat index)) inverts
+    those decisions in the backward pass -- the tests accept a device gradient that matches the exact gradient of ONE of the
+    decision patterns float32 cannot tell apart (tests/test_resnet_train_gpu.py)."""
     heads = width * 32 // 64
     g = {}
     tape = []                         # (kind, saved...) in forward order
+    masks = {}
+
+    def relu_site(site, pre):
+        m = pre > 0
+        if near_zero is not None and delta > 0:
+            idx = (pre.abs() < delta).reshape(-1).nonzero().reshape(-1).tolist()
+            near_zero.extend((site, i, float(pre.reshape(-1)[i])) for i in idx)
+        if flips:
+            mf = m.reshape(-1).clone()
+            for s_, i in flips:
+                if s_ == site:
+                    mf[i] = ~mf[i]
+            m = mf.reshape(m.shape)
+        masks[site] = m
+        return F.relu(pre)
 
     def conv_bn(x_in, conv, bn, stride, padding, relu, residual=None):
         z = F.conv2d(x_in, sd[conv + ".weight"], stride=stride, padding=padding)
@@ -287,7 +309,7 @@ def train_step_grads_by_steps(sd, layers, width, x, probe):
         if residual is not None:
             y = y + residual
         if relu:
-            y = F.relu(y)
+            y = relu_site(conv, y)
         tape.append(("conv_bn", conv, bn, stride, padding, relu, x_in, xh, rstd, y))
         return y
 
@@ -309,7 +331,7 @@ def train_step_grads_by_steps(sd, layers, width, x, probe):
                 z = F.conv2d(x_in, sd[conv + ".weight"], padding=padding)
                 y, (xh, rstd) = _bn_train_fwd(z, sd[bn + ".weight"], sd[bn + ".bias"])
                 t_.append((conv, bn, padding, x_in, xh, rstd))
-                return F.relu(y) if relu else y
+                return relu_site(conv, y) if relu else y
             o1 = cb(h, p_ + ".conv1", p_ + ".bn1", 0, True)
             o2 = cb(o1, p_ + ".conv2", p_ + ".bn2", 1, True)
             o2p = F.avg_pool2d(o2, stride) if stride > 1 else o2
@@ -322,7 +344,7 @@ def train_step_grads_by_steps(sd, layers, width, x, probe):
                 rec["down"] = t_[0]
             else:
                 ident = h
-            h = F.relu(o3 + ident)
+            h = relu_site(p_ + ".out", o3 + ident)
             rec["y"] = h
             btape.append(rec)
         out, dx, ga = _attention_pool_fwd_bwd(sd, h, heads, probe)
@@ -335,15 +357,15 @@ def train_step_grads_by_steps(sd, layers, width, x, probe):
             return dxi
 
         for rec in reversed(btape):
-            dsum = dx * (rec["y"] > 0)                                    # ReLU after the residual add
+            dsum = dx * masks[rec["p"] + ".out"]                           # ReLU after the residual add
             stride = rec["stride"]
             m1, m2, m3 = rec["main"]
             d = cb_bwd(dsum, m3)
             if stride > 1:
                 d = _avgpool_bwd(d, stride)
-            d = d * (rec["o2"] > 0)
+            d = d * masks[rec["p"] + ".conv2"]
             d = cb_bwd(d, m2)
-            d = d * (rec["o1"] > 0)
+            d = d * masks[rec["p"] + ".conv1"]
             d = cb_bwd(d, m1)
             if "down" in rec:
                 di = cb_bwd(dsum, rec["down"])
@@ -354,7 +376,7 @@ def train_step_grads_by_steps(sd, layers, width, x, probe):
             dx = d + di
         dx = _avgpool_bwd(dx, 2)
         for kind, conv, bn, stride, padding, relu, x_in, xh, rstd, y in reversed([t for t in tape if t[0] == "conv_bn"]):
-            dx = dx * (y > 0)
+            dx = dx * masks[conv]
             dz, g[bn + ".weight"], g[bn + ".bias"] = _bn_train_bwd(dx, xh, rstd, sd[bn + ".weight"])
             dx, g[conv + ".weight"] = _conv_bwd(x_in, sd[conv + ".weight"], dz, stride, padding)
     return out, g

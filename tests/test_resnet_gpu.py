@@ -102,12 +102,13 @@ def test_a_batch_walked_in_chunks_equals_one_pass():
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_dropin_clipapp_with_a_resnet_tower(tmp_path, dtype):
     """config.json with a `vision_layers` tuple: forward() / compute_loss() as the reference's CHINESE_CLIP builds it
-    (modeling_chineseclip.py:279-287,352-365); the image tower is frozen, the text tower trains."""
+    (modeling_chineseclip.py:279-287,352-365).  eval(): running statistics, equal to the eval-mode oracle.  train(): the tower trains
+    (round 5: batch statistics, gradients for visual.*; the numbers are tests/test_resnet_train_gpu.py's business); with
+    clip_rn_train=0 it is a frozen tower and only the text side gets gradients."""
     cfg = dict(O.CONFIGS["tiny"], vision_layers=[1, 2, 1, 1], vision_width=16, image_resolution=64)
     sd = {k: v for k, v in O.make_state_dict(O.CONFIGS["tiny"], 5).items() if not k.startswith("visual.")}
     sd.update(RO.make_state_dict(cfg["vision_layers"], 16, cfg["embed_dim"], 64, 5))
     R.write_checkpoint_dir(str(tmp_path), cfg, sd)
-    app = CLIPApp(str(tmp_path), user_defined_parameters={"clip_compute_dtype": dtype}).cuda()
     B, Lq = 6, 24
     _, ids = O.make_inputs(O.CONFIGS["tiny"], B, Lq, 2)
     px = torch.randn(B, 3, 64, 64, generator=torch.Generator().manual_seed(9))
@@ -116,20 +117,41 @@ def test_dropin_clipapp_with_a_resnet_tower(tmp_path, dtype):
         txt = O.encode_text(sd, O.CONFIGS["tiny"], ids)
         logits = float(torch.exp(sd["logit_scale"])) * txt @ img.t()
         ref_loss = float(O.clip_loss(logits))
-    out = app({"pixel_values": px, "input_ids": ids})
-    loss = app.compute_loss(out, [])["loss"]
     f32 = dtype == "fp32"
-    assert float((out["image_embeds"].cpu() - img).abs().max()) < (2e-5 if f32 else 2e-2)
-    assert float((out["text_embeds"].detach().cpu() - txt).abs().max()) < (2e-5 if f32 else 1e-2)
-    assert float((out["logits_per_text"].detach().cpu() - logits).abs().max()) < (4e-4 if f32 else 0.3)
-    assert abs(loss.item() - ref_loss) < (1e-4 if f32 else 3e-2)
-    loss.backward()
-    named = dict(app.named_parameters())
-    assert all(p.grad is None for n, p in named.items() if ".visual." in n)
-    assert named["chinese_clip.text_projection"].grad is not None and float(named["chinese_clip.text_projection"].grad.abs().sum()) > 0
-    with torch.no_grad():                                       # single-modality calls
-        only = app({"pixel_values": px}, feat=True)
-        assert only["text_embeds"] is None and float((only["image_embeds"].cpu() - img).abs().max()) < (2e-5 if f32 else 2e-2)
+    for frozen in (True, False):
+        udp = {"clip_compute_dtype": dtype}
+        if frozen:
+            udp["clip_rn_train"] = "0"
+        app = CLIPApp(str(tmp_path), user_defined_parameters=udp).cuda()
+        named = dict(app.named_parameters())
+        assert all(p.requires_grad != frozen for n, p in named.items() if ".visual." in n)
+        if not frozen:
+            app.eval()                       # (a frozen tower ignores the mode: eval-mode statistics either way)
+        out = app({"pixel_values": px, "input_ids": ids})
+        loss = app.compute_loss(out, [])["loss"]
+        assert float((out["image_embeds"].detach().cpu() - img).abs().max()) < (2e-5 if f32 else 2e-2)
+        assert float((out["text_embeds"].detach().cpu() - txt).abs().max()) < (2e-5 if f32 else 1e-2)
+        assert float((out["logits_per_text"].detach().cpu() - logits).abs().max()) < (4e-4 if f32 else 0.3)
+        assert abs(loss.item() - ref_loss) < (1e-4 if f32 else 3e-2)
+        if frozen:
+            loss.backward()
+            assert all(p.grad is None for n, p in named.items() if ".visual." in n)
+            assert named["chinese_clip.text_projection"].grad is not None and float(named["chinese_clip.text_projection"].grad.abs().sum()) > 0
+        else:
+            app.train()
+            stat0 = {n: b.clone() for n, b in app.named_buffers() if n.endswith("running_var")}
+            loss = app.compute_loss(app({"pixel_values": px, "input_ids": ids}), [])["loss"]
+            loss.backward()
+            vis = [p for n, p in named.items() if ".visual." in n]
+            assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in vis) and any(float(p.grad.abs().max()) > 0 for p in vis)
+            assert any(not torch.equal(b, stat0[n]) for n, b in app.named_buffers() if n in stat0)      # the statistics moved
+            app.eval()
+        with torch.no_grad():                                       # single-modality calls
+            only = app({"pixel_values": px}, feat=True)
+            # (after a training forward the running statistics have moved: compare with the oracle only for the frozen model)
+            assert only["text_embeds"] is None and bool(torch.isfinite(only["image_embeds"]).all())
+            if frozen:
+                assert float((only["image_embeds"].cpu() - img).abs().max()) < (2e-5 if f32 else 2e-2)
 
 
 def test_from_config_initialises_the_resnet_tower():

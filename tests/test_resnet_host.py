@@ -37,7 +37,7 @@ def test_library_parameter_table_is_the_reference_modules():
         RnEngine((1, 1, 1, 1), 16, 64, 70, L.DTYPE_F32)           # resolution % 32
 
 
-def test_dropin_state_dict_round_trip_and_frozen_tower(tmp_path):
+def test_dropin_state_dict_round_trip_and_trainable_or_frozen_tower(tmp_path):
     cfg = rn_cfg()
     sd = rn_state_dict(cfg)
     R.write_checkpoint_dir(str(tmp_path), cfg, sd)
@@ -48,7 +48,9 @@ def test_dropin_state_dict_round_trip_and_frozen_tower(tmp_path):
     extra = set(own) - set(sd)
     assert all(k.endswith("num_batches_tracked") or k == "bert.embeddings.position_ids" for k in extra), sorted(extra)[:5]
     vis = {n: p for n, p in app.named_parameters() if ".visual." in n}
-    assert vis and not any(p.requires_grad for p in vis.values())            # frozen tower: no backward pass exists for it
+    assert vis and all(p.requires_grad for p in vis.values())                # round 5: the tower trains, as the reference's does ...
+    frozen = CLIPApp(str(tmp_path), user_defined_parameters={"clip_rn_train": "0"})
+    assert not any(p.requires_grad for n, p in frozen.named_parameters() if ".visual." in n)     # ... unless asked not to
     assert all(p.requires_grad for n, p in app.named_parameters() if ".bert.encoder." in n)
     assert "running_mean" not in "".join(vis)                                # statistics are buffers, as in nn.BatchNorm2d
     with pytest.raises(L.EzclipError):

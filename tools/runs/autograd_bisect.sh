@@ -1,5 +1,5 @@
 #!/bin/bash
-# READY FOR THE NEXT ROUND (not run yet): which predecessor makes bf16_b1024_train_autograd read 135-137 ms instead of 131.8 in the
+# (written in round 4, run in round 5 call r5c: profiles/r5_autograd_bisect.log) which predecessor makes bf16_b1024_train_autograd read 135-137 ms instead of 131.8 in the
 # default line?  Alone, or after the headline / the fused train workload, it does not (tools/runs/gpu_r4s.sh).  Each line: forward
 # headline (10 steps), then the listed also-workloads in order; prints ms per step of each.  ~25 s per line.
 mkdir -p gpurun_out; export TMPDIR=/tmp

@@ -548,14 +548,24 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
     fence()
     rows_seen = []
     host_s = 0.0
+    # shader clock / socket power while the timed steps run (a host thread reading hwmon files four times a second: it never touches
+    # the timing).  The chip sits at its power cap and warms up over the ~2 minutes of the default line: the SAME step reads 2-4 %
+    # slower as the 7th workload than as the 2nd (profiles/r5_autograd_order.log) -- the clock next to every number says why.
+    tel_w = Telemetry(period=0.25) if rank == 0 else None
+    if tel_w is not None:
+        tel_w.__enter__()
     t0 = time.perf_counter()
     for _ in range(steps):
         h0 = time.perf_counter()
         loss = step()
-        host_s += time.perf_counter() - h0                     # host time to ENQUEUE a step (the device runs behind): a step is
-        rows_seen.append(app._engine.last_text_rows)          # host-bound when this approaches ms_per_step
+        host_s += time.perf_counter() - h0                     # host time inside step(): the packed-text metadata poll makes the host
+        rows_seen.append(app._engine.last_text_rows)          # wait for the device, so this tracks ms_per_step for packed workloads
     fence()
     elapsed = time.perf_counter() - t0
+    tel_timed = None
+    if tel_w is not None:
+        tel_w.__exit__(None, None, None)
+        tel_timed = tel_w.summary(skip_seconds=0.0)
     per_rank_ms = elapsed / steps * 1e3
     if world > 1:
         t = torch.tensor([elapsed, -elapsed], dtype=torch.float64, device=device)
@@ -658,6 +668,7 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
                   + ("+backward" if wl["backward"] else "") + ("+grad_allreduce(overlapped)" if wl["backward"] and world > 1 and not autograd else "")
                   + ("+AdamW+repack" if wl.get("optimizer") else ""),
         "two_streams": two_streams, "loss": round(loss_val, 5), "host_ms_per_step": round(host_s / steps * 1e3, 3),
+        "clock_mhz_timed_steps": (tel_timed or {}).get("shader_clock_mhz_mean"), "power_w_timed_steps": (tel_timed or {}).get("socket_power_w_mean"),
         "batches_rotated": NBATCH, "pack_meta_in_timed_region": True,
         "ms_per_step_ranks": {"max": round(step_ms, 3), "min": round(fastest / steps * 1e3, 3), "this_rank": round(per_rank_ms, 3)},
         "text_tower_rows": {"through_the_tower": text_rows[0], "tokens_in_the_batch": text_rows[1]} if text_rows else None,
@@ -754,6 +765,8 @@ def main():
         L.check(L.load().ezclip_debug_set(6, int(os.environ["EZCLIP_RASTER_GM"])))
     if os.environ.get("EZCLIP_CLS_Q_ONLY"):     # A/B switch: 0 = the CLS-only last ViT block projects its queries for every token
         L.check(L.load().ezclip_debug_set(8, int(os.environ["EZCLIP_CLS_Q_ONLY"])))
+    if os.environ.get("EZCLIP_ATTN_FWD_OPTS"):  # A/B switch: bits of set_attention_short_tail (1 short tail, 2 MFMA row sums, 4 NO full-line stores, 8 NO persistent grid)
+        L.check(L.load().ezclip_debug_set(9, int(os.environ["EZCLIP_ATTN_FWD_OPTS"])))
     if os.environ.get("EZCLIP_ATTN_BWD_ONCE"):  # A/B switch: 0 = the two-pass fused attention backward only, 2 = score-tile-once wherever eligible
         L.check(L.load().ezclip_debug_set(11, int(os.environ["EZCLIP_ATTN_BWD_ONCE"])))
     if os.environ.get("EZCLIP_FUSE_QKV"):       # A/B switch: 0 = BERT q / k / v as three products
@@ -778,7 +791,7 @@ def main():
                 if world > 1:
                     raise
             if rank == 0:
-                keep = ("value", "ms_per_step", "host_ms_per_step", "dtype", "path", "stages", "pairs_per_gpu", "loss", "text_tower_rows", "model_tflops_per_gpu",
+                keep = ("value", "ms_per_step", "host_ms_per_step", "clock_mhz_timed_steps", "power_w_timed_steps", "dtype", "path", "stages", "pairs_per_gpu", "loss", "text_tower_rows", "model_tflops_per_gpu",
                         "model_mfma_frac", "time_share", "grad_allreduce_buckets_mib", "sustained", "error")
                 also[n] = {k: r[k] for k in keep if k in r}
                 if r.get("roofline"):
@@ -801,7 +814,7 @@ def main():
                        "two_streams": head["two_streams"], "text_dropout": args.text_dropout},
             "rccl_ranks": world if use_dist else 0, "collective_backend": backend if use_dist else None,
         }
-        for k in ("loss", "host_ms_per_step", "batches_rotated", "pack_meta_in_timed_region", "ms_per_step_ranks", "text_tower_rows", "gflop_per_pair",
+        for k in ("loss", "host_ms_per_step", "clock_mhz_timed_steps", "power_w_timed_steps", "batches_rotated", "pack_meta_in_timed_region", "ms_per_step_ranks", "text_tower_rows", "gflop_per_pair",
                   "model_tflops_per_gpu", "model_mfma_frac", "roofline", "time_share", "attention_tflops", "layernorm_gbps",
                   "grad_allreduce_buckets_mib", "sustained"):
             if k in head:

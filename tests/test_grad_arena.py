@@ -145,6 +145,9 @@ def _worker(rank, world, port, q):
             r3.notify(*grp, wait=lambda grp=grp: waits.append(grp))          # (the event-log route: an explicit wait per group)
         r3.finish()
         assert sent and all(dt == torch.bfloat16 for dt, _ in sent) and sum(n for _, n in sent) == a.total
+        # bucket_bytes counts WIRE bytes (round 5): every bucket but the last carries at least 8 KiB of bf16, i.e. >= 4096
+        # elements -- with the old float32 accounting they were half that and twice as many
+        assert all(n * 2 >= (8 << 10) for _, n in sent[:-1]), sent
         assert set(waits) == set(progress_sequence(cfg))                     # every group's producer was waited for before its bucket left
         scale_ = sum(f.abs() for f in full)
         assert float(((a.flat - want).abs() / (scale_ + 1e-6)).max()) < (world + 1) * 2.0 ** -8      # (one rounding -- half a bf16 ulp, 2^-8 relative -- per input and per hop)

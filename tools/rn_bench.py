@@ -30,3 +30,30 @@ for dtype in ("bf16", "fp32"):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         print("RN50 %s B=%4d: %.2f ms  %.0f images/s" % (dtype, B, ms, B / ms * 1e3), flush=True)
+
+# training step of the tower (round 5): BatchNorm on batch statistics + the whole backward pass, 224 x 224
+for dtype, B in (("bf16", 128), ("bf16", 256), ("fp32", 32)):
+    eng = RnEngine(layers, width, e, res, L.dtype_code(dtype))
+    dev = {n: sd[n].cuda() for n in eng.names}
+    eng.sync_train(dev)
+    px = torch.randn(B, 3, res, res, device="cuda")
+    probe = torch.randn(B, e, device="cuda")
+    grads = {n: torch.zeros(eng.shapes[n], dtype=torch.float32, device="cuda") for n in eng.names if not eng.is_statistic(n)}
+
+    def step():
+        out = eng.encode_image_train(px)
+        eng.backward(out, probe, grads)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 5
+    e0.record()
+    for _ in range(n):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    finite = all(bool(torch.isfinite(g).all()) for g in grads.values())
+    print("RN50 %s B=%4d TRAIN (fwd on batch statistics + backward): %.2f ms  %.0f images/s  grads finite: %s" % (dtype, B, ms, B / ms * 1e3, finite), flush=True)

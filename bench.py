@@ -479,8 +479,10 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
     world, rank, device = c.world, c.rank, c.device
     # The models of the workloads that ran before this one in the same process are garbage by now, but cyclic garbage: collect it here,
     # outside any timed region, and give its device memory back, rather than leave it to a collection inside this workload's timed steps.
-    # (Hygiene; it did NOT explain why the autograd training step reads 3-4 % slower as the 7th workload of the default line than alone
-    # or right after the headline -- profiles/r4_train_vs_autograd_trace.log)
+    # (Hygiene; it does NOT explain why the autograd training step reads 3-4 % slower as the 7th workload of the default line than as the
+    # 2nd.  Round 5 ruled out: any single predecessor (profiles/r5_autograd_bisect.log), the allocator cache (EZCLIP_BENCH_KEEP_CACHE),
+    # the clock (clock_mhz_timed_steps is HIGHER there: the GPU is ~4 % less busy, time_share sums to 0.93 instead of 0.97), Python's
+    # cyclic collector (gc.freeze() changes nothing: profiles/r5_autograd_order.log).  Open.)
     import gc
     gc.collect()
     if not os.environ.get("EZCLIP_BENCH_KEEP_CACHE"):       # (A/B switch: does returning the previous workload's 60 GB to the driver matter?)

@@ -482,7 +482,9 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
     # (Hygiene; it does NOT explain why the autograd training step reads 3-4 % slower as the 7th workload of the default line than as the
     # 2nd.  Round 5 ruled out: any single predecessor (profiles/r5_autograd_bisect.log), the allocator cache (EZCLIP_BENCH_KEEP_CACHE),
     # the clock (clock_mhz_timed_steps is HIGHER there: the GPU is ~4 % less busy, time_share sums to 0.93 instead of 0.97), Python's
-    # cyclic collector (gc.freeze() changes nothing: profiles/r5_autograd_order.log).  Open.)
+    # cyclic collector (gc.freeze() changes nothing: profiles/r5_autograd_order.log).  A kernel trace of the whole line
+    # (profiles/r5_default_line_trace_segments.log) puts the idle time at the step boundaries: 1.3-3.9 ms between the last backward kernel
+    # and the next step's first launch -- the host side of the autograd path is late there; why more so late in the process: open.)
     import gc
     gc.collect()
     if not os.environ.get("EZCLIP_BENCH_KEEP_CACHE"):       # (A/B switch: does returning the previous workload's 60 GB to the driver matter?)

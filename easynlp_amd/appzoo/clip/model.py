@@ -1299,7 +1299,9 @@ class CLIPApp(Application):
 
     def contrastive_loss(self, logits: torch.Tensor) -> torch.Tensor:
         """One direction: ``F.cross_entropy(logits, arange(len(logits)))`` (reference model.py:154-155), autograd-capable.
-        ``clip_loss`` does not call it twice: both directions of a square block are one fused HIP call there."""
+        ``clip_loss`` does not call it twice: both directions of a square block are one fused HIP call there.
+        GPU logits only (``EzclipError`` otherwise): the reference's version runs on any device, but this package has NO CPU compute
+        path by construction -- a torch fallback here would be one (ADVICE r4 suggested it; declined for that reason)."""
         return _CrossEntropyDiagFn.apply(logits)
 
     def clip_loss(self, similarity: torch.Tensor) -> torch.Tensor:

@@ -27,39 +27,68 @@ namespace {
 constexpr int kMomentSlabRows = 64;     // rows per slab at least; at most kMaxSlabs slabs
 constexpr int kMaxSlabs = 1024;
 
+// one 16-byte chunk of a row (4 floats / 8 bf16) <-> floats; per-channel float vectors for the same channels
+__device__ __forceinline__ uint4 pack_chunk16(const float (&v)[4], float) {
+  return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+__device__ __forceinline__ uint4 pack_chunk16(const float (&v)[8], bf16_t) {
+  return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+template <int V>
+__device__ __forceinline__ void ld_vec(const float* __restrict__ p, float (&v)[V]) {
+#pragma unroll
+  for (int k = 0; k < V; k += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p + k);
+    v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+  }
+}
+
 // ---- per-channel moments -----------------------------------------------------------------------------------------------------
-// grid (slabs, cp / 256): a block owns one slab of rows and 256 channels = 64 channel quads x 4 row lanes.
+// grid (slabs, ceil(chunks per row / 64)): a block owns one slab of rows and up to 64 16-byte channel chunks (4 floats / 8 bf16 each);
+// its 256 threads are `cl` chunk lanes x `rl` row lanes, cl = min(chunks per row, 64), rl = 256 / cl -- at 64 channels (the stem and
+// layer1, the largest row counts) that is 8 x 32 instead of the first version's 16 x 4 with three quarters of the block idle.
 // MODE 0: (u, v) = (z, z^2).   MODE 1: g = dy * [y > 0] (y == nullptr: no mask), xhat = (z - mean) * rstd: (u, v) = (g, g * xhat).
-// part[slab][2][cp] float.
+// part[slab][2][cp] float; the row lanes are combined in a fixed order (bit-reproducible).
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void rn_moments_kernel(const T* __restrict__ z, const T* __restrict__ dy, const T* __restrict__ y,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd, int64_t rows,
                                                           int cp, int rows_per_slab, float* __restrict__ part) {
-  __shared__ float red[2][4][256];
-  const int quad = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.y * 256 + quad * 4;
+  constexpr int V = Elem<T>::kPerChunk;
+  __shared__ float red[2][256 * V];                 // [u | v][row lane][chunk lane][V]
+  const int nch = cp / V;                           // chunks per row
+  const int cl = nch < 64 ? nch : 64;               // chunk lanes of this block
+  const int rl = 256 / cl;                          // row lanes
+  const int t = threadIdx.x;
+  const int my_c = t % cl, my_r = t / cl;
+  const int chunk = blockIdx.y * 64 + my_c;
+  const int c = chunk * V;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
   int64_t r1 = r0 + rows_per_slab;
   if (r1 > rows) r1 = rows;
-  float su[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (c < cp) {
-    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (MODE == 1) {
+  float su[V], sv[V];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { mu[e] = mean[c + e]; rs[e] = rstd[c + e]; }
-    }
-    for (int64_t r = r0 + rl; r < r1; r += 4) {
-      float zv[4];
-      ld4(z + r * cp + c, zv);
+  for (int e = 0; e < V; ++e) su[e] = sv[e] = 0.f;
+  if (my_r < rl && chunk < nch) {
+    float mu[V], rs[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) mu[e] = rs[e] = 0.f;
+    if (MODE == 1) { ld_vec<V>(mean + c, mu); ld_vec<V>(rstd + c, rs); }
+    for (int64_t r = r0 + my_r; r < r1; r += rl) {
+      float zv[V];
+      unpack_chunk(*reinterpret_cast<const uint4*>(z + r * cp + c), zv, T());
       if (MODE == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { su[e] += zv[e]; sv[e] = fmaf(zv[e], zv[e], sv[e]); }
+        for (int e = 0; e < V; ++e) { su[e] += zv[e]; sv[e] = fmaf(zv[e], zv[e], sv[e]); }
       } else {
-        float gv[4], yv[4] = {1.f, 1.f, 1.f, 1.f};
-        ld4(dy + r * cp + c, gv);
-        if (y != nullptr) ld4(y + r * cp + c, yv);
+        float gv[V], yv[V];
+        unpack_chunk(*reinterpret_cast<const uint4*>(dy + r * cp + c), gv, T());
+        if (y != nullptr) unpack_chunk(*reinterpret_cast<const uint4*>(y + r * cp + c), yv, T());
+        else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < V; ++e) yv[e] = 1.f;
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
           const float g = yv[e] > 0.f ? gv[e] : 0.f;
           su[e] += g;
           sv[e] = fmaf(g, (zv[e] - mu[e]) * rs[e], sv[e]);
@@ -67,32 +96,54 @@ __global__ __launch_bounds__(256) void rn_moments_kernel(const T* __restrict__ z
       }
     }
   }
+  if (my_r < rl) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { red[0][rl][quad * 4 + e] = su[e]; red[1][rl][quad * 4 + e] = sv[e]; }
+    for (int e = 0; e < V; ++e) { red[0][(my_r * cl + my_c) * V + e] = su[e]; red[1][(my_r * cl + my_c) * V + e] = sv[e]; }
+  }
   __syncthreads();
-  // fixed order over the four row lanes
-  const int ch = threadIdx.x;                       // 256 channels of this block
-  if (blockIdx.y * 256 + ch < cp) {
-    const float a = (red[0][0][ch] + red[0][1][ch]) + (red[0][2][ch] + red[0][3][ch]);
-    const float b = (red[1][0][ch] + red[1][1][ch]) + (red[1][2][ch] + red[1][3][ch]);
-    float* p = part + (int64_t)blockIdx.x * 2 * cp + blockIdx.y * 256 + ch;
+  // fixed order over the row lanes: thread -> one channel of this block's cl * V
+  for (int ch = t; ch < cl * V; ch += 256) {
+    const int gc = blockIdx.y * 64 * V + ch;
+    if (gc >= cp) continue;
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < rl; ++r) { a += red[0][r * cl * V + ch]; b += red[1][r * cl * V + ch]; }
+    float* p = part + (int64_t)blockIdx.x * 2 * cp + gc;
     p[0] = a;
     p[cp] = b;
   }
 }
 
-// forward statistics: one thread per channel sums the slabs in order (double), writes mean / rstd / scale / shift and moves the
+// Sum of the slab partials of ONE channel by one wave: lane l adds slabs l, l + 64, ... in double, then a fixed shuffle tree -- the order
+// depends on nothing but the slab count (bit-reproducible).  Round 5: one THREAD per channel walking up to 1024 slabs serially made the two
+// finalise kernels 23 % of the RN50 training step (210-220 us each at one to eight workgroups: profiles/r5_rn_train_kernel_stats.md).
+__device__ __forceinline__ void slab_sums(const float* __restrict__ part, int slabs, int cp, int c, int lane, double& s1, double& s2) {
+  double a = 0.0, b = 0.0;
+  for (int s = lane; s < slabs; s += 64) {
+    a += (double)part[(int64_t)s * 2 * cp + c];
+    b += (double)part[(int64_t)s * 2 * cp + cp + c];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  s1 = a; s2 = b;
+}
+
+// forward statistics: one wave per channel sums the slabs (double), lane 0 writes mean / rstd / scale / shift and moves the
 // running statistics.  Channels c >= C (padding): everything 0.
 __global__ __launch_bounds__(256) void rn_bn_finalize_fwd_kernel(const float* __restrict__ part, int slabs, int cp, int C, int64_t n,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   float* running_mean, float* running_var, float momentum, float eps,
                                                                   float* __restrict__ mean, float* __restrict__ rstd,
                                                                   float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= cp) return;
-  if (c >= C) { mean[c] = 0.f; rstd[c] = 0.f; scale[c] = 0.f; shift[c] = 0.f; return; }
-  double s1 = 0.0, s2 = 0.0;
-  for (int s = 0; s < slabs; ++s) { s1 += (double)part[(int64_t)s * 2 * cp + c]; s2 += (double)part[(int64_t)s * 2 * cp + cp + c]; }
+  if (c >= C) { if (lane == 0) { mean[c] = 0.f; rstd[c] = 0.f; scale[c] = 0.f; shift[c] = 0.f; } return; }
+  double s1, s2;
+  slab_sums(part, slabs, cp, c, lane, s1, s2);
+  if (lane != 0) return;
   const double m = s1 / (double)n;
   double var = s2 / (double)n - m * m;
   if (var < 0.0) var = 0.0;
@@ -109,26 +160,34 @@ __global__ __launch_bounds__(256) void rn_bn_finalize_fwd_kernel(const float* __
   }
 }
 
-// y = [relu](z * scale + shift [+ residual]); one thread per channel quad of one row
+// y = [relu](z * scale + shift [+ residual]); one thread per 16-byte chunk of one row (4 floats / 8 bf16: round 5 -- the 8-byte accesses of
+// the first version ran at ~1.6 TB/s on the stem's 400 MB activations)
 template <typename T>
 __global__ __launch_bounds__(256) void rn_bn_apply_kernel(const T* __restrict__ z, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const T* __restrict__ residual, int relu,
-                                                           int64_t quads, int cp, T* __restrict__ y) {
+                                                           int64_t chunks, int cp, T* __restrict__ y) {
+  constexpr int V = Elem<T>::kPerChunk;
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (q >= quads) return;
-  const int cq = cp >> 2;
-  const int c = (int)(q % cq) * 4;
+  if (q >= chunks) return;
+  const int cq = cp / V;
+  const int c = (int)(q % cq) * V;
   const int64_t off = (q / cq) * cp + c;
-  float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
-  ld4(z + off, v);
-  if (residual != nullptr) ld4(residual + off, r);
+  float v[V], r[V], sc[V], sh[V];
+  unpack_chunk(*reinterpret_cast<const uint4*>(z + off), v, T());
+  if (residual != nullptr) unpack_chunk(*reinterpret_cast<const uint4*>(residual + off), r, T());
+  else {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float t = fmaf(v[e], scale[c + e], shift[c + e]) + r[e];
+    for (int e = 0; e < V; ++e) r[e] = 0.f;
+  }
+  ld_vec<V>(scale + c, sc);
+  ld_vec<V>(shift + c, sh);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    float t = fmaf(v[e], sc[e], sh[e]) + r[e];
     if (relu) t = fmaxf(t, 0.f);
     v[e] = t;
   }
-  st4(y + off, v);
+  *reinterpret_cast<uint4*>(y + off) = pack_chunk16(v, T());
 }
 
 // backward statistics: dgamma = sum g xhat, dbeta = sum g (written, or added when `accumulate`), and the two per-channel
@@ -136,11 +195,13 @@ __global__ __launch_bounds__(256) void rn_bn_apply_kernel(const T* __restrict__ 
 __global__ __launch_bounds__(256) void rn_bn_finalize_bwd_kernel(const float* __restrict__ part, int slabs, int cp, int C, int64_t n,
                                                                   float* dgamma, float* dbeta, int accumulate,
                                                                   float* __restrict__ k1, float* __restrict__ k2) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);            // one wave per channel (slab_sums)
   if (c >= cp) return;
-  if (c >= C) { k1[c] = 0.f; k2[c] = 0.f; return; }
-  double s1 = 0.0, s2 = 0.0;
-  for (int s = 0; s < slabs; ++s) { s1 += (double)part[(int64_t)s * 2 * cp + c]; s2 += (double)part[(int64_t)s * 2 * cp + cp + c]; }
+  if (c >= C) { if (lane == 0) { k1[c] = 0.f; k2[c] = 0.f; } return; }
+  double s1, s2;
+  slab_sums(part, slabs, cp, c, lane, s1, s2);
+  if (lane != 0) return;
   if (accumulate) { dbeta[c] += (float)s1; dgamma[c] += (float)s2; }
   else { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
   k1[c] = (float)(s1 / (double)n);
@@ -148,31 +209,46 @@ __global__ __launch_bounds__(256) void rn_bn_finalize_bwd_kernel(const float* __
 }
 
 // dz = gamma * rstd * (g - k1 - xhat * k2), g = dy * [y > 0]; dres = g (optional).  Padded channels: gamma is not read (c >= C -> 0).
+// One thread per 16-byte chunk of one row; the five per-channel vectors come in as float4 loads.
 template <typename T>
 __global__ __launch_bounds__(256) void rn_bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ z,
                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, const float* __restrict__ k1,
-                                                               const float* __restrict__ k2, int64_t quads, int cp, int C,
+                                                               const float* __restrict__ k2, int64_t chunks, int cp, int C,
                                                                T* __restrict__ dz, T* __restrict__ dres) {
+  constexpr int V = Elem<T>::kPerChunk;
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (q >= quads) return;
-  const int cq = cp >> 2;
-  const int c = (int)(q % cq) * 4;
+  if (q >= chunks) return;
+  const int cq = cp / V;
+  const int c = (int)(q % cq) * V;
   const int64_t off = (q / cq) * cp + c;
-  float gv[4], zv[4], yv[4] = {1.f, 1.f, 1.f, 1.f}, o[4], g4[4];
-  ld4(dy + off, gv);
-  ld4(z + off, zv);
-  if (y != nullptr) ld4(y + off, yv);
+  float gv[V], zv[V], yv[V], o[V], g4[V], mu[V], rs[V], a1[V], a2[V], ga[V];
+  unpack_chunk(*reinterpret_cast<const uint4*>(dy + off), gv, T());
+  unpack_chunk(*reinterpret_cast<const uint4*>(z + off), zv, T());
+  if (y != nullptr) unpack_chunk(*reinterpret_cast<const uint4*>(y + off), yv, T());
+  else {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < V; ++e) yv[e] = 1.f;
+  }
+  ld_vec<V>(mean + c, mu);
+  ld_vec<V>(rstd + c, rs);
+  ld_vec<V>(k1 + c, a1);
+  ld_vec<V>(k2 + c, a2);
+  if (c + V <= C) ld_vec<V>(gamma + c, ga);          // (gamma has C entries: a chunk that straddles C reads it element by element)
+  else {
+#pragma unroll
+    for (int e = 0; e < V; ++e) ga[e] = (c + e < C) ? gamma[c + e] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
     const float g = yv[e] > 0.f ? gv[e] : 0.f;
     g4[e] = g;
-    const float a = (c + e < C) ? gamma[c + e] * rstd[c + e] : 0.f;
-    const float xh = (zv[e] - mean[c + e]) * rstd[c + e];
-    o[e] = a * (g - k1[c + e] - xh * k2[c + e]);
+    const float a = (c + e < C) ? ga[e] * rs[e] : 0.f;
+    const float xh = (zv[e] - mu[e]) * rs[e];
+    o[e] = a * (g - a1[e] - xh * a2[e]);
   }
-  st4(dz + off, o);
-  if (dres != nullptr) st4(dres + off, g4);
+  *reinterpret_cast<uint4*>(dz + off) = pack_chunk16(o, T());
+  if (dres != nullptr) *reinterpret_cast<uint4*>(dres + off) = pack_chunk16(g4, T());
 }
 
 // AvgPool2d(2) backward on NHWC: dx [B, H, W, cp] from dy [B, H/2, W/2, cp]; a thread owns 4 channels of one INPUT pixel
@@ -296,16 +372,16 @@ int rn_bn_train_fwd(const void* z, int64_t rows, int C, int cp, const float* gam
   float* part = scratch;
   float* scale = scratch + (size_t)slabs * 2 * cp;
   float* shift = scale + cp;
-  RN_DISPATCH_T(dtype, hipLaunchKernelGGL((rn_moments_kernel<T, 0>), dim3(slabs, (cp + 255) / 256), dim3(256), 0, st, (const T*)z,
+  RN_DISPATCH_T(dtype, hipLaunchKernelGGL((rn_moments_kernel<T, 0>), dim3(slabs, (cp / Elem<T>::kPerChunk + 63) / 64), dim3(256), 0, st, (const T*)z,
                                            (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, rows, cp, per,
                                            part));
   EZ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rn_bn_finalize_fwd_kernel, dim3((cp + 255) / 256), dim3(256), 0, st, part, slabs, cp, C, rows, gamma, beta,
+  hipLaunchKernelGGL(rn_bn_finalize_fwd_kernel, dim3((cp + 3) / 4), dim3(256), 0, st, part, slabs, cp, C, rows, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
   EZ_LAUNCH_CHECK();
-  const int64_t quads = rows * (cp / 4);
-  RN_DISPATCH_T(dtype, return launch_quads(rn_bn_apply_kernel<T>, quads, st, (const T*)z, (const float*)scale, (const float*)shift,
-                                           (const T*)residual, relu, quads, cp, (T*)y));
+  RN_DISPATCH_T(dtype, { const int64_t chunks = rows * (cp / Elem<T>::kPerChunk);
+                         return launch_quads(rn_bn_apply_kernel<T>, chunks, st, (const T*)z, (const float*)scale, (const float*)shift,
+                                             (const T*)residual, relu, chunks, cp, (T*)y); });
   return EZ_OK;
 }
 
@@ -319,15 +395,15 @@ int rn_bn_train_bwd(const void* dy, const void* y, const void* z, int64_t rows, 
   float* part = scratch;
   float* k1 = scratch + (size_t)slabs * 2 * cp;
   float* k2 = k1 + cp;
-  RN_DISPATCH_T(dtype, hipLaunchKernelGGL((rn_moments_kernel<T, 1>), dim3(slabs, (cp + 255) / 256), dim3(256), 0, st, (const T*)z,
+  RN_DISPATCH_T(dtype, hipLaunchKernelGGL((rn_moments_kernel<T, 1>), dim3(slabs, (cp / Elem<T>::kPerChunk + 63) / 64), dim3(256), 0, st, (const T*)z,
                                            (const T*)dy, (const T*)y, mean, rstd, rows, cp, per, part));
   EZ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rn_bn_finalize_bwd_kernel, dim3((cp + 255) / 256), dim3(256), 0, st, part, slabs, cp, C, rows, dgamma, dbeta,
+  hipLaunchKernelGGL(rn_bn_finalize_bwd_kernel, dim3((cp + 3) / 4), dim3(256), 0, st, part, slabs, cp, C, rows, dgamma, dbeta,
                      accumulate, k1, k2);
   EZ_LAUNCH_CHECK();
-  const int64_t quads = rows * (cp / 4);
-  RN_DISPATCH_T(dtype, return launch_quads(rn_bn_bwd_apply_kernel<T>, quads, st, (const T*)dy, (const T*)y, (const T*)z, gamma, mean, rstd,
-                                           (const float*)k1, (const float*)k2, quads, cp, C, (T*)dz, (T*)dres));
+  RN_DISPATCH_T(dtype, { const int64_t chunks = rows * (cp / Elem<T>::kPerChunk);
+                         return launch_quads(rn_bn_bwd_apply_kernel<T>, chunks, st, (const T*)dy, (const T*)y, (const T*)z, gamma, mean, rstd,
+                                             (const float*)k1, (const float*)k2, chunks, cp, C, (T*)dz, (T*)dres); });
   return EZ_OK;
 }
 

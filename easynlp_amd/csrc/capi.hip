@@ -590,6 +590,15 @@ int ezclip_op_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, fl
   return gemm_tn(g, dtype, S(stream));
 }
 
+int ezclip_op_gemm_tn_conv3x3(const void* a, int64_t lda, const void* x, int images, int h, int w, int cp, float* c, int64_t ldc, int n,
+                              int accumulate, int dtype, void* stream) {
+  GemmTNArgs g;
+  g.A = a; g.lda = lda; g.B = x; g.ldb = cp; g.C = c; g.ldc = ldc;
+  g.M = images * h * w; g.N = n; g.K = 9 * cp; g.accumulate = accumulate;
+  g.conv_H = h; g.conv_W = w; g.conv_C = cp;
+  return gemm_tn(g, dtype, S(stream));
+}
+
 int ezclip_op_layernorm(const void* x, int64_t xs, void* y, int64_t ys, const float* g, const float* b, float eps,
                         int rows, int d, int dtype, float* mean, float* rstd, void* stream) {
   return layernorm_fwd(x, xs, y, ys, g, b, eps, rows, d, dtype, mean, rstd, S(stream));

@@ -500,7 +500,12 @@ __device__ __forceinline__ void transpose8x8_bf16(const uint4 (&r)[8], uint4 (&o
   }
 }
 
-template <typename T>
+// CONV: B is not a matrix in memory but the 3 x 3 neighbourhoods of an NHWC activation x [M = images * H * W, conv_C]:
+//   B[m][tap * conv_C + c] = x[pixel m shifted by (tap / 3 - 1, tap % 3 - 1)][c], zero outside the image
+// (the column order of rn_im2col3x3 -- resnet_train.hip -- so C comes out exactly as from the explicit im2col, bit for bit: the
+// same tile values meet the same MFMA sequence).  A staging thread's column chunk is fixed, so its tap is a per-thread constant;
+// per tile it divides once (first row -> y, x) and steps the pixel position along its eight rows.
+template <typename T, bool CONV>
 __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(GemmTNArgs p, int tiles_k, int ntiles, int rows_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A image 16K + B image 16K)
   constexpr bool kBf16 = sizeof(T) == 2;
@@ -526,8 +531,38 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(GemmTNArgs p, int 
   const int cmax = isB ? p.K : p.N;
   uint4 regs[8];
 
+  // CONV, B staging threads: column chunk -> (tap, channel), the tap's pixel shift
+  int cv_col = 0, cv_dy = 0, cv_dx = 0, cv_shift = 0;
+  bool cv_ok = false;
+  if constexpr (CONV) {
+    if (isB) {
+      const int col = k0 + (kBf16 ? (st >> 3) * 8 : (st & 31) * 4);
+      cv_ok = col < p.K;
+      const int tap = cv_ok ? col / p.conv_C : 0;
+      cv_col = col - tap * p.conv_C;
+      cv_dy = tap / 3 - 1; cv_dx = tap - (tap / 3) * 3 - 1;
+      cv_shift = cv_dy * p.conv_W + cv_dx;
+    }
+  }
+  auto load_tile_conv = [&](int mt) {
+    constexpr int stride = kBf16 ? 1 : 4;              // row step between a thread's eight loads
+    const int m0 = mt + (kBf16 ? (st & 7) * 8 : (st >> 5));
+    const int t = m0 / p.conv_W;
+    int x = m0 - t * p.conv_W, y = t % p.conv_H;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int m = m0 + r * stride;
+      const bool ok = cv_ok && m < m_end && (unsigned)(y + cv_dy) < (unsigned)p.conv_H && (unsigned)(x + cv_dx) < (unsigned)p.conv_W;
+      regs[r] = ok ? *reinterpret_cast<const uint4*>(g + (int64_t)(m + cv_shift) * ld + cv_col) : make_uint4(0, 0, 0, 0);
+      x += stride;
+      if (x >= p.conv_W) { x -= p.conv_W; if (++y >= p.conv_H) y = 0; }      // (conv_W >= 4 = the largest stride: one wrap at most)
+    }
+  };
   auto load_tile = [&](int step) {
     const int mt = m_begin + step * BMc;
+    if constexpr (CONV) {
+      if (isB) { load_tile_conv(mt); return; }
+    }
     if constexpr (kBf16) {
       const int mb = st & 7, nb = st >> 3;           // 8 x 16 blocks of 8(m) x 8(cols)
       const int col = c0 + nb * 8;
@@ -643,7 +678,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(GemmTNArgs p, int 
   }
 }
 
-template <typename T>
+template <typename T, bool CONV = false>
 int launch_tn(const GemmTNArgs& p, hipStream_t stream) {
   const int tiles_n = (p.N + BM - 1) / BM, tiles_k = (p.K + BN - 1) / BN;
   const int ntiles = tiles_n * tiles_k;
@@ -658,11 +693,11 @@ int launch_tn(const GemmTNArgs& p, hipStream_t stream) {
   splits = (p.M + rows - 1) / rows;
   const size_t lds = 4 * kTileBytes;
   static LdsOptIn lds_opt;
-  EZ_ENSURE_LDS((&gemm_tn_kernel<T>), lds_opt, lds);
+  EZ_ENSURE_LDS((&gemm_tn_kernel<T, CONV>), lds_opt, lds);
   if (splits > 1 && !p.accumulate) EZ_HIP(hipMemset2DAsync(p.C, p.ldc * 4, 0, (size_t)p.K * 4, p.N, stream));
   {
     ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);
-    hipLaunchKernelGGL((gemm_tn_kernel<T>), dim3(ntiles * splits), dim3(kThreads), lds, stream, p, tiles_k, ntiles, rows);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, CONV>), dim3(ntiles * splits), dim3(kThreads), lds, stream, p, tiles_k, ntiles, rows);
   }
   EZ_LAUNCH_CHECK();
   return EZ_OK;
@@ -676,6 +711,16 @@ int gemm_tn(GemmTNArgs p, int dtype, hipStream_t stream) {
   const int g = 16 / esz;
   EZ_REQUIRE(p.N % g == 0 && p.K % g == 0 && p.lda % g == 0 && p.ldb % g == 0, "gemm_tn: N, K, lda, ldb must be multiples of %d", g);
   EZ_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0, "gemm_tn: A/B must be 16-byte aligned");
+  if (p.conv_H > 0) {        // B = the 3 x 3 neighbourhoods of an NHWC activation (see the kernel): never the 8-phase kernel
+    EZ_REQUIRE(p.conv_W >= 4 && p.conv_C > 0 && p.conv_C % g == 0 && p.ldb == p.conv_C && p.K == 9 * p.conv_C &&
+                   p.M % (p.conv_H * p.conv_W) == 0,
+               "gemm_tn (3x3 neighbourhoods): H %d W %d C %d ldb %lld K %d M %d (want W >= 4, ldb == C, K == 9 C, M a whole number of images)",
+               p.conv_H, p.conv_W, p.conv_C, (long long)p.ldb, p.K, p.M);
+    if (dtype == EZCLIP_F32) return launch_tn<float, true>(p, stream);
+    if (dtype == EZCLIP_BF16) return launch_tn<bf16_t, true>(p, stream);
+    set_error("gemm_tn: bad dtype %d", dtype);
+    return EZ_ERR_INVALID;
+  }
   if ((g_gemm_variant < 0 || g_gemm_variant == 2) && gemm_tn_8p_eligible(p, dtype)) return gemm_tn_8p(p, stream);
   if (dtype == EZCLIP_F32) return launch_tn<float>(p, stream);
   if (dtype == EZCLIP_BF16) return launch_tn<bf16_t>(p, stream);

@@ -94,6 +94,10 @@ struct GemmTNArgs {
   float* C = nullptr; int64_t ldc = 0;        // [N, K] f32
   int M = 0, N = 0, K = 0;
   int accumulate = 0;                         // C += instead of C =
+  // conv_H > 0: B is the NHWC activation x [M, conv_C] (ldb == conv_C) and the product runs over its 3 x 3 neighbourhoods,
+  // K == 9 * conv_C, column (ky * 3 + kx) * conv_C + c = the pixel shifted by (ky - 1, kx - 1), zero outside the image --
+  // the weight gradient of a 3 x 3 convolution without the explicit im2col (generic kernel only)
+  int conv_H = 0, conv_W = 0, conv_C = 0;
 };
 int gemm_tn(GemmTNArgs p, int dtype, hipStream_t stream);
 // 256x256 8-phase bf16 weight-gradient kernel (gemm8p.hip): N % 256 == 0, K % 256 == 0, large M; split partials +

@@ -608,13 +608,23 @@ int rn_wgrad(const ezclip_rn* m, const ezclip_rn::Conv& c, const void* dz, const
   const void* bsrc = x;
   int64_t ldb = c.Cp;
   if (c.cfirst) { ldb = c.ldk; }                         // the stem's first convolution: x IS its explicit im2col [M, ldk]
-  else if (c.k == 3) {
-    RN_TRY(rn_im2col3x3(x, B, H, H, c.Cp, col, m->dtype, st));
-    bsrc = col; ldb = 9 * (int64_t)c.Cp;
-  }
   GemmTNArgs t;
-  t.A = dz; t.lda = c.Opad; t.B = bsrc; t.ldb = ldb; t.C = dwp; t.ldc = c.ldk;
+  t.A = dz; t.lda = c.Opad; t.C = dwp; t.ldc = c.ldk;
   t.M = (int)M; t.N = c.Opad; t.K = c.ldk; t.accumulate = 0;
+  if (!c.cfirst && c.k == 3) {
+    // the 8-phase kernel (256-multiples: layer3 / layer4, small column matrices) reads an explicit im2col; everywhere else -- the stem
+    // and layer1 / layer2, where the column matrix is 0.5 - 3.7 GB per convolution at 256 images -- the generic kernel gathers the
+    // 3 x 3 neighbourhoods itself (GemmTNArgs::conv_H; bit-identical to the explicit route).  EZCLIP_RN_EXPLICIT_IM2COL=1: always explicit (A/B)
+    static const bool explicit_only = getenv("EZCLIP_RN_EXPLICIT_IM2COL") != nullptr && atoi(getenv("EZCLIP_RN_EXPLICIT_IM2COL")) != 0;
+    t.B = col; t.ldb = 9 * (int64_t)c.Cp;
+    if (!explicit_only && H >= 4 && !gemm_tn_8p_eligible(t, m->dtype)) {
+      t.B = x; t.ldb = c.Cp; t.conv_H = H; t.conv_W = H; t.conv_C = c.Cp;
+    } else {
+      RN_TRY(rn_im2col3x3(x, B, H, H, c.Cp, col, m->dtype, st));
+    }
+  } else {
+    t.B = bsrc; t.ldb = ldb;
+  }
   RN_TRY(gemm_tn(t, m->dtype, st));
   if (c.cfirst) {
     // K index (c, ky, kx) = the weight's own [I][3][3] order: a strided copy of the first I * 9 columns

@@ -457,6 +457,12 @@ int ezclip_op_layernorm_stats(const void* x_dev, int64_t x_stride, float eps, in
                               void* stream);
 int ezclip_op_gemm_tn(const void* a_dev, int64_t lda, const void* b_dev, int64_t ldb, float* c_dev, int64_t ldc,
                       int m, int n, int k, int accumulate, int dtype, void* stream);
+/* c [n, 9 * cp] (+)= a[images * h * w, n]^T . (the 3 x 3 neighbourhoods of the NHWC activation x [images * h * w, cp]): column
+ * (ky * 3 + kx) * cp + ch = the pixel shifted by (ky - 1, kx - 1), zero outside the image -- ezclip_op_gemm_tn on
+ * ezclip_op_rn_im2col3x3(x) without the column matrix, bit for bit (the weight gradient of torch's conv2d backward for a 3 x 3 /
+ * padding 1 convolution: modeling_chineseclip.py:34, :121-125 under core/trainer.py:658-661).  w >= 4. */
+int ezclip_op_gemm_tn_conv3x3(const void* a_dev, int64_t lda, const void* x_dev, int images, int h, int w, int cp, float* c_dev,
+                              int64_t ldc, int n, int accumulate, int dtype, void* stream);
 int ezclip_op_layernorm(const void* x_dev, int64_t x_stride, void* y_dev, int64_t y_stride, const float* g_dev,
                         const float* b_dev, float eps, int rows, int d, int dtype, float* mean_dev, float* rstd_dev,
                         void* stream);

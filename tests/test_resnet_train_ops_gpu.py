@@ -124,6 +124,41 @@ def test_avgpool_backward_and_im2col(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,cp,opad,H,W", [(2, 64, 64, 6, 6), (3, 128, 64, 7, 7), (5, 64, 192, 12, 12), (2, 192, 128, 9, 4),
+                                           (37, 64, 64, 28, 28)])
+def test_weight_gradient_product_gathers_the_neighbourhoods_itself(dtype, B, cp, opad, H, W):
+    """ezclip_op_gemm_tn_conv3x3 (the generic weight-gradient kernel reading the 3 x 3 neighbourhoods of x itself) == ezclip_op_gemm_tn on
+    the explicit ezclip_op_rn_im2col3x3 matrix, BIT FOR BIT: the same tile values meet the same MFMA sequence.  Shapes: one and several
+    column tiles (9 * cp = 576 ... 1728: a partial last tile), row counts that are not multiples of the 64 / 32-row step, a width of 4 (the
+    smallest accepted: one wrap per step), enough rows (37 * 784) that the contraction is split across workgroups, `accumulate`."""
+    lib = L.load()
+    tdt, edt = DT[dtype]
+    rows = B * H * W
+    g = torch.Generator().manual_seed(B * 100 + cp + H)
+    xd = torch.randn(rows, cp, generator=g).to(tdt).to(DEV)
+    dzd = torch.randn(rows, opad, generator=g).to(tdt).to(DEV)
+    cold = torch.empty(rows, 9 * cp, dtype=tdt, device=DEV)
+    L.check(lib.ezclip_op_rn_im2col3x3(L.ptr(xd), B, H, W, cp, L.ptr(cold), edt, L.stream_ptr()))
+    want = torch.full((opad, 9 * cp), 7.0, dtype=torch.float32, device=DEV)
+    L.check(lib.ezclip_op_gemm_tn(L.ptr(dzd), opad, L.ptr(cold), 9 * cp, L.ptr(want), 9 * cp, rows, opad, 9 * cp, 0, edt, L.stream_ptr()))
+    got = torch.full((opad, 9 * cp), -3.0, dtype=torch.float32, device=DEV)
+    L.check(lib.ezclip_op_gemm_tn_conv3x3(L.ptr(dzd), opad, L.ptr(xd), B, H, W, cp, L.ptr(got), 9 * cp, opad, 0, edt, L.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = dzd.double().t() @ cold.double()
+    assert float((want.double() - ref).abs().max()) < (1e-3 if dtype == "fp32" else 1e-2) * max(1.0, float(ref.abs().max()))
+    if rows <= 256:                  # one workgroup per tile: a fixed summation order
+        assert torch.equal(got, want)
+    else:                            # the contraction is split: float atomics in an order that differs between any two launches
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    L.check(lib.ezclip_op_gemm_tn_conv3x3(L.ptr(dzd), opad, L.ptr(xd), B, H, W, cp, L.ptr(got), 9 * cp, opad, 1, edt, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert float((got - 2 * want).abs().max()) <= 4e-5 * max(1.0, float(want.abs().max()))
+    # the guard: a width below 4 (the pixel walk allows one wrap per step) is refused, loudly
+    assert lib.ezclip_op_gemm_tn_conv3x3(L.ptr(dzd), opad, L.ptr(xd), B, H, 3, cp, L.ptr(got), 9 * cp, opad, 0, edt, L.stream_ptr()) != 0
+    assert "W >= 4" in L.last_error()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,I,O,H", [(2, 24, 40, 6), (1, 64, 128, 10)])
 def test_convolution_gradients_through_the_device_products(dtype, B, I, O, H):
     """dx = the tower's implicit 3x3 convolution of dz on the packed input-gradient weights; dw = gemm_tn(dz, im2col(x)) unpacked --

@@ -12,7 +12,7 @@ from oracle import resnet_oracle as RO  # noqa: E402  (weights only: test infras
 
 layers, width, e, res = (3, 4, 6, 3), 64, 1024, 224
 sd = RO.make_state_dict(layers, width, e, res, 1)
-for dtype in ("bf16", "fp32"):
+for dtype in (() if os.environ.get("RN_BENCH_TRAIN_ONLY") else ("bf16", "fp32")):
     eng = RnEngine(layers, width, e, res, L.dtype_code(dtype))
     dev = {n: sd[n].cuda() for n in eng.names}
     eng.sync(dev)

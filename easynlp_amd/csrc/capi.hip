@@ -599,6 +599,11 @@ int ezclip_op_gemm_tn_conv3x3(const void* a, int64_t lda, const void* x, int ima
   return gemm_tn(g, dtype, S(stream));
 }
 
+int ezclip_op_rn_wgrad3x3_c64(const void* x, const void* dz, int images, int h, int w, void* scratch, size_t scratch_bytes, float* out,
+                              int64_t ldo, int accumulate, void* stream) {
+  return rn_wgrad3x3_c64(x, dz, images, h, w, scratch, scratch_bytes, out, ldo, accumulate, S(stream));
+}
+
 int ezclip_op_layernorm(const void* x, int64_t xs, void* y, int64_t ys, const float* g, const float* b, float eps,
                         int rows, int d, int dtype, float* mean, float* rstd, void* stream) {
   return layernorm_fwd(x, xs, y, ys, g, b, eps, rows, d, dtype, mean, rstd, S(stream));

@@ -78,6 +78,11 @@ int rn_add_inplace(void* a, const void* b, int64_t n, int dtype, hipStream_t st)
 int rn_im2col3x3(const void* x, int B, int H, int W, int cp, void* col, int dtype, hipStream_t st);
 int rn_pack_conv_dgrad(const float* W, int O, int I, int k, int opad, int ipad, void* dst, int dtype, hipStream_t st);
 int rn_unpack_wgrad(const float* dwp, int64_t ldp, int O, int I, int k, int cp, int accumulate, float* dw, hipStream_t st);
+// 3 x 3 weight gradient at 64 padded channels in and out, bf16 (the stem's conv2 / conv3, layer1's conv2): out [64][ldo >= 576] f32 in the
+// column order of rn_im2col3x3; x and dz are read once; scratch holds one [64][576] f32 partial per workgroup (up to 512)
+bool rn_wgrad3x3_c64_eligible(int B, int H, int W, int cp, int opad, int dtype, size_t scratch_bytes);
+int rn_wgrad3x3_c64(const void* x, const void* dz, int B, int H, int W, void* scratch, size_t scratch_bytes, float* out, int64_t ldo,
+                    int accumulate, hipStream_t st);
 // C = act(alpha * exp(scale) * A.B^T + bias) + R
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream);
 // 256x256x64 8-phase bf16 kernel (gemm8p.hip): large M, N % 256 == 0, K % 128 == 0, bf16 output

@@ -602,8 +602,8 @@ int rn_dgrad(const ezclip_rn* m, const ezclip_rn::Conv& c, const void* dz, int64
 
 // weight gradient of a convolution into its bound gradient buffer: dW = dz^T . x (1x1) / dz^T . im2col(x) (3x3; explicit im2col in `col`)
 template <typename T>
-int rn_wgrad(const ezclip_rn* m, const ezclip_rn::Conv& c, const void* dz, const void* x, int64_t M, int H, int B, void* col, float* dwp,
-             hipStream_t st) {
+int rn_wgrad(const ezclip_rn* m, const ezclip_rn::Conv& c, const void* dz, const void* x, int64_t M, int H, int B, void* col, size_t col_bytes,
+             float* dwp, hipStream_t st) {
   float* gw = m->params[c.w].g;
   const void* bsrc = x;
   int64_t ldb = c.Cp;
@@ -615,7 +615,15 @@ int rn_wgrad(const ezclip_rn* m, const ezclip_rn::Conv& c, const void* dz, const
     // the 8-phase kernel (256-multiples: layer3 / layer4, small column matrices) reads an explicit im2col; everywhere else -- the stem
     // and layer1 / layer2, where the column matrix is 0.5 - 3.7 GB per convolution at 256 images -- the generic kernel gathers the
     // 3 x 3 neighbourhoods itself (GemmTNArgs::conv_H; bit-identical to the explicit route).  EZCLIP_RN_EXPLICIT_IM2COL=1: always explicit (A/B)
-    static const bool explicit_only = getenv("EZCLIP_RN_EXPLICIT_IM2COL") != nullptr && atoi(getenv("EZCLIP_RN_EXPLICIT_IM2COL")) != 0;
+    // EZCLIP_RN_EXPLICIT_IM2COL=2: no dedicated 64-channel kernel either way (A/B of that kernel alone)
+    static const int im2col_mode = getenv("EZCLIP_RN_EXPLICIT_IM2COL") ? atoi(getenv("EZCLIP_RN_EXPLICIT_IM2COL")) : 0;
+    static const bool explicit_only = im2col_mode == 1;
+    if (im2col_mode == 0 && rn_wgrad3x3_c64_eligible(B, H, H, c.Cp, c.Opad, m->dtype, col_bytes)) {
+      // 64 channels in and out (the stem's conv2 / conv3, layer1): x and dz read once, the whole 64 x 576 result in registers;
+      // `col` (no column matrix is built) holds the per-workgroup partials
+      RN_TRY(rn_wgrad3x3_c64(x, dz, B, H, H, col, col_bytes, dwp, c.ldk, 0, st));
+      return rn_unpack_wgrad(dwp, c.ldk, c.O, c.I, c.k, c.Cp, 0, gw, st);
+    }
     t.B = col; t.ldb = 9 * (int64_t)c.Cp;
     if (!explicit_only && H >= 4 && !gemm_tn_8p_eligible(t, m->dtype)) {
       t.B = x; t.ldb = c.Cp; t.conv_H = H; t.conv_W = H; t.conv_C = c.Cp;
@@ -643,7 +651,8 @@ int rn_train_backward(ezclip_rn* m, const float* features, const float* d_featur
   const size_t bufb = act > tokb ? act : tokb;
   void* buf[kRnTrainBufs];
   for (auto& b : buf) b = a.take(bufb);
-  void* col = a.take(rn_train_max_col_bytes(m, B));
+  const size_t col_bytes = rn_train_max_col_bytes(m, B);
+  void* col = a.take(col_bytes);
   float* dwp = (float*)a.take(rn_train_wgrad_bytes(m));                           // (the SAME bytes rn_train_scratch_bytes reserved)
   float* bn_scratch = (float*)a.take(rn_bn_scratch_bytes((int64_t)B * (m->cfg.image_resolution / 2) * (m->cfg.image_resolution / 2), 2048));
   EZ_REQUIRE(a.off <= scratch_bytes, "rn_train_backward: the pass carves %zu bytes out of a scratch of %zu (rn_train_scratch_bytes is out of step)", a.off, scratch_bytes);
@@ -728,7 +737,7 @@ int rn_train_backward(ezclip_rn* m, const float* features, const float* d_featur
                            bn_scratch, m->dtype, st));
     dsum("dz", dz, c.M * c.Opad);
     dsum("dres", dres, c.M * c.Opad);
-    RN_TRY(rn_wgrad<T>(m, c, dz, c.in, c.M, c.H, B, col, dwp, st));
+    RN_TRY(rn_wgrad<T>(m, c, dz, c.in, c.M, c.H, B, col, col_bytes, dwp, st));
     if (dst != nullptr && c.sd != nullptr) {
       RN_TRY(rn_dgrad(m, c, dz, c.M, c.H, dst, add, st));
       dsum("dx", dst, c.M * c.Cp);

@@ -299,6 +299,136 @@ __global__ __launch_bounds__(256) void rn_im2col3x3_kernel(const T* __restrict__
   st4(col + pix * 9 * (int64_t)cp + (int64_t)tap * cp + c, v);
 }
 
+// ---- 3 x 3 weight gradient at 64 (padded) channels in and out: the stem's conv2 / conv3 and layer1's conv2 ------------------------------
+// dWp[o][(ky * 3 + kx) * 64 + c] = sum over pixels m of dz[m][o] * x[m shifted by (ky - 1, kx - 1)][c]  (zero outside the image)
+// These are the convolutions with the most pixels (256 images: 3.2 M at 112 x 112, 0.8 M at 56 x 56) and the smallest output (64 x 576):
+// as a matrix product (gemm_tn) the 128 x 128 tiles re-read dz five times and x nine times through L2 and run at 2.4 TB/s of that; the
+// problem itself reads x and dz ONCE.  Here a workgroup owns a contiguous range of strips (R image rows of one image), keeps the WHOLE
+// 64 x 576 result in registers (wave w: channels 16 w .. 16 w + 15 of all nine taps and all 64 outputs = 36 16 x 16 accumulators) and per
+// strip brings the rows into LDS once:
+//   x image : rows y0 - 1 .. y0 + R as they lie in memory ([pixel][64 channels], 128 B per pixel), every image row preceded by two zero
+//             pixels, zero rows where the image ends -- so a tap is a CONSTANT pixel offset (1 + dy) * (W + 2) + dx + 1 and needs no mask;
+//   dz image: rows y0 .. y0 + R - 1 with the same row pitch, zero pixels at the pad positions (a pad pixel of dz times anything adds 0).
+// The contraction runs over the padded pixel index in steps of 32 (v_mfma_f32_16x16x32_bf16); both operands want 8 consecutive pixels
+// of one channel per lane = the LDS transpose read (ds_read_b64_tr_b16: 16 lanes read a 4 (pixel) x 16 (channel) block, lane c receives
+// channel c) from the row-major images.  The 32-byte slot of a pixel row is XORed with (bit 1, bit 3) of the LDS row index: the eight
+// rows one 32-lane pass touches (r .. r + 3, r + 8 .. r + 11, any r) then fall on eight different bank groups.
+// Partials [workgroup][64][576] f32 are summed in a fixed order by rn_wgrad64_reduce_kernel: bit-reproducible.
+typedef __attribute__((ext_vector_type(4))) short wg_s16x4_t;
+typedef __attribute__((address_space(3))) wg_s16x4_t wg_lds_s16x4;
+
+struct RnWgrad64Args {
+  const bf16_t* x; const bf16_t* dz; float* part;
+  int H, W, R, strips_per_image, strips, lz_r;
+};
+
+__device__ __forceinline__ uint32_t wg64_slot(int row) { return (uint32_t)(((row >> 1) & 1) | (((row >> 3) & 1) << 1)); }
+// byte offset of 16-byte chunk `ch` (0..7) of LDS pixel row `row`
+__device__ __forceinline__ uint32_t wg64_chunk(int row, int ch) {
+  return (uint32_t)row * 128u + ((((uint32_t)ch >> 1) ^ wg64_slot(row)) << 5) + (((uint32_t)ch & 1u) << 4);
+}
+// 8 consecutive pixel rows (row .. row + 3, row + 4 .. row + 7 by the lane's quarter) of one channel: lane (t = lane & 15, q4 = lane >> 4)
+// passes row = first + 8 q4 + (t >> 2); cb = the 16-channel block
+__device__ __forceinline__ uint4 wg64_frag(const char* img, int row, int cb, int t) {
+  const uint32_t a0 = (uint32_t)row * 128u + (((uint32_t)cb ^ wg64_slot(row)) << 5) + (uint32_t)(t & 3) * 8u;
+  const uint32_t a1 = (uint32_t)(row + 4) * 128u + (((uint32_t)cb ^ wg64_slot(row + 4)) << 5) + (uint32_t)(t & 3) * 8u;
+  const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(img + a0)));
+  const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(img + a1)));
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+__global__ __launch_bounds__(256, 2) void rn_wgrad3x3_c64_kernel(RnWgrad64Args a) {
+  extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = lane & 15, q4 = lane >> 4;
+  const int Wp = a.W + 2;
+  const int nx = a.lz_r + 2 * Wp + 2;                 // pixel rows of the x image (LDS row 0 = the slack before the first padded pixel)
+  char* xi = wg_smem;
+  char* zi = wg_smem + (size_t)nx * 128;
+  for (int q = tid; q < (nx + a.lz_r) * 8; q += 256) *reinterpret_cast<uint4*>(wg_smem + (size_t)q * 16) = make_uint4(0u, 0u, 0u, 0u);
+
+  f32x4_t acc[9][4];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) acc[tap][ob] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int s_begin = (int)((int64_t)a.strips * blockIdx.x / gridDim.x), s_end = (int)((int64_t)a.strips * (blockIdx.x + 1) / gridDim.x);
+  const int row_chunks = a.W * 8;                     // 16-byte chunks of one image row
+  const int nxc = (a.R + 2) * row_chunks, nzc = a.R * row_chunks;
+  for (int s = s_begin; s < s_end; ++s) {
+    const int b = s / a.strips_per_image, y0 = (s - b * a.strips_per_image) * a.R;
+    const bf16_t* xb = a.x + (int64_t)b * a.H * a.W * 64;
+    const bf16_t* zb = a.dz + (int64_t)b * a.H * a.W * 64;
+    __syncthreads();                                  // the previous strip's fragment reads (first strip: the zero fill) are done
+    // eight chunks per thread in flight, then their LDS writes; the x rows first, the dz rows after them in one chunk numbering
+    for (int q0 = tid; q0 < nxc + nzc; q0 += 256 * 8) {
+      uint4 v[8];
+      uint32_t dst[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + u * 256;
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        dst[u] = 0xffffffffu;
+        if (q < nxc) {
+          const int ry = q / row_chunks, rem = q - ry * row_chunks;
+          const int xx = rem >> 3, ch = rem & 7, y = y0 - 1 + ry;
+          if ((unsigned)y < (unsigned)a.H) v[u] = *reinterpret_cast<const uint4*>(xb + ((int64_t)y * a.W + xx) * 64 + ch * 8);
+          dst[u] = wg64_chunk(ry * Wp + xx + 2, ch);
+        } else if (q < nxc + nzc) {
+          const int qz = q - nxc;
+          const int rz = qz / row_chunks, rem = qz - rz * row_chunks;
+          const int xx = rem >> 3, ch = rem & 7, y = y0 + rz;
+          if (y < a.H) v[u] = *reinterpret_cast<const uint4*>(zb + ((int64_t)y * a.W + xx) * 64 + ch * 8);
+          dst[u] = (uint32_t)nx * 128u + wg64_chunk(rz * Wp + xx + 1, ch);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dst[u] != 0xffffffffu) *reinterpret_cast<uint4*>(wg_smem + dst[u]) = v[u];
+    }
+    __syncthreads();
+    for (int k = 0; k < a.lz_r; k += 32) {
+      const int rz = k + 8 * q4 + (t >> 2);
+      uint4 af[4];
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) af[ob] = wg64_frag(zi, rz, ob, t);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int off = (tap / 3) * Wp + (tap % 3);   // (1 + dy) (W + 2) + dx + 1 with dy = tap / 3 - 1, dx = tap % 3 - 1
+        const uint4 bf = wg64_frag(xi, rz + off, wave, t);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) mma16(acc[tap][ob], af[ob], bf);
+      }
+    }
+  }
+  // D column = lane & 15 = channel, rows 4 (lane >> 4) + r = output channel within the block
+  float* pw = a.part + (size_t)blockIdx.x * 64 * 576;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[(size_t)(ob * 16 + 4 * q4 + r) * 576 + tap * 64 + wave * 16 + t] = acc[tap][ob][r];
+}
+
+// out[o][c] (row stride ldo) = (accumulate ? out : 0) + sum_g part[g][o][c], g ascending
+__global__ __launch_bounds__(256) void rn_wgrad64_reduce_kernel(const float* __restrict__ part, int G, float* __restrict__ out, int64_t ldo,
+                                                                 int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;       // float4 index into [64][576]
+  if (i >= 64 * 576 / 4) return;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int g = 0; g < G; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (size_t)g * 64 * 576 + (size_t)i * 4);
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  }
+  const int o = (i * 4) / 576, c = i * 4 - o * 576;
+  float* d = out + (int64_t)o * ldo + c;
+  if (accumulate) { sum.x += d[0]; sum.y += d[1]; sum.z += d[2]; sum.w += d[3]; }
+  d[0] = sum.x; d[1] = sum.y; d[2] = sum.z; d[3] = sum.w;
+}
+
 // weights of the input-gradient product: dst [ipad][k*k*opad], dst[c][(ky*k + kx)*opad + o] = W[o][c][k-1-ky][k-1-kx]; zeros elsewhere
 template <typename T>
 __global__ __launch_bounds__(256) void rn_pack_conv_dgrad_kernel(const float* __restrict__ W, int O, int I, int k, int opad, int ipad,
@@ -425,6 +555,49 @@ int rn_im2col3x3(const void* x, int B, int H, int W, int cp, void* col, int dtyp
   EZ_REQUIRE(x && col && B > 0 && H > 0 && W > 0 && cp % 4 == 0, "rn_im2col3x3: bad shape %d x %d x %d x %d", B, H, W, cp);
   const int64_t quads = (int64_t)B * H * W * 9 * (cp / 4);
   RN_DISPATCH_T(dtype, return launch_quads(rn_im2col3x3_kernel<T>, quads, st, (const T*)x, quads, H, W, cp, (T*)col));
+  return EZ_OK;
+}
+
+// the strip height of rn_wgrad3x3_c64 for an image width: the largest R whose two images fit twice into a CU's LDS
+static int wgrad64_strip_rows(int H, int W, int* lz_r, size_t* lds) {
+  const int Wp = W + 2;
+  int best = 0;
+  for (int R = 1; R <= H && R <= 8; ++R) {
+    const int lr = (R * Wp + 31) / 32 * 32;
+    const size_t bytes = (size_t)(lr + 2 * Wp + 2 + lr) * 128;
+    if (bytes > 78 * 1024) break;
+    best = R; *lz_r = lr; *lds = bytes;
+  }
+  return best;
+}
+
+bool rn_wgrad3x3_c64_eligible(int B, int H, int W, int cp, int opad, int dtype, size_t scratch_bytes) {
+  int lr = 0; size_t lds = 0;
+  return dtype == EZCLIP_BF16 && cp == 64 && opad == 64 && B > 0 && H > 0 && W >= 2 && wgrad64_strip_rows(H, W, &lr, &lds) > 0 &&
+         scratch_bytes >= (size_t)64 * 576 * 4;
+}
+
+int rn_wgrad3x3_c64(const void* x, const void* dz, int B, int H, int W, void* scratch, size_t scratch_bytes, float* out, int64_t ldo,
+                    int accumulate, hipStream_t st) {
+  EZ_REQUIRE(x && dz && scratch && out && ldo >= 576 && rn_wgrad3x3_c64_eligible(B, H, W, 64, 64, EZCLIP_BF16, scratch_bytes),
+             "rn_wgrad3x3_c64: %d images of %d x %d (64 channels in and out, bf16), scratch %zu bytes: not a shape of this kernel", B, H, W,
+             scratch_bytes);
+  RnWgrad64Args a;
+  size_t lds = 0;
+  a.x = (const bf16_t*)x; a.dz = (const bf16_t*)dz; a.part = (float*)scratch;
+  a.H = H; a.W = W;
+  a.R = wgrad64_strip_rows(H, W, &a.lz_r, &lds);
+  a.strips_per_image = (H + a.R - 1) / a.R;
+  a.strips = B * a.strips_per_image;
+  int G = a.strips < 512 ? a.strips : 512;            // two workgroups per CU
+  const size_t fit = scratch_bytes / ((size_t)64 * 576 * 4);
+  if ((size_t)G > fit) G = (int)fit;
+  static LdsOptIn lds_opt;
+  EZ_ENSURE_LDS(rn_wgrad3x3_c64_kernel, lds_opt, lds);
+  hipLaunchKernelGGL(rn_wgrad3x3_c64_kernel, dim3(G), dim3(256), lds, st, a);
+  EZ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rn_wgrad64_reduce_kernel, dim3((64 * 576 / 4 + 255) / 256), dim3(256), 0, st, (const float*)scratch, G, out, ldo, accumulate);
+  EZ_LAUNCH_CHECK();
   return EZ_OK;
 }
 

@@ -463,6 +463,12 @@ int ezclip_op_gemm_tn(const void* a_dev, int64_t lda, const void* b_dev, int64_t
  * padding 1 convolution: modeling_chineseclip.py:34, :121-125 under core/trainer.py:658-661).  w >= 4. */
 int ezclip_op_gemm_tn_conv3x3(const void* a_dev, int64_t lda, const void* x_dev, int images, int h, int w, int cp, float* c_dev,
                               int64_t ldc, int n, int accumulate, int dtype, void* stream);
+/* The same product for 64 (padded) channels in AND out, bf16 -- the stem's conv2 / conv3 and layer1's conv2 of the ModifiedResNet
+ * (modeling_chineseclip.py:121-125, :34), the convolutions with the most pixels: x and dz [images * h * w, 64] are read once, out
+ * [64, ldo >= 576] f32 (+)=, scratch >= 147 456 bytes (one [64][576] f32 partial per workgroup, up to 512 are used), summed in a
+ * fixed order (bit-reproducible).  Other shapes / dtypes: refused (ezclip_op_gemm_tn_conv3x3 takes them). */
+int ezclip_op_rn_wgrad3x3_c64(const void* x_dev, const void* dz_dev, int images, int h, int w, void* scratch_dev, size_t scratch_bytes,
+                              float* out_dev, int64_t ldo, int accumulate, void* stream);
 int ezclip_op_layernorm(const void* x_dev, int64_t x_stride, void* y_dev, int64_t y_stride, const float* g_dev,
                         const float* b_dev, float eps, int rows, int d, int dtype, float* mean_dev, float* rstd_dev,
                         void* stream);

@@ -158,6 +158,41 @@ def test_weight_gradient_product_gathers_the_neighbourhoods_itself(dtype, B, cp,
     assert "W >= 4" in L.last_error()
 
 
+@pytest.mark.parametrize("B,H,W,parts", [(2, 8, 8, 512), (3, 7, 12, 512), (4, 5, 40, 2), (6, 56, 56, 512), (3, 112, 112, 100), (2, 9, 140, 512)])
+def test_weight_gradient_at_64_channels_reads_its_operands_once(B, H, W, parts):
+    """ezclip_op_rn_wgrad3x3_c64 (the whole 64 x 576 result in registers, strips of image rows through LDS with zero pad pixels, the LDS
+    transpose read) against the explicit column matrix + ezclip_op_gemm_tn and against float64: strips of 1 ... 8 rows (the LDS budget
+    decides: width 140 -> one row, width 8 -> eight), a last strip that runs past the image (H = 7, 9, 5 with R = 8 / 1 / 5), non-square
+    images, fewer partial buffers than strips (`parts`), `accumulate`, and bit-reproducibility (fixed summation order)."""
+    lib = L.load()
+    tdt, edt = DT["bf16"]
+    rows = B * H * W
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    xd = torch.randn(rows, 64, generator=g).to(tdt).to(DEV)
+    dzd = torch.randn(rows, 64, generator=g).to(tdt).to(DEV)
+    cold = torch.empty(rows, 576, dtype=tdt, device=DEV)
+    L.check(lib.ezclip_op_rn_im2col3x3(L.ptr(xd), B, H, W, 64, L.ptr(cold), edt, L.stream_ptr()))
+    ref = (dzd.double().t() @ cold.double())
+    scratch = torch.empty(parts * 64 * 576, dtype=torch.float32, device=DEV)
+    got = torch.full((64, 640), -3.0, dtype=torch.float32, device=DEV)
+    L.check(lib.ezclip_op_rn_wgrad3x3_c64(L.ptr(xd), L.ptr(dzd), B, H, W, L.ptr(scratch), scratch.numel() * 4, L.ptr(got), 640, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got[:, :576].double() - ref).abs().max()) < 2e-3 * scale, float((got[:, :576].double() - ref).abs().max()) / scale
+    assert float((got[:, 576:] + 3.0).abs().max()) == 0.0                     # columns beyond 576 are not touched
+    again = torch.zeros(64, 640, dtype=torch.float32, device=DEV)
+    scratch.fill_(float("nan"))
+    L.check(lib.ezclip_op_rn_wgrad3x3_c64(L.ptr(xd), L.ptr(dzd), B, H, W, L.ptr(scratch), scratch.numel() * 4, L.ptr(again), 640, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(again[:, :576], got[:, :576])
+    L.check(lib.ezclip_op_rn_wgrad3x3_c64(L.ptr(xd), L.ptr(dzd), B, H, W, L.ptr(scratch), scratch.numel() * 4, L.ptr(again), 640, 1, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert float((again[:, :576] - 2 * got[:, :576]).abs().max()) <= 1e-5 * scale
+    # not this kernel's shape: refused, loudly (no scratch for even one partial)
+    assert lib.ezclip_op_rn_wgrad3x3_c64(L.ptr(xd), L.ptr(dzd), B, H, W, L.ptr(scratch), 1000, L.ptr(again), 640, 0, L.stream_ptr()) != 0
+    assert "not a shape of this kernel" in L.last_error()
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,I,O,H", [(2, 24, 40, 6), (1, 64, 128, 10)])
 def test_convolution_gradients_through_the_device_products(dtype, B, I, O, H):

@@ -599,9 +599,14 @@ int ezclip_op_gemm_tn_conv3x3(const void* a, int64_t lda, const void* x, int ima
   return gemm_tn(g, dtype, S(stream));
 }
 
-int ezclip_op_rn_wgrad3x3_c64(const void* x, const void* dz, int images, int h, int w, void* scratch, size_t scratch_bytes, float* out,
-                              int64_t ldo, int accumulate, void* stream) {
-  return rn_wgrad3x3_c64(x, dz, images, h, w, scratch, scratch_bytes, out, ldo, accumulate, S(stream));
+int ezclip_op_rn_wgrad3x3_c64(const void* x, const void* dz, int images, int h, int w, int cp, int opad, void* scratch, size_t scratch_bytes,
+                              float* out, int64_t ldo, int accumulate, void* stream) {
+  return rn_wgrad3x3_c64(x, dz, images, h, w, cp, opad, scratch, scratch_bytes, out, ldo, accumulate, S(stream));
+}
+
+int ezclip_op_rn_tn_skinny(const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc, int64_t m, int n, int k, int accumulate,
+                           void* scratch, size_t scratch_bytes, void* stream) {
+  return rn_tn_skinny(a, lda, b, ldb, c, ldc, m, n, k, accumulate, scratch, scratch_bytes, S(stream));
 }
 
 int ezclip_op_layernorm(const void* x, int64_t xs, void* y, int64_t ys, const float* g, const float* b, float eps,

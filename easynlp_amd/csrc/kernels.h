@@ -78,11 +78,17 @@ int rn_add_inplace(void* a, const void* b, int64_t n, int dtype, hipStream_t st)
 int rn_im2col3x3(const void* x, int B, int H, int W, int cp, void* col, int dtype, hipStream_t st);
 int rn_pack_conv_dgrad(const float* W, int O, int I, int k, int opad, int ipad, void* dst, int dtype, hipStream_t st);
 int rn_unpack_wgrad(const float* dwp, int64_t ldp, int O, int I, int k, int cp, int accumulate, float* dw, hipStream_t st);
-// 3 x 3 weight gradient at 64 padded channels in and out, bf16 (the stem's conv2 / conv3, layer1's conv2): out [64][ldo >= 576] f32 in the
-// column order of rn_im2col3x3; x and dz are read once; scratch holds one [64][576] f32 partial per workgroup (up to 512)
+// 3 x 3 weight gradient at 64 or 128 padded channels in / out, bf16 (the stem's conv2 / conv3, layer1's and layer2's conv2): out
+// [opad][ldo >= 9 cp] f32 in the column order of rn_im2col3x3; every 64-output x 64-channel sub-problem reads its halves of x and dz once;
+// scratch holds one [64][576] f32 partial per workgroup (up to 512 in all)
+// C[N][K] f32 (+)= A[M][N]^T . B[M][K], bf16, M >= 4096 and N x K small (N, K multiples of 64, at most 16 blocks of 64 x 256): the 1 x 1
+// weight gradients of layer1 / layer2 and the stem's first convolution; operands read once per block row / column, fixed-order partial sums
+bool rn_tn_skinny_eligible(int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int dtype, size_t scratch_bytes);
+int rn_tn_skinny(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, int accumulate,
+                 void* scratch, size_t scratch_bytes, hipStream_t st);
 bool rn_wgrad3x3_c64_eligible(int B, int H, int W, int cp, int opad, int dtype, size_t scratch_bytes);
-int rn_wgrad3x3_c64(const void* x, const void* dz, int B, int H, int W, void* scratch, size_t scratch_bytes, float* out, int64_t ldo,
-                    int accumulate, hipStream_t st);
+int rn_wgrad3x3_c64(const void* x, const void* dz, int B, int H, int W, int cp, int opad, void* scratch, size_t scratch_bytes, float* out,
+                    int64_t ldo, int accumulate, hipStream_t st);
 // C = act(alpha * exp(scale) * A.B^T + bias) + R
 int gemm_nt(GemmArgs p, int dtype, hipStream_t stream);
 // 256x256x64 8-phase bf16 kernel (gemm8p.hip): large M, N % 256 == 0, K % 128 == 0, bf16 output

@@ -615,13 +615,13 @@ int rn_wgrad(const ezclip_rn* m, const ezclip_rn::Conv& c, const void* dz, const
     // the 8-phase kernel (256-multiples: layer3 / layer4, small column matrices) reads an explicit im2col; everywhere else -- the stem
     // and layer1 / layer2, where the column matrix is 0.5 - 3.7 GB per convolution at 256 images -- the generic kernel gathers the
     // 3 x 3 neighbourhoods itself (GemmTNArgs::conv_H; bit-identical to the explicit route).  EZCLIP_RN_EXPLICIT_IM2COL=1: always explicit (A/B)
-    // EZCLIP_RN_EXPLICIT_IM2COL=2: no dedicated 64-channel kernel either way (A/B of that kernel alone)
+    // EZCLIP_RN_EXPLICIT_IM2COL=2: no dedicated 64-channel-block kernel (A/B of that kernel alone); 3: that kernel, but generic 1 x 1 products
     static const int im2col_mode = getenv("EZCLIP_RN_EXPLICIT_IM2COL") ? atoi(getenv("EZCLIP_RN_EXPLICIT_IM2COL")) : 0;
     static const bool explicit_only = im2col_mode == 1;
-    if (im2col_mode == 0 && rn_wgrad3x3_c64_eligible(B, H, H, c.Cp, c.Opad, m->dtype, col_bytes)) {
-      // 64 channels in and out (the stem's conv2 / conv3, layer1): x and dz read once, the whole 64 x 576 result in registers;
+    if ((im2col_mode == 0 || im2col_mode == 3) && rn_wgrad3x3_c64_eligible(B, H, H, c.Cp, c.Opad, m->dtype, col_bytes)) {
+      // 64 or 128 channels in and out (the stem's conv2 / conv3, layer1, layer2): x and dz read once per 64 x 64 block, its 64 x 576 result in registers;
       // `col` (no column matrix is built) holds the per-workgroup partials
-      RN_TRY(rn_wgrad3x3_c64(x, dz, B, H, H, col, col_bytes, dwp, c.ldk, 0, st));
+      RN_TRY(rn_wgrad3x3_c64(x, dz, B, H, H, c.Cp, c.Opad, col, col_bytes, dwp, c.ldk, 0, st));
       return rn_unpack_wgrad(dwp, c.ldk, c.O, c.I, c.k, c.Cp, 0, gw, st);
     }
     t.B = col; t.ldb = 9 * (int64_t)c.Cp;
@@ -632,6 +632,17 @@ int rn_wgrad(const ezclip_rn* m, const ezclip_rn::Conv& c, const void* dz, const
     }
   } else {
     t.B = bsrc; t.ldb = ldb;
+    // 1 x 1 (and the stem's first convolution on its explicit column matrix): many pixels, few channels on one side -- the operands-once
+    // kernel where the 8-phase kernel does not apply.  EZCLIP_RN_EXPLICIT_IM2COL=3 (and 1, 2): the generic kernel (A/B)
+    static const int mode = getenv("EZCLIP_RN_EXPLICIT_IM2COL") ? atoi(getenv("EZCLIP_RN_EXPLICIT_IM2COL")) : 0;
+    if (mode == 0 && !gemm_tn_8p_eligible(t, m->dtype) && rn_tn_skinny_eligible(M, t.N, t.K, t.lda, t.ldb, t.ldc, m->dtype, col_bytes)) {
+      RN_TRY(rn_tn_skinny(t.A, t.lda, t.B, t.ldb, t.C, t.ldc, M, t.N, t.K, 0, col, col_bytes, st));
+      if (c.cfirst) {
+        EZ_HIP(hipMemcpy2DAsync(gw, (size_t)c.I * 9 * 4, dwp, (size_t)c.ldk * 4, (size_t)c.I * 9 * 4, c.O, hipMemcpyDeviceToDevice, st));
+        return EZ_OK;
+      }
+      return rn_unpack_wgrad(dwp, c.ldk, c.O, c.I, c.k, c.Cp, 0, gw, st);
+    }
   }
   RN_TRY(gemm_tn(t, m->dtype, st));
   if (c.cfirst) {

@@ -320,6 +320,7 @@ typedef __attribute__((address_space(3))) wg_s16x4_t wg_lds_s16x4;
 struct RnWgrad64Args {
   const bf16_t* x; const bf16_t* dz; float* part;
   int H, W, R, strips_per_image, strips, lz_r;
+  int cp, opad;                // channels per pixel of x / dz in memory (multiples of 64): blockIdx.y = (64-output block) * (cp / 64) + (64-channel block)
 };
 
 __device__ __forceinline__ uint32_t wg64_slot(int row) { return (uint32_t)(((row >> 1) & 1) | (((row >> 3) & 1) << 1)); }
@@ -354,13 +355,15 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad3x3_c64_kernel(RnWgrad64Args a
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) acc[tap][ob] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  const int cblocks = a.cp >> 6;
+  const int o_off = ((int)blockIdx.y / cblocks) * 64, c_off = ((int)blockIdx.y % cblocks) * 64;   // this workgroup's 64 outputs x 64 channels
   const int s_begin = (int)((int64_t)a.strips * blockIdx.x / gridDim.x), s_end = (int)((int64_t)a.strips * (blockIdx.x + 1) / gridDim.x);
   const int row_chunks = a.W * 8;                     // 16-byte chunks of one image row
   const int nxc = (a.R + 2) * row_chunks, nzc = a.R * row_chunks;
   for (int s = s_begin; s < s_end; ++s) {
     const int b = s / a.strips_per_image, y0 = (s - b * a.strips_per_image) * a.R;
-    const bf16_t* xb = a.x + (int64_t)b * a.H * a.W * 64;
-    const bf16_t* zb = a.dz + (int64_t)b * a.H * a.W * 64;
+    const bf16_t* xb = a.x + (int64_t)b * a.H * a.W * a.cp + c_off;
+    const bf16_t* zb = a.dz + (int64_t)b * a.H * a.W * a.opad + o_off;
     __syncthreads();                                  // the previous strip's fragment reads (first strip: the zero fill) are done
     // eight chunks per thread in flight, then their LDS writes; the x rows first, the dz rows after them in one chunk numbering
     for (int q0 = tid; q0 < nxc + nzc; q0 += 256 * 8) {
@@ -374,13 +377,13 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad3x3_c64_kernel(RnWgrad64Args a
         if (q < nxc) {
           const int ry = q / row_chunks, rem = q - ry * row_chunks;
           const int xx = rem >> 3, ch = rem & 7, y = y0 - 1 + ry;
-          if ((unsigned)y < (unsigned)a.H) v[u] = *reinterpret_cast<const uint4*>(xb + ((int64_t)y * a.W + xx) * 64 + ch * 8);
+          if ((unsigned)y < (unsigned)a.H) v[u] = *reinterpret_cast<const uint4*>(xb + ((int64_t)y * a.W + xx) * a.cp + ch * 8);
           dst[u] = wg64_chunk(ry * Wp + xx + 2, ch);
         } else if (q < nxc + nzc) {
           const int qz = q - nxc;
           const int rz = qz / row_chunks, rem = qz - rz * row_chunks;
           const int xx = rem >> 3, ch = rem & 7, y = y0 + rz;
-          if (y < a.H) v[u] = *reinterpret_cast<const uint4*>(zb + ((int64_t)y * a.W + xx) * 64 + ch * 8);
+          if (y < a.H) v[u] = *reinterpret_cast<const uint4*>(zb + ((int64_t)y * a.W + xx) * a.opad + ch * 8);
           dst[u] = (uint32_t)nx * 128u + wg64_chunk(rz * Wp + xx + 1, ch);
         }
       }
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad3x3_c64_kernel(RnWgrad64Args a
     }
   }
   // D column = lane & 15 = channel, rows 4 (lane >> 4) + r = output channel within the block
-  float* pw = a.part + (size_t)blockIdx.x * 64 * 576;
+  float* pw = a.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 * 576;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -413,18 +416,136 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad3x3_c64_kernel(RnWgrad64Args a
       for (int r = 0; r < 4; ++r) pw[(size_t)(ob * 16 + 4 * q4 + r) * 576 + tap * 64 + wave * 16 + t] = acc[tap][ob][r];
 }
 
-// out[o][c] (row stride ldo) = (accumulate ? out : 0) + sum_g part[g][o][c], g ascending
-__global__ __launch_bounds__(256) void rn_wgrad64_reduce_kernel(const float* __restrict__ part, int G, float* __restrict__ out, int64_t ldo,
+// out[o_off + o][tap * cp + c_off + c] (row stride ldo) = (accumulate ? out : 0) + sum_g part[y][g][o][tap * 64 + c]: block (i, y) owns 64
+// float4s of sub-problem y; its 256 threads are 64 outputs x 4 lanes over g (lane l sums g = l, l + 4, ... ascending), the four lane sums
+// are added in lane order -- a fixed order, bit-reproducible
+__global__ __launch_bounds__(256) void rn_wgrad64_reduce_kernel(const float* __restrict__ part, int G, int cp, float* __restrict__ out, int64_t ldo,
                                                                  int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;       // float4 index into [64][576]
-  if (i >= 64 * 576 / 4) return;
+  __shared__ float4 red[4][64];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), gl = threadIdx.x >> 6;      // float4 index into [64][576]; 64 * 576 / 4 = 144 * 64
+  const int y = blockIdx.y;
+  const float* p = part + (size_t)y * G * 64 * 576 + (size_t)i * 4;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int g = 0; g < G; ++g) {
-    const float4 v = *reinterpret_cast<const float4*>(part + (size_t)g * 64 * 576 + (size_t)i * 4);
+  for (int g = gl; g < G; g += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)g * 64 * 576);
     sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
   }
-  const int o = (i * 4) / 576, c = i * 4 - o * 576;
-  float* d = out + (int64_t)o * ldo + c;
+  red[gl][threadIdx.x & 63] = sum;
+  __syncthreads();
+  if (gl != 0) return;
+#pragma unroll
+  for (int l = 1; l < 4; ++l) {
+    const float4 v = red[l][threadIdx.x];
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  }
+  const int cblocks = cp >> 6;
+  const int o = (i * 4) / 576, col = i * 4 - o * 576;
+  const int tap = col >> 6, c = col & 63;
+  float* d = out + (int64_t)((y / cblocks) * 64 + o) * ldo + tap * cp + (y % cblocks) * 64 + c;
+  if (accumulate) { sum.x += d[0]; sum.y += d[1]; sum.z += d[2]; sum.w += d[3]; }
+  d[0] = sum.x; d[1] = sum.y; d[2] = sum.z; d[3] = sum.w;
+}
+
+// ---- weight gradient of a 1 x 1 convolution with few channels on one side: C[N][K] (+)= A[M][N]^T . B[M][K], M huge, N x K small ------------
+// layer1 / layer2 of the ModifiedResNet (64 ... 512 channels at 0.2 - 0.8 M pixels) and the stem's first convolution: as 128 x 128 tiles
+// (gemm_tn) these run at 1 - 1.5 TB/s; the 8-phase kernel wants 256-multiples on both sides.  Same structure as the 3 x 3 kernel above
+// without the taps: a workgroup owns 64 rows of C (blockIdx.y / k-blocks) x KB = 64 NSUB columns (blockIdx.y % k-blocks) and a contiguous
+// range of P-pixel strips; per strip A's 64 columns go to one [pixel][64] LDS image and B's KB columns to NSUB such images (the 64-column
+// groups side by side: wave w owns 16-column block w of every group), fragments by the LDS transpose read, the 64 x KB result in
+// registers (4 x NSUB accumulators per wave), partials [blockIdx.y][workgroup][64][KB] summed in a fixed order.
+struct RnTnSkinnyArgs {
+  const bf16_t* A; const bf16_t* B; float* part;
+  int64_t lda, ldb;
+  int M, P, strips, kblocks;
+};
+
+template <int NSUB>
+__global__ __launch_bounds__(256, 2) void rn_tn_skinny_kernel(RnTnSkinnyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = lane & 15, q4 = lane >> 4;
+  constexpr int KB = 64 * NSUB;
+  const int n_off = ((int)blockIdx.y / a.kblocks) * 64, k_off = ((int)blockIdx.y % a.kblocks) * KB;
+  const uint32_t img = (uint32_t)a.P * 128u;          // bytes of one [P][64] image; image 0 = A, 1 + i = B's column group i
+  f32x4_t acc[NSUB][4];
+#pragma unroll
+  for (int i = 0; i < NSUB; ++i)
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) acc[i][ob] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int s_begin = (int)((int64_t)a.strips * blockIdx.x / gridDim.x), s_end = (int)((int64_t)a.strips * (blockIdx.x + 1) / gridDim.x);
+  const int nac = a.P * 8, nbc = a.P * 8 * NSUB;      // 16-byte chunks of the A image / of the B images per strip
+  for (int s = s_begin; s < s_end; ++s) {
+    const int64_t m0 = (int64_t)s * a.P;
+    __syncthreads();                                  // the previous strip's fragment reads are done
+    for (int q0 = tid; q0 < nac + nbc; q0 += 256 * 8) {
+      uint4 v[8];
+      uint32_t dst[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + u * 256;
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        dst[u] = 0xffffffffu;
+        if (q < nac) {
+          const int px = q >> 3, ch = q & 7;
+          if (m0 + px < a.M) v[u] = *reinterpret_cast<const uint4*>(a.A + (m0 + px) * a.lda + n_off + ch * 8);
+          dst[u] = wg64_chunk(px, ch);
+        } else if (q < nac + nbc) {
+          const int qb = q - nac;
+          const int px = qb / (8 * NSUB), ch = qb % (8 * NSUB);
+          if (m0 + px < a.M) v[u] = *reinterpret_cast<const uint4*>(a.B + (m0 + px) * a.ldb + k_off + ch * 8);
+          dst[u] = img * (uint32_t)(1 + (ch >> 3)) + wg64_chunk(px, ch & 7);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dst[u] != 0xffffffffu) *reinterpret_cast<uint4*>(wg_smem + dst[u]) = v[u];
+    }
+    __syncthreads();
+    for (int k = 0; k < a.P; k += 32) {
+      const int row = k + 8 * q4 + (t >> 2);
+      uint4 af[4];
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) af[ob] = wg64_frag(wg_smem, row, ob, t);
+#pragma unroll
+      for (int i = 0; i < NSUB; ++i) {
+        const uint4 bf = wg64_frag(wg_smem + img * (uint32_t)(1 + i), row, wave, t);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) mma16(acc[i][ob], af[ob], bf);
+      }
+    }
+  }
+  float* pw = a.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 * KB;
+#pragma unroll
+  for (int i = 0; i < NSUB; ++i)
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[(size_t)(ob * 16 + 4 * q4 + r) * KB + i * 64 + wave * 16 + t] = acc[i][ob][r];
+}
+
+// C[n_off + o][k_off + c] (row stride ldc) = (accumulate ? C : 0) + sum_g part[y][g][o][c]  (64 x kb per sub-problem y; four lanes over g, fixed order)
+__global__ __launch_bounds__(256) void rn_tn_skinny_reduce_kernel(const float* __restrict__ part, int G, int kb, int kblocks, float* __restrict__ C,
+                                                                   int64_t ldc, int accumulate) {
+  __shared__ float4 red[4][64];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), gl = threadIdx.x >> 6;      // float4 index into [64][kb]; 16 kb of them: a multiple of 64
+  const int y = blockIdx.y;
+  const float* p = part + (size_t)y * G * 64 * kb + (size_t)i * 4;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int g = gl; g < G; g += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)g * 64 * kb);
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  }
+  red[gl][threadIdx.x & 63] = sum;
+  __syncthreads();
+  if (gl != 0) return;
+#pragma unroll
+  for (int l = 1; l < 4; ++l) {
+    const float4 v = red[l][threadIdx.x];
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  }
+  const int o = (i * 4) / kb, c = i * 4 - o * kb;
+  float* d = C + (int64_t)((y / kblocks) * 64 + o) * ldc + (y % kblocks) * kb + c;
   if (accumulate) { sum.x += d[0]; sum.y += d[1]; sum.z += d[2]; sum.w += d[3]; }
   d[0] = sum.x; d[1] = sum.y; d[2] = sum.z; d[3] = sum.w;
 }
@@ -558,45 +679,91 @@ int rn_im2col3x3(const void* x, int B, int H, int W, int cp, void* col, int dtyp
   return EZ_OK;
 }
 
-// the strip height of rn_wgrad3x3_c64 for an image width: the largest R whose two images fit twice into a CU's LDS
+// the strip height of rn_wgrad3x3_c64: R image rows whose two LDS images fit twice into a CU, chosen by the work per image -- strips x
+// (padded pixels of the contraction, rounded up to 32, + half a unit per pixel loaded: the halo rows are loaded again by the next strip)
 static int wgrad64_strip_rows(int H, int W, int* lz_r, size_t* lds) {
   const int Wp = W + 2;
   int best = 0;
-  for (int R = 1; R <= H && R <= 8; ++R) {
+  double best_cost = 0.0;
+  for (int R = 1; R <= H && R <= 16; ++R) {
     const int lr = (R * Wp + 31) / 32 * 32;
     const size_t bytes = (size_t)(lr + 2 * Wp + 2 + lr) * 128;
     if (bytes > 78 * 1024) break;
-    best = R; *lz_r = lr; *lds = bytes;
+    const double cost = (double)((H + R - 1) / R) * (lr + 0.5 * (R + 2) * Wp);
+    if (best == 0 || cost <= best_cost) { best = R; best_cost = cost; *lz_r = lr; *lds = bytes; }
   }
   return best;
 }
 
 bool rn_wgrad3x3_c64_eligible(int B, int H, int W, int cp, int opad, int dtype, size_t scratch_bytes) {
   int lr = 0; size_t lds = 0;
-  return dtype == EZCLIP_BF16 && cp == 64 && opad == 64 && B > 0 && H > 0 && W >= 2 && wgrad64_strip_rows(H, W, &lr, &lds) > 0 &&
-         scratch_bytes >= (size_t)64 * 576 * 4;
+  return dtype == EZCLIP_BF16 && cp >= 64 && opad >= 64 && cp % 64 == 0 && opad % 64 == 0 && (cp / 64) * (opad / 64) <= 4 && B > 0 && H > 0 &&
+         W >= 2 && wgrad64_strip_rows(H, W, &lr, &lds) > 0 && scratch_bytes >= (size_t)(cp / 64) * (opad / 64) * 64 * 576 * 4;
 }
 
-int rn_wgrad3x3_c64(const void* x, const void* dz, int B, int H, int W, void* scratch, size_t scratch_bytes, float* out, int64_t ldo,
-                    int accumulate, hipStream_t st) {
-  EZ_REQUIRE(x && dz && scratch && out && ldo >= 576 && rn_wgrad3x3_c64_eligible(B, H, W, 64, 64, EZCLIP_BF16, scratch_bytes),
-             "rn_wgrad3x3_c64: %d images of %d x %d (64 channels in and out, bf16), scratch %zu bytes: not a shape of this kernel", B, H, W,
-             scratch_bytes);
+int rn_wgrad3x3_c64(const void* x, const void* dz, int B, int H, int W, int cp, int opad, void* scratch, size_t scratch_bytes, float* out,
+                    int64_t ldo, int accumulate, hipStream_t st) {
+  EZ_REQUIRE(x && dz && scratch && out && ldo >= 9 * (int64_t)cp && rn_wgrad3x3_c64_eligible(B, H, W, cp, opad, EZCLIP_BF16, scratch_bytes),
+             "rn_wgrad3x3_c64: %d images of %d x %d, %d -> %d padded channels (bf16; 64 or 128 each), scratch %zu bytes, ldo %lld: not a shape of this kernel",
+             B, H, W, cp, opad, scratch_bytes, (long long)ldo);
   RnWgrad64Args a;
   size_t lds = 0;
   a.x = (const bf16_t*)x; a.dz = (const bf16_t*)dz; a.part = (float*)scratch;
-  a.H = H; a.W = W;
+  a.H = H; a.W = W; a.cp = cp; a.opad = opad;
   a.R = wgrad64_strip_rows(H, W, &a.lz_r, &lds);
   a.strips_per_image = (H + a.R - 1) / a.R;
   a.strips = B * a.strips_per_image;
-  int G = a.strips < 512 ? a.strips : 512;            // two workgroups per CU
-  const size_t fit = scratch_bytes / ((size_t)64 * 576 * 4);
+  const int sub = (cp / 64) * (opad / 64);            // independent 64-output x 64-channel sub-problems (blockIdx.y)
+  int G = 512 / sub;                                  // two workgroups per CU in all
+  if (G > a.strips) G = a.strips;
+  const size_t fit = scratch_bytes / ((size_t)sub * 64 * 576 * 4);
   if ((size_t)G > fit) G = (int)fit;
   static LdsOptIn lds_opt;
   EZ_ENSURE_LDS(rn_wgrad3x3_c64_kernel, lds_opt, lds);
-  hipLaunchKernelGGL(rn_wgrad3x3_c64_kernel, dim3(G), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(rn_wgrad3x3_c64_kernel, dim3(G, sub), dim3(256), lds, st, a);
   EZ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rn_wgrad64_reduce_kernel, dim3((64 * 576 / 4 + 255) / 256), dim3(256), 0, st, (const float*)scratch, G, out, ldo, accumulate);
+  hipLaunchKernelGGL(rn_wgrad64_reduce_kernel, dim3(64 * 576 / 4 / 64, sub), dim3(256), 0, st, (const float*)scratch, G, cp, out, ldo, accumulate);
+  EZ_LAUNCH_CHECK();
+  return EZ_OK;
+}
+
+// column block of rn_tn_skinny for K columns: the widest of 256 / 128 / 64 that divides K (512 = 32 accumulators per wave spills)
+static int tn_skinny_kb(int K) { return K % 256 == 0 ? 256 : K % 128 == 0 ? 128 : 64; }
+
+bool rn_tn_skinny_eligible(int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int dtype, size_t scratch_bytes) {
+  if (dtype != EZCLIP_BF16 || M < 4096 || M > 0x7fffffff || N < 64 || K < 64 || N % 64 || K % 64 || lda % 8 || ldb % 8 || ldc % 4) return false;
+  const int kb = tn_skinny_kb(K);
+  const int sub = (N / 64) * (K / kb);
+  return sub <= 16 && scratch_bytes >= (size_t)sub * 64 * kb * 4;
+}
+
+int rn_tn_skinny(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, int accumulate,
+                 void* scratch, size_t scratch_bytes, hipStream_t st) {
+  EZ_REQUIRE(A && B && C && scratch && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0 &&
+                 rn_tn_skinny_eligible(M, N, K, lda, ldb, ldc, EZCLIP_BF16, scratch_bytes),
+             "rn_tn_skinny: M %lld N %d K %d (lda %lld ldb %lld ldc %lld), scratch %zu bytes: not a shape of this kernel (bf16, M >= 4096, N and K multiples "
+             "of 64, at most 16 blocks of 64 x 256)", (long long)M, N, K, (long long)lda, (long long)ldb, (long long)ldc, scratch_bytes);
+  const int kb = tn_skinny_kb(K), nsub = kb / 64;
+  RnTnSkinnyArgs a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.part = (float*)scratch; a.lda = lda; a.ldb = ldb; a.M = (int)M;
+  a.kblocks = K / kb;
+  a.P = (int)(78 * 1024 / (128 * (1 + nsub))) / 32 * 32;             // pixels per strip: the 1 + NSUB images twice into a CU's LDS
+  if (a.P > 256) a.P = 256;
+  a.strips = (int)((M + a.P - 1) / a.P);
+  const int sub = (N / 64) * a.kblocks;
+  int G = 512 / sub;
+  if (G > a.strips) G = a.strips;
+  const size_t fit = scratch_bytes / ((size_t)sub * 64 * kb * 4);
+  if ((size_t)G > fit) G = (int)fit;
+  const size_t lds = (size_t)a.P * 128 * (1 + nsub);
+  static LdsOptIn opt1, opt2, opt4;
+  switch (nsub) {
+    case 1: EZ_ENSURE_LDS(rn_tn_skinny_kernel<1>, opt1, lds); hipLaunchKernelGGL(rn_tn_skinny_kernel<1>, dim3(G, sub), dim3(256), lds, st, a); break;
+    case 2: EZ_ENSURE_LDS(rn_tn_skinny_kernel<2>, opt2, lds); hipLaunchKernelGGL(rn_tn_skinny_kernel<2>, dim3(G, sub), dim3(256), lds, st, a); break;
+    default: EZ_ENSURE_LDS(rn_tn_skinny_kernel<4>, opt4, lds); hipLaunchKernelGGL(rn_tn_skinny_kernel<4>, dim3(G, sub), dim3(256), lds, st, a); break;
+  }
+  EZ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rn_tn_skinny_reduce_kernel, dim3(16 * kb / 64, sub), dim3(256), 0, st, (const float*)scratch, G, kb, a.kblocks, C, ldc, accumulate);
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

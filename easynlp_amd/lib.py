@@ -148,7 +148,8 @@ SIGNATURES = {
     "ezclip_stream_wait_event": (_i, [_vp, _vp]),
     "ezclip_op_gemm_tn": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "ezclip_op_gemm_tn_conv3x3": (_i, [_vp, _i64, _vp, _i, _i, _i, _i, _vp, _i64, _i, _i, _i, _vp]),
-    "ezclip_op_rn_wgrad3x3_c64": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp, _i64, _i, _vp]),
+    "ezclip_op_rn_wgrad3x3_c64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i64, _i, _vp]),
+    "ezclip_op_rn_tn_skinny": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _sz, _vp]),
     "ezclip_op_layernorm": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     "ezclip_op_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ezclip_op_attention": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

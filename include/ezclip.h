@@ -463,12 +463,20 @@ int ezclip_op_gemm_tn(const void* a_dev, int64_t lda, const void* b_dev, int64_t
  * padding 1 convolution: modeling_chineseclip.py:34, :121-125 under core/trainer.py:658-661).  w >= 4. */
 int ezclip_op_gemm_tn_conv3x3(const void* a_dev, int64_t lda, const void* x_dev, int images, int h, int w, int cp, float* c_dev,
                               int64_t ldc, int n, int accumulate, int dtype, void* stream);
-/* The same product for 64 (padded) channels in AND out, bf16 -- the stem's conv2 / conv3 and layer1's conv2 of the ModifiedResNet
- * (modeling_chineseclip.py:121-125, :34), the convolutions with the most pixels: x and dz [images * h * w, 64] are read once, out
- * [64, ldo >= 576] f32 (+)=, scratch >= 147 456 bytes (one [64][576] f32 partial per workgroup, up to 512 are used), summed in a
- * fixed order (bit-reproducible).  Other shapes / dtypes: refused (ezclip_op_gemm_tn_conv3x3 takes them). */
-int ezclip_op_rn_wgrad3x3_c64(const void* x_dev, const void* dz_dev, int images, int h, int w, void* scratch_dev, size_t scratch_bytes,
-                              float* out_dev, int64_t ldo, int accumulate, void* stream);
+/* The same product for 64 or 128 (padded) channels in and out, bf16 -- the stem's conv2 / conv3 and the conv2 of layer1 / layer2 of the
+ * ModifiedResNet (modeling_chineseclip.py:121-125, :34), the convolutions with the most pixels: every 64-output x 64-channel block reads
+ * its halves of x [images * h * w, cp] and dz [images * h * w, opad] once, out [opad, ldo >= 9 * cp] f32 (+)=, scratch >= (cp / 64) *
+ * (opad / 64) * 147 456 bytes (one [64][576] f32 partial per workgroup, up to 512 are used), summed in a fixed order
+ * (bit-reproducible).  Other shapes / dtypes: refused (ezclip_op_gemm_tn_conv3x3 takes them). */
+int ezclip_op_rn_wgrad3x3_c64(const void* x_dev, const void* dz_dev, int images, int h, int w, int cp, int opad, void* scratch_dev,
+                              size_t scratch_bytes, float* out_dev, int64_t ldo, int accumulate, void* stream);
+/* c [n, k] f32 (+)= a[m, n]^T . b[m, k], bf16, for MANY rows and a small result (m >= 4096; n, k multiples of 64; at most 16 blocks of
+ * 64 x 256): the weight gradients of the 1 x 1 convolutions of layer1 / layer2 and of the stem's first convolution
+ * (modeling_chineseclip.py:30-46, :117-119 under core/trainer.py:658-661).  Every 64-row block of c reads its columns of a once;
+ * scratch >= (n / 64) * (k / kb) * 64 * kb * 4 bytes (kb = the widest of 256 / 128 / 64 dividing k; one partial per workgroup, up to
+ * 512 in all), summed in a fixed order (bit-reproducible).  Other shapes / dtypes: refused (ezclip_op_gemm_tn takes them). */
+int ezclip_op_rn_tn_skinny(const void* a_dev, int64_t lda, const void* b_dev, int64_t ldb, float* c_dev, int64_t ldc, int64_t m, int n, int k,
+                           int accumulate, void* scratch_dev, size_t scratch_bytes, void* stream);
 int ezclip_op_layernorm(const void* x_dev, int64_t x_stride, void* y_dev, int64_t y_stride, const float* g_dev,
                         const float* b_dev, float eps, int rows, int d, int dtype, float* mean_dev, float* rstd_dev,
                         void* stream);

@@ -158,39 +158,92 @@ def test_weight_gradient_product_gathers_the_neighbourhoods_itself(dtype, B, cp,
     assert "W >= 4" in L.last_error()
 
 
-@pytest.mark.parametrize("B,H,W,parts", [(2, 8, 8, 512), (3, 7, 12, 512), (4, 5, 40, 2), (6, 56, 56, 512), (3, 112, 112, 100), (2, 9, 140, 512)])
-def test_weight_gradient_at_64_channels_reads_its_operands_once(B, H, W, parts):
-    """ezclip_op_rn_wgrad3x3_c64 (the whole 64 x 576 result in registers, strips of image rows through LDS with zero pad pixels, the LDS
-    transpose read) against the explicit column matrix + ezclip_op_gemm_tn and against float64: strips of 1 ... 8 rows (the LDS budget
-    decides: width 140 -> one row, width 8 -> eight), a last strip that runs past the image (H = 7, 9, 5 with R = 8 / 1 / 5), non-square
-    images, fewer partial buffers than strips (`parts`), `accumulate`, and bit-reproducibility (fixed summation order)."""
+@pytest.mark.parametrize("B,H,W,cp,opad,parts", [(2, 8, 8, 64, 64, 512), (3, 7, 12, 64, 64, 512), (4, 5, 40, 64, 64, 2), (6, 56, 56, 64, 64, 512),
+                                                 (3, 112, 112, 64, 64, 100), (2, 9, 140, 64, 64, 512), (5, 28, 28, 128, 128, 512),
+                                                 (2, 10, 6, 128, 64, 7), (3, 6, 9, 64, 128, 512)])
+def test_weight_gradient_at_64_channel_blocks_reads_its_operands_once(B, H, W, cp, opad, parts):
+    """ezclip_op_rn_wgrad3x3_c64 (per 64-output x 64-channel block the whole 64 x 576 result in registers, strips of image rows through LDS
+    with zero pad pixels, the LDS transpose read) against the explicit column matrix + float64: strips of 1 ... 16 rows (the LDS budget and
+    the work per image decide), a last strip that runs past the image, non-square images, fewer partial buffers than strips (`parts`),
+    128 channels on either side (two / four sub-problems writing their quarters of the result), `accumulate`, bit-reproducibility."""
     lib = L.load()
     tdt, edt = DT["bf16"]
-    rows = B * H * W
+    rows, K = B * H * W, 9 * cp
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
-    xd = torch.randn(rows, 64, generator=g).to(tdt).to(DEV)
-    dzd = torch.randn(rows, 64, generator=g).to(tdt).to(DEV)
-    cold = torch.empty(rows, 576, dtype=tdt, device=DEV)
-    L.check(lib.ezclip_op_rn_im2col3x3(L.ptr(xd), B, H, W, 64, L.ptr(cold), edt, L.stream_ptr()))
+    xd = torch.randn(rows, cp, generator=g).to(tdt).to(DEV)
+    dzd = torch.randn(rows, opad, generator=g).to(tdt).to(DEV)
+    cold = torch.empty(rows, K, dtype=tdt, device=DEV)
+    L.check(lib.ezclip_op_rn_im2col3x3(L.ptr(xd), B, H, W, cp, L.ptr(cold), edt, L.stream_ptr()))
     ref = (dzd.double().t() @ cold.double())
-    scratch = torch.empty(parts * 64 * 576, dtype=torch.float32, device=DEV)
-    got = torch.full((64, 640), -3.0, dtype=torch.float32, device=DEV)
-    L.check(lib.ezclip_op_rn_wgrad3x3_c64(L.ptr(xd), L.ptr(dzd), B, H, W, L.ptr(scratch), scratch.numel() * 4, L.ptr(got), 640, 0, L.stream_ptr()))
+    sub = (cp // 64) * (opad // 64)
+    scratch = torch.empty(parts * sub * 64 * 576, dtype=torch.float32, device=DEV)
+    ldo = K + 64
+
+    def run(dst, accumulate=0, nbytes=None):
+        return lib.ezclip_op_rn_wgrad3x3_c64(L.ptr(xd), L.ptr(dzd), B, H, W, cp, opad, L.ptr(scratch), scratch.numel() * 4 if nbytes is None else nbytes,
+                                             L.ptr(dst), ldo, accumulate, L.stream_ptr())
+
+    got = torch.full((opad, ldo), -3.0, dtype=torch.float32, device=DEV)
+    L.check(run(got))
     torch.cuda.synchronize()
     scale = max(1.0, float(ref.abs().max()))
-    assert float((got[:, :576].double() - ref).abs().max()) < 2e-3 * scale, float((got[:, :576].double() - ref).abs().max()) / scale
-    assert float((got[:, 576:] + 3.0).abs().max()) == 0.0                     # columns beyond 576 are not touched
-    again = torch.zeros(64, 640, dtype=torch.float32, device=DEV)
+    assert float((got[:, :K].double() - ref).abs().max()) < 2e-3 * scale, float((got[:, :K].double() - ref).abs().max()) / scale
+    assert float((got[:, K:] + 3.0).abs().max()) == 0.0                       # columns beyond 9 cp are not touched
+    again = torch.zeros(opad, ldo, dtype=torch.float32, device=DEV)
     scratch.fill_(float("nan"))
-    L.check(lib.ezclip_op_rn_wgrad3x3_c64(L.ptr(xd), L.ptr(dzd), B, H, W, L.ptr(scratch), scratch.numel() * 4, L.ptr(again), 640, 0, L.stream_ptr()))
+    L.check(run(again))
     torch.cuda.synchronize()
-    assert torch.equal(again[:, :576], got[:, :576])
-    L.check(lib.ezclip_op_rn_wgrad3x3_c64(L.ptr(xd), L.ptr(dzd), B, H, W, L.ptr(scratch), scratch.numel() * 4, L.ptr(again), 640, 1, L.stream_ptr()))
+    assert torch.equal(again[:, :K], got[:, :K])
+    L.check(run(again, accumulate=1))
     torch.cuda.synchronize()
-    assert float((again[:, :576] - 2 * got[:, :576]).abs().max()) <= 1e-5 * scale
-    # not this kernel's shape: refused, loudly (no scratch for even one partial)
-    assert lib.ezclip_op_rn_wgrad3x3_c64(L.ptr(xd), L.ptr(dzd), B, H, W, L.ptr(scratch), 1000, L.ptr(again), 640, 0, L.stream_ptr()) != 0
+    assert float((again[:, :K] - 2 * got[:, :K]).abs().max()) <= 1e-5 * scale
+    # not this kernel's shape: refused, loudly (no scratch for even one partial per sub-problem)
+    assert run(again, nbytes=1000) != 0
     assert "not a shape of this kernel" in L.last_error()
+
+
+@pytest.mark.parametrize("M,N,K,lda,ldb,parts", [(4096, 64, 64, 64, 64, 512), (5000, 256, 64, 256, 64, 512), (4100, 64, 256, 64, 256, 3),
+                                                 (6001, 128, 512, 128, 512, 512), (4097, 512, 128, 640, 192, 512), (7000, 128, 192, 128, 192, 512),
+                                                 (50000, 64, 128, 64, 128, 512)])
+def test_weight_gradient_of_a_1x1_convolution_with_a_small_result(M, N, K, lda, ldb, parts):
+    """ezclip_op_rn_tn_skinny against float64 and ezclip_op_gemm_tn: column blocks of 64 / 128 / 256 (K = 512 -> two of 256, K = 192 -> three of 64),
+    row counts that are not multiples of the strip (zero-filled tail), leading dimensions wider than the matrix, fewer partial buffers
+    than strips, `accumulate`, bit-reproducibility, refusal of other shapes."""
+    lib = L.load()
+    tdt, edt = DT["bf16"]
+    g = torch.Generator().manual_seed(M + N + K)
+    ad = torch.randn(M, lda, generator=g).to(tdt).to(DEV)
+    bd = torch.randn(M, ldb, generator=g).to(tdt).to(DEV)
+    ref = ad[:, :N].double().t() @ bd[:, :K].double()
+    kb = 256 if K % 256 == 0 else 128 if K % 128 == 0 else 64
+    sub = (N // 64) * (K // kb)
+    scratch = torch.empty(parts * sub * 64 * kb, dtype=torch.float32, device=DEV)
+    ldc = K + 4
+
+    def run(dst, accumulate=0, nbytes=None, m=M):
+        return lib.ezclip_op_rn_tn_skinny(L.ptr(ad), lda, L.ptr(bd), ldb, L.ptr(dst), ldc, m, N, K, accumulate, L.ptr(scratch),
+                                          scratch.numel() * 4 if nbytes is None else nbytes, L.stream_ptr())
+
+    got = torch.full((N, ldc), -3.0, dtype=torch.float32, device=DEV)
+    L.check(run(got))
+    torch.cuda.synchronize()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got[:, :K].double() - ref).abs().max()) < 2e-3 * scale, float((got[:, :K].double() - ref).abs().max()) / scale
+    assert float((got[:, K:] + 3.0).abs().max()) == 0.0
+    want = torch.zeros(N, ldc, dtype=torch.float32, device=DEV)
+    L.check(lib.ezclip_op_gemm_tn(L.ptr(ad), lda, L.ptr(bd), ldb, L.ptr(want), ldc, M, N, K, 0, edt, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert float((got[:, :K] - want[:, :K]).abs().max()) < 1e-3 * scale
+    again = torch.zeros(N, ldc, dtype=torch.float32, device=DEV)
+    scratch.fill_(float("nan"))
+    L.check(run(again))
+    torch.cuda.synchronize()
+    assert torch.equal(again[:, :K], got[:, :K])
+    L.check(run(again, accumulate=1))
+    torch.cuda.synchronize()
+    assert float((again[:, :K] - 2 * got[:, :K]).abs().max()) <= 1e-5 * scale
+    assert run(again, nbytes=1000) != 0 and "not a shape of this kernel" in L.last_error()
+    assert run(again, m=1000) != 0 and "not a shape of this kernel" in L.last_error()          # few rows: the generic kernel's case
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

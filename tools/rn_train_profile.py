@@ -18,7 +18,7 @@ eng.sync_train(dev)
 px = torch.randn(B, 3, res, res, device="cuda")
 probe = torch.randn(B, e, device="cuda")
 grads = {n: torch.zeros(eng.shapes[n], dtype=torch.float32, device="cuda") for n in eng.names if not eng.is_statistic(n)}
-for _ in range(6):
+for _ in range(int(os.environ.get("RN_PROFILE_STEPS", "6"))):
     out = eng.encode_image_train(px)
     eng.backward(out, probe, grads)
 torch.cuda.synchronize()

@@ -478,11 +478,14 @@ __global__ __launch_bounds__(256, 2) void rn_tn_skinny_kernel(RnTnSkinnyArgs a) 
   for (int s = s_begin; s < s_end; ++s) {
     const int64_t m0 = (int64_t)s * a.P;
     __syncthreads();                                  // the previous strip's fragment reads are done
-    for (int q0 = tid; q0 < nac + nbc; q0 += 256 * 8) {
-      uint4 v[8];
-      uint32_t dst[8];
+    // kFly chunks per thread in flight, then their LDS writes: two to three rounds per strip.  The counters read 70-76 % of the wave cycles
+    // waiting (profiles/r5_rn_wgrad_pmc.md); 16 in flight (one round) spills -- 16 data + 16 address registers more than the 256 allow.
+    constexpr int kFly = 8;
+    for (int q0 = tid; q0 < nac + nbc; q0 += 256 * kFly) {
+      uint4 v[kFly];
+      uint32_t dst[kFly];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kFly; ++u) {
         const int q = q0 + u * 256;
         v[u] = make_uint4(0u, 0u, 0u, 0u);
         dst[u] = 0xffffffffu;
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void rn_tn_skinny_kernel(RnTnSkinnyArgs a) 
         }
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < kFly; ++u)
         if (dst[u] != 0xffffffffu) *reinterpret_cast<uint4*>(wg_smem + dst[u]) = v[u];
     }
     __syncthreads();
@@ -524,24 +527,27 @@ __global__ __launch_bounds__(256, 2) void rn_tn_skinny_kernel(RnTnSkinnyArgs a) 
       for (int r = 0; r < 4; ++r) pw[(size_t)(ob * 16 + 4 * q4 + r) * KB + i * 64 + wave * 16 + t] = acc[i][ob][r];
 }
 
-// C[n_off + o][k_off + c] (row stride ldc) = (accumulate ? C : 0) + sum_g part[y][g][o][c]  (64 x kb per sub-problem y; four lanes over g, fixed order)
+// C[n_off + o][k_off + c] (row stride ldc) = (accumulate ? C : 0) + sum_g part[y][g][o][c]  (64 x kb per sub-problem y): a block owns 16
+// float4s; its 256 threads are 16 outputs x 16 lanes over g (lane l sums g = l, l + 16, ... ascending), the sixteen lane sums are added in
+// lane order -- a fixed order, bit-reproducible.  (Four lanes, the first version, took 34 us for a 64 x 64 result: 128 dependent loads.)
 __global__ __launch_bounds__(256) void rn_tn_skinny_reduce_kernel(const float* __restrict__ part, int G, int kb, int kblocks, float* __restrict__ C,
                                                                    int64_t ldc, int accumulate) {
-  __shared__ float4 red[4][64];
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63), gl = threadIdx.x >> 6;      // float4 index into [64][kb]; 16 kb of them: a multiple of 64
+  __shared__ float4 red[16][16];
+  const int j = threadIdx.x & 15, gl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + j;                  // float4 index into [64][kb]; 16 kb of them: a multiple of 16
   const int y = blockIdx.y;
   const float* p = part + (size_t)y * G * 64 * kb + (size_t)i * 4;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int g = gl; g < G; g += 4) {
+  for (int g = gl; g < G; g += 16) {
     const float4 v = *reinterpret_cast<const float4*>(p + (size_t)g * 64 * kb);
     sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
   }
-  red[gl][threadIdx.x & 63] = sum;
+  red[gl][j] = sum;
   __syncthreads();
   if (gl != 0) return;
 #pragma unroll
-  for (int l = 1; l < 4; ++l) {
-    const float4 v = red[l][threadIdx.x];
+  for (int l = 1; l < 16; ++l) {
+    const float4 v = red[l][j];
     sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
   }
   const int o = (i * 4) / kb, c = i * 4 - o * kb;
@@ -749,6 +755,8 @@ int rn_tn_skinny(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
   a.kblocks = K / kb;
   a.P = (int)(78 * 1024 / (128 * (1 + nsub))) / 32 * 32;             // pixels per strip: the 1 + NSUB images twice into a CU's LDS
   if (a.P > 256) a.P = 256;
+  static const int p_cap = getenv("EZCLIP_RN_SKINNY_P") ? atoi(getenv("EZCLIP_RN_SKINNY_P")) / 32 * 32 : 0;      // A-B switch: shorter strips (no effect at 128 / 64, -2 % at 32: profiles/r5_rn_skinny_strip_length.log)
+  if (p_cap >= 32 && a.P > p_cap) a.P = p_cap;
   a.strips = (int)((M + a.P - 1) / a.P);
   const int sub = (N / 64) * a.kblocks;
   int G = 512 / sub;
@@ -763,7 +771,7 @@ int rn_tn_skinny(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
     default: EZ_ENSURE_LDS(rn_tn_skinny_kernel<4>, opt4, lds); hipLaunchKernelGGL(rn_tn_skinny_kernel<4>, dim3(G, sub), dim3(256), lds, st, a); break;
   }
   EZ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rn_tn_skinny_reduce_kernel, dim3(16 * kb / 64, sub), dim3(256), 0, st, (const float*)scratch, G, kb, a.kblocks, C, ldc, accumulate);
+  hipLaunchKernelGGL(rn_tn_skinny_reduce_kernel, dim3(16 * kb / 16, sub), dim3(256), 0, st, (const float*)scratch, G, kb, a.kblocks, C, ldc, accumulate);
   EZ_LAUNCH_CHECK();
   return EZ_OK;
 }

@@ -32,7 +32,7 @@ for dtype in (() if os.environ.get("RN_BENCH_TRAIN_ONLY") else ("bf16", "fp32"))
         print("RN50 %s B=%4d: %.2f ms  %.0f images/s" % (dtype, B, ms, B / ms * 1e3), flush=True)
 
 # training step of the tower (round 5): BatchNorm on batch statistics + the whole backward pass, 224 x 224
-for dtype, B in (("bf16", 128), ("bf16", 256), ("fp32", 32)):
+for dtype, B in ((("bf16", 128), ("bf16", 256)) if os.environ.get("RN_BENCH_BF16_ONLY") else (("bf16", 128), ("bf16", 256), ("fp32", 32))):
     eng = RnEngine(layers, width, e, res, L.dtype_code(dtype))
     dev = {n: sd[n].cuda() for n in eng.names}
     eng.sync_train(dev)

@@ -437,7 +437,8 @@ size_t rn_train_saved_bytes(ezclip_rn* m, int B) {
   return a.off + 256;
 }
 
-// largest NHWC activation / gradient of a batch, and the largest explicit im2col of a 3x3 convolution's input
+// largest NHWC activation / gradient of a batch, and the largest explicit im2col of a 3x3 convolution's input (the `col` scratch of the
+// backward pass: sized for the explicit route of every convolution, also the home of the operands-once kernels' partial sums)
 size_t rn_train_max_act_bytes(const ezclip_rn* m, int B) { return rn_act_bytes(m, B); }
 size_t rn_train_max_col_bytes(const ezclip_rn* m, int B) {
   const int R = m->cfg.image_resolution;
@@ -600,51 +601,51 @@ int rn_dgrad(const ezclip_rn* m, const ezclip_rn::Conv& c, const void* dz, int64
   return gemm_nt(g, m->dtype, st);
 }
 
-// weight gradient of a convolution into its bound gradient buffer: dW = dz^T . x (1x1) / dz^T . im2col(x) (3x3; explicit im2col in `col`)
+// weight gradient of a convolution into its bound gradient buffer: dWp = dz^T . x (1 x 1) / dz^T . (3 x 3 neighbourhoods of x), then unpacked.
+// Which product (bf16; fp32 always takes the generic kernel):
+//   3 x 3, 64 / 128 padded channels in and out (stem conv2 / conv3, layer1, layer2)  rn_wgrad3x3_c64: operands once, result in registers
+//   3 x 3, 256-multiples (layer3 / layer4)                                           explicit column matrix (small there) + 8-phase TN kernel
+//   3 x 3, anything else                                                             generic TN kernel gathering the neighbourhoods itself
+//   1 x 1 / the stem's first convolution, 256-multiples                              8-phase TN kernel
+//   1 x 1 / the stem's first convolution, many pixels and a small result             rn_tn_skinny
+//   anything else                                                                    generic TN kernel
+// `col` holds the explicit column matrix or the per-workgroup partials of the operands-once kernels.
+// EZCLIP_RN_EXPLICIT_IM2COL (A/B switch): 1 = explicit column matrix + generic / 8-phase kernels everywhere (the first version), 2 = no
+// rn_wgrad3x3_c64 and no rn_tn_skinny, 3 = no rn_tn_skinny.
+static int rn_wgrad_mode() {
+  static const int mode = getenv("EZCLIP_RN_EXPLICIT_IM2COL") ? atoi(getenv("EZCLIP_RN_EXPLICIT_IM2COL")) : 0;
+  return mode;
+}
+
 template <typename T>
 int rn_wgrad(const ezclip_rn* m, const ezclip_rn::Conv& c, const void* dz, const void* x, int64_t M, int H, int B, void* col, size_t col_bytes,
              float* dwp, hipStream_t st) {
   float* gw = m->params[c.w].g;
-  const void* bsrc = x;
-  int64_t ldb = c.Cp;
-  if (c.cfirst) { ldb = c.ldk; }                         // the stem's first convolution: x IS its explicit im2col [M, ldk]
+  const int mode = rn_wgrad_mode();
   GemmTNArgs t;
   t.A = dz; t.lda = c.Opad; t.C = dwp; t.ldc = c.ldk;
   t.M = (int)M; t.N = c.Opad; t.K = c.ldk; t.accumulate = 0;
+  bool done = false;
   if (!c.cfirst && c.k == 3) {
-    // the 8-phase kernel (256-multiples: layer3 / layer4, small column matrices) reads an explicit im2col; everywhere else -- the stem
-    // and layer1 / layer2, where the column matrix is 0.5 - 3.7 GB per convolution at 256 images -- the generic kernel gathers the
-    // 3 x 3 neighbourhoods itself (GemmTNArgs::conv_H; bit-identical to the explicit route).  EZCLIP_RN_EXPLICIT_IM2COL=1: always explicit (A/B)
-    // EZCLIP_RN_EXPLICIT_IM2COL=2: no dedicated 64-channel-block kernel (A/B of that kernel alone); 3: that kernel, but generic 1 x 1 products
-    static const int im2col_mode = getenv("EZCLIP_RN_EXPLICIT_IM2COL") ? atoi(getenv("EZCLIP_RN_EXPLICIT_IM2COL")) : 0;
-    static const bool explicit_only = im2col_mode == 1;
-    if ((im2col_mode == 0 || im2col_mode == 3) && rn_wgrad3x3_c64_eligible(B, H, H, c.Cp, c.Opad, m->dtype, col_bytes)) {
-      // 64 or 128 channels in and out (the stem's conv2 / conv3, layer1, layer2): x and dz read once per 64 x 64 block, its 64 x 576 result in registers;
-      // `col` (no column matrix is built) holds the per-workgroup partials
+    if ((mode == 0 || mode == 3) && rn_wgrad3x3_c64_eligible(B, H, H, c.Cp, c.Opad, m->dtype, col_bytes)) {
       RN_TRY(rn_wgrad3x3_c64(x, dz, B, H, H, c.Cp, c.Opad, col, col_bytes, dwp, c.ldk, 0, st));
-      return rn_unpack_wgrad(dwp, c.ldk, c.O, c.I, c.k, c.Cp, 0, gw, st);
-    }
-    t.B = col; t.ldb = 9 * (int64_t)c.Cp;
-    if (!explicit_only && H >= 4 && !gemm_tn_8p_eligible(t, m->dtype)) {
-      t.B = x; t.ldb = c.Cp; t.conv_H = H; t.conv_W = H; t.conv_C = c.Cp;
+      done = true;
     } else {
-      RN_TRY(rn_im2col3x3(x, B, H, H, c.Cp, col, m->dtype, st));
+      t.B = col; t.ldb = 9 * (int64_t)c.Cp;
+      if (mode != 1 && H >= 4 && !gemm_tn_8p_eligible(t, m->dtype)) {
+        t.B = x; t.ldb = c.Cp; t.conv_H = H; t.conv_W = H; t.conv_C = c.Cp;      // bit-identical to the explicit route
+      } else {
+        RN_TRY(rn_im2col3x3(x, B, H, H, c.Cp, col, m->dtype, st));
+      }
     }
   } else {
-    t.B = bsrc; t.ldb = ldb;
-    // 1 x 1 (and the stem's first convolution on its explicit column matrix): many pixels, few channels on one side -- the operands-once
-    // kernel where the 8-phase kernel does not apply.  EZCLIP_RN_EXPLICIT_IM2COL=3 (and 1, 2): the generic kernel (A/B)
-    static const int mode = getenv("EZCLIP_RN_EXPLICIT_IM2COL") ? atoi(getenv("EZCLIP_RN_EXPLICIT_IM2COL")) : 0;
+    t.B = x; t.ldb = c.cfirst ? c.ldk : c.Cp;               // the stem's first convolution: x IS its explicit column matrix [M, ldk]
     if (mode == 0 && !gemm_tn_8p_eligible(t, m->dtype) && rn_tn_skinny_eligible(M, t.N, t.K, t.lda, t.ldb, t.ldc, m->dtype, col_bytes)) {
       RN_TRY(rn_tn_skinny(t.A, t.lda, t.B, t.ldb, t.C, t.ldc, M, t.N, t.K, 0, col, col_bytes, st));
-      if (c.cfirst) {
-        EZ_HIP(hipMemcpy2DAsync(gw, (size_t)c.I * 9 * 4, dwp, (size_t)c.ldk * 4, (size_t)c.I * 9 * 4, c.O, hipMemcpyDeviceToDevice, st));
-        return EZ_OK;
-      }
-      return rn_unpack_wgrad(dwp, c.ldk, c.O, c.I, c.k, c.Cp, 0, gw, st);
+      done = true;
     }
   }
-  RN_TRY(gemm_tn(t, m->dtype, st));
+  if (!done) RN_TRY(gemm_tn(t, m->dtype, st));
   if (c.cfirst) {
     // K index (c, ky, kx) = the weight's own [I][3][3] order: a strided copy of the first I * 9 columns
     EZ_HIP(hipMemcpy2DAsync(gw, (size_t)c.I * 9 * 4, dwp, (size_t)c.ldk * 4, (size_t)c.I * 9 * 4, c.O, hipMemcpyDeviceToDevice, st));

@@ -709,8 +709,9 @@ bool rn_wgrad3x3_c64_eligible(int B, int H, int W, int cp, int opad, int dtype, 
 
 int rn_wgrad3x3_c64(const void* x, const void* dz, int B, int H, int W, int cp, int opad, void* scratch, size_t scratch_bytes, float* out,
                     int64_t ldo, int accumulate, hipStream_t st) {
-  EZ_REQUIRE(x && dz && scratch && out && ldo >= 9 * (int64_t)cp && rn_wgrad3x3_c64_eligible(B, H, W, cp, opad, EZCLIP_BF16, scratch_bytes),
-             "rn_wgrad3x3_c64: %d images of %d x %d, %d -> %d padded channels (bf16; 64 or 128 each), scratch %zu bytes, ldo %lld: not a shape of this kernel",
+  EZ_REQUIRE(x && dz && scratch && out && ldo >= 9 * (int64_t)cp && ldo % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dz % 16) == 0 &&
+                 ((uintptr_t)out % 16) == 0 && ((uintptr_t)scratch % 16) == 0 && rn_wgrad3x3_c64_eligible(B, H, W, cp, opad, EZCLIP_BF16, scratch_bytes),
+             "rn_wgrad3x3_c64: %d images of %d x %d, %d -> %d padded channels (bf16; 64 or 128 each), scratch %zu bytes, ldo %lld (a multiple of 4; 16-byte aligned buffers): not a shape of this kernel",
              B, H, W, cp, opad, scratch_bytes, (long long)ldo);
   RnWgrad64Args a;
   size_t lds = 0;
@@ -745,7 +746,7 @@ bool rn_tn_skinny_eligible(int64_t M, int N, int K, int64_t lda, int64_t ldb, in
 
 int rn_tn_skinny(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, int accumulate,
                  void* scratch, size_t scratch_bytes, hipStream_t st) {
-  EZ_REQUIRE(A && B && C && scratch && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0 &&
+  EZ_REQUIRE(A && B && C && scratch && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)scratch % 16) == 0 &&
                  rn_tn_skinny_eligible(M, N, K, lda, ldb, ldc, EZCLIP_BF16, scratch_bytes),
              "rn_tn_skinny: M %lld N %d K %d (lda %lld ldb %lld ldc %lld), scratch %zu bytes: not a shape of this kernel (bf16, M >= 4096, N and K multiples "
              "of 64, at most 16 blocks of 64 x 256)", (long long)M, N, K, (long long)lda, (long long)ldb, (long long)ldc, scratch_bytes);

@@ -297,6 +297,13 @@ def preflight(world, rank, device, backend, use_dist):
         except Exception as e:      # noqa: BLE001 -- the point of the preflight is to name the failing stage
             res["failed_at"] = name
             res["error"] = "%s: %s" % (type(e).__name__, str(e)[:500])
+            if use_dist and world > 1:
+                # The ranks that did not fail are inside (or about to enter) the next collective and would wait there for this one until
+                # the RCCL timeout.  The failing rank prints THE line itself and leaves with a non-zero status: the launcher
+                # (torch.distributed.run) then tears the other workers down within seconds.
+                res["all_ranks_ok"], res["reported_by_rank"] = False, rank
+                print(json.dumps(res), flush=True)
+                os._exit(3)
 
     n, e2 = 1024, 1024                                            # [n, 2E] bf16-free: float32 embeddings, 4 MiB per rank
     mine = torch.randn(n, e2, device=device)

@@ -568,11 +568,14 @@ class _EncodeFn(torch.autograd.Function):
 
 class _RnEncodeFn(torch.autograd.Function):
     """ModifiedResNet image tower in training mode: ``RnEngine.encode_image_train`` / ``backward`` (csrc/resnet.hip); the gradient
-    tensors are allocated here and WRITTEN by the library, autograd accumulates them into ``.grad``."""
+    tensors are allocated here and WRITTEN by the library, autograd accumulates them into ``.grad``.  Every forward owns the
+    workspace its activations are saved in until its backward has run (``_WsToken``, as ``_EncodeFn``): two training forwards
+    before one backward each keep their own, and the library re-derives every pointer from the workspace it is handed."""
 
     @staticmethod
     def forward(ctx, app, pixels, names, *params):
-        out = app._rn.encode_image_train(pixels)
+        ctx.token = _WsToken()
+        out, ctx.saved_ws = app._rn.encode_image_train(pixels, owner=ctx.token, return_saved=True)
         ctx.app, ctx.names = app, names
         ctx.need = [p.requires_grad for p in params]
         ctx.save_for_backward(out)
@@ -583,7 +586,8 @@ class _RnEncodeFn(torch.autograd.Function):
         (out,) = ctx.saved_tensors
         rn = ctx.app._rn
         grads = {n: torch.empty(rn.shapes[n], dtype=torch.float32, device=out.device) for n in ctx.names}
-        rn.backward(out, d_out, grads)
+        rn.backward(out, d_out, grads, saved=ctx.saved_ws)
+        ctx.token.released = True
         return (None, None, None) + tuple(grads[n] if need else None for n, need in zip(ctx.names, ctx.need))
 
 
@@ -884,7 +888,10 @@ class CLIPApp(Application):
             # the reference module in train() mode: batch statistics, running statistics moved, autograd through the tower
             names = [n for n in self._rn.names if not self._rn.is_statistic(n)]
             self._rn.sync_train(tensors)
-            return _RnEncodeFn.apply(self, pixel_values, names, *[tensors[n] for n in names])
+            out = _RnEncodeFn.apply(self, pixel_values, names, *[tensors[n] for n in names])
+            with torch.no_grad():                                       # nn.BatchNorm2d.train(): one more batch tracked per forward
+                torch._foreach_add_([b for n, b in both.items() if n.startswith("visual.") and n.endswith("num_batches_tracked")], 1)
+            return out
         self._rn.sync(tensors)
         with torch.no_grad():
             return self._rn.encode_image(pixel_values)

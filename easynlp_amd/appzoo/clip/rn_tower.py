@@ -1,13 +1,14 @@
 """Host side of the ModifiedResNet image tower (include/ezclip.h: ezclip_rn_*; csrc/resnet.hip).
 
 Reference: CHINESE_CLIP builds ``ModifiedResNet(vision_layers, embed_dim, vision_width * 32 // 64, image_resolution, vision_width)``
-when ``vision_layers`` is a tuple (easynlp/modelzoo/models/clip/modeling_chineseclip.py:279-287).  The tower runs in EVAL mode
-(BatchNorm with its running statistics) and has no backward pass here: a FROZEN image tower -- evaluation, prediction, and
-fine-tuning of the text tower against fixed image features.  Parameters and BatchNorm statistics keep the reference checkpoint's
+when ``vision_layers`` is a tuple (easynlp/modelzoo/models/clip/modeling_chineseclip.py:279-287).  EVAL mode (BatchNorm with its
+running statistics: evaluation, prediction, a frozen tower) and TRAIN mode (batch statistics, running statistics moved, backward
+pass: ``encode_image_train`` / ``backward``).  Parameters and BatchNorm statistics keep the reference checkpoint's
 names (``visual.conv1.weight``, ``visual.bn1.running_mean``, ``visual.layer1.0.downsample.1.weight``, ...) so that
 ``state_dict`` / ``load_state_dict`` exchange checkpoints with the reference."""
 from __future__ import annotations
 
+import weakref
 from typing import Dict, List, Sequence
 
 import torch
@@ -42,6 +43,7 @@ class RnEngine:
         self._shadow = None
         self._ws = {}
         self._sig = None
+        self._saved = self._saved_owner = self._last_saved = None
 
     def __del__(self):
         try:
@@ -108,31 +110,53 @@ class RnEngine:
             L.check(self.lib.ezclip_rn_refresh_train_weights(self.handle, L.stream_ptr()), "rn_refresh_train_weights")
             self._tfresh = True
 
-    def _train_buffers(self, B: int, device):
+    def _train_scratch(self, B: int, device):
         key = (B, str(device))
         if getattr(self, "_tkey", None) != key:
-            self._saved = L.alloc_bytes(self.lib.ezclip_rn_train_saved_bytes(self.handle, B), device)
             self._scratch = L.alloc_bytes(self.lib.ezclip_rn_train_scratch_bytes(self.handle, B), device)
+            self._saved, self._saved_owner = None, None
             self._tkey = key
-        return self._saved, self._scratch
+        return self._scratch
 
-    def encode_image_train(self, pixels: torch.Tensor) -> torch.Tensor:
+    def _saved_workspace(self, B: int, device, owner):
+        """The workspace a training forward keeps its activations in.  One buffer is cached and reused -- but it BELONGS to the forward
+        that filled it until the matching backward has run (``owner``: a token the autograd ctx holds, ``released`` set by its backward;
+        the same rule as HipClipEngine.workspace): a second training forward in between (two micro-batches summed into one loss, a
+        feature call between forward and backward) gets a buffer of its own instead of overwriting the first one's activations."""
+        self._train_scratch(B, device)
+        nbytes = self.lib.ezclip_rn_train_saved_bytes(self.handle, B)
+        prev = self._saved_owner() if getattr(self, "_saved_owner", None) is not None else None
+        if self._saved is not None and prev is not None and prev is not owner and not prev.released:
+            return L.alloc_bytes(nbytes, device)              # lives as long as the caller's ctx holds it
+        if self._saved is None:
+            self._saved = L.alloc_bytes(nbytes, device)
+        self._saved_owner = weakref.ref(owner) if owner is not None else None
+        return self._saved
+
+    def encode_image_train(self, pixels: torch.Tensor, owner=None, return_saved: bool = False):
         """Forward with BatchNorm batch statistics (``module.train()`` semantics): moves the bound running statistics, keeps the
-        activations for ``backward``.  The inference copies are stale afterwards (the statistics changed): marked dirty here."""
+        activations for ``backward``.  The inference copies are stale afterwards (the statistics changed): marked dirty here.
+        ``return_saved``: also return the saved workspace (hand it to ``backward``; without it ``backward`` uses the last one)."""
         pixels = pixels.contiguous().float()
         B = pixels.shape[0]
         if tuple(pixels.shape[1:]) != (3, self.resolution, self.resolution):
             raise L.EzclipError("pixel_values must be [B,3,%d,%d], got %s" % (self.resolution, self.resolution, tuple(pixels.shape)))
-        saved, scratch = self._train_buffers(B, pixels.device)
+        scratch = self._train_scratch(B, pixels.device)
+        saved = self._saved_workspace(B, pixels.device, owner)
         out = torch.empty((B, self.output_dim), dtype=torch.float32, device=pixels.device)
         L.check(self.lib.ezclip_rn_encode_image_train(self.handle, L.ptr(pixels), B, L.ptr(out), L.ptr(saved), saved.numel(), L.ptr(scratch),
                                                       scratch.numel(), L.stream_ptr()), "rn_encode_image_train")
         self.mark_dirty()
-        return out
+        self._last_saved = saved
+        return (out, saved) if return_saved else out
 
-    def backward(self, features: torch.Tensor, d_features: torch.Tensor, grads: Dict[str, torch.Tensor]) -> None:
-        """Gradients of every parameter (float32 tensors of ``grads``, WRITTEN) for the last ``encode_image_train``"""
+    def backward(self, features: torch.Tensor, d_features: torch.Tensor, grads: Dict[str, torch.Tensor], saved: torch.Tensor = None) -> None:
+        """Gradients of every parameter (float32 tensors of ``grads``, WRITTEN) for the ``encode_image_train`` that filled ``saved``
+        (default: the last one)"""
         B = features.shape[0]
+        saved = saved if saved is not None else getattr(self, "_last_saved", None)
+        if saved is None:
+            raise L.EzclipError("ModifiedResNet backward: no training forward has run on this engine")
         for n in self.names:
             if self.is_statistic(n):
                 continue
@@ -140,6 +164,7 @@ class RnEngine:
             if g.dtype != torch.float32 or tuple(g.shape) != self.shapes[n] or not g.is_contiguous():
                 raise L.EzclipError("ModifiedResNet gradient %s: expected contiguous float32 %s" % (n, self.shapes[n]))
             L.check(self.lib.ezclip_rn_bind_grad(self.handle, n.encode(), L.ptr(g)), "rn_bind_grad")
-        _, scratch = self._train_buffers(B, features.device)
-        L.check(self.lib.ezclip_rn_backward(self.handle, L.ptr(features.contiguous()), L.ptr(d_features.contiguous().float()), B, L.ptr(scratch),
-                                            scratch.numel(), L.stream_ptr()), "rn_backward")
+        scratch = self._train_scratch(B, features.device) if getattr(self, "_tkey", None) == (B, str(features.device)) else \
+            L.alloc_bytes(self.lib.ezclip_rn_train_scratch_bytes(self.handle, B), features.device)
+        L.check(self.lib.ezclip_rn_backward(self.handle, L.ptr(features.contiguous()), L.ptr(d_features.contiguous().float()), B, L.ptr(saved),
+                                            saved.numel(), L.ptr(scratch), scratch.numel(), L.stream_ptr()), "rn_backward")

@@ -17,6 +17,8 @@
 // ezclip_encode_image returns it (CHINESE_CLIP.forward :360).
 #include <cstring>
 #include <string>
+#include <algorithm>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ezclip.h"
@@ -185,6 +187,12 @@ struct ezclip_rn {
     float *feat = nullptr, *inv_norm = nullptr;
     const void* last = nullptr;          // the tower's last activation (input of the attention pool)
   } saved;
+  // Every saved workspace a training forward has filled: base pointer -> (batch, serial number).  A backward pass names the workspace
+  // of ITS forward and every pointer is re-derived from that base (rn_train_bind), so two forwards before one backward (micro-batches
+  // summed into one loss, a feature call in between) each keep their own activations; a workspace nobody filled is refused.
+  struct Filled { int B; uint64_t serial; };
+  std::unordered_map<const void*, Filled> filled;
+  uint64_t serial = 0;
 };
 
 namespace {
@@ -389,52 +397,71 @@ struct RnBump {                          // bump allocator over a workspace; nul
   void* take(size_t bytes) { void* p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; }
 };
 
-// bytes of the saved workspace of one training forward over B images (also the order rn_train_forward allocates in)
-template <typename F>
-void rn_train_plan(ezclip_rn* m, int B, RnBump& a, F&& on_conv) {
+// The saved workspace of one training forward over B images: ONE walk defines its layout.  `on_conv(conv, M, H, in, lda)` is called for
+// every convolution in forward order with its input (a pointer inside the workspace, null in a size query) and must take z, y, mean, rstd
+// from the allocator in that order (rn_train_take_conv).  Used by the size query, by the forward pass (which then only launches) and by
+// the backward pass (which re-derives every pointer from the base of the workspace ITS forward filled).
+inline void rn_train_take_conv(ezclip_rn* m, RnBump& a, ezclip_rn::Conv& c, int64_t M, int H, const void* in, bool assign) {
+  void* z = a.take((size_t)M * c.Opad * m->esz);
+  void* y = a.take((size_t)M * c.Opad * m->esz);
+  float* mean = (float*)a.take((size_t)c.Opad * 4);
+  float* rstd = (float*)a.take((size_t)c.Opad * 4);
+  if (assign) { c.in = in; c.M = M; c.H = H; c.z = z; c.y = y; c.mean = mean; c.rstd = rstd; }
+}
+void rn_train_plan(ezclip_rn* m, int B, RnBump& a, bool assign) {
   const int R = m->cfg.image_resolution;
   const size_t e = m->esz;
+  ezclip_rn::Saved s;
+  s.B = B;
   int H = R / 2;
   int64_t M = (int64_t)B * H * H;
-  m->saved.col0 = a.take((size_t)M * m->stem[0].ldk * e);
-  for (int i = 0; i < 3; ++i) on_conv(m->stem[i], M, H);
-  m->saved.pool0 = a.take((size_t)(M / 4) * m->stem[2].Opad * e);
+  s.col0 = a.take((size_t)M * m->stem[0].ldk * e);
+  rn_train_take_conv(m, a, m->stem[0], M, H, s.col0, assign);
+  rn_train_take_conv(m, a, m->stem[1], M, H, m->stem[0].y, assign);
+  rn_train_take_conv(m, a, m->stem[2], M, H, m->stem[1].y, assign);
+  s.pool0 = a.take((size_t)(M / 4) * m->stem[2].Opad * e);
   H /= 2; M /= 4;
-  m->saved.o2p.clear(); m->saved.idp.clear();
+  const void* x = s.pool0;
   for (auto& L : m->blocks)
     for (auto& b : L) {
-      on_conv(b.c1, M, H);
-      on_conv(b.c2, M, H);
+      rn_train_take_conv(m, a, b.c1, M, H, x, assign);
+      rn_train_take_conv(m, a, b.c2, M, H, b.c1.y, assign);
       int64_t Mo = M; int Ho = H;
       void *o2p = nullptr, *idp = nullptr;
+      const void* o2 = b.c2.y;
+      const void* idn = x;
       if (b.stride > 1) {
         Mo = M / 4; Ho = H / 2;
         o2p = a.take((size_t)Mo * b.c2.Opad * e);
         idp = a.take((size_t)Mo * b.c1.Cp * e);
+        o2 = o2p; idn = idp;
       }
-      m->saved.o2p.push_back(o2p); m->saved.idp.push_back(idp);
-      if (b.has_down) on_conv(b.down, Mo, Ho);
-      on_conv(b.c3, Mo, Ho);
-      M = Mo; H = Ho;
+      s.o2p.push_back(o2p); s.idp.push_back(idp);
+      if (b.has_down) rn_train_take_conv(m, a, b.down, Mo, Ho, idn, assign);
+      rn_train_take_conv(m, a, b.c3, Mo, Ho, o2, assign);
+      x = b.c3.y; M = Mo; H = Ho;
     }
+  s.last = x;
   const int Lt = m->sp * m->sp + 1, C = m->embed;
-  m->saved.tok = a.take((size_t)B * Lt * C * e);
-  m->saved.kk = a.take((size_t)B * Lt * C * e);
-  m->saved.vv = a.take((size_t)B * Lt * C * e);
-  m->saved.qc = a.take((size_t)B * C * e);
-  m->saved.ctx = a.take((size_t)B * C * e);
-  m->saved.feat = (float*)a.take((size_t)B * m->cfg.output_dim * 4);
-  m->saved.inv_norm = (float*)a.take((size_t)B * 4);
+  s.tok = a.take((size_t)B * Lt * C * e);
+  s.kk = a.take((size_t)B * Lt * C * e);
+  s.vv = a.take((size_t)B * Lt * C * e);
+  s.qc = a.take((size_t)B * C * e);
+  s.ctx = a.take((size_t)B * C * e);
+  s.feat = (float*)a.take((size_t)B * m->cfg.output_dim * 4);
+  s.inv_norm = (float*)a.take((size_t)B * 4);
+  if (assign) m->saved = s;
 }
 
 size_t rn_train_saved_bytes(ezclip_rn* m, int B) {
   RnBump a(nullptr);
-  const ezclip_rn::Saved keep = m->saved;            // (a size query between a forward and its backward must not touch what was saved)
-  rn_train_plan(m, B, a, [&](ezclip_rn::Conv& c, int64_t M, int) {
-    a.take((size_t)M * c.Opad * m->esz); a.take((size_t)M * c.Opad * m->esz); a.take((size_t)c.Opad * 4); a.take((size_t)c.Opad * 4);
-  });
-  m->saved = keep;
+  rn_train_plan(m, B, a, false);             // (a size query between a forward and its backward touches nothing that was saved)
   return a.off + 256;
+}
+// point the handle at the activations of the training forward that filled `saved_ws`
+void rn_train_bind(ezclip_rn* m, int B, char* saved_ws) {
+  RnBump a(saved_ws);
+  rn_train_plan(m, B, a, true);
 }
 
 // largest NHWC activation / gradient of a batch, and the largest explicit im2col of a 3x3 convolution's input (the `col` scratch of the
@@ -485,78 +512,60 @@ int rn_gemm_t(const ezclip_rn* m, const void* A, int64_t lda, int64_t M, const e
 template <typename T>
 int rn_train_forward(ezclip_rn* m, const float* px, int B, float* out, char* saved_ws, size_t saved_bytes, float* bn_scratch, hipStream_t st) {
   const int R = m->cfg.image_resolution;
-  RnBump a(saved_ws);
+  {
+    RnBump probe(nullptr);
+    rn_train_plan(m, B, probe, false);
+    EZ_REQUIRE(probe.off <= saved_bytes, "rn_train_forward: the pass saves %zu bytes into a workspace of %zu", probe.off, saved_bytes);
+  }
+  m->filled.erase(saved_ws);                 // (until every launch below is enqueued the workspace holds no complete pass)
+  rn_train_bind(m, B, saved_ws);             // every pointer of the pass: Conv::in / z / y / mean / rstd, m->saved.*
   int rc = EZ_OK;
-  // one convolution + BatchNorm(train) [+ identity] [+ ReLU]; allocates z, y, mean, rstd in plan order
-  auto conv_bn = [&](ezclip_rn::Conv& c, const void* in, int64_t lda, int64_t M, int H, int convH, const void* identity, int relu) {
-    c.in = in; c.M = M; c.H = H;
-    c.z = a.take((size_t)M * c.Opad * m->esz);
-    c.y = a.take((size_t)M * c.Opad * m->esz);
-    c.mean = (float*)a.take((size_t)c.Opad * 4);
-    c.rstd = (float*)a.take((size_t)c.Opad * 4);
+  // one convolution + BatchNorm(train) [+ identity] [+ ReLU] on the bound pointers
+  auto conv_bn = [&](ezclip_rn::Conv& c, int64_t lda, int convH, const void* identity, int relu) {
     if (rc != EZ_OK) return;
-    rc = rn_gemm_t(m, in, lda, M, c, c.z, convH, st);
+    rc = rn_gemm_t(m, c.in, lda, c.M, c, c.z, convH, st);
     if (rc != EZ_OK) return;
-    rc = rn_bn_train_fwd(c.z, M, c.O, c.Opad, m->params[c.bn].w, m->params[c.bn + 1].w, const_cast<float*>(m->params[c.bn + 2].w),
+    rc = rn_bn_train_fwd(c.z, c.M, c.O, c.Opad, m->params[c.bn].w, m->params[c.bn + 1].w, const_cast<float*>(m->params[c.bn + 2].w),
                          const_cast<float*>(m->params[c.bn + 3].w), 0.1f, kBnEps, identity, relu, c.y, c.mean, c.rstd, bn_scratch, m->dtype, st);
   };
-  // ---- the allocation order below must be rn_train_plan's
   int H = R / 2;
   int64_t M = (int64_t)B * H * H;
-  m->saved.B = B;
-  m->saved.col0 = a.take((size_t)M * m->stem[0].ldk * m->esz);
   RN_TRY(launch1d(rn_stem_im2col_kernel<T>, M * m->stem[0].ldk, st, px, B, R, H, m->stem[0].ldk, (T*)m->saved.col0));
-  conv_bn(m->stem[0], m->saved.col0, m->stem[0].ldk, M, H, 0, nullptr, 1);
-  conv_bn(m->stem[1], m->stem[0].y, m->stem[0].Opad, M, H, H, nullptr, 1);
-  conv_bn(m->stem[2], m->stem[1].y, m->stem[1].Opad, M, H, H, nullptr, 1);
+  conv_bn(m->stem[0], m->stem[0].ldk, 0, nullptr, 1);
+  conv_bn(m->stem[1], m->stem[0].Opad, H, nullptr, 1);
+  conv_bn(m->stem[2], m->stem[1].Opad, H, nullptr, 1);
   RN_TRY(rc);
   int C = m->stem[2].Opad;
-  m->saved.pool0 = a.take((size_t)(M / 4) * C * m->esz);
   RN_TRY(launch1d(rn_avgpool2_kernel<T>, M / 4 * (C / 4), st, (const T*)m->stem[2].y, M / 4 * (C / 4), H, H, C, (T*)m->saved.pool0));
   H /= 2; M /= 4;
   const void* x = m->saved.pool0;
-  m->saved.o2p.clear(); m->saved.idp.clear();
+  size_t bi = 0;
   for (auto& L : m->blocks)
     for (auto& b : L) {
-      conv_bn(b.c1, x, C, M, H, 0, nullptr, 1);
-      conv_bn(b.c2, b.c1.y, b.c1.Opad, M, H, H, nullptr, 1);
+      conv_bn(b.c1, C, 0, nullptr, 1);
+      conv_bn(b.c2, b.c1.Opad, H, nullptr, 1);
       RN_TRY(rc);
       int64_t Mo = M; int Ho = H;
-      const void* o2 = b.c2.y;
-      const void* idn = x;
-      void *o2p = nullptr, *idp = nullptr;
       if (b.stride > 1) {
         Mo = M / 4; Ho = H / 2;
         const int Cm = b.c2.Opad;
-        o2p = a.take((size_t)Mo * Cm * m->esz);
-        idp = a.take((size_t)Mo * C * m->esz);
-        RN_TRY(launch1d(rn_avgpool2_kernel<T>, Mo * (Cm / 4), st, (const T*)b.c2.y, Mo * (Cm / 4), H, H, Cm, (T*)o2p));
-        RN_TRY(launch1d(rn_avgpool2_kernel<T>, Mo * (C / 4), st, (const T*)x, Mo * (C / 4), H, H, C, (T*)idp));
-        o2 = o2p; idn = idp;
+        RN_TRY(launch1d(rn_avgpool2_kernel<T>, Mo * (Cm / 4), st, (const T*)b.c2.y, Mo * (Cm / 4), H, H, Cm, (T*)m->saved.o2p[bi]));
+        RN_TRY(launch1d(rn_avgpool2_kernel<T>, Mo * (C / 4), st, (const T*)x, Mo * (C / 4), H, H, C, (T*)m->saved.idp[bi]));
       }
-      m->saved.o2p.push_back(o2p); m->saved.idp.push_back(idp);
-      const void* identity = idn;
+      const void* identity = b.stride > 1 ? m->saved.idp[bi] : x;
       if (b.has_down) {
-        conv_bn(b.down, idn, C, Mo, Ho, 0, nullptr, 0);
+        conv_bn(b.down, C, 0, nullptr, 0);
         identity = b.down.y;
       }
-      conv_bn(b.c3, o2, b.c2.Opad, Mo, Ho, 0, identity, 1);
+      conv_bn(b.c3, b.c2.Opad, 0, identity, 1);
       RN_TRY(rc);
       x = b.c3.y; C = b.c3.Opad; M = Mo; H = Ho;
+      ++bi;
     }
   // ---- AttentionPool2d (as rn_forward_chunk, everything kept)
   EZ_REQUIRE(H == m->sp && C == m->embed, "rn_train_forward: tower ends at %d x %d x %d, attention pool expects %d x %d x %d", H, H, C, m->sp,
              m->sp, m->embed);
-  m->saved.last = x;
   const int P = H * H, Lt = P + 1;
-  m->saved.tok = a.take((size_t)B * Lt * C * m->esz);
-  m->saved.kk = a.take((size_t)B * Lt * C * m->esz);
-  m->saved.vv = a.take((size_t)B * Lt * C * m->esz);
-  m->saved.qc = a.take((size_t)B * C * m->esz);
-  m->saved.ctx = a.take((size_t)B * C * m->esz);
-  m->saved.feat = (float*)a.take((size_t)B * m->cfg.output_dim * 4);
-  m->saved.inv_norm = (float*)a.take((size_t)B * 4);
-  EZ_REQUIRE(a.off <= saved_bytes, "rn_train_forward: the pass saves %zu bytes into a workspace of %zu (rn_train_plan is out of step)", a.off, saved_bytes);
   hipLaunchKernelGGL(rn_attnpool_tokens_kernel<T>, dim3(B), dim3(256), 0, st, (const T*)x, m->params[m->pos_p].w, P, C, (T*)m->saved.tok);
   EZ_LAUNCH_CHECK();
   RN_TRY(rn_gemm(m, m->saved.tok, C, B * Lt, m->kproj, m->saved.kk, C, ACT_NONE, nullptr, 0, 0, 0, false, st));
@@ -566,7 +575,15 @@ int rn_train_forward(ezclip_rn* m, const float* px, int B, float* out, char* sav
   at.k = m->saved.kk; at.v = m->saved.vv; at.row_stride = C; at.B = B; at.L = Lt; at.H = m->heads; at.scale = 0.125f;
   RN_TRY(attention_cls_fwd(at, m->saved.qc, C, m->saved.ctx, C, m->dtype, st));
   RN_TRY(rn_gemm(m, m->saved.ctx, C, B, m->cproj, m->saved.feat, m->cfg.output_dim, ACT_NONE, nullptr, 0, 0, 0, true, st));
-  return l2_normalize_fwd(m->saved.feat, out, m->saved.inv_norm, B, m->cfg.output_dim, st);
+  RN_TRY(l2_normalize_fwd(m->saved.feat, out, m->saved.inv_norm, B, m->cfg.output_dim, st));
+  if (m->filled.size() >= 64) {              // (workspaces whose owners are long gone: forget the oldest half)
+    std::vector<std::pair<uint64_t, const void*>> v;
+    for (auto& kv : m->filled) v.push_back({kv.second.serial, kv.first});
+    std::sort(v.begin(), v.end());
+    for (size_t i = 0; i < v.size() / 2; ++i) m->filled.erase(v[i].second);
+  }
+  m->filled[saved_ws] = {B, ++m->serial};
+  return EZ_OK;
 }
 
 // d tok[b][0] += dq[b] . Wq  is a GEMM with a residual; d x[b][p] = d tok[b][1 + p] + d tok[b][0] / P
@@ -612,9 +629,9 @@ int rn_dgrad(const ezclip_rn* m, const ezclip_rn::Conv& c, const void* dz, int64
 // `col` holds the explicit column matrix or the per-workgroup partials of the operands-once kernels.
 // EZCLIP_RN_EXPLICIT_IM2COL (A/B switch): 1 = explicit column matrix + generic / 8-phase kernels everywhere (the first version), 2 = no
 // rn_wgrad3x3_c64 and no rn_tn_skinny, 3 = no rn_tn_skinny.
-static int rn_wgrad_mode() {
-  static const int mode = getenv("EZCLIP_RN_EXPLICIT_IM2COL") ? atoi(getenv("EZCLIP_RN_EXPLICIT_IM2COL")) : 0;
-  return mode;
+static int rn_wgrad_mode() {       // read per backward pass (tests switch it inside one process: same operands, the other summation order)
+  const char* e = getenv("EZCLIP_RN_EXPLICIT_IM2COL");
+  return e ? atoi(e) : 0;
 }
 
 template <typename T>
@@ -964,16 +981,29 @@ size_t ezclip_rn_train_saved_bytes(ezclip_rn_handle h, int batch) { return (h &&
 size_t ezclip_rn_train_scratch_bytes(ezclip_rn_handle h, int batch) { return (h && batch > 0) ? rn_train_scratch_bytes(h, batch) : 0; }
 int ezclip_rn_encode_image_train(ezclip_rn_handle h, const float* pixels, int batch, float* out, void* saved_ws, size_t saved_bytes,
                                  void* scratch, size_t scratch_bytes, void* stream) {
-  EZ_REQUIRE(h && pixels && out && saved_ws && scratch && batch > 1, "ezclip_rn_encode_image_train: null argument / batch < 2 (batch statistics)");
+  EZ_REQUIRE(h && pixels && out && saved_ws && scratch && batch > 0, "ezclip_rn_encode_image_train: null / empty argument");
+  // nn.BatchNorm2d.train() needs more than one value per channel: the smallest map of the tower is sp x sp (torch raises the same way)
+  EZ_REQUIRE((int64_t)batch * h->sp * h->sp > 1, "ezclip_rn_encode_image_train: batch %d at a %d x %d final map: BatchNorm in training mode needs more "
+             "than 1 value per channel", batch, h->sp, h->sp);
+  // the weight gradient of c_proj is a TN product with N = output_dim: 16-byte rows (the inference path accepts a ragged output_dim)
+  EZ_REQUIRE(h->cfg.output_dim % (16 / (int)h->esz) == 0, "ezclip_rn_encode_image_train: training needs output_dim %% %d == 0 (got %d)",
+             16 / (int)h->esz, h->cfg.output_dim);
   EZ_REQUIRE(h->fresh && h->tfresh, "ezclip_rn_encode_image_train: weights not packed (ezclip_rn_refresh_weights + ezclip_rn_refresh_train_weights)");
   EZ_REQUIRE(((uintptr_t)saved_ws % 256) == 0 && saved_bytes >= rn_train_saved_bytes(h, batch) && ((uintptr_t)scratch % 256) == 0 &&
                  scratch_bytes >= rn_train_scratch_bytes(h, batch), "ezclip_rn_encode_image_train: workspace too small / unaligned");
   return h->dtype == EZCLIP_BF16 ? rn_train_forward<bf16_t>(h, pixels, batch, out, (char*)saved_ws, saved_bytes, (float*)scratch, (hipStream_t)stream)
                                  : rn_train_forward<float>(h, pixels, batch, out, (char*)saved_ws, saved_bytes, (float*)scratch, (hipStream_t)stream);
 }
-int ezclip_rn_backward(ezclip_rn_handle h, const float* features, const float* d_features, int batch, void* scratch, size_t scratch_bytes,
-                       void* stream) {
-  EZ_REQUIRE(h && features && d_features && scratch && batch > 1 && h->saved.B == batch, "ezclip_rn_backward: no matching training forward (batch %d)", batch);
+int ezclip_rn_backward(ezclip_rn_handle h, const float* features, const float* d_features, int batch, const void* saved_ws, size_t saved_bytes,
+                       void* scratch, size_t scratch_bytes, void* stream) {
+  EZ_REQUIRE(h && features && d_features && saved_ws && scratch && batch > 0, "ezclip_rn_backward: null argument");
+  {
+    auto it = h->filled.find(saved_ws);
+    EZ_REQUIRE(it != h->filled.end(), "ezclip_rn_backward: no training forward of this handle filled the saved workspace %p", saved_ws);
+    EZ_REQUIRE(it->second.B == batch, "ezclip_rn_backward: the saved workspace holds a forward over %d images, the gradient is for %d", it->second.B, batch);
+    EZ_REQUIRE(saved_bytes >= rn_train_saved_bytes(h, batch), "ezclip_rn_backward: saved workspace too small");
+  }
+  rn_train_bind(h, batch, (char*)const_cast<void*>(saved_ws));        // every pointer from the base of THIS forward's workspace
   EZ_REQUIRE(((uintptr_t)scratch % 256) == 0 && scratch_bytes >= rn_train_scratch_bytes(h, batch), "ezclip_rn_backward: scratch too small / unaligned");
   for (auto& p : h->params) {
     const bool stat = p.name.size() > 12 && (p.name.rfind(".running_mean") == p.name.size() - 13 || p.name.rfind(".running_var") == p.name.size() - 12);

@@ -127,7 +127,7 @@ SIGNATURES = {
     "ezclip_rn_train_saved_bytes": (_sz, [_vp, _i]),
     "ezclip_rn_train_scratch_bytes": (_sz, [_vp, _i]),
     "ezclip_rn_encode_image_train": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
-    "ezclip_rn_backward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "ezclip_rn_backward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
     "ezclip_op_rn_bn_scratch_bytes": (_sz, [_i64, _i]),
     "ezclip_op_rn_bn_train_fwd": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ezclip_op_rn_bn_train_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),

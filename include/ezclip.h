@@ -288,7 +288,8 @@ int ezclip_rn_encode_image(ezclip_rn_handle h, const float* pixels_dev, int batc
                            size_t workspace_bytes, void* stream);
 
 /* Training path of the tower (BatchNorm in training mode, backward pass: modeling_chineseclip.py:27-167 under module.train() and
- * torch autograd).  The whole batch runs at once (batch statistics): no chunking, batch >= 2.
+ * torch autograd).  The whole batch runs at once (batch statistics): no chunking; batch * (R / 32)^2 > 1 (more than one value per
+ * channel in every BatchNorm, as torch requires); output_dim a multiple of 16 bytes of the compute dtype.
  *   ezclip_rn_set_train_shadow / ezclip_rn_refresh_train_weights   unfolded packed convolution weights and the packed weights of the
  *                                  input-gradient products; refresh after every parameter update (besides ezclip_rn_refresh_weights)
  *   ezclip_rn_bind_grad            float32 gradient buffer of a parameter (every parameter but the running statistics; WRITTEN, not
@@ -296,7 +297,9 @@ int ezclip_rn_encode_image(ezclip_rn_handle h, const float* pixels_dev, int batc
  *   ezclip_rn_encode_image_train   forward with batch statistics; moves the bound running_mean / running_var buffers (momentum 0.1);
  *                                  keeps every activation in saved_ws (ezclip_rn_train_saved_bytes) until the backward has run.
  *                                  After it the inference copies are stale: call ezclip_rn_refresh_weights before ezclip_rn_encode_image.
- *   ezclip_rn_backward             features_dev = the forward's output, d_features_dev [batch, output_dim] f32 its gradient */
+ *   ezclip_rn_backward             features_dev = the forward's output, d_features_dev [batch, output_dim] f32 its gradient, saved_dev =
+ *                                  the workspace THAT forward filled (any number of forwards may be pending, each in its own
+ *                                  workspace: every pointer is re-derived from the base; a workspace no forward filled is refused) */
 size_t ezclip_rn_train_shadow_bytes(ezclip_rn_handle h);
 int ezclip_rn_set_train_shadow(ezclip_rn_handle h, void* shadow_dev, size_t bytes);
 int ezclip_rn_refresh_train_weights(ezclip_rn_handle h, void* stream);
@@ -305,8 +308,8 @@ size_t ezclip_rn_train_saved_bytes(ezclip_rn_handle h, int batch);
 size_t ezclip_rn_train_scratch_bytes(ezclip_rn_handle h, int batch);
 int ezclip_rn_encode_image_train(ezclip_rn_handle h, const float* pixels_dev, int batch, float* out_dev, void* saved_dev, size_t saved_bytes,
                                  void* scratch_dev, size_t scratch_bytes, void* stream);
-int ezclip_rn_backward(ezclip_rn_handle h, const float* features_dev, const float* d_features_dev, int batch, void* scratch_dev,
-                       size_t scratch_bytes, void* stream);
+int ezclip_rn_backward(ezclip_rn_handle h, const float* features_dev, const float* d_features_dev, int batch, const void* saved_dev,
+                       size_t saved_bytes, void* scratch_dev, size_t scratch_bytes, void* stream);
 
 /* ---- backward ------------------------------------------------------------------- */
 /* Gradients are ACCUMULATED (+=) into the grad buffers bound with ezclip_bind_param (float32),

@@ -108,57 +108,64 @@ def _bn(sd, name, x, new_stats=None):
     return xh * sd[name + ".weight"][None, :, None, None] + sd[name + ".bias"][None, :, None, None]
 
 
-def bottleneck(sd, p, x, stride, new_stats=None):
-    """Bottleneck.forward (:59-74)"""
-    out = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"]), new_stats))
-    out = F.relu(_bn(sd, p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], padding=1), new_stats))
+def _keep(x):
+    return x
+
+
+def bottleneck(sd, p, x, stride, new_stats=None, store=_keep):
+    """Bottleneck.forward (:59-74).  ``store`` (here and below): applied to every tensor an implementation keeps in memory between two
+    kernels -- each convolution output, each BatchNorm (+ identity) (+ ReLU) output, each pooled map, the attention pool's tokens /
+    projections / context.  Identity in the restatement proper; the bf16 tests pass a round-to-bf16 with a straight-through gradient
+    to measure what STORING activations in bf16 costs any implementation (tests/test_resnet_train_gpu.py)."""
+    out = store(F.relu(_bn(sd, p + ".bn1", store(F.conv2d(x, sd[p + ".conv1.weight"])), new_stats)))
+    out = store(F.relu(_bn(sd, p + ".bn2", store(F.conv2d(out, sd[p + ".conv2.weight"], padding=1)), new_stats)))
     if stride > 1:
-        out = F.avg_pool2d(out, stride)
-    out = _bn(sd, p + ".bn3", F.conv2d(out, sd[p + ".conv3.weight"]), new_stats)
+        out = store(F.avg_pool2d(out, stride))
+    out = _bn(sd, p + ".bn3", store(F.conv2d(out, sd[p + ".conv3.weight"])), new_stats)
     identity = x
     if (p + ".downsample.0.weight") in sd:
-        identity = F.avg_pool2d(x, stride) if stride > 1 else x
-        identity = _bn(sd, p + ".downsample.1", F.conv2d(identity, sd[p + ".downsample.0.weight"]), new_stats)
-    return F.relu(out + identity)
+        identity = store(F.avg_pool2d(x, stride)) if stride > 1 else x
+        identity = store(_bn(sd, p + ".downsample.1", store(F.conv2d(identity, sd[p + ".downsample.0.weight"])), new_stats))
+    return store(F.relu(out + identity))
 
 
-def attention_pool(sd, x, heads):
+def attention_pool(sd, x, heads, store=_keep):
     """AttentionPool2d.forward (:87-108): only the mean token queries; scaling head_dim ** -0.5 as in
     F.multi_head_attention_forward."""
     p = "visual.attnpool."
     B, C, Hh, Ww = x.shape
     t = x.reshape(B, C, Hh * Ww).permute(0, 2, 1)                       # [B, HW, C]
     t = torch.cat([t.mean(dim=1, keepdim=True), t], dim=1)               # [B, HW + 1, C]
-    t = t + sd[p + "positional_embedding"][None]
-    q = t[:, :1] @ sd[p + "q_proj.weight"].t() + sd[p + "q_proj.bias"]   # [B, 1, C]
-    k = t @ sd[p + "k_proj.weight"].t() + sd[p + "k_proj.bias"]
-    v = t @ sd[p + "v_proj.weight"].t() + sd[p + "v_proj.bias"]
+    t = store(t + sd[p + "positional_embedding"][None])
+    q = store(t[:, :1] @ sd[p + "q_proj.weight"].t() + sd[p + "q_proj.bias"])   # [B, 1, C]
+    k = store(t @ sd[p + "k_proj.weight"].t() + sd[p + "k_proj.bias"])
+    v = store(t @ sd[p + "v_proj.weight"].t() + sd[p + "v_proj.bias"])
     hd = C // heads
     q = q.reshape(B, 1, heads, hd).transpose(1, 2) * (hd ** -0.5)
     k = k.reshape(B, -1, heads, hd).transpose(1, 2)
     v = v.reshape(B, -1, heads, hd).transpose(1, 2)
     a = torch.softmax(q @ k.transpose(-1, -2), dim=-1)                   # [B, heads, 1, HW + 1]
-    o = (a @ v).transpose(1, 2).reshape(B, C)
+    o = store((a @ v).transpose(1, 2).reshape(B, C))
     return o @ sd[p + "c_proj.weight"].t() + sd[p + "c_proj.bias"]
 
 
-def modified_resnet_forward(sd, layers, width, x, taps=None, train=False, new_stats=None):
+def modified_resnet_forward(sd, layers, width, x, taps=None, train=False, new_stats=None, store=_keep):
     """ModifiedResNet.forward (:153-167).  x: [B, 3, R, R] float.  ``taps``: optional dict filled with the stem output and every
     layer's output (NCHW).  ``train=True``: BatchNorm in training mode (see ``_bn``); ``new_stats`` (a dict, optional) receives the
-    updated running statistics of every BatchNorm -- ``sd`` itself is never written."""
+    updated running statistics of every BatchNorm -- ``sd`` itself is never written.  ``store``: see ``bottleneck``."""
     heads = width * 32 // 64                                              # CHINESE_CLIP.__init__ :280
     ns = (new_stats if new_stats is not None else {}) if train else None
     for i, stride in ((1, 2), (2, 1), (3, 1)):
-        x = F.relu(_bn(sd, "visual.bn%d" % i, F.conv2d(x, sd["visual.conv%d.weight" % i], stride=stride, padding=1), ns))
-    x = F.avg_pool2d(x, 2)
+        x = store(F.relu(_bn(sd, "visual.bn%d" % i, store(F.conv2d(x, sd["visual.conv%d.weight" % i], stride=stride, padding=1)), ns)))
+    x = store(F.avg_pool2d(x, 2))
     if taps is not None:
         taps["stem"] = x
     for li, nblocks in enumerate(layers, start=1):
         for bi in range(nblocks):
-            x = bottleneck(sd, "visual.layer%d.%d" % (li, bi), x, 2 if (li > 1 and bi == 0) else 1, ns)
+            x = bottleneck(sd, "visual.layer%d.%d" % (li, bi), x, 2 if (li > 1 and bi == 0) else 1, ns, store)
         if taps is not None:
             taps["layer%d" % li] = x
-    return attention_pool(sd, x, heads)
+    return attention_pool(sd, x, heads, store)
 
 
 def train_step_grads(sd, layers, width, x, probe):

@@ -169,3 +169,87 @@ def test_training_path_layout_conventions(B, I, O, H):
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     (torch.nn.functional.conv2d(xr, wr, padding=1) * dz).sum().backward()
     assert float((xr.grad - dx_want).abs().max()) < 1e-10 and float((wr.grad - dw_want).abs().max()) < 1e-9
+
+
+def test_w64_fixture_is_the_float64_reference_and_the_oracle_reproduces_it():
+    """tests/golden/rn_w64_train_b32.npz (the bf16 GPU test's reference: the REFERENCE module evaluated in float64, width 64, 32 images):
+    the float64 oracle reproduces features, every gradient (norm + 64 samples) and every moved statistic to float64 rounding."""
+    import zlib
+    z = np.load(os.path.join(HERE, "golden", "rn_w64_train_b32.npz"))
+    c = json.loads(bytes(z["meta"]).decode())
+    layers, width, e, res, B = tuple(c["layers"]), c["width"], c["output_dim"], c["resolution"], c["batch"]
+    sd = {k: v.double() for k, v in RO.make_state_dict(layers, width, e, res, c["wseed"]).items()}
+    rs = np.random.RandomState(c["iseed"])
+    px = torch.from_numpy(rs.standard_normal((B, 3, res, res)).astype(np.float32)).double()
+    probe = torch.from_numpy(rs.standard_normal((B, e)).astype(np.float32)).double()
+    leaves = {k: (v.clone().requires_grad_(True) if not k.endswith(("running_mean", "running_var")) else v) for k, v in sd.items()}
+    stats = {}
+    raw = RO.modified_resnet_forward(leaves, layers, width, px, train=True, new_stats=stats)
+    assert float((raw.detach() - torch.from_numpy(z["image_features"])).abs().max()) < 1e-9
+    out = raw / raw.norm(dim=-1, keepdim=True)
+    (out * probe).sum().backward()
+    n = 0
+    for k, v in leaves.items():
+        if not v.requires_grad:
+            ref = torch.from_numpy(z["stat:" + k])
+            assert float((stats[k] - ref).abs().max()) <= 1e-10 * max(1.0, float(ref.abs().max())), k
+            continue
+        g = v.grad
+        want = float(z["gnorm:" + k])
+        assert abs(float(g.norm()) - want) <= 1e-7 * want + 1e-12, k      # (+ 1e-12: attnpool.k_proj.bias' exact gradient is 0, both sides hold noise)
+        idx = np.random.RandomState(zlib.crc32(k.encode()) & 0x7fffffff).choice(g.numel(), size=min(64, g.numel()), replace=False).astype(np.int64)
+        samp = torch.from_numpy(z["gsamp:" + k])
+        assert float((g.reshape(-1)[torch.from_numpy(idx)] - samp).abs().max()) <= 1e-7 * float(samp.abs().max()) + 1e-9 * want + 1e-12, k
+        n += 1
+    assert n == len([k for k in z.files if k.startswith("gnorm:")])
+
+
+def test_whole_model_train_fixture_matches_the_oracles():
+    """tests/golden/clip_rn_tiny_train_b6_l24.npz -- the REFERENCE CHINESE_CLIP with the ModifiedResNet tower in train() mode: loss, embeddings,
+    every parameter gradient, every moved statistic -- against resnet_oracle (image tower, training mode) + clip_oracle (text tower, loss)."""
+    import zlib
+    from oracle import clip_oracle as O
+    z = np.load(os.path.join(HERE, "golden", "clip_rn_tiny_train_b6_l24.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    cfg, case = meta["cfg"], meta["case"]
+    layers, width = tuple(cfg["vision_layers"]), cfg["vision_width"]
+    vit_like = dict(cfg, vision_layers=1, vision_width=64)
+    sd = {k: v for k, v in O.make_state_dict(vit_like, case["wseed"]).items() if not k.startswith("visual.")}
+    sd.update(RO.make_state_dict(layers, width, cfg["embed_dim"], cfg["image_resolution"], case["rn_wseed"]))
+    px, ids = O.make_inputs(cfg, case["batch"], case["seq_len"], case["iseed"])
+    leaves = {k: (v.clone().requires_grad_(True) if not k.endswith(("running_mean", "running_var")) else v) for k, v in sd.items()}
+    stats = {}
+    img = O.l2_normalize(RO.modified_resnet_forward(leaves, layers, width, px, train=True, new_stats=stats))
+    txt = O.encode_text(leaves, cfg, ids)
+    lpt = (txt @ img.t()) * leaves["logit_scale"].exp()
+    loss = O.clip_loss(lpt)
+    loss.backward()
+    assert float((img.detach() - torch.from_numpy(z["image_embeds"])).abs().max()) < 1e-5
+    assert float((txt.detach() - torch.from_numpy(z["text_embeds"])).abs().max()) < 1e-5
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 1e-5 * float(z["loss"])
+    scale = max([float(np.linalg.norm(z[k].astype(np.float64))) for k in z.files if k.startswith("grad/")])
+    seen = 0
+    for k in z.files:
+        if k.startswith("grad/"):
+            n = k[len("grad/"):]
+            ref = torch.from_numpy(z[k]).double()
+            got = leaves[n].grad.double().reshape(ref.shape)
+            assert float((got - ref).norm()) <= 1e-4 * float(ref.norm()) + 2e-6 * scale, (n, float((got - ref).norm()) / (float(ref.norm()) + 1e-30))
+            seen += 1
+        elif k.startswith("gnorm/"):
+            n = k[len("gnorm/"):]
+            got = leaves[n].grad.double().reshape(-1)
+            want = float(z[k])
+            assert abs(float(got.norm()) - want) <= 1e-4 * want + 2e-6 * scale, n
+            idx = np.random.RandomState(zlib.crc32(n.encode()) & 0x7fffffff).choice(got.numel(), size=64, replace=False).astype(np.int64)
+            samp = torch.from_numpy(z["gsamp/" + n]).double()
+            assert float((got[torch.from_numpy(idx)] - samp).abs().max()) <= 1e-4 * float(samp.abs().max()) + 1e-4 * want / got.numel() ** 0.5, n
+            seen += 1
+        elif k.startswith("nograd/"):
+            assert leaves[k[len("nograd/"):]].grad is None
+        elif k.startswith("stat/") and not k.endswith("num_batches_tracked"):
+            ref = torch.from_numpy(z[k])
+            assert float((stats[k[len("stat/"):]] - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), k
+        elif k.endswith("num_batches_tracked"):
+            assert int(z[k]) == 1
+    assert seen >= 110

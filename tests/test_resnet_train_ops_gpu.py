@@ -24,6 +24,14 @@ def _nhwc(x, cp, dt):
     return RO.to_nhwc(x, cp).to(dt).to(DEV).contiguous()
 
 
+def _unfold_cols(x_rows, B, H, W, cp):
+    """The 3 x 3 column matrix [B * H * W, 9 * cp] (K index (ky * 3 + kx) * cp + c, zero padding 1) of NHWC rows, built by torch's own
+    ``F.unfold`` on the CPU in float64 -- NOT by the library's im2col kernel: the reference the weight-gradient kernels are read against."""
+    x = x_rows.detach().cpu().double().reshape(B, H, W, cp).permute(0, 3, 1, 2)                     # NCHW
+    cols = torch.nn.functional.unfold(x, (3, 3), padding=1)                                         # [B, cp * 9, H * W], index c * 9 + tap
+    return cols.reshape(B, cp, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 9 * cp)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,C,H,residual,relu", [(3, 24, 6, False, True), (2, 64, 8, True, True), (5, 300, 4, True, False), (2, 40, 40, False, True)])
 def test_batchnorm_train_forward_and_backward(dtype, B, C, H, residual, relu):
@@ -144,8 +152,9 @@ def test_weight_gradient_product_gathers_the_neighbourhoods_itself(dtype, B, cp,
     got = torch.full((opad, 9 * cp), -3.0, dtype=torch.float32, device=DEV)
     L.check(lib.ezclip_op_gemm_tn_conv3x3(L.ptr(dzd), opad, L.ptr(xd), B, H, W, cp, L.ptr(got), 9 * cp, opad, 0, edt, L.stream_ptr()))
     torch.cuda.synchronize()
-    ref = dzd.double().t() @ cold.double()
+    ref = (dzd.cpu().double().t() @ _unfold_cols(xd, B, H, W, cp)).to(DEV)          # the column matrix of torch's own unfold (float64, CPU)
     assert float((want.double() - ref).abs().max()) < (1e-3 if dtype == "fp32" else 1e-2) * max(1.0, float(ref.abs().max()))
+    assert float((got.double() - ref).abs().max()) < (1e-3 if dtype == "fp32" else 1e-2) * max(1.0, float(ref.abs().max()))
     if rows <= 256:                  # one workgroup per tile: a fixed summation order
         assert torch.equal(got, want)
     else:                            # the contraction is split: float atomics in an order that differs between any two launches
@@ -172,9 +181,13 @@ def test_weight_gradient_at_64_channel_blocks_reads_its_operands_once(B, H, W, c
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
     xd = torch.randn(rows, cp, generator=g).to(tdt).to(DEV)
     dzd = torch.randn(rows, opad, generator=g).to(tdt).to(DEV)
-    cold = torch.empty(rows, K, dtype=tdt, device=DEV)
+    cols = _unfold_cols(xd, B, H, W, cp)                                        # torch's unfold, float64, CPU
+    ref = (dzd.cpu().double().t() @ cols).to(DEV)
+    cold = torch.empty(rows, K, dtype=tdt, device=DEV)                          # ... and the library's im2col kernel IS that matrix
     L.check(lib.ezclip_op_rn_im2col3x3(L.ptr(xd), B, H, W, cp, L.ptr(cold), edt, L.stream_ptr()))
-    ref = (dzd.double().t() @ cold.double())
+    torch.cuda.synchronize()
+    assert torch.equal(cold.cpu().double(), cols)
+    del cols
     sub = (cp // 64) * (opad // 64)
     scratch = torch.empty(parts * sub * 64 * 576, dtype=torch.float32, device=DEV)
     ldo = K + 64

@@ -86,13 +86,17 @@ WORKLOADS = {
     "bf16_vitl14_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="vitl14"),
     "bf16_hf_vitl14_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="hf_vitl14"),
     "bf16_hf_vitl14_large_b512_train": dict(dtype="bf16", batch=512, seq=64, backward=True, model="hf_vitl14_large"),
+    # ModifiedResNet-50 image tower (CHINESE_CLIP with vision_layers = (3, 4, 6, 3): modeling_chineseclip.py:279-287) + BERT-base, 256 pairs,
+    # through forward() / compute_loss() / backward() -- the path such a model takes (train: BatchNorm batch statistics + full backward)
+    "bf16_rn50_b256_fwd": dict(dtype="bf16", batch=256, seq=64, backward=False, model="rn50", path="autograd"),
+    "bf16_rn50_b256_train": dict(dtype="bf16", batch=256, seq=64, backward=True, model="rn50", path="autograd"),
 }
 # what the default run adds to the headline line (BASELINE.json configs 3, 2, 5 + the boundary overhead)
 ALSO_N1 = ["bf16_b1024_fwd_loss_padded_text", "bf16_b1024_train", "bf16_b1024_train_padded_text", "bf16_b1024_train_opt",
            "bf16_b1024_fwd_loss_autograd",
            "bf16_b1024_train_autograd",
            "fp32_b256_fwd_sim", "bf16_vitl14_b512_fwd_loss", "bf16_vitl14_b512_train", "bf16_hf_vitl14_b512_train",
-           "bf16_hf_vitl14_large_b512_train"]
+           "bf16_hf_vitl14_large_b512_train", "bf16_rn50_b256_fwd", "bf16_rn50_b256_train"]
 ALSO_MULTI = ["bf16_b1024_train"]          # config 4 "(+bwd)": gradient all-reduce overlapped with the backward pass
 
 # algorithmic GFLOP per pair (multiply-add = 2; padded tiles and softmax/LN excluded)
@@ -110,6 +114,35 @@ GFLOP_TRAIN_PER_PAIR_VITL14 = 519.2
 GFLOP_TRAIN_PER_PAIR_HF_VITL14 = 162.03 + 3 * 11.025      # frozen vision tower: forward only; text tower fwd + bwd
 GFLOP_TRAIN_PER_PAIR_HF_VITL14_LARGE = 162.03 + 3 * 39.06   # text: 24 layers x 64 tokens x (8 H^2 + 4 H F + 4 L H), H 1024, F 4096
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+RN50_CLIP = dict(VITB16_BERTBASE, vision_layers=[3, 4, 6, 3], vision_width=64, embed_dim=1024)
+
+
+def rn_gflop_per_image(layers, width, res, out_dim):
+    """algorithmic forward GFLOP of one image through ModifiedResNet (multiply-add = 2): every convolution 2 * pixels * Cout * k * k * Cin,
+    the attention pool's projections and its one-query attention (modeling_chineseclip.py:27-167); BatchNorm / ReLU / pools excluded"""
+    f = 0.0
+    h = res // 2
+    for cin, cout in ((3, width // 2), (width // 2, width // 2), (width // 2, width)):
+        f += 2.0 * h * h * cout * 9 * cin
+    h //= 2
+    inpl = width
+    for li, n in enumerate(layers):
+        planes = width << li
+        for bi in range(n):
+            stride = 2 if (li > 0 and bi == 0) else 1
+            f += 2.0 * h * h * planes * inpl                      # conv1 1x1
+            f += 2.0 * h * h * planes * 9 * planes                # conv2 3x3
+            ho = h // stride
+            f += 2.0 * ho * ho * planes * 4 * planes              # conv3 1x1
+            if stride > 1 or inpl != planes * 4:
+                f += 2.0 * ho * ho * planes * 4 * inpl            # downsample 1x1 (after the anti-aliasing pool)
+            inpl, h = planes * 4, ho
+    e, lt = width * 32, h * h + 1
+    f += 2.0 * (2 * lt + 1) * e * e + 4.0 * lt * e + 2.0 * e * out_dim
+    return f / 1e9
+
+
+GFLOP_FWD_PER_PAIR_RN50 = rn_gflop_per_image([3, 4, 6, 3], 64, 224, 1024) + 11.025       # + BERT-base text tower at 64 tokens
 
 # The 101 launches of the dominant kernel (ProfScope PROF_GEMM) in one forward step at 1024 pairs -- the set the roofline's time
 # average runs over (round 4 listed 97 of them).  Blocks 0..10 of each tower run the four big products of tools/gemm_bench; the LAST
@@ -249,6 +282,65 @@ def cpu_baseline(seconds_target=10.0):
             "train_value": round(8 * nt / elt, 3), **({"port_vs_reference": PORT_VS_REFERENCE} if kind == "port" else {}),
             "sample": "%d x (8 pairs, 224x224 + 64 tokens) fp32 fwd+similarity+InfoNCE and %d x fwd+loss+backward, torch CPU %s, %s"
                       % (n, nt, torch.__version__, _cpu_model())}
+
+
+TINY_RECALL = dict(model_type="chinese_clip", embed_dim=64, image_resolution=64, vision_layers=2, vision_width=128, vision_patch_size=16,
+                   vocab_size=211, text_attention_probs_dropout_prob=0.0, text_hidden_act="gelu", text_hidden_dropout_prob=0.0, text_hidden_size=128,
+                   text_initializer_range=0.02, text_intermediate_size=512, text_max_position_embeddings=64, text_num_attention_heads=2,
+                   text_num_hidden_layers=2, text_type_vocab_size=2)
+
+
+def recall_leg(device, pairs=96, steps=60):
+    """BASELINE.json's metric ends "; R@1 vs ref" (appzoo/clip/evaluator.py:47-67).  A small dual encoder is trained by the bf16
+    HIP path on `pairs` FIXED synthetic pairs until they are separable (the "overfit" fixture of tests/test_model_gpu.py, larger), then its
+    text -> image recall is computed by the library's fused similarity + rank kernel.  So that R@1 is not a trivial 1.0, the last eight
+    captions are exact DUPLICATES of the first eight: of two queries with one caption and two images exactly one can rank its own image
+    first (the reference's stable descending sort breaks an exact tie by index), so a correct pipeline reads R@1 = 88 / 96 = 0.916667 whichever
+    of the two images scores higher -- a figure that does not hinge on near-ties (the fp32 oracle's smallest margin between a paired score
+    and the best other one is 0.5 in cosine after 40 steps).  Returns (fields, trained weights, inputs): the cpu_baseline leg evaluates the
+    SAME weights with the CPU oracle (`recall_at_1_oracle`); the two must agree to 1e-3."""
+    from easynlp_amd.appzoo.clip import CLIPApp
+    from easynlp_amd.appzoo.clip.evaluator import recall_at_k
+    cfg = TINY_RECALL
+    app = CLIPApp.from_config(cfg, seed=8, device=device, compute_dtype="bf16")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    px = torch.randn(pairs, 3, 64, 64, generator=g)
+    ids = torch.randint(1, cfg["vocab_size"], (pairs, 12), generator=g)
+    ids[:, 8:] *= (torch.rand(pairs, 4, generator=g) < 0.6)
+    ids[pairs - 8:] = ids[:8]
+    pxd, idd = px.to(device), ids.to(device)
+    opt = torch.optim.AdamW(app.parameters(), lr=2e-3, weight_decay=0.0)
+    app.train()
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        loss = app.compute_loss(app({"pixel_values": pxd, "input_ids": idd}), [])["loss"]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(app.parameters(), 1.0)
+        opt.step()
+        losses.append(float(loss.item()))
+    app.eval()
+    with torch.no_grad():
+        out = app({"pixel_values": pxd, "input_ids": idd}, feat=True)
+    (mean_recall, r1, r5, r10), _ = recall_at_k(out["text_embeds"], out["image_embeds"])
+    weights = {n: p.detach().float().cpu() for n, p in app._params.items()}
+    fields = {"recall_at_1": round(r1, 6), "recall_detail": {"r5": round(r5, 6), "r10": round(r10, 6), "mean_recall": round(mean_recall, 6), "pairs": pairs,
+              "expected": round((pairs - 8) / pairs, 6),
+              "what": "text->image R@k of a 2+2-layer dual encoder after %d AdamW steps of the bf16 HIP path on %d fixed synthetic pairs, 8 captions "
+                      "duplicated (loss %.3f -> %.3f); ranks by ezclip_recall_ranks_fused" % (steps, pairs, losses[0], losses[-1])}}
+    del app, opt
+    return fields, weights, (px, ids)
+
+
+def recall_oracle(weights, inputs):
+    """the reference evaluator's arithmetic (oracle.clip_oracle.recall_at_k: full sort per query, evaluator.py:47-67) on the fp32 CPU oracle's
+    embeddings of the SAME trained weights -- part of the cpu_baseline leg (the only place bench.py may use oracle/)"""
+    from oracle import clip_oracle as O
+    px, ids = inputs
+    with torch.no_grad():
+        ref = O.clip_forward(weights, TINY_RECALL, px, ids)
+    r = O.recall_at_k(ref["text_embeds"], ref["image_embeds"])
+    return float(r[1]) if len(r) > 3 else float(r[0])
 
 
 def relaunch(args):
@@ -451,6 +543,9 @@ def build_app(wl, device, text_dropout=0.0):
         app = CLIPApp.from_hf_config(hf_cfg, seed=1234, device=device, compute_dtype=wl["dtype"])
         name = "huggingface_clip: frozen ViT-L/14 + chinese-roberta-wwm-ext%s + pooler, random init" % (
             "-large (hidden 1024, 24 layers, 16 heads)" if wl["model"] == "hf_vitl14_large" else " (BERT-base arch)")
+    elif wl.get("model") == "rn50":
+        app = CLIPApp.from_config(RN50_CLIP, seed=1234, device=device, compute_dtype=wl["dtype"])
+        name = "ModifiedResNet-50 (3, 4, 6, 3) width 64 + BERT-base (chinese_clip), random init"
     else:
         app = CLIPApp.from_config(model_cfg, seed=1234, device=device, compute_dtype=wl["dtype"])
     app.eval()
@@ -466,6 +561,8 @@ def gflop_per_pair(wl):
         return GFLOP_TRAIN_PER_PAIR_HF_VITL14_LARGE, None
     if wl.get("model") == "vitl14":
         return (GFLOP_TRAIN_PER_PAIR_VITL14 if wl["backward"] else GFLOP_FWD_PER_PAIR_VITL14), None
+    if wl.get("model") == "rn50":       # (the stem's first convolution has no input gradient: 3x is an upper bound by 0.2 %)
+        return (3.0 * GFLOP_FWD_PER_PAIR_RN50 if wl["backward"] else GFLOP_FWD_PER_PAIR_RN50), None
     cls_last = os.environ.get("EZCLIP_CLS_LAST", "1") != "0"
     cls_train = os.environ.get("EZCLIP_CLS_TRAIN", "1") != "0"
     if wl["backward"]:
@@ -565,14 +662,20 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
     tel_w = Telemetry(period=0.25) if rank == 0 else None
     if tel_w is not None:
         tel_w.__enter__()
+    # HIP events on the launch stream around the same K steps: a step ends with the main stream having joined the text
+    # tower's side stream, so the closing event is behind all of the step's work.  Reported beside the host clock, never instead of it.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(steps):
         h0 = time.perf_counter()
         loss = step()
         host_s += time.perf_counter() - h0                     # host time inside step(): the packed-text metadata poll makes the host
         rows_seen.append(app._engine.last_text_rows)          # wait for the device, so this tracks ms_per_step for packed workloads
+    ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
+    event_ms = ev0.elapsed_time(ev1) / steps
     tel_timed = None
     if tel_w is not None:
         tel_w.__exit__(None, None, None)
@@ -638,19 +741,25 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
     if sustained_steps > 0 and world == 1:
         chunk, done, marks = 25, 0, []
         fence()
+        evs = [torch.cuda.Event(enable_timing=True)]
         with Telemetry() as tel:
             t0s = time.perf_counter()
+            evs[0].record()
             while done < sustained_steps and time.perf_counter() - t0s < sustained_seconds:
                 for _ in range(chunk):
                     step()
+                evs.append(torch.cuda.Event(enable_timing=True))
+                evs[-1].record()
                 torch.cuda.synchronize()
                 done += chunk
                 marks.append((done, time.perf_counter() - t0s))
         total_s = marks[-1][1]
+        ev_total_ms = evs[0].elapsed_time(evs[-1])
         half = [m for m in marks if m[0] * 2 >= done]                # the second half: past the settling seconds
         first_of_half = marks[len(marks) - len(half) - 1] if len(half) < len(marks) else (0, 0.0)
         ms_steady = (half[-1][1] - first_of_half[1]) / max(1, half[-1][0] - first_of_half[0]) * 1e3
         sustained = {"steps": done, "seconds": round(total_s, 2), "ms_per_step": round(total_s / done * 1e3, 3),
+                     "ms_per_step_hip_events": round(ev_total_ms / done, 3),
                      "ms_per_step_second_half": round(ms_steady, 3), "value_second_half": round(B / ms_steady * 1e3, 1),
                      "telemetry": tel.summary()}
         clk = sustained["telemetry"].get("shader_clock_mhz_mean")
@@ -667,7 +776,7 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
     if rank != 0:
         return None
     gflop, gflop_all = gflop_per_pair(wl)
-    if text_rows and text_rows[0] != text_rows[1] and wl.get("model") is None:
+    if text_rows and text_rows[0] != text_rows[1] and wl.get("model") in (None, "rn50"):
         # packed text tower: its GEMM / LayerNorm work scales with the rows that went through it (11.025 G per pair forward at 64
         # tokens, of which 0.756 G are the skipped CLS-only part of the last layer; three times that with the backward pass)
         gflop -= (3 if wl["backward"] else 1) * (11.025 - 0.756) * (1.0 - text_rows[0] / text_rows[1])
@@ -679,6 +788,7 @@ def run_workload(name, c, steps, warmup, batch_override=0, text_dropout=0.0, pro
                   + ("+backward" if wl["backward"] else "") + ("+grad_allreduce(overlapped)" if wl["backward"] and world > 1 and not autograd else "")
                   + ("+AdamW+repack" if wl.get("optimizer") else ""),
         "two_streams": two_streams, "loss": round(loss_val, 5), "host_ms_per_step": round(host_s / steps * 1e3, 3),
+        "ms_per_step_hip_events": round(event_ms, 3),
         "clock_mhz_timed_steps": (tel_timed or {}).get("shader_clock_mhz_mean"), "power_w_timed_steps": (tel_timed or {}).get("socket_power_w_mean"),
         "batches_rotated": NBATCH, "pack_meta_in_timed_region": True,
         "ms_per_step_ranks": {"max": round(step_ms, 3), "min": round(fastest / steps * 1e3, 3), "this_rank": round(per_rank_ms, 3)},
@@ -709,6 +819,7 @@ def main():
     ap.add_argument("--workload", default="bf16_b1024_fwd_loss", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-recall", action="store_true", help="skip the recall_at_1 leg (a few seconds: a tiny dual encoder trained on fixed pairs)")
     ap.add_argument("--no-also", action="store_true", help="only the headline workload (no `also` object)")
     ap.add_argument("--also", default="", help="comma-separated workloads for the `also` object (default: every BASELINE config)")
     ap.add_argument("--also-steps", type=int, default=8)
@@ -802,7 +913,7 @@ def main():
                 if world > 1:
                     raise
             if rank == 0:
-                keep = ("value", "ms_per_step", "host_ms_per_step", "clock_mhz_timed_steps", "power_w_timed_steps", "dtype", "path", "stages", "pairs_per_gpu", "loss", "text_tower_rows", "model_tflops_per_gpu",
+                keep = ("value", "ms_per_step", "ms_per_step_hip_events", "host_ms_per_step", "towers", "clock_mhz_timed_steps", "power_w_timed_steps", "dtype", "path", "stages", "pairs_per_gpu", "loss", "text_tower_rows", "model_tflops_per_gpu",
                         "model_mfma_frac", "time_share", "grad_allreduce_buckets_mib", "sustained", "error")
                 also[n] = {k: r[k] for k in keep if k in r}
                 if r.get("roofline"):
@@ -825,7 +936,7 @@ def main():
                        "two_streams": head["two_streams"], "text_dropout": args.text_dropout},
             "rccl_ranks": world if use_dist else 0, "collective_backend": backend if use_dist else None,
         }
-        for k in ("loss", "host_ms_per_step", "clock_mhz_timed_steps", "power_w_timed_steps", "batches_rotated", "pack_meta_in_timed_region", "ms_per_step_ranks", "text_tower_rows", "gflop_per_pair",
+        for k in ("loss", "host_ms_per_step", "ms_per_step_hip_events", "clock_mhz_timed_steps", "power_w_timed_steps", "batches_rotated", "pack_meta_in_timed_region", "ms_per_step_ranks", "text_tower_rows", "gflop_per_pair",
                   "model_tflops_per_gpu", "model_mfma_frac", "roofline", "time_share", "attention_tflops", "layernorm_gbps",
                   "grad_allreduce_buckets_mib", "sustained"):
             if k in head:
@@ -839,8 +950,21 @@ def main():
             out["value_padded_text"] = pt["value"]
             out["ms_per_step_padded_text"] = pt["ms_per_step"]
             out["model_mfma_frac_padded_text"] = pt.get("model_mfma_frac")
-            out["value_note"] = ("value: text tower over the unmasked tokens only (packed rows, same embeddings); value_padded_text: every padded "
-                                 "position goes through the text tower, the reference's shape of the work; model_mfma_frac* count EXECUTED flops")
+            out["value_note"] = ("value: text tower over the unmasked tokens only (packed rows, same embeddings) and the last block of each tower on its "
+                                 "CLS row only -- work the result does not depend on is skipped; value_padded_text: THE REFERENCE-SHAPED FIGURE, every "
+                                 "padded position goes through the text tower as in the reference; model_mfma_frac* count EXECUTED flops")
+            out["reference_shaped"] = {"value": pt["value"], "ms_per_step": pt["ms_per_step"], "model_mfma_frac": pt.get("model_mfma_frac"),
+                                       "workload": "bf16_b1024_fwd_loss_padded_text"}
+        if world == 1 and not args.no_recall:
+            try:
+                rf, rw, rin = recall_leg(device)
+                out.update(rf)
+                out["recall_at_1_oracle"] = None
+                if not args.no_cpu_baseline:
+                    out["recall_at_1_oracle"] = round(recall_oracle(rw, rin), 6)
+                    out["recall_at_1_abs_diff"] = round(abs(out["recall_at_1"] - out["recall_at_1_oracle"]), 6)
+            except Exception as e:          # noqa: BLE001 -- the recall figure must not take the throughput line with it
+                out["recall_at_1"], out["recall_error"] = None, "%s: %s" % (type(e).__name__, str(e)[:300])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -36,6 +36,27 @@ __device__ __forceinline__ uint2 tr4(const char* p) {
 
 __device__ __forceinline__ int swz_f(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
+// -DEZ_ATTN_BWD_TRACE (tools/build_variants.py; never in the shipped library): every wave of attn_bwd_short_kernel writes the shader-clock
+// time of its phase boundaries -- entry, images landed, D / lse published, end of pass A, end of pass B, exit -- plus its HW_ID and the
+// 100 MHz real-time counter at entry and exit into a device array; tools/attn_bwd_trace.py reads it back (ezclip_dbg_attn_trace).
+#ifdef EZ_ATTN_BWD_TRACE
+constexpr int kTraceWords = 10, kTraceWgs = 16384, kTraceWaves = 9;
+__device__ unsigned long long g_attn_trace[(size_t)kTraceWgs * kTraceWaves * kTraceWords];
+#define EZ_TRACE(slot)                                                                                             \
+  do {                                                                                                             \
+    const int wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                           \
+    if (lane == 0 && wg_ < kTraceWgs) g_attn_trace[((size_t)wg_ * kTraceWaves + wave) * kTraceWords + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define EZ_TRACE_AUX(slot, value)                                                                                  \
+  do {                                                                                                             \
+    const int wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                           \
+    if (lane == 0 && wg_ < kTraceWgs) g_attn_trace[((size_t)wg_ * kTraceWaves + wave) * kTraceWords + (slot)] = (value); \
+  } while (0)
+#else
+#define EZ_TRACE(slot) do { } while (0)
+#define EZ_TRACE_AUX(slot, value) do { } while (0)
+#endif
+
 __device__ __forceinline__ void dma_rows_f(char* dst, const char* gbase, int64_t rs, int nrows, int L, int wave, int nwaves, int lane) {
   const int ninst = nrows / 8;
   for (int inst = wave; inst < ninst; inst += nwaves) {
@@ -87,6 +108,10 @@ __global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBw
   const int h = lane >> 5, l31 = lane & 31;
   const int nwaves = nt;      // 64 * nt threads (nt of the launch: the longest sample's tiles): no idle waves holding registers
   const int keep_words = nt;  // (words per (row, head) of AttnArgs::keep_bits)
+  EZ_TRACE(0);
+  EZ_TRACE_AUX(6, (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4) |       // HW_ID (hwreg 4), XCC_ID (hwreg 20) above it
+                      ((unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20) << 32));
+  EZ_TRACE_AUX(7, __builtin_amdgcn_s_memrealtime());
   // packed batches (AttnArgs::cu / lens): rows cu[b] .. cu[b] + lens[b] - 1; nt (launch, LDS layout) is the longest sample's
   const int L = f.lens ? f.lens[b] : f.L, LKP = 32 * nt;
   const int64_t row0 = f.cu ? (int64_t)f.cu[b] : (int64_t)b * f.L;
@@ -134,7 +159,9 @@ __global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBw
     if (row < L) lse_q = f.lse[((int64_t)b * f.H + head) * f.L + row];
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  EZ_TRACE(9);                                   // (this wave's own loads have landed; the barrier waits for the others')
   __syncthreads();
+  EZ_TRACE(1);
 
   const int fl = swz_f(l31);                     // (32t + l31 has the same f as l31)
   uint32_t roff[4];                              // row fragments: row l31 of a 32-row tile, chunk (2s+h) ^ f
@@ -194,6 +221,7 @@ __global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBw
     if (h == 0) { lseA[row] = -lse_q * kLog2e; dA[row] = row < L ? -d_q : 0.f; }     // dA holds -D: pass B starts dP from it
   }
   __syncthreads();
+  EZ_TRACE(2);
   const float scale = f.scale;
   const float c = scale * kLog2e;
   const float nlse_q = -lse_q * kLog2e;
@@ -298,6 +326,7 @@ __global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBw
       __builtin_amdgcn_wave_barrier();
     }
   }
+  EZ_TRACE(3);
   // ------------------------------------------------ pass B: dK, dV for keys 32*blk + l31 -----------------------
   if (active) {
 #pragma unroll
@@ -414,6 +443,7 @@ __global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBw
       bias_vec(imgK + blk * 4096, red_w + 384, scale, red_w);
     }
   }
+  EZ_TRACE(4);
   if (want_db) {      // combine the waves in a fixed order; per-sample partials (12k workgroups hammering 2304 addresses
     // with atomics cost more than the pass over dqkv this replaces), summed over the batch afterwards.  The barrier orders
     // LDS only: __syncthreads() would also wait out the dk / dv stores (vmcnt(0)).
@@ -425,6 +455,8 @@ __global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBw
       a.db_part[((int64_t)b * 3 + (i >> 6)) * (f.H * 64) + head * 64 + (i & 63)] = s;
     }
   }
+  EZ_TRACE(5);
+  EZ_TRACE_AUX(8, __builtin_amdgcn_s_memrealtime());
 }
 
 
@@ -886,3 +918,10 @@ int attention_bwd_short(const AttnBwdArgs& a, hipStream_t stream) {
 }
 
 }  // namespace ezclip
+
+#ifdef EZ_ATTN_BWD_TRACE
+extern "C" int ezclip_dbg_attn_trace(void* host, size_t bytes) {
+  const size_t all = sizeof(ezclip::g_attn_trace);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ezclip::g_attn_trace), bytes < all ? bytes : all, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -27,8 +27,8 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def make_app(tmp_path, cfg, seed, dtype):
-    sd = O.make_state_dict(cfg, seed)
+def make_app(tmp_path, cfg, seed, dtype, residual_gain=1.0):
+    sd = O.make_state_dict(cfg, seed, residual_gain)
     R.write_checkpoint_dir(str(tmp_path), cfg, sd)
     app = CLIPApp(str(tmp_path), user_defined_parameters={"clip_compute_dtype": dtype}).cuda()
     return app, sd
@@ -141,12 +141,15 @@ def _activation_rounding_floor(sd, cfg, px, ids):
         O.layer_norm, O.linear = ln, lin
 
 
-@pytest.mark.parametrize("name", ["vitb16_bertbase_b4_l64", "large_text_b24_l40"])
+@pytest.mark.parametrize("name", ["vitb16_bertbase_b4_l64", "large_text_b24_l40", "vitb16_bertbase_rg03_b4_l64"])
 def test_bf16_gradient_error_table(tmp_path, name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     cfg_name, B, Lq, wseed, iseed = [str(x) for x in z["meta"][:5]]
     cfg, B, Lq, wseed, iseed = O.CONFIGS[cfg_name], int(B), int(Lq), int(wseed), int(iseed)
-    app, sd = make_app(tmp_path, cfg, wseed, "bf16")
+    # round 6: `_rg03`: every residual branch's output layer at 0.3 of its random-init scale (clip_oracle.make_state_dict): the 12 + 12-layer
+    # model is no longer rank-collapsed and the bf16 gradients of the deep query / key weights are a SIGNAL -- no per-kind rescaling below
+    rgain = float(z["residual_gain"]) if "residual_gain" in z.files else 1.0
+    app, sd = make_app(tmp_path, cfg, wseed, "bf16", rgain)
     app.train()
     px, ids = O.make_inputs(cfg, B, Lq, iseed)
     # the fp32 oracle's full gradients (the fixture keeps norms + 16 samples per parameter of the REFERENCE's: pin the oracle to
@@ -203,7 +206,7 @@ def test_bf16_gradient_error_table(tmp_path, name):
     above = [i for i in order if err[i] > 2e-2]
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, "r5_bf16_grad_error_%s.md" % name), "w") as f:
+    with open(os.path.join(out_dir, "r6_bf16_grad_error_%s.md" % name), "w") as f:
         f.write("# bf16 pipeline: per-parameter gradient error vs the fp32 oracle (= the reference at 1e-4), fixture `%s`\n\n" % name)
         f.write("Written by tests/test_amp_and_grad_error_gpu.py::test_bf16_gradient_error_table on the GPU box.  rel-L2 = |g_hip - g_ref| / |g_ref| per "
                 "parameter (fused step / autograd path).  `floor` = the same measure for the fp32 ORACLE with every LayerNorm / Linear output rounded "
@@ -223,6 +226,16 @@ def test_bf16_gradient_error_table(tmp_path, name):
             f.write("| %s | %s | %.3e | %.3e | %.3e | %.3e | %.3e | %.3e |\n" % (n, "x".join(str(d) for d in ref_g[n].shape), gnorm[i], rows[n]["fused"],
                                                                                 rows[n]["autograd"], flo[i], rel_scale[i], dev[i]))
     assert max(rows["__loss__"].values()) <= 5e-3, rows["__loss__"]
+    if rgain != 1.0:
+        # The non-degenerate full-depth fixture: every parameter's OWN relative error, no rescaling by kind.  Its activation-rounding floor is
+        # 2.6e-2 in the median and 4e-2 at worst (one common error: the rounding of the last LayerNorm outputs times logit_scale = 14.3 in a
+        # softmax over four pairs), so SURVEY's 2e-2 is below what ANY bf16-activation pipeline can do here; asserted: no parameter above
+        # max(3e-2, 2 x its own floor) -- in particular none above 10 x floor, the deep query / key weights included -- and the median
+        # within max(2.2e-2, 1.75 x the floor's).
+        worst = [(names[i], float(err[i]), float(flo[i])) for i in range(len(names)) if err[i] > max(3e-2, 2.0 * flo[i])]
+        assert not worst, worst[:8]
+        assert med <= max(2.2e-2, 1.75 * fmed), (med, fmed)
+        return
     # SURVEY 8c's bar for the bf16 pipeline is 2e-2 rel-L2.  What these two fixtures allow: on the wide-text fixture (2 + 2 layers) the
     # floor's median is 1.3e-2 and the measured median 2.0e-2 -- every parameter between 1.9e-2 and 2.6e-2, one common error, no outliers;
     # on the 12 + 12-layer ViT-B/16 + BERT-base fixture the floor ITSELF has a median of 3.2e-2 (rank-collapsed random-init towers: the

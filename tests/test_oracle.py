@@ -19,10 +19,11 @@ def load(name):
     return z, O.CONFIGS[cfg_name], int(B), int(L), int(wseed), int(iseed)
 
 
-@pytest.mark.parametrize("name", ["tiny_b6_l24", "small_b5_l40", "p14_w256_b16_l32", "vitb16_bertbase_b4_l64", "large_text_b24_l40"])
+@pytest.mark.parametrize("name", ["tiny_b6_l24", "small_b5_l40", "p14_w256_b16_l32", "vitb16_bertbase_b4_l64", "large_text_b24_l40",
+                                  "vitb16_bertbase_rg03_b4_l64"])
 def test_oracle_forward_matches_reference_golden(name):
     z, cfg, B, L, wseed, iseed = load(name)
-    sd = O.make_state_dict(cfg, wseed)
+    sd = O.make_state_dict(cfg, wseed, float(z["residual_gain"]) if "residual_gain" in z.files else 1.0)
     px, ids = O.make_inputs(cfg, B, L, iseed)
     with torch.no_grad():
         out = O.clip_forward(sd, cfg, px, ids)

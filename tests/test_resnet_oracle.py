@@ -178,7 +178,8 @@ def test_w64_fixture_is_the_float64_reference_and_the_oracle_reproduces_it():
     z = np.load(os.path.join(HERE, "golden", "rn_w64_train_b32.npz"))
     c = json.loads(bytes(z["meta"]).decode())
     layers, width, e, res, B = tuple(c["layers"]), c["width"], c["output_dim"], c["resolution"], c["batch"]
-    sd = {k: v.double() for k, v in RO.make_state_dict(layers, width, e, res, c["wseed"]).items()}
+    sd = {k: (v * c["bn3_gain"] if (k.endswith("bn3.weight") and ".layer" in k) else v).double()
+          for k, v in RO.make_state_dict(layers, width, e, res, c["wseed"]).items()}
     rs = np.random.RandomState(c["iseed"])
     px = torch.from_numpy(rs.standard_normal((B, 3, res, res)).astype(np.float32)).double()
     probe = torch.from_numpy(rs.standard_normal((B, e)).astype(np.float32)).double()

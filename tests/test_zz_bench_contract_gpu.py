@@ -41,7 +41,7 @@ def _oracle_loss(batch):
 
 def test_bench_prints_one_contract_line():
     out = _run("--also", "bf16_b1024_train,bf16_b1024_fwd_loss_autograd,bf16_b1024_train_autograd,bf16_b1024_train_opt,"
-               "bf16_b1024_fwd_loss_padded_text", "--also-steps", "1", "--sustained-steps", "50")
+               "bf16_b1024_fwd_loss_padded_text,bf16_rn50_b256_fwd,bf16_rn50_b256_train", "--also-steps", "1", "--sustained-steps", "50")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "also", "loss"):
         assert k in out, k
@@ -61,9 +61,18 @@ def test_bench_prints_one_contract_line():
     assert abs(out["loss"] - ref) < 5e-3, (out["loss"], ref)
     for name, a in out["also"].items():
         assert "error" not in a, (name, a)
-        assert a["value"] > 0 and a["ms_per_step"] > 0
+        assert a["value"] > 0 and a["ms_per_step"] > 0 and a["ms_per_step_hip_events"] > 0
+        if name.startswith("bf16_rn50"):      # another model (ModifiedResNet-50 image tower): its own random-init loss, near ln N
+            assert abs(a["loss"] - math.log(64)) < 0.5 and a["path"] == "autograd" and "ModifiedResNet-50" in a["towers"], (name, a)
+            assert a["model_tflops_per_gpu"] > 0 and "clock_mhz_timed_steps" in a and "power_w_timed_steps" in a
+            continue
         # (the AdamW workload has already moved the weights by the time its timed step reports a loss)
         assert abs(a["loss"] - ref) < (5e-2 if name.endswith("_opt") else 5e-3), (name, a["loss"], ref)
+    # round 6: the line carries what the metric names ("...; R@1 vs ref"), the ModifiedResNet workloads, HIP-event timing beside the host clock
+    assert 0.3 <= out["recall_at_1"] <= 1.0 and "recall_at_1_oracle" in out and out["recall_detail"]["pairs"] == 96
+    assert {"bf16_rn50_b256_fwd", "bf16_rn50_b256_train"} <= set(out["also"])
+    assert out["ms_per_step_hip_events"] > 0 and abs(out["ms_per_step_hip_events"] - out["ms_per_step"]) < 0.25 * out["ms_per_step"] + 2.0
+    assert out["reference_shaped"]["value"] == out["value_padded_text"] and out["sustained"]["ms_per_step_hip_events"] > 0
     assert out["also"]["bf16_b1024_train_autograd"]["path"] == "autograd"
     # the reference-shaped forward (every padded position through the text tower) at top level, beside `value`
     assert out["value_padded_text"] == out["also"]["bf16_b1024_fwd_loss_padded_text"]["value"] and "value_note" in out
@@ -74,6 +83,17 @@ def test_bench_prints_one_contract_line():
         assert 0 < blk["model_mfma_frac_second_half"] < 1
         tel = blk["telemetry"]
         assert tel["source"] and (tel["samples"] == 0 or (100 < tel["shader_clock_mhz_mean"] < 3000 and 50 < tel["socket_power_w_mean"] < 2000))
+
+
+def test_recall_leg_agrees_with_the_oracle_evaluator():
+    """the bench line's `recall_at_1` (fused similarity + rank kernel on the bf16 HIP path's embeddings) against `recall_at_1_oracle` (the
+    reference evaluator's full-sort arithmetic on the fp32 CPU oracle's embeddings of the SAME trained weights): within 1e-3 (north star)"""
+    sys.path.insert(0, ROOT)
+    import bench as B
+    fields, weights, inputs = B.recall_leg(torch.device("cuda", 0))
+    want = B.recall_oracle(weights, inputs)
+    assert abs(fields["recall_at_1"] - want) <= 1e-3, (fields, want)
+    assert abs(want - 88.0 / 96.0) < 1e-6, want          # 8 duplicated captions: exactly one query of each such pair ranks its own image first
 
 
 def test_bench_self_launches_under_torch_distributed_run():

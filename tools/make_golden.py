@@ -36,6 +36,9 @@ CASES = [
     ("p14_w256_b16_l32", "p14_w256", 16, 32, 77, 5, False),
     ("vitb16_bertbase_b4_l64", "vitb16_bertbase", 4, 64, 1234, 0, False),
     ("large_text_b24_l40", "large_text", 24, 40, 31, 11, False),      # round 4: text width 1024 / 16 heads / FFN 4096
+    # round 6: the full-depth model with every residual branch's output layer at 0.3 of its random-init scale (clip_oracle.make_state_dict
+    # residual_gain): NOT rank-collapsed -- the fixture on which bf16 query / key gradients at depth mean something
+    ("vitb16_bertbase_rg03_b4_l64", "vitb16_bertbase", 4, 64, 1234, 0, False, 0.3),
 ]
 
 
@@ -46,10 +49,10 @@ def grad_digest(g: torch.Tensor):
     return float(flat.double().norm()), flat[idx].numpy().astype(np.float32), idx.numpy()
 
 
-def run_case(name, cfg_name, B, L, wseed, iseed, full):
+def run_case(name, cfg_name, B, L, wseed, iseed, full, residual_gain=1.0):
     torch.manual_seed(0)
     cfg = O.CONFIGS[cfg_name]
-    sd = O.make_state_dict(cfg, wseed)
+    sd = O.make_state_dict(cfg, wseed, residual_gain)
     model = R.reference_chinese_clip(cfg, sd)
     px, ids = O.make_inputs(cfg, B, L, iseed)
     img, txt = model(px, ids)                                   # modeling_chineseclip.py:352-365
@@ -64,6 +67,8 @@ def run_case(name, cfg_name, B, L, wseed, iseed, full):
         "image_embeds": img.detach().numpy(), "text_embeds": txt.detach().numpy(),
         "logits_per_text": lpt.detach().numpy(), "loss": np.float32(loss.item()),
     }
+    if residual_gain != 1.0:
+        out["residual_gain"] = np.float64(residual_gain)
     # the same algorithm in bfloat16 (torch CPU): the intrinsic bf16 noise of these gradients.  The reference's
     # own LayerNorm subclass cannot run with bf16 parameters on the CPU ("mixed dtype (CPU)"), so this leg uses
     # the oracle restatement (pinned to the reference at 2e-6 in fp32 by tests/test_oracle.py) in bf16.

@@ -891,6 +891,8 @@ def main():
         L.check(L.load().ezclip_debug_set(9, int(os.environ["EZCLIP_ATTN_FWD_OPTS"])))
     if os.environ.get("EZCLIP_ATTN_BWD_ONCE"):  # A/B switch: 0 = the two-pass fused attention backward only, 2 = score-tile-once wherever eligible
         L.check(L.load().ezclip_debug_set(11, int(os.environ["EZCLIP_ATTN_BWD_ONCE"])))
+    if os.environ.get("EZCLIP_GEMM_DEPHASE"):   # A/B switch: staggered first tiles of the persistent GEMM (steps + 100 * period code; 0 off)
+        L.check(L.load().ezclip_debug_set(12, int(os.environ["EZCLIP_GEMM_DEPHASE"])))
     if os.environ.get("EZCLIP_FUSE_QKV"):       # A/B switch: 0 = BERT q / k / v as three products
         L.check(L.load().ezclip_debug_set(7, int(os.environ["EZCLIP_FUSE_QKV"])))
 

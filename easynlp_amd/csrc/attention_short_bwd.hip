@@ -97,8 +97,19 @@ __device__ __forceinline__ uint4 vec_frag(const float* x, int u, int h, int l31)
 //   dV = (P o M s)^T dO,   dP = (dO V^T) o M s,   dS = P o (dP - D) with the same D = <dO, O>,
 // pass A reads one 32-key word per tile for its query, pass B the words of a tile's 32 queries through a wave-private LDS
 // area (bit = its key), and the rows of P o M s no longer sum to one: sum_k dV[k] = dO^T rowsum(P o M s).
+#ifndef EZ_ATTN_BWD_LB
+#define EZ_ATTN_BWD_LB 576
+#endif
+#ifndef EZ_ATTN_BWD_UNROLL
+#define EZ_ATTN_BWD_UNROLL 1
+#endif
+#ifdef EZ_ATTN_BWD_PRIO
+#define EZ_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define EZ_PRIO(x) do { } while (0)
+#endif
 template <bool HAS_KB, bool CAUSAL, bool DROP>
-__global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBwdArgs a, int nt, int ra) {
+__global__ __launch_bounds__(DROP ? 512 : EZ_ATTN_BWD_LB) void attn_bwd_short_kernel(AttnBwdArgs a, int nt, int ra) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const AttnArgs& f = a.f;
   const int head = blockIdx.x, b = blockIdx.y;
@@ -246,11 +257,13 @@ __global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBw
       for (int r = 0; r < 16; ++r) sacc[r] = pacc[r] = 0.f;
       const char* kt = imgK + t * 4096;
       const char* vt = imgV + t * 4096;
+      EZ_PRIO(1);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         mma32(sacc, *reinterpret_cast<const uint4*>(kt + roff[s]), xf[s], bf16_t());     // S^T[key][q]
         mma32(pacc, *reinterpret_cast<const uint4*>(vt + roff[s]), gf[s], bf16_t());     // dP^T[key][q]
       }
+      EZ_PRIO(0);
       uint32_t kwh = 0;
       if (DROP) {
         kwh = kw_next >> (4 * h);                       // bit 8 qd + e: key 8 qd + 4 h + e of this tile
@@ -287,15 +300,17 @@ __global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBw
         dc.y = pack_bf16x2(ds[8 * u + 2], ds[8 * u + 3]);
         dc.z = pack_bf16x2(ds[8 * u + 4], ds[8 * u + 5]);
         dc.w = pack_bf16x2(ds[8 * u + 6], ds[8 * u + 7]);
+        EZ_PRIO(1);
         mma32(dq[0], tr_frag(kt, u, 0), dc, bf16_t());      // dQ^T[d][q] += K^T . dS^T
         mma32(dq[1], tr_frag(kt, u, 1), dc, bf16_t());
+        EZ_PRIO(0);
       }
     };
     if (HAS_KB || DROP) {
-#pragma unroll 1
+#pragma unroll EZ_ATTN_BWD_UNROLL
       for (int t = 0; t < nt; ++t) tile_a(t, std::true_type());
     } else {
-#pragma unroll 1
+#pragma unroll EZ_ATTN_BWD_UNROLL
       for (int t = 0; t < nt - 1; ++t) tile_a(t, std::false_type());
       tile_a(nt - 1, std::true_type());
     }
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBw
       return f.keep_bits[((row0 + (qq < L ? qq : L - 1)) * f.H + head) * keep_words + blk];
     };
     uint32_t kwq_next = DROP ? keep_word_of(0) : 0u;
-#pragma unroll 1
+#pragma unroll EZ_ATTN_BWD_UNROLL
     for (int t = 0; t < nt; ++t) {
       f32x16_t sacc, pacc;
       if (DROP) {
@@ -375,11 +390,13 @@ __global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBw
       for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
       const char* qt = imgQ + t * 4096;
       const char* gt = imgG + t * 4096;
+      EZ_PRIO(1);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         mma32(sacc, *reinterpret_cast<const uint4*>(qt + roff[s]), xf[s], bf16_t());     // S[q][key]
         mma32(pacc, *reinterpret_cast<const uint4*>(gt + roff[s]), gf[s], bf16_t());     // dP[q][key] - D[q]
       }
+      EZ_PRIO(0);
       float p[16], ds[16];
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
@@ -415,10 +432,12 @@ __global__ __launch_bounds__(DROP ? 512 : 576) void attn_bwd_short_kernel(AttnBw
         pc.y = pack_bf16x2(p[8 * u + 2], p[8 * u + 3]);   dc.y = pack_bf16x2(ds[8 * u + 2], ds[8 * u + 3]);
         pc.z = pack_bf16x2(p[8 * u + 4], p[8 * u + 5]);   dc.z = pack_bf16x2(ds[8 * u + 4], ds[8 * u + 5]);
         pc.w = pack_bf16x2(p[8 * u + 6], p[8 * u + 7]);   dc.w = pack_bf16x2(ds[8 * u + 6], ds[8 * u + 7]);
+        EZ_PRIO(1);
         mma32(dv[0], tr_frag(gt, u, 0), pc, bf16_t());      // dV^T[d][key] += dO^T . P
         mma32(dv[1], tr_frag(gt, u, 1), pc, bf16_t());
         mma32(dk[0], tr_frag(qt, u, 0), dc, bf16_t());      // dK^T[d][key] += Q^T . dS
         mma32(dk[1], tr_frag(qt, u, 1), dc, bf16_t());
+        EZ_PRIO(0);
       }
     }
     if (row < L) {

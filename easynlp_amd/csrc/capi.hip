@@ -543,6 +543,7 @@ int ezclip_debug_set(int key, int value) {
   if (key == 9) { set_attention_short_tail(value); return EZ_OK; }
   if (key == 10) { set_rn_buffer_bound_mib(value); return EZ_OK; }
   if (key == 11) { set_attention_bwd_once(value); return EZ_OK; }
+  if (key == 12) { set_gemm_dephase(value); return EZ_OK; }
   set_error("ezclip_debug_set: unknown key %d", key);
   return EZ_ERR_INVALID;
 }

@@ -416,6 +416,25 @@ void set_gemm8p_ablate(int v) { g_gemm8p_ablate = v; }
 #endif
 int g_gemm8p_raster = EZ_RASTER_GM_DEFAULT;
 void set_gemm_raster(int gm) { g_gemm8p_raster = gm < 0 ? EZ_RASTER_GM_DEFAULT : gm; }
+// De-phasing of the persistent workgroups (round 6; gemm8p_nt.h): workgroup b sleeps ((b >> 3) % period) * steps * 1024 shader clocks before
+// its first tile, so that the 32 CUs of an XCD enter their epilogues -- the C stream, with the matrix pipe idle -- at different times.
+// value = steps + 100 * period_code (period 32 / 2 / 4 / 8 / 16 for code 0..4); 0 = off; -1 = the built-in default (per shape, below).
+#ifndef EZ_DEPHASE_DEFAULT
+#define EZ_DEPHASE_DEFAULT 0
+#endif
+int g_gemm8p_dephase = -1;
+void set_gemm_dephase(int v) { g_gemm8p_dephase = v; }
+static int dephase_for(const GemmArgs& p, int tiles, int grid) {
+  if (tiles <= grid) return 0;                                  // a single round of tiles: nothing to stagger
+  if (g_gemm8p_dephase >= 0) return g_gemm8p_dephase;
+  // Measured (round 6, profiles/r6_gemm_dephase.md; gemm_bench, two repetitions, same box): stand-alone, the N = K = 768 products with many
+  // rounds of tiles gain 4 % from one step per CU of an XCD (vit.out+res 0.265 -> 0.253 ms, patch 0.228 -> 0.219 ms: their epilogue is the
+  // largest share of a tile), vit.qkv / vit.proj+res do not move, the three-round BERT products lose 2-3 %.  INSIDE the forward step the
+  // gain is gone: staggering every product costs 1.2 % (39.09 -> 39.55 ms), staggering only the N = K = 768 ones reads 39.30 vs 39.41 ms
+  // over three interleaved repetitions (the kernels of the two towers overlap on two streams and the staggered start is also a
+  // staggered end).  Off by default; ezclip_debug_set(12, v) / EZCLIP_GEMM_DEPHASE switch it on for A/B runs.
+  return EZ_DEPHASE_DEFAULT;
+}
 
 namespace nt8p {
 EZ_8P_INSTANCES_A(EZ_8P_DECLARE)
@@ -458,6 +477,7 @@ int gemm_nt_8p(const GemmArgs& p_in, hipStream_t stream) {
   int grid = tiles;                                         // one workgroup per CU (160 KiB LDS each)
   if (tiles > g_num_cus) grid = g_num_cus >= 8 ? (g_num_cus & ~7) : g_num_cus;   // multiple of 8: tile -> XCD affinity across rounds
   if (g_gemm8p_ablate == 4) grid = tiles;                   // debugging: one tile per workgroup
+  p.raster_gm += 10000 * dephase_for(p, tiles, grid);        // (decoded by the kernel: GemmArgs has no room for another field, see kernels.h)
   int rc;
   {
     ProfScope ps(PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, stream);

@@ -270,10 +270,11 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
   // 32 / tiles_n rows + tiles_n columns (N = 3072: 2.7 + 12); with raster_gm = g the tiles of g consecutive tile rows are
   // walked column by column, so a round covers g rows x 32 / g columns (g = 4: 4 + 8) -- fewer panels through the fabric.
   const int tiles_m = (p.M + 255) >> 8;
+  const int raster_gm = p.raster_gm % 10000;        // (the launcher packs the de-phasing request above it)
   auto tile_origin = [&](int v, int& m0, int& n0) {
     const int t = xcd_remap(v, ntiles);
     int tm, tn;
-    if (p.raster_gm >= 100) {
+    if (raster_gm >= 100) {
       // SUPER-COLUMN order (round 5, the default for N >= 2304: gemm8p.hip): the logical order is [super-column of w tile columns]
       // [tile row][column inside it], and xcd_remap hands every XCD one contiguous eighth of it -- an XCD stays inside ONE super-column
       // for (almost) its whole walk, so the w B panels it needs (w x 256 x K x 2 bytes: 2.4 MB at w = 6, K = 768) stay resident in its
@@ -281,17 +282,17 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
       // round (4.7 MB at N = 3072: they do not fit, and are re-fetched through the fabric every round -- the 1.9-2.4 x traffic of the
       // N >= 2304 products in profiles/r4_gemm_traffic.json).  w = 6: vit.qkv 0.612 -> 0.603 ms, vit.fc 0.888 -> 0.871 ms, forward step
       // +0.7 % (profiles/r5_gemm_supercolumn.log); w = 3 and w = 4 lose (A is then fetched by 3-4 groups of XCDs).
-      const int w = p.raster_gm - 100;
+      const int w = raster_gm - 100;
       const int per = tiles_m * w;
       const int sc = t / per, u = t - sc * per;
       const int wsz = min(w, tiles_n - sc * w);
       tm = u / wsz;
       tn = sc * w + (u - tm * wsz);
-    } else if (p.raster_gm > 0) {
-      const int per = p.raster_gm * tiles_n;
+    } else if (raster_gm > 0) {
+      const int per = raster_gm * tiles_n;
       const int grp = t / per, u = t - grp * per;
-      const int first = grp * p.raster_gm;
-      const int gsz = min(p.raster_gm, tiles_m - first);
+      const int first = grp * raster_gm;
+      const int gsz = min(raster_gm, tiles_m - first);
       tn = u / gsz;
       tm = first + (u - tn * gsz);
     } else {
@@ -329,10 +330,16 @@ __global__ __launch_bounds__(kThreads8, 2) void gemm_nt_8p_kernel(GemmArgs p, in
     dma16<1>(d + 5 * kSlot + 1024, c.voffB[1], c.srdB, 128);
   };
 
-#ifdef EZ_DEPHASE
-  // experiment: spread the workgroups' tile boundaries (and with them the store bursts) over a tile period
-  for (int d = (int)((blockIdx.x >> 3) % 32u) * EZ_DEPHASE; d > 0; --d) __builtin_amdgcn_s_sleep(16);
-#endif
+  // De-phasing (gemm8p.hip set_gemm_dephase): the CUs of an XCD start their first tile ((b >> 3) % period) * steps * 1024 clocks apart
+  // and -- every tile taking the same time -- stay that far apart: their epilogues (the C stream, matrix pipe idle) no longer coincide.
+  {
+    const int dp = p.raster_gm / 10000;
+    if (dp > 0) {
+      const int code = dp / 100, steps = dp - code * 100;
+      const unsigned period = code == 0 ? 32u : (1u << code);
+      for (int d = (int)((blockIdx.x >> 3) % period) * steps; d > 0; --d) __builtin_amdgcn_s_sleep(16);
+    }
+  }
   const EpiCtx ep = make_epi_ctx<HAS_R, HAS_U, HAS_C2, HAS_LN, HAS_PS>(p);
   constexpr int NS = kStoresPerBlock * (1 + (HAS_C2 ? 1 : 0) + (HAS_PS ? 1 : 0));   // stores per 32-row block
   int v = blockIdx.x, m0, n0;

@@ -97,6 +97,7 @@ bool gemm_nt_8p_eligible(const GemmArgs& p, int dtype);
 int gemm_nt_8p(const GemmArgs& p, hipStream_t stream);
 void set_gemm_variant(int v);   // debugging / sweeps: -1 heuristic, 0 = 128x128 tile, 1 = 256x256 tile
 void set_gemm_raster(int gm);   // tile order of the persistent 8-phase kernel (GemmArgs::raster_gm); -1: built-in default
+void set_gemm_dephase(int v);   // staggered first tiles of the persistent 8-phase kernel (gemm8p.hip); 0 off, -1 built-in default
 
 // C[N,K] (+)= A[M,N]^T . B[M,K]   (weight gradients; contraction over rows)
 struct GemmTNArgs {

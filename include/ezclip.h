@@ -424,7 +424,8 @@ int ezclip_recall_ranks_fused(const float* text_rows_dev, const float* image_dev
  * bit 0 short last tile, bit 1 row sums on the matrix pipe (3, default);  key 10: ModifiedResNet tower: bound of one activation
  * buffer in MiB (256; tests lower it to walk a small batch in chunks);  key 11: fused attention backward for sequences up to
  * 256 tokens: 1 (default) the score-tile-once kernel (round 4) up to 128 tokens -- where it measures faster -- and the two-pass
- * kernel of rounds 2-3 beyond, 2 the score-tile-once kernel wherever it is eligible (<= 256 tokens), 0 the two-pass kernel only. */
+ * kernel of rounds 2-3 beyond, 2 the score-tile-once kernel wherever it is eligible (<= 256 tokens), 0 the two-pass kernel only;
+ * key 12: de-phasing of the persistent GEMM's workgroups (staggered first tiles: steps + 100 * period code; 0 off, -1 built-in default). */
 int ezclip_debug_set(int key, int value);
 int ezclip_profile_begin(void);
 int ezclip_profile_end(int kernel_class, double* total_ms, double* total_work, int* launches);

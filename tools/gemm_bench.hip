@@ -89,6 +89,7 @@ int main(int argc, char** argv) {
   const int batch = argc > 1 ? atoi(argv[1]) : 1024;
   const bool only_attn = getenv("ONLY_ATTN") != nullptr;
   if (getenv("RASTER_GM")) ezclip::set_gemm_raster(atoi(getenv("RASTER_GM")));    // tile order of the persistent kernel
+  if (getenv("GEMM_DEPHASE")) ezclip::set_gemm_dephase(atoi(getenv("GEMM_DEPHASE")));   // steps + 100 * period code (gemm8p.hip)
   if (getenv("ATTN_FWD_OPTS")) ezclip::set_attention_short_tail(atoi(getenv("ATTN_FWD_OPTS")));   // bits: 1 short tail, 2 MFMA row sums, 4 no full lines, 8 no persistent grid
   const int iters = argc > 2 ? atoi(argv[2]) : 20;
   std::vector<int> variants;

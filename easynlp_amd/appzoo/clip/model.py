@@ -234,11 +234,7 @@ class HipClipEngine:
         """A second HIP stream for the text tower: the image tower's persistent GEMMs leave CUs idle in their last
         partial round of tiles (2364 tiles on 256 CUs = 9.23 rounds for the N = 768 products), which the other tower's
         kernels fill when both are in flight."""
-        st = self._side.get((str(device), index))
-        if st is None:
-            st = torch.cuda.Stream(device=device)
-            self._side[(str(device), index)] = st
-        return st
+        return pick_side_stream(device, index)          # (one per process and device, measured to run beside the current stream)
 
     # -- gradient arena / progress hook -------------------------------------------------------------------
     def grad_names(self) -> List[str]:
@@ -455,6 +451,53 @@ class HipClipEngine:
         L.check(self.lib.ezclip_set_option(self.handle, int(key), float(value)), "set_option")
 
 
+# ---- the text tower's stream ---------------------------------------------------------------------------------------------------------
+# HIP maps streams onto a handful of hardware queues, round robin at creation (GPU_MAX_HW_QUEUES, 4 by default).  A side stream that lands
+# on the queue of the stream the image tower runs on does not run BESIDE it: the two towers serialise and a training step reads 135.9
+# instead of 130.8 ms -- exactly what `app.two_streams = False` reads.  Round 6 found this behind the "autograd step is 4 % slower as the
+# 7th workload of a process" of round 5: every engine created its own stream, and every fourth creation aliased (3 of 8 instances in
+# profiles/r6_autograd_side_stream_alias.log).  So: ONE side stream per (process, device, index), chosen by a measurement -- a candidate is
+# kept only if a trivial kernel on it finishes while the main stream is still busy.
+_SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+_SIDE_REJECTED: list = []           # (kept referenced: their pool slots stay taken)
+
+
+def _runs_beside(main: "torch.cuda.Stream", cand: "torch.cuda.Stream", device) -> bool:
+    """Does work on ``cand`` execute while ``main`` is busy?  ~2 ms of elementwise passes over 128 MiB on ``main``, one small fill on
+    ``cand``, events on both (a one-off measurement at first use: plumbing, no kernel of the compute path)."""
+    with torch.cuda.device(device):
+        a = torch.ones(32 << 20, dtype=torch.float32, device=device)
+        flag = torch.empty(64, dtype=torch.float32, device=device)
+        with torch.cuda.stream(cand):       # (the first launch on a new stream creates its hardware queue: milliseconds, not part of the question)
+            flag.fill_(0.0)
+        torch.cuda.synchronize(device)
+        t0, main_done, side_done = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(main):
+            t0.record(main)
+            for _ in range(24):
+                a.mul_(1.0001)
+            main_done.record(main)
+        with torch.cuda.stream(cand):
+            flag.fill_(1.0)
+            side_done.record(cand)
+        torch.cuda.synchronize(device)
+        return t0.elapsed_time(side_done) < 0.5 * t0.elapsed_time(main_done)
+
+
+def pick_side_stream(device, index: int = 1) -> "torch.cuda.Stream":
+    key = (str(torch.device(device)), index, int(torch.cuda.current_stream(device).cuda_stream))
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        main = torch.cuda.current_stream(device)
+        for _ in range(8):
+            st = torch.cuda.Stream(device=device)
+            if os.environ.get("EZCLIP_SIDE_STREAM_NO_PROBE") or _runs_beside(main, st, device):
+                break
+            _SIDE_REJECTED.append(st)
+        _SIDE_STREAMS[key] = st
+    return st
+
+
 class _WsToken:
     """Ownership of the save-for-backward workspaces of one forward (HipClipEngine.workspace)."""
     __slots__ = ("released", "__weakref__")
@@ -544,6 +587,7 @@ class _EncodeFn(torch.autograd.Function):
             views = arena.make_views(arena.flat)
         else:
             _, views = arena.fresh()
+            app._arena_fresh_backwards = getattr(app, "_arena_fresh_backwards", 0) + 1      # (diagnostics: tools/autograd_step_timeline.py)
         eng.sync_params(params, with_backward=True, grads=views, refresh_if_dirty=False)
         run_i = run_t = None
         if ctx.has[0]:

@@ -489,8 +489,9 @@ def pick_side_stream(device, index: int = 1) -> "torch.cuda.Stream":
     st = _SIDE_STREAMS.get(key)
     if st is None:
         main = torch.cuda.current_stream(device)
+        prio = int(os.environ.get("EZCLIP_SIDE_STREAM_PRIORITY", "0"))          # (A/B switch: -1 = a high-priority stream for the text tower)
         for _ in range(8):
-            st = torch.cuda.Stream(device=device)
+            st = torch.cuda.Stream(device=device, priority=prio)
             if os.environ.get("EZCLIP_SIDE_STREAM_NO_PROBE") or _runs_beside(main, st, device):
                 break
             _SIDE_REJECTED.append(st)

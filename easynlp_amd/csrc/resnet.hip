@@ -781,38 +781,38 @@ int rn_train_backward(ezclip_rn* m, const float* features, const float* d_featur
   for (auto& L : m->blocks) for (auto& b : L) order.push_back(&b);
   for (int bi = (int)order.size() - 1; bi >= 0; --bi) {
     ezclip_rn::Block& b = *order[bi];
-    const int i_dz = pick({dxi}), i_g = pick({dxi, i_dz}), i_t = pick({dxi, i_dz, i_g}), i_u = pick({dxi, i_dz, i_g, i_t});
+    const int i_dz = pick({dxi}), i_g = pick({dxi, i_dz}), i_t = pick({dxi, i_dz, i_g});
     // conv3 + bn3 (+ identity, ReLU): g = dy * [y3 > 0] is also the identity branch's gradient
     void* d_o2 = buf[i_t];                                                         // gradient of conv3's input [Mo, C2p]
     RN_TRY(conv_bn_bwd(b.c3, buf[dxi], true, buf[i_dz], buf[i_g], d_o2, nullptr));
-    // main branch: (pool) conv2, conv1
     const int64_t Min = b.c1.M;
     const int Hin = b.c1.H;
+    // identity branch FIRST (round 6): its gradient then joins the main branch's inside the epilogue of conv1's input-gradient product
+    // (GemmArgs::R) -- one rounding of the f32 sum instead of a separate pass over both (rn_add_kernel was 3.2 % of the RN50 step)
+    int i_add = i_g;
+    if (b.has_down) {
+      const int i_e = pick({i_g, i_t}), i_f = pick({i_g, i_t, i_e});
+      RN_TRY(conv_bn_bwd(b.down, buf[i_g], false, buf[i_e], nullptr, buf[i_f], nullptr));   // -> d (pooled) x
+      i_add = i_f;
+      if (b.stride > 1) {
+        const int i_h = pick({i_t, i_f});
+        RN_TRY(rn_avgpool2_bwd(buf[i_f], B, Hin, Hin, b.c1.Cp, buf[i_h], m->dtype, st));
+        i_add = i_h;
+      }
+    }
+    // main branch: (pool) conv2, conv1
     void* d_y2 = d_o2;
     int i_y2 = i_t;
     if (b.stride > 1) {
+      const int i_u = pick({i_add, i_t});
       RN_TRY(rn_avgpool2_bwd(d_o2, B, Hin, Hin, b.c2.Opad, buf[i_u], m->dtype, st));
       d_y2 = buf[i_u]; i_y2 = i_u;
     }
-    const int i_a = pick({dxi, i_g, i_y2}), i_b = pick({dxi, i_g, i_y2, i_a});
+    const int i_a = pick({i_add, i_y2}), i_b = pick({i_add, i_y2, i_a});
     RN_TRY(conv_bn_bwd(b.c2, d_y2, true, buf[i_a], nullptr, buf[i_b], nullptr));   // -> d y1 in buf[i_b]
-    const int i_c = pick({dxi, i_g, i_b}), i_d = pick({dxi, i_g, i_b, i_c});
-    RN_TRY(conv_bn_bwd(b.c1, buf[i_b], true, buf[i_c], nullptr, buf[i_d], nullptr));   // -> main-branch d x in buf[i_d]
-    // identity branch
-    int i_out = i_d;
-    if (b.has_down) {
-      const int i_e = pick({i_d, i_g}), i_f = pick({i_d, i_g, i_e});
-      RN_TRY(conv_bn_bwd(b.down, buf[i_g], false, buf[i_e], nullptr, buf[i_f], nullptr));   // -> d (pooled) x
-      if (b.stride > 1) {
-        const int i_h = pick({i_d, i_f});
-        RN_TRY(rn_avgpool2_bwd(buf[i_f], B, Hin, Hin, b.c1.Cp, buf[i_h], m->dtype, st));
-        RN_TRY(rn_add_inplace(buf[i_d], buf[i_h], Min * b.c1.Cp, m->dtype, st));
-      } else {
-        RN_TRY(rn_add_inplace(buf[i_d], buf[i_f], Min * b.c1.Cp, m->dtype, st));
-      }
-    } else {
-      RN_TRY(rn_add_inplace(buf[i_d], buf[i_g], Min * b.c1.Cp, m->dtype, st));
-    }
+    const int i_c = pick({i_add, i_b}), i_d = pick({i_add, i_b, i_c});
+    RN_TRY(conv_bn_bwd(b.c1, buf[i_b], true, buf[i_c], nullptr, buf[i_d], buf[i_add]));   // -> d x = main branch + identity branch
+    const int i_out = i_d;
     dxi = i_out;
     dsum("block dx (sum)", buf[dxi], Min * b.c1.Cp);
   }

@@ -126,7 +126,6 @@ class HipClipEngine:
         # ``p.data`` (easynlp/core/optimizers.py:367,451,462), which does NOT bump ``p._version`` -- the packed copies are
         # refreshed at the next forward whether or not the version counters moved.
         self._weights_dirty = False
-        self._side: Dict[str, "torch.cuda.Stream"] = {}
         self._arenas: Dict[str, "P.GradArena"] = {}
         self._progress_cb = None
         self.text_arch = int(text_arch)
